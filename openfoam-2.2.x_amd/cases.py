@@ -1,0 +1,168 @@
+"""Synthetic lduMatrix problems as plain numpy arrays.
+
+Every problem is a dict with the arrays OpenFOAM hands over at the
+lduMatrix::solver boundary:
+  nCells (int), lowerAddr/upperAddr int32[nF] (owner / neighbour, upper-triangular
+  order: sorted by owner, then neighbour), diag f64[nC], upper f64[nF],
+  lower f64[nF] (asymmetric only), source f64[nC], psi f64[nC] (initial guess),
+  faceWeights f64[nF] (what faceAreaPairGAMGAgglomeration derives from Sf).
+
+Random numbers come from a counter-based splitmix64 so that any language can
+regenerate the identical matrix from (seed, face index).
+"""
+import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(_M64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def u01(seed, n):
+    """n uniform doubles in [0,1): u01(seed, f) = (splitmix64(seed*2^32 + f) >> 11) * 2^-53."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) + (np.uint64(seed) << np.uint64(32))
+        z = _splitmix64(idx)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def amul(p, x):
+    """y = A x with the LDU face loop (numpy; order of summation NOT the reference's)."""
+    l, u = p["lowerAddr"], p["upperAddr"]
+    lower = p.get("lower", p["upper"])
+    y = p["diag"] * x
+    y += np.bincount(u, weights=lower * x[l], minlength=p["nCells"])
+    y += np.bincount(l, weights=p["upper"] * x[u], minlength=p["nCells"])
+    return y
+
+
+def box_addressing(nx, ny, nz):
+    """Owner/neighbour of a structured hex box in blockMesh's natural ordering (i fastest).
+
+    Faces sorted by owner then neighbour (c+1 < c+nx < c+nx*ny), i.e. upper-triangular
+    order (reference: lduAddressing.H:36-63).  Returns lowerAddr, upperAddr, dir (0/1/2).
+    """
+    nC = nx * ny * nz
+    c = np.arange(nC, dtype=np.int64)
+    i = c % nx
+    j = (c // nx) % ny
+    k = c // (nx * ny)
+    valid = np.stack([i < nx - 1, j < ny - 1, k < nz - 1], axis=1)
+    nbr = np.stack([c + 1, c + nx, c + nx * ny], axis=1)
+    own = np.repeat(c[:, None], 3, axis=1)
+    d = np.tile(np.arange(3, dtype=np.int8), (nC, 1))
+    m = valid.ravel()
+    return (own.ravel()[m].astype(np.int32), nbr.ravel()[m].astype(np.int32), d.ravel()[m])
+
+
+def _neg_sum_diag(nC, l, u, lower, upper):
+    """lduMatrix::negSumDiag (lduMatrixOperations.C:50-64): diag[l] -= lower; diag[u] -= upper."""
+    d = np.zeros(nC)
+    d -= np.bincount(l, weights=lower, minlength=nC)
+    d -= np.bincount(u, weights=upper, minlength=nC)
+    return d
+
+
+def laplacian2d(nx=40, ny=40):
+    """SURVEY.md 8c known-answer case: 5-point Laplacian, upper=-1, diag=-sum(offdiag),
+    diag[0]+=1, b_i=sin(0.37 i), psi0=0.  Reference: DICPCG 78 iterations to 9.4088e-11."""
+    l, u, d = box_addressing(nx, ny, 1)
+    nC = nx * ny
+    upper = -np.ones(l.size)
+    diag = _neg_sum_diag(nC, l, u, upper, upper)
+    diag[0] += 1.0
+    return dict(nCells=nC, lowerAddr=l, upperAddr=u, diag=diag, upper=upper,
+                source=np.sin(0.37 * np.arange(nC)), psi=np.zeros(nC),
+                faceWeights=np.where(d == 0, 1.0, 1.01))
+
+
+def box3d(nx, ny=None, nz=None, asym=False, seed=12345, seed_asym=54321):
+    """SURVEY.md 8d C3 stand-in for the 10 M-cell motorBike p-matrix (n=216):
+    variable-coefficient 7-point Laplacian upper[f] = -(1 + 0.5*u01(seed,f))*a_dir,
+    a=(1,1.01,1.02); symmetric: diag=-sum(offdiag); asym: lower = upper - 0.3*(2*u01(seed2,f)-1),
+    diag = negSumDiag.  One reference row diag[0]*=2, b = A x*, x*_i = sin(1e-3 i), psi0 = 0."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    l, u, d = box_addressing(nx, ny, nz)
+    nC = nx * ny * nz
+    nF = l.size
+    a = np.array([1.0, 1.01, 1.02])[d]
+    upper = -(1.0 + 0.5 * u01(seed, nF)) * a
+    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, upper=upper, faceWeights=a.copy())
+    if asym:
+        phi = 0.3 * (2.0 * u01(seed_asym, nF) - 1.0)
+        lower = upper - phi
+        p["lower"] = lower
+        diag = _neg_sum_diag(nC, l, u, lower, upper)
+    else:
+        diag = _neg_sum_diag(nC, l, u, upper, upper)
+    diag[0] *= 2.0
+    p["diag"] = diag
+    xstar = np.sin(1e-3 * np.arange(nC))
+    p["source"] = amul(p, xstar)
+    p["psi"] = np.zeros(nC)
+    return p
+
+
+def jump2d(nx, ny, ratio=1000.0):
+    """SURVEY.md 8d C5 twin (damBreak p_rgh): 2-D 5-point with the face coefficient jumping
+    1 <-> ratio across the diagonal i+j = (nx+ny)/2 (two-phase density ratio)."""
+    l, u, d = box_addressing(nx, ny, 1)
+    nC = nx * ny
+    il, jl = l % nx, l // nx
+    iu, ju = u % nx, u // nx
+    heavy = ((il + jl) + (iu + ju)) < (nx + ny)
+    upper = -np.where(heavy, ratio, 1.0)
+    diag = _neg_sum_diag(nC, l, u, upper, upper)
+    diag[0] *= 2.0
+    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, diag=diag, upper=upper,
+             faceWeights=np.where(d == 0, 1.0, 1.01), psi=np.zeros(nC))
+    p["source"] = amul(p, np.cos(3e-3 * np.arange(nC)))
+    return p
+
+
+def random_graph(nC, avg_deg=4, band=50, asym=False, seed=7):
+    """Irregular ('unstructured') addressing: each cell connects to a few random
+    higher-numbered cells within a band.  Exercises ragged rows, empty rows and
+    non-uniform dependency levels in the triangular sweeps."""
+    rng = np.random.RandomState(seed)
+    own = []
+    nbr = []
+    for c in range(nC - 1):
+        k = rng.poisson(avg_deg / 2.0)
+        if k == 0:
+            continue
+        hi = min(nC - 1, c + band)
+        cand = np.unique(rng.randint(c + 1, hi + 1, size=k))
+        own.extend([c] * cand.size)
+        nbr.extend(cand.tolist())
+    l = np.array(own, dtype=np.int32)
+    u = np.array(nbr, dtype=np.int32)
+    nF = l.size
+    upper = -(0.5 + rng.rand(nF))
+    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, upper=upper,
+             faceWeights=0.5 + rng.rand(nF))
+    if asym:
+        lower = upper - 0.3 * (2 * rng.rand(nF) - 1)
+        p["lower"] = lower
+        diag = _neg_sum_diag(nC, l, u, lower, upper)
+    else:
+        diag = _neg_sum_diag(nC, l, u, upper, upper)
+    diag += 0.05 + 0.1 * rng.rand(nC)
+    p["diag"] = diag
+    p["source"] = rng.randn(nC)
+    p["psi"] = 0.1 * rng.randn(nC)
+    return p
+
+
+def to_ldub_dict(p):
+    out = {"nCells": np.array([p["nCells"]], dtype=np.int32)}
+    for k in ("lowerAddr", "upperAddr", "diag", "upper", "lower", "source", "psi", "faceWeights"):
+        if k in p:
+            out[k] = p[k]
+    return out
