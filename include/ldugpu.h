@@ -1,0 +1,172 @@
+/*
+ * ldugpu.h - C ABI of the MI355X-native lduMatrix solver hot path.
+ *
+ * Drop-in boundary = OpenFOAM-2.2.x's lduMatrix::solver / preconditioner /
+ * smoother interface (src/OpenFOAM/matrices/lduMatrix/lduMatrix/lduMatrix.H:91-506).
+ * The OpenFOAM-side shim (openfoam-2.2.x_amd/plugin/) and the
+ * host mirror (openfoam-2.2.x_amd/host/) are the only callers; both hand over
+ * exactly what the reference hands to its solvers (SURVEY.md 8b "data handed over"):
+ * raw contiguous f64 coefficient arrays, int32 addressing, psi and source.
+ *
+ * Plain pointers and sizes only.  Pointers may be host or device pointers
+ * (detected with hipPointerGetAttributes); device pointers avoid the PCIe copy.
+ * All functions return 0 on success or a negative error code; ldu_last_error()
+ * returns the message (the OpenFOAM shim turns it into FatalErrorIn(...)).
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef LDUGPU_H
+#define LDUGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ldu_ctx ldu_ctx;       /* device context: stream, scratch, communicator   */
+typedef struct ldu_addr ldu_addr;     /* device image of one lduAddressing (+ coupled patches) */
+typedef struct ldu_matrix ldu_matrix; /* device image of one lduMatrix (coefficients)    */
+
+/* ---- enums (names = the reference's run-time-selection keys) ------------------- */
+enum { LDU_SOLVER_PCG = 0, LDU_SOLVER_PBICG = 1, LDU_SOLVER_SMOOTH = 2, LDU_SOLVER_GAMG = 3,
+       LDU_SOLVER_DIAGONAL = 4 };
+enum { LDU_PRE_NONE = 0, LDU_PRE_DIAGONAL = 1, LDU_PRE_DIC = 2, LDU_PRE_FDIC = 3, LDU_PRE_DILU = 4,
+       LDU_PRE_GAMG = 5 };
+enum { LDU_SM_GAUSSSEIDEL = 0, LDU_SM_SYMGAUSSSEIDEL = 1, LDU_SM_DIC = 2, LDU_SM_DILU = 3,
+       LDU_SM_DICGAUSSSEIDEL = 4, LDU_SM_DILUGAUSSSEIDEL = 5, LDU_SM_FDIC = 6 };
+enum { LDU_AGG_FACEAREAPAIR = 0, LDU_AGG_ALGEBRAICPAIR = 1 };
+
+/* Solver controls = the keys the reference reads from the fvSolution sub-dictionary:
+ * lduMatrixSolver.C:164-169 (maxIter 1000, tolerance 1e-6, relTol 0), smoothSolver.C:73
+ * (nSweeps), GAMGSolver.C:157-181, GAMGAgglomeration.C:79 / pairGAMGAgglomeration.C:45,
+ * GAMGPreconditioner.C:77 (nVcycles). */
+typedef struct ldu_controls {
+    int32_t solver, preconditioner, smoother;
+    double tolerance, relTol;
+    int32_t maxIter;
+    int32_t nSweeps;
+    int32_t cacheAgglomeration;
+    int32_t nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps;
+    int32_t nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps;
+    int32_t nFinestSweeps;
+    int32_t interpolateCorrection;
+    int32_t scaleCorrection;      /* -1 = matrix.symmetric() (GAMGSolver.C:74) */
+    int32_t directSolveCoarsest;  /* unsupported (default false, GAMGSolver.C:76) */
+    int32_t nCellsInCoarsestLevel, mergeLevels, agglomerator;
+    int32_t nVcycles;
+    int32_t historyCapacity;      /* residual history entries the caller's buffer holds */
+} ldu_controls;
+
+/* SolverPerformance<scalar> (src/OpenFOAM/matrices/LduMatrix/LduMatrix/SolverPerformance.H) */
+typedef struct ldu_perf {
+    double initialResidual, finalResidual, normFactor;
+    int32_t nIterations, converged, singular;
+    int32_t nHistory;             /* residual-history entries written */
+    double solveSeconds;          /* wall time inside the solve (device-synchronised) */
+    double setupSeconds;          /* coefficient upload / preconditioner / level setup */
+} ldu_perf;
+
+const char* ldu_last_error(void);
+void ldu_default_controls(ldu_controls* c);
+
+/* ---- context ------------------------------------------------------------------- */
+/* One context per rank/GPU (reference: one MPI rank per sub-domain, UPstream). */
+int ldu_ctx_create(ldu_ctx** ctx, int device);
+int ldu_ctx_destroy(ldu_ctx* ctx);
+int ldu_ctx_sync(ldu_ctx* ctx);
+/* Multi-GPU: RCCL communicator from a 128-byte unique id shared out-of-band
+ * (replaces UPstream::init / MPI_COMM_WORLD, src/Pstream/mpi/UPstream.C). */
+int ldu_comm_unique_id(uint8_t id[128]);
+int ldu_ctx_comm_init(ldu_ctx* ctx, int rank, int nRanks, const uint8_t id[128]);
+
+/* ---- addressing (lduAddressing.H:111-199, lduPrimitiveMesh.H:83-99) ------------ */
+/* lower/upper = lowerAddr()/upperAddr(), upper-triangular order (sorted by owner).  */
+int ldu_addr_create(ldu_ctx* ctx, ldu_addr** a, int32_t nCells, int32_t nFaces,
+                    const int32_t* lowerAddr, const int32_t* upperAddr);
+/* Coupled (processor) patch: lduAddr().patchAddr(patchI) = faceCells; neighbour rank
+ * (processorLduInterface::neighbProcNo).  Patches must be added in patch order. */
+int ldu_addr_add_patch(ldu_addr* a, int32_t nPatchFaces, const int32_t* faceCells, int32_t nbrRank);
+/* Call after the last add_patch (builds the device-side schedule). */
+int ldu_addr_finalize(ldu_addr* a);
+int ldu_addr_destroy(ldu_addr* a);
+/* Diagnostics: dependency levels of the triangular sweeps etc. */
+int ldu_addr_info(const ldu_addr* a, int32_t* nLevels, int32_t* nSlices, int64_t* nEntriesPadded);
+/* Face weights for the geometric agglomerator (faceAreaPairGAMGAgglomeration.C:48-73
+ * computes them from Sf; the shim passes mag(cmptMultiply(Sf/sqrt(magSf),(1,1.01,1.02)))). */
+int ldu_addr_set_face_weights(ldu_addr* a, const double* faceWeights);
+
+/* ---- matrix (lduMatrix.H:82-85; symmetric <=> lower == NULL, lduMatrix.C:198-215) -- */
+int ldu_matrix_create(ldu_addr* a, ldu_matrix** m);
+int ldu_matrix_destroy(ldu_matrix* m);
+/* Re-read every solve (fvScalarMatrix.C:152-174 modifies diag around the call). */
+int ldu_matrix_set_coeffs(ldu_matrix* m, const double* diag, const double* upper,
+                          const double* lower /* NULL = symmetric */);
+/* interfaceBouCoeffs[patchI] / interfaceIntCoeffs[patchI] of coupled patch patchI */
+int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bouCoeffs,
+                                const double* intCoeffs);
+
+/* ---- matrix operations on caller vectors (original cell order) -------------------- */
+/* lduMatrix::Amul / Tmul / sumA / residual (lduMatrixATmul.C:34-280) */
+int ldu_amul(ldu_matrix* m, double* Apsi, const double* psi);
+int ldu_tmul(ldu_matrix* m, double* Tpsi, const double* psi);
+int ldu_sumA(ldu_matrix* m, double* sumA);
+int ldu_residual(ldu_matrix* m, double* rA, const double* psi, const double* source);
+/* lduMatrix::H / H1 / faceH (lduMatrixTemplates.C:34-110, lduMatrixATmul.C:298-327) */
+int ldu_H(ldu_matrix* m, double* H, const double* psi);
+int ldu_H1(ldu_matrix* m, double* H1);
+int ldu_faceH(ldu_matrix* m, double* faceH, const double* psi);
+/* gSumProd / gSumMag (FieldFunctions.C:477-503): rank-local device reduction + RCCL all-reduce */
+int ldu_gSumProd(ldu_matrix* m, const double* a, const double* b, double* result);
+int ldu_gSumMag(ldu_matrix* m, const double* a, double* result);
+
+/* lduMatrix::preconditioner::precondition / preconditionT (lduMatrix.H:482-505) */
+int ldu_precondition(ldu_matrix* m, int32_t preconditioner, double* wA, const double* rA,
+                     int32_t transpose);
+/* lduMatrix::smoother::smooth (lduMatrix.H:391-397) */
+int ldu_smooth(ldu_matrix* m, int32_t smoother, double* psi, const double* source, int32_t nSweeps);
+
+/* ---- whole solvers: lduMatrix::solver::solve (lduMatrix.H:242-247) ------------------ */
+/* psi in/out, source in; resHistory (may be NULL) receives the residual after every
+ * checkConvergence call like the reference's debug>=2 print (SolverPerformance.C:65-71). */
+int ldu_solve(ldu_matrix* m, const ldu_controls* controls, double* psi, const double* source,
+              ldu_perf* perf, double* resHistory);
+
+/* GAMG hierarchy introspection (tests): level sizes and restrict maps */
+int ldu_gamg_levels(ldu_matrix* m, const ldu_controls* controls, int32_t* nLevels,
+                    int32_t* nCellsPerLevel /* [50] */, int32_t* nFacesPerLevel /* [50] */);
+int ldu_gamg_level_data(ldu_matrix* m, int32_t level, int32_t* restrictAddr /* fine nCells */,
+                        double* diag, double* upper, double* lower /* may be NULL */);
+
+/* ---- finite-volume stencils feeding the matrix ------------- */
+typedef struct ldu_mesh_geom {
+    /* internal faces */
+    const double* Sf;        /* [nFaces*3] face area vectors (fvMesh::Sf) */
+    const double* magSf;     /* [nFaces]   */
+    const double* weights;   /* [nFaces] linear interpolation weights (surfaceInterpolation.C:175-185) */
+    const double* deltaCoeffs; /* [nFaces] (surfaceInterpolation.C:239-242) */
+    const double* V;         /* [nCells] cell volumes */
+} ldu_mesh_geom;
+/* surfaceInterpolationScheme::interpolate (surfaceInterpolationScheme.C:293-296):
+ * sf[f] = lambda[f]*(vf[own]-vf[nei]) + vf[nei]; nComp = 1 (scalar) or 3 (vector) */
+int ldu_fv_interpolate(ldu_addr* a, int32_t nComp, const double* lambdas, const double* vf, double* sf);
+/* fvc::surfaceIntegrate internal-face part (fvcSurfaceIntegrate.C:43-76), divided by V */
+int ldu_fvc_surfaceIntegrate(ldu_addr* a, int32_t nComp, const double* ssf, const double* V,
+                             double* ivf);
+/* fv::gaussGrad::gradf internal part (gaussGrad.C:41-110): grad = sum_f Sf*ssf / V */
+int ldu_fvc_gaussGrad(ldu_addr* a, const double* Sf, const double* ssf, const double* V, double* grad);
+/* snGradScheme::snGrad (snGradScheme.C:139-143): ssf[f] = delta[f]*(vf[nei]-vf[own]) */
+int ldu_fvc_snGrad(ldu_addr* a, const double* deltaCoeffs, const double* vf, double* ssf);
+/* gaussLaplacianScheme::fvmLaplacianUncorrected (gaussLaplacianScheme.C:46-88):
+ * upper = deltaCoeffs*gammaMagSf; diag = negSumDiag */
+int ldu_fvm_laplacian(ldu_addr* a, const double* deltaCoeffs, const double* gammaMagSf,
+                      double* diag, double* upper);
+/* gaussConvectionScheme::fvmDiv (gaussConvectionScheme.C:68-107): lower = -w*phi;
+ * upper = lower + phi; negSumDiag */
+int ldu_fvm_div(ldu_addr* a, const double* weights, const double* faceFlux, double* diag,
+                double* upper, double* lower);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,333 @@
+"""ctypes binding of libldugpu.so (include/ldugpu.h) - the host-side Python mirror used by
+the tests and bench.py.  Thin: it only marshals numpy arrays / device pointers (torch tensors'
+data_ptr) into the C ABI.  Fails loudly when the HIP library is missing or no GPU is visible:
+there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libldugpu.so")
+
+SOLVERS = {"PCG": 0, "PBiCG": 1, "smoothSolver": 2, "GAMG": 3, "diagonal": 4}
+PRECONDITIONERS = {"none": 0, "diagonal": 1, "DIC": 2, "FDIC": 3, "DILU": 4, "GAMG": 5}
+SMOOTHERS = {"GaussSeidel": 0, "symGaussSeidel": 1, "DIC": 2, "DILU": 3, "DICGaussSeidel": 4,
+             "DILUGaussSeidel": 5, "FDIC": 6}
+AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
+
+EXPORTS = [
+    "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
+    "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_addr_create", "ldu_addr_add_patch",
+    "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
+    "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
+    "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
+    "ldu_gSumProd", "ldu_gSumMag", "ldu_precondition", "ldu_smooth", "ldu_solve", "ldu_gamg_levels",
+    "ldu_gamg_level_data", "ldu_fv_interpolate", "ldu_fvc_surfaceIntegrate", "ldu_fvc_gaussGrad",
+    "ldu_fvc_snGrad", "ldu_fvm_laplacian", "ldu_fvm_div",
+]
+
+
+class Controls(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("preconditioner", C.c_int32), ("smoother", C.c_int32),
+                ("tolerance", C.c_double), ("relTol", C.c_double), ("maxIter", C.c_int32),
+                ("nSweeps", C.c_int32), ("cacheAgglomeration", C.c_int32),
+                ("nPreSweeps", C.c_int32), ("preSweepsLevelMultiplier", C.c_int32),
+                ("maxPreSweeps", C.c_int32), ("nPostSweeps", C.c_int32),
+                ("postSweepsLevelMultiplier", C.c_int32), ("maxPostSweeps", C.c_int32),
+                ("nFinestSweeps", C.c_int32), ("interpolateCorrection", C.c_int32),
+                ("scaleCorrection", C.c_int32), ("directSolveCoarsest", C.c_int32),
+                ("nCellsInCoarsestLevel", C.c_int32), ("mergeLevels", C.c_int32),
+                ("agglomerator", C.c_int32), ("nVcycles", C.c_int32), ("historyCapacity", C.c_int32)]
+
+
+class Perf(C.Structure):
+    _fields_ = [("initialResidual", C.c_double), ("finalResidual", C.c_double),
+                ("normFactor", C.c_double), ("nIterations", C.c_int32), ("converged", C.c_int32),
+                ("singular", C.c_int32), ("nHistory", C.c_int32), ("solveSeconds", C.c_double),
+                ("setupSeconds", C.c_double)]
+
+
+_LIB = None
+
+
+def build_library():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "csrc"), "-j8"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libldugpu.so is not built (%s): run __graft_entry__.build(); "
+                               "there is no CPU fallback for the lduMatrix GPU path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ldu_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+class LduError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise LduError("libldugpu error %d: %s" % (rc, lib().ldu_last_error().decode()))
+
+
+def _ptr(x):
+    """numpy array, torch tensor, int address or None -> c_void_p"""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+def _f64(x):
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.float64)
+    return x
+
+
+def make_controls(**kw):
+    c = Controls()
+    lib().ldu_default_controls(C.byref(c))
+    for k, v in kw.items():
+        if k == "solver":
+            v = SOLVERS[v]
+        elif k == "preconditioner":
+            v = PRECONDITIONERS[v]
+        elif k == "smoother":
+            v = SMOOTHERS[v]
+        elif k == "agglomerator":
+            v = AGGLOMERATORS[v]
+        if isinstance(v, bool):
+            v = int(v)
+        setattr(c, k, v)
+    return c
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().ldu_ctx_create(C.byref(self.h), int(device)))
+
+    def comm_init(self, rank, n_ranks, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _chk(lib().ldu_ctx_comm_init(self.h, int(rank), int(n_ranks), buf))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _chk(lib().ldu_comm_unique_id(buf))
+        return bytes(buf)
+
+    def sync(self):
+        _chk(lib().ldu_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            lib().ldu_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Addressing:
+    """Device image of one lduAddressing (+ coupled patches)."""
+
+    def __init__(self, ctx, nCells, lowerAddr, upperAddr, faceWeights=None, patches=()):
+        self.ctx = ctx
+        self.nCells = int(nCells)
+        l = np.ascontiguousarray(lowerAddr, dtype=np.int32)
+        u = np.ascontiguousarray(upperAddr, dtype=np.int32)
+        self.nFaces = int(l.size)
+        self.h = C.c_void_p()
+        _chk(lib().ldu_addr_create(ctx.h, C.byref(self.h), self.nCells, self.nFaces, _ptr(l), _ptr(u)))
+        for p in patches:
+            fc = np.ascontiguousarray(p["faceCells"], dtype=np.int32)
+            _chk(lib().ldu_addr_add_patch(self.h, int(fc.size), _ptr(fc), int(p["nbrRank"])))
+        if patches:
+            _chk(lib().ldu_addr_finalize(self.h))
+        if faceWeights is not None:
+            w = np.ascontiguousarray(faceWeights, dtype=np.float64)
+            _chk(lib().ldu_addr_set_face_weights(self.h, _ptr(w)))
+
+    def info(self):
+        nl, ns, ne = C.c_int32(), C.c_int32(), C.c_int64()
+        _chk(lib().ldu_addr_info(self.h, C.byref(nl), C.byref(ns), C.byref(ne)))
+        return dict(nLevels=nl.value, nSlices=ns.value, nEntriesPadded=ne.value)
+
+    def close(self):
+        if self.h:
+            lib().ldu_addr_destroy(self.h)
+            self.h = C.c_void_p()
+
+    # ---- fv stencils (numpy in / numpy out)
+    def interpolate(self, lambdas, vf):
+        vf = _f64(vf)
+        nComp = 1 if vf.ndim == 1 else vf.shape[1]
+        sf = np.zeros((self.nFaces,) if nComp == 1 else (self.nFaces, nComp))
+        _chk(lib().ldu_fv_interpolate(self.h, nComp, _ptr(_f64(lambdas)), _ptr(vf), _ptr(sf)))
+        return sf
+
+    def surfaceIntegrate(self, ssf, V):
+        ssf = _f64(ssf)
+        nComp = 1 if ssf.ndim == 1 else ssf.shape[1]
+        out = np.zeros((self.nCells,) if nComp == 1 else (self.nCells, nComp))
+        _chk(lib().ldu_fvc_surfaceIntegrate(self.h, nComp, _ptr(ssf), _ptr(_f64(V)), _ptr(out)))
+        return out
+
+    def gaussGrad(self, Sf, ssf, V):
+        out = np.zeros((self.nCells, 3))
+        _chk(lib().ldu_fvc_gaussGrad(self.h, _ptr(_f64(Sf)), _ptr(_f64(ssf)), _ptr(_f64(V)), _ptr(out)))
+        return out
+
+    def snGrad(self, deltaCoeffs, vf):
+        out = np.zeros(self.nFaces)
+        _chk(lib().ldu_fvc_snGrad(self.h, _ptr(_f64(deltaCoeffs)), _ptr(_f64(vf)), _ptr(out)))
+        return out
+
+    def fvmLaplacian(self, deltaCoeffs, gammaMagSf):
+        diag, upper = np.zeros(self.nCells), np.zeros(self.nFaces)
+        _chk(lib().ldu_fvm_laplacian(self.h, _ptr(_f64(deltaCoeffs)), _ptr(_f64(gammaMagSf)),
+                                     _ptr(diag), _ptr(upper)))
+        return diag, upper
+
+    def fvmDiv(self, weights, phi):
+        diag, upper, lower = np.zeros(self.nCells), np.zeros(self.nFaces), np.zeros(self.nFaces)
+        _chk(lib().ldu_fvm_div(self.h, _ptr(_f64(weights)), _ptr(_f64(phi)), _ptr(diag), _ptr(upper),
+                               _ptr(lower)))
+        return diag, upper, lower
+
+
+class Matrix:
+    """Device image of one lduMatrix; mirrors lduMatrix::solver / preconditioner / smoother."""
+
+    def __init__(self, addr):
+        self.addr = addr
+        self.h = C.c_void_p()
+        _chk(lib().ldu_matrix_create(addr.h, C.byref(self.h)))
+        self._keep = None
+
+    def set_coeffs(self, diag, upper, lower=None):
+        diag, upper, lower = _f64(diag), _f64(upper), _f64(lower)
+        self._keep = (diag, upper, lower)
+        _chk(lib().ldu_matrix_set_coeffs(self.h, _ptr(diag), _ptr(upper), _ptr(lower)))
+
+    def set_patch_coeffs(self, patchI, bou, intc):
+        bou, intc = _f64(bou), _f64(intc)
+        _chk(lib().ldu_matrix_set_patch_coeffs(self.h, int(patchI), _ptr(bou), _ptr(intc)))
+        self.addr.ctx.sync()
+
+    def _vec(self):
+        return np.zeros(self.addr.nCells)
+
+    def Amul(self, psi):
+        y = self._vec()
+        _chk(lib().ldu_amul(self.h, _ptr(y), _ptr(_f64(psi))))
+        return y
+
+    def Tmul(self, psi):
+        y = self._vec()
+        _chk(lib().ldu_tmul(self.h, _ptr(y), _ptr(_f64(psi))))
+        return y
+
+    def sumA(self):
+        y = self._vec()
+        _chk(lib().ldu_sumA(self.h, _ptr(y)))
+        return y
+
+    def residual(self, psi, source):
+        y = self._vec()
+        _chk(lib().ldu_residual(self.h, _ptr(y), _ptr(_f64(psi)), _ptr(_f64(source))))
+        return y
+
+    def H(self, psi):
+        y = self._vec()
+        _chk(lib().ldu_H(self.h, _ptr(y), _ptr(_f64(psi))))
+        return y
+
+    def H1(self):
+        y = self._vec()
+        _chk(lib().ldu_H1(self.h, _ptr(y)))
+        return y
+
+    def faceH(self, psi):
+        y = np.zeros(self.addr.nFaces)
+        _chk(lib().ldu_faceH(self.h, _ptr(y), _ptr(_f64(psi))))
+        return y
+
+    def gSumProd(self, a, b):
+        r = C.c_double()
+        _chk(lib().ldu_gSumProd(self.h, _ptr(_f64(a)), _ptr(_f64(b)), C.byref(r)))
+        return r.value
+
+    def gSumMag(self, a):
+        r = C.c_double()
+        _chk(lib().ldu_gSumMag(self.h, _ptr(_f64(a)), C.byref(r)))
+        return r.value
+
+    def precondition(self, kind, rA, transpose=False):
+        w = self._vec()
+        _chk(lib().ldu_precondition(self.h, PRECONDITIONERS[kind], _ptr(w), _ptr(_f64(rA)), int(transpose)))
+        return w
+
+    def smooth(self, smoother, psi, source, nSweeps):
+        x = np.array(psi, dtype=np.float64, copy=True)
+        _chk(lib().ldu_smooth(self.h, SMOOTHERS[smoother], _ptr(x), _ptr(_f64(source)), int(nSweeps)))
+        return x
+
+    def solve(self, psi, source, history=True, **controls):
+        """psi, source: numpy arrays (psi is copied) or device tensors (psi updated in place)."""
+        c = make_controls(**controls)
+        cap = c.maxIter + 3
+        hist = np.zeros(cap)
+        c.historyCapacity = cap if history else 0
+        perf = Perf()
+        if isinstance(psi, np.ndarray):
+            x = np.array(psi, dtype=np.float64, copy=True)
+        else:
+            x = psi
+        _chk(lib().ldu_solve(self.h, C.byref(c), _ptr(x), _ptr(_f64(source)), C.byref(perf), _ptr(hist)))
+        n = min(perf.nHistory, cap)
+        return x, dict(initialResidual=perf.initialResidual, finalResidual=perf.finalResidual,
+                       normFactor=perf.normFactor, nIterations=perf.nIterations,
+                       converged=bool(perf.converged), singular=bool(perf.singular),
+                       history=hist[:n].copy(), solveSeconds=perf.solveSeconds)
+
+    def gamg_levels(self, **controls):
+        c = make_controls(**controls)
+        nl = C.c_int32()
+        nc = (C.c_int32 * 50)()
+        nf = (C.c_int32 * 50)()
+        _chk(lib().ldu_gamg_levels(self.h, C.byref(c), C.byref(nl), nc, nf))
+        out = []
+        nFine = self.addr.nCells
+        for i in range(nl.value):
+            r = np.zeros(nFine, dtype=np.int32)
+            d = np.zeros(nc[i])
+            up = np.zeros(nf[i])
+            lo = np.zeros(nf[i])
+            _chk(lib().ldu_gamg_level_data(self.h, i, _ptr(r), _ptr(d), _ptr(up), _ptr(lo)))
+            out.append(dict(nCells=nc[i], nFaces=nf[i], restrict=r, diag=d, upper=up, lower=lo))
+            nFine = nc[i]
+        return out
+
+    def close(self):
+        if self.h:
+            lib().ldu_matrix_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def from_problem(ctx, p):
+    """cases.py problem dict -> (Addressing, Matrix) with coefficients set."""
+    a = Addressing(ctx, p["nCells"], p["lowerAddr"], p["upperAddr"], p.get("faceWeights"),
+                   patches=p.get("patches_dev", ()))
+    m = Matrix(a)
+    m.set_coeffs(p["diag"], p["upper"], p.get("lower"))
+    return a, m

@@ -1,0 +1,638 @@
+// extern "C" entry points declared in include/ldugpu.h.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "ldu_internal.hpp"
+
+static thread_local std::string g_err;
+void ldu_set_error(const std::string& msg) { g_err = msg; }
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static bool is_device_ptr(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess)
+    {
+        (void)hipGetLastError();   // unregistered host memory
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+extern "C" {
+
+const char* ldu_last_error(void) { return g_err.c_str(); }
+
+void ldu_default_controls(ldu_controls* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->solver = LDU_SOLVER_PCG;
+    c->preconditioner = LDU_PRE_DIC;
+    c->smoother = LDU_SM_GAUSSSEIDEL;
+    c->tolerance = 1e-6;          // lduMatrixSolver.C:164-169
+    c->relTol = 0;
+    c->maxIter = 1000;
+    c->nSweeps = 1;               // smoothSolver.C:73
+    c->cacheAgglomeration = 0;    // GAMGSolver.C:65-76
+    c->nPreSweeps = 0;
+    c->preSweepsLevelMultiplier = 1;
+    c->maxPreSweeps = 4;
+    c->nPostSweeps = 2;
+    c->postSweepsLevelMultiplier = 1;
+    c->maxPostSweeps = 4;
+    c->nFinestSweeps = 2;
+    c->interpolateCorrection = 0;
+    c->scaleCorrection = -1;
+    c->directSolveCoarsest = 0;
+    c->nCellsInCoarsestLevel = 10;
+    c->mergeLevels = 1;
+    c->agglomerator = LDU_AGG_FACEAREAPAIR;
+    c->nVcycles = 2;              // GAMGPreconditioner.C:60
+    c->historyCapacity = 0;
+}
+
+// ---------------------------------------------------------------- context
+
+int ldu_ctx_create(ldu_ctx** out, int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    {
+        ldu_set_error("no HIP device available: the lduMatrix GPU path cannot run (no CPU fallback)");
+        return -10;
+    }
+    LDU_CHECK_HIP(hipSetDevice(device));
+    ldu_ctx* c = new ldu_ctx();
+    c->device = device;
+    LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    LDU_CHECK_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * 2 * (size_t)c->maxRedBlocks));
+    LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * S_NSLOTS));
+    LDU_CHECK_HIP(hipMemset(c->d_scalars, 0, sizeof(double) * S_NSLOTS));
+    LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * S_NSLOTS, hipHostMallocDefault));
+    const char* e = getenv("LDU_NO_GRAPH");
+    if (e && atoi(e)) c->useGraphs = false;
+    e = getenv("LDU_FUSE_ROWS");
+    if (e) c->fuseRows = atoi(e);
+    *out = c;
+    return 0;
+}
+
+int ldu_ctx_destroy(ldu_ctx* c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c);
+    (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_scalars);
+    (void)hipHostFree(c->h_scalars);
+    (void)hipEventDestroy(c->evFork);
+    (void)hipEventDestroy(c->evJoin);
+    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream2);
+    delete c;
+    return 0;
+}
+
+int ldu_ctx_sync(ldu_ctx* c)
+{
+    LDU_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- addressing
+
+int addr_create_internal(ldu_ctx* ctx, ldu_addr** out, int nCells, int nFaces, const int* l, const int* u)
+{
+    ldu_addr* a = new ldu_addr();
+    a->ctx = ctx;
+    a->nCells = nCells;
+    a->nFaces = nFaces;
+    a->l.assign(l, l + nFaces);
+    a->u.assign(u, u + nFaces);
+    int rc = plan_build(a);
+    if (rc) { plan_free(a); delete a; return rc; }
+    a->finalized = true;   // no patches unless added
+    *out = a;
+    return 0;
+}
+
+extern "C" {
+
+int ldu_addr_create(ldu_ctx* ctx, ldu_addr** a, int32_t nCells, int32_t nFaces, const int32_t* lowerAddr,
+                    const int32_t* upperAddr)
+{
+    if (!ctx) { ldu_set_error("null context"); return -11; }
+    LDU_CHECK_HIP(hipSetDevice(ctx->device));
+    std::vector<int> l(nFaces), u(nFaces);
+    if (nFaces)
+    {
+        LDU_CHECK_HIP(hipMemcpy(l.data(), lowerAddr, sizeof(int) * nFaces, hipMemcpyDefault));
+        LDU_CHECK_HIP(hipMemcpy(u.data(), upperAddr, sizeof(int) * nFaces, hipMemcpyDefault));
+    }
+    return addr_create_internal(ctx, a, nCells, nFaces, l.data(), u.data());
+}
+
+int ldu_addr_add_patch(ldu_addr* a, int32_t n, const int32_t* faceCells, int32_t nbrRank)
+{
+    Patch p;
+    p.n = n;
+    p.nbrRank = nbrRank;
+    p.faceCells.assign(faceCells, faceCells + n);
+    for (int i = 0; i < n; i++)
+        if (faceCells[i] < 0 || faceCells[i] >= a->nCells) { ldu_set_error("patch faceCells out of range"); return -12; }
+    a->patches.push_back(p);
+    a->finalized = false;
+    return 0;
+}
+
+int ldu_addr_finalize(ldu_addr* a) { return plan_finalize_patches(a); }
+
+int ldu_addr_destroy(ldu_addr* a)
+{
+    if (!a) return 0;
+    (void)hipStreamSynchronize(a->ctx->stream);
+    plan_free(a);
+    delete a;
+    return 0;
+}
+
+int ldu_addr_info(const ldu_addr* a, int32_t* nLevels, int32_t* nSlices, int64_t* nEntriesPadded)
+{
+    if (nLevels) *nLevels = a->nLevels;
+    if (nSlices) *nSlices = a->nSlices;
+    if (nEntriesPadded) *nEntriesPadded = a->nEntries;
+    return 0;
+}
+
+int ldu_addr_set_face_weights(ldu_addr* a, const double* w)
+{
+    a->faceWeights.resize(a->nFaces);
+    if (a->nFaces) LDU_CHECK_HIP(hipMemcpy(a->faceWeights.data(), w, sizeof(double) * a->nFaces, hipMemcpyDefault));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- matrix
+
+int matrix_alloc(ldu_addr* a, ldu_matrix** out)
+{
+    ldu_matrix* m = new ldu_matrix();
+    m->a = a;
+    const size_t nC = (size_t)a->nCells + 1, nF = (size_t)a->nFaces + 1;
+    const size_t nE = (size_t)(a->nEntries > 0 ? a->nEntries : 1);
+    LDU_CHECK_HIP(hipMalloc((void**)&m->d_diagO, sizeof(double) * nC));
+    LDU_CHECK_HIP(hipMalloc((void**)&m->d_upperO, sizeof(double) * nF));
+    m->d_lowerO = m->d_upperO;
+    LDU_CHECK_HIP(hipMalloc((void**)&m->d_diag, sizeof(double) * nC));
+    LDU_CHECK_HIP(hipMalloc((void**)&m->d_valA, sizeof(double) * nE));
+    m->d_valT = m->d_valA;
+    if (a->nPatchFaces)
+    {
+        LDU_CHECK_HIP(hipMalloc((void**)&m->d_bou, sizeof(double) * (size_t)a->nPatchFaces));
+        LDU_CHECK_HIP(hipMalloc((void**)&m->d_int, sizeof(double) * (size_t)a->nPatchFaces));
+        LDU_CHECK_HIP(hipMemset(m->d_bou, 0, sizeof(double) * (size_t)a->nPatchFaces));
+        LDU_CHECK_HIP(hipMemset(m->d_int, 0, sizeof(double) * (size_t)a->nPatchFaces));
+    }
+    *out = m;
+    return 0;
+}
+
+void matrix_free(ldu_matrix* m)
+{
+    if (!m) return;
+    if (m->gamg) gamg_free(m->gamg);
+    if (m->d_lowerO && m->d_lowerO != m->d_upperO) (void)hipFree(m->d_lowerO);
+    if (m->d_valT && m->d_valT != m->d_valA) (void)hipFree(m->d_valT);
+    void* ptrs[] = {m->d_diagO, m->d_upperO, m->d_diag, m->d_valA, m->d_bou, m->d_int, m->d_rD,
+                    m->d_valP, m->d_valPT, m->d_rDiag};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (double* p : m->work) if (p) (void)hipFree(p);
+    delete m;
+}
+
+// LDU-space device coefficients (original order) -> level-ordered diag + sliced-ELL values.
+int matrix_refresh_layout(ldu_matrix* m)
+{
+    ldu_addr* a = m->a;
+    hipStream_t s = a->ctx->stream;
+    const size_t nE = (size_t)(a->nEntries > 0 ? a->nEntries : 1);
+    if (k_permute_in(a, m->d_diag, m->d_diagO, s)) return -1;
+    if (k_fill_sell(a, m->d_lowerO, m->d_upperO, m->d_valA, s)) return -1;
+    if (!m->sym)
+    {
+        if (m->d_valT == m->d_valA) LDU_CHECK_HIP(hipMalloc((void**)&m->d_valT, sizeof(double) * nE));
+        if (k_fill_sell(a, m->d_upperO, m->d_lowerO, m->d_valT, s)) return -1;
+    }
+    else if (m->d_valT != m->d_valA)
+    {
+        (void)hipFree(m->d_valT);
+        m->d_valT = m->d_valA;
+    }
+    m->rDKind = -1;
+    m->rDiagValid = false;
+    m->coeffEpoch++;
+    m->haveCoeffs = true;
+    return 0;
+}
+
+extern "C" {
+
+int ldu_matrix_create(ldu_addr* a, ldu_matrix** m)
+{
+    if (!a->finalized) { ldu_set_error("ldu_addr_finalize() must follow ldu_addr_add_patch()"); return -13; }
+    LDU_CHECK_HIP(hipSetDevice(a->ctx->device));
+    return matrix_alloc(a, m);
+}
+
+int ldu_matrix_destroy(ldu_matrix* m)
+{
+    if (!m) return 0;
+    (void)hipStreamSynchronize(m->a->ctx->stream);
+    matrix_free(m);
+    return 0;
+}
+
+int ldu_matrix_set_coeffs(ldu_matrix* m, const double* diag, const double* upper, const double* lower)
+{
+    ldu_addr* a = m->a;
+    hipStream_t s = a->ctx->stream;
+    LDU_CHECK_HIP(hipSetDevice(a->ctx->device));
+    const bool sym = (lower == nullptr) || (lower == upper);
+    if (!sym && m->d_lowerO == m->d_upperO)
+        LDU_CHECK_HIP(hipMalloc((void**)&m->d_lowerO, sizeof(double) * ((size_t)a->nFaces + 1)));
+    if (sym && m->d_lowerO != m->d_upperO)
+    {
+        (void)hipFree(m->d_lowerO);
+        m->d_lowerO = m->d_upperO;
+    }
+    m->sym = sym;
+    LDU_CHECK_HIP(hipMemcpyAsync(m->d_diagO, diag, sizeof(double) * a->nCells, hipMemcpyDefault, s));
+    if (a->nFaces)
+    {
+        LDU_CHECK_HIP(hipMemcpyAsync(m->d_upperO, upper, sizeof(double) * a->nFaces, hipMemcpyDefault, s));
+        if (!sym) LDU_CHECK_HIP(hipMemcpyAsync(m->d_lowerO, lower, sizeof(double) * a->nFaces, hipMemcpyDefault, s));
+    }
+    return matrix_refresh_layout(m);
+}
+
+int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bou, const double* intc)
+{
+    ldu_addr* a = m->a;
+    if (patchI < 0 || patchI >= (int)a->patches.size()) { ldu_set_error("bad patch index"); return -14; }
+    const Patch& p = a->patches[patchI];
+    hipStream_t s = a->ctx->stream;
+    if (p.n)
+    {
+        LDU_CHECK_HIP(hipMemcpyAsync(m->d_bou + p.offset, bou, sizeof(double) * p.n, hipMemcpyDefault, s));
+        LDU_CHECK_HIP(hipMemcpyAsync(m->d_int + p.offset, intc, sizeof(double) * p.n, hipMemcpyDefault, s));
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- vector staging
+// User vectors are in the ORIGINAL cell order, host or device.  in(): -> device, level order.
+
+struct Stager {
+    ldu_matrix* m;
+    ldu_addr* a;
+    hipStream_t s;
+    int nextScratch = 0, nextWork = 20;
+    explicit Stager(ldu_matrix* mm) : m(mm), a(mm->a), s(mm->a->ctx->stream) {}
+
+    // returns device pointer in level order
+    double* in(const double* user)
+    {
+        const double* devOrig = user;
+        if (!is_device_ptr(user))
+        {
+            double* st = a->scratchVec(nextScratch++);
+            if (!st) return nullptr;
+            if (a->nCells && hipMemcpyAsync(st, user, sizeof(double) * a->nCells, hipMemcpyHostToDevice, s) != hipSuccess)
+                return nullptr;
+            devOrig = st;
+        }
+        double* w = m->workVec(nextWork++);
+        if (!w) return nullptr;
+        if (a->nCells && k_permute_in(a, w, devOrig, s)) return nullptr;
+        return w;
+    }
+    double* tmp() { return m->workVec(nextWork++); }
+    int out(double* user, const double* devNew)
+    {
+        if (!a->nCells) return 0;
+        if (is_device_ptr(user)) return k_permute_out(a, user, devNew, s);
+        double* st = a->scratchVec(nextScratch++);
+        if (!st) return -1;
+        if (k_permute_out(a, st, devNew, s)) return -1;
+        LDU_CHECK_HIP(hipMemcpyAsync(user, st, sizeof(double) * a->nCells, hipMemcpyDeviceToHost, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+};
+
+#define NEED_COEFFS(m)                                                                    \
+    do {                                                                                  \
+        if (!(m) || !(m)->haveCoeffs) { ldu_set_error("ldu_matrix_set_coeffs() not called"); return -15; } \
+        LDU_CHECK_HIP(hipSetDevice((m)->a->ctx->device));                                 \
+    } while (0)
+
+extern "C" {
+
+int ldu_amul(ldu_matrix* m, double* Apsi, const double* psi)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    double* x = S.in(psi);
+    double* y = S.tmp();
+    if (!x || !y) return -1;
+    if (dev_amul(m, y, x, false)) return -1;
+    return S.out(Apsi, y);
+}
+
+int ldu_tmul(ldu_matrix* m, double* Tpsi, const double* psi)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    double* x = S.in(psi);
+    double* y = S.tmp();
+    if (!x || !y) return -1;
+    if (dev_amul(m, y, x, true)) return -1;
+    return S.out(Tpsi, y);
+}
+
+int ldu_sumA(ldu_matrix* m, double* sumA)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    double* y = S.tmp();
+    if (!y) return -1;
+    if (dev_sumA(m, y)) return -1;
+    return S.out(sumA, y);
+}
+
+int ldu_residual(ldu_matrix* m, double* rA, const double* psi, const double* source)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    double* x = S.in(psi);
+    double* b = S.in(source);
+    double* y = S.tmp();
+    if (!x || !b || !y) return -1;
+    if (dev_residual(m, y, x, b)) return -1;
+    return S.out(rA, y);
+}
+
+int ldu_H(ldu_matrix* m, double* H, const double* psi)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    double* x = S.in(psi);
+    double* y = S.tmp();
+    if (!x || !y) return -1;
+    if (k_offdiag(m, y, x, 0, S.s)) return -1;
+    return S.out(H, y);
+}
+
+int ldu_H1(ldu_matrix* m, double* H1)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    double* y = S.tmp();
+    if (!y) return -1;
+    if (k_offdiag(m, y, nullptr, 1, S.s)) return -1;
+    return S.out(H1, y);
+}
+
+int ldu_faceH(ldu_matrix* m, double* faceH, const double* psi)
+{
+    NEED_COEFFS(m);
+    ldu_addr* a = m->a;
+    hipStream_t s = a->ctx->stream;
+    const double* x = psi;
+    if (!is_device_ptr(psi))
+    {
+        double* st = a->scratchVec(0);
+        LDU_CHECK_HIP(hipMemcpyAsync(st, psi, sizeof(double) * a->nCells, hipMemcpyHostToDevice, s));
+        x = st;
+    }
+    double* out = is_device_ptr(faceH) ? faceH : a->scratchVec(1);
+    if (k_faceH(m, out, x, s)) return -1;
+    if (out != faceH)
+    {
+        LDU_CHECK_HIP(hipMemcpyAsync(faceH, out, sizeof(double) * a->nFaces, hipMemcpyDeviceToHost, s));
+    }
+    LDU_CHECK_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ldu_gSumProd(ldu_matrix* m, const double* a_, const double* b_, double* result)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    ldu_ctx* ctx = m->a->ctx;
+    double* x = S.in(a_);
+    double* y = S.in(b_);
+    if (!x || !y) return -1;
+    if (k_reduce(ctx, m->a->nCells, RED_DOT, x, y, nullptr, nullptr, S_TMP0, S.s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_TMP0, 1, S.s)) return -1;
+    return dev_read_scalars(ctx, S_TMP0, 1, result);
+}
+
+int ldu_gSumMag(ldu_matrix* m, const double* a_, double* result)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    ldu_ctx* ctx = m->a->ctx;
+    double* x = S.in(a_);
+    if (!x) return -1;
+    if (k_reduce(ctx, m->a->nCells, RED_SUMMAG, x, nullptr, nullptr, nullptr, S_TMP0, S.s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_TMP0, 1, S.s)) return -1;
+    return dev_read_scalars(ctx, S_TMP0, 1, result);
+}
+
+int ldu_precondition(ldu_matrix* m, int32_t pre, double* wA, const double* rA, int32_t transpose)
+{
+    NEED_COEFFS(m);
+    if (!m->sym && (pre == LDU_PRE_DIC || pre == LDU_PRE_FDIC))
+    {
+        ldu_set_error("DIC/FDIC are symmetric-matrix preconditioners (lduMatrixPreconditioner.C:98-124)");
+        return -16;
+    }
+    if (pre == LDU_PRE_GAMG) { ldu_set_error("use ldu_solve with preconditioner GAMG"); return -16; }
+    Stager S(m);
+    double* r = S.in(rA);
+    double* w = S.tmp();
+    if (!r || !w) return -1;
+    if (dev_precondition(m, pre, w, r, transpose != 0, S.s)) return -1;
+    return S.out(wA, w);
+}
+
+int ldu_smooth(ldu_matrix* m, int32_t smoother, double* psi, const double* source, int32_t nSweeps)
+{
+    NEED_COEFFS(m);
+    Stager S(m);
+    double* x = S.in(psi);
+    double* b = S.in(source);
+    if (!x || !b) return -1;
+    if (dev_smooth(m, smoother, x, b, nSweeps)) return -1;
+    return S.out(psi, x);
+}
+
+int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
+              double* resHistory)
+{
+    NEED_COEFFS(m);
+    if (c->directSolveCoarsest)
+    {
+        ldu_set_error("directSolveCoarsest is not supported");
+        return -17;
+    }
+    memset(perf, 0, sizeof(*perf));
+    Stager S(m);
+    double* x = S.in(psi);
+    double* b = S.in(source);
+    if (!x || !b) return -1;
+    LDU_CHECK_HIP(hipStreamSynchronize(S.s));
+    const double t0 = now_s();
+    int rc = dev_solve(m, c, x, b, perf, resHistory);
+    LDU_CHECK_HIP(hipStreamSynchronize(S.s));
+    perf->solveSeconds = now_s() - t0;
+    if (rc) return rc;
+    return S.out(psi, x);
+}
+
+int ldu_gamg_levels(ldu_matrix* m, const ldu_controls* c, int32_t* nLevels, int32_t* nCells, int32_t* nFaces)
+{
+    NEED_COEFFS(m);
+    if (gamg_build_for_query(m, c)) return -1;
+    return gamg_query(m, nLevels, nCells, nFaces);
+}
+
+int ldu_gamg_level_data(ldu_matrix* m, int32_t level, int32_t* restrictAddr, double* diag, double* upper,
+                        double* lower)
+{
+    return gamg_level_data(m, level, restrictAddr, diag, upper, lower);
+}
+
+// ---------------------------------------------------------------- fv stencils
+// Fields are device or host arrays in the ORIGINAL numbering; results likewise.
+
+struct FvBuf {
+    ldu_addr* a;
+    hipStream_t s;
+    std::vector<void*> owned;
+    explicit FvBuf(ldu_addr* aa) : a(aa), s(aa->ctx->stream) {}
+    ~FvBuf() { for (void* p : owned) (void)hipFree(p); }
+    const double* in(const double* user, size_t n)
+    {
+        if (!user || is_device_ptr(user)) return user;
+        double* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(double) * (n ? n : 1)) != hipSuccess) return nullptr;
+        owned.push_back(d);
+        (void)hipMemcpyAsync(d, user, sizeof(double) * n, hipMemcpyHostToDevice, s);
+        return d;
+    }
+    double* outBuf(double* user, size_t n)
+    {
+        if (is_device_ptr(user)) return user;
+        double* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(double) * (n ? n : 1)) != hipSuccess) return nullptr;
+        owned.push_back(d);
+        return d;
+    }
+    int finish(double* user, double* dev, size_t n)
+    {
+        if (user != dev) LDU_CHECK_HIP(hipMemcpyAsync(user, dev, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+};
+
+int ldu_fv_interpolate(ldu_addr* a, int32_t nComp, const double* lambdas, const double* vf, double* sf)
+{
+    FvBuf B(a);
+    const double* lam = B.in(lambdas, a->nFaces);
+    const double* v = B.in(vf, (size_t)a->nCells * nComp);
+    double* o = B.outBuf(sf, (size_t)a->nFaces * nComp);
+    if (k_fv_interpolate(a, nComp, lam, v, o, B.s)) return -1;
+    return B.finish(sf, o, (size_t)a->nFaces * nComp);
+}
+
+int ldu_fvc_surfaceIntegrate(ldu_addr* a, int32_t nComp, const double* ssf, const double* V, double* ivf)
+{
+    FvBuf B(a);
+    const double* f = B.in(ssf, (size_t)a->nFaces * nComp);
+    const double* v = B.in(V, a->nCells);
+    double* o = B.outBuf(ivf, (size_t)a->nCells * nComp);
+    if (k_fv_surfaceIntegrate(a, nComp, f, nullptr, v, o, B.s)) return -1;
+    return B.finish(ivf, o, (size_t)a->nCells * nComp);
+}
+
+int ldu_fvc_gaussGrad(ldu_addr* a, const double* Sf, const double* ssf, const double* V, double* grad)
+{
+    FvBuf B(a);
+    const double* sfv = B.in(Sf, (size_t)a->nFaces * 3);
+    const double* f = B.in(ssf, a->nFaces);
+    const double* v = B.in(V, a->nCells);
+    double* o = B.outBuf(grad, (size_t)a->nCells * 3);
+    if (k_fv_surfaceIntegrate(a, 3, f, sfv, v, o, B.s)) return -1;
+    return B.finish(grad, o, (size_t)a->nCells * 3);
+}
+
+int ldu_fvc_snGrad(ldu_addr* a, const double* deltaCoeffs, const double* vf, double* ssf)
+{
+    FvBuf B(a);
+    const double* d = B.in(deltaCoeffs, a->nFaces);
+    const double* v = B.in(vf, a->nCells);
+    double* o = B.outBuf(ssf, a->nFaces);
+    if (k_fv_snGrad(a, d, v, o, B.s)) return -1;
+    return B.finish(ssf, o, a->nFaces);
+}
+
+int ldu_fvm_laplacian(ldu_addr* a, const double* deltaCoeffs, const double* gammaMagSf, double* diag,
+                      double* upper)
+{
+    FvBuf B(a);
+    const double* d = B.in(deltaCoeffs, a->nFaces);
+    const double* g = B.in(gammaMagSf, a->nFaces);
+    double* up = B.outBuf(upper, a->nFaces);
+    double* dg = B.outBuf(diag, a->nCells);
+    if (k_fv_laplacian_coeffs(a->nFaces, d, g, up, B.s)) return -1;
+    if (k_fv_negSumDiag(a, up, up, dg, B.s)) return -1;
+    if (B.finish(upper, up, a->nFaces)) return -1;
+    return B.finish(diag, dg, a->nCells);
+}
+
+int ldu_fvm_div(ldu_addr* a, const double* weights, const double* faceFlux, double* diag, double* upper,
+                double* lower)
+{
+    FvBuf B(a);
+    const double* w = B.in(weights, a->nFaces);
+    const double* phi = B.in(faceFlux, a->nFaces);
+    double* up = B.outBuf(upper, a->nFaces);
+    double* lo = B.outBuf(lower, a->nFaces);
+    double* dg = B.outBuf(diag, a->nCells);
+    if (k_fv_div_coeffs(a->nFaces, w, phi, lo, up, B.s)) return -1;
+    if (k_fv_negSumDiag(a, lo, up, dg, B.s)) return -1;
+    if (B.finish(upper, up, a->nFaces)) return -1;
+    if (B.finish(lower, lo, a->nFaces)) return -1;
+    return B.finish(diag, dg, a->nCells);
+}
+
+}  // extern "C"

@@ -1,0 +1,629 @@
+// GAMG: pair agglomeration (host, order-dependent greedy algorithm), level matrices
+// (device, rebuilt from the fine coefficients every solve like the reference), V-cycle.
+//
+// Reference: solvers/GAMG/GAMGSolver.C:44-127, GAMGSolverSolve.C:34-487, GAMGSolverScale.C,
+// GAMGSolverAgglomerateMatrix.C, GAMGAgglomerations/pairGAMGAgglomeration/pairGAMGAgglomerate.C,
+// GAMGAgglomeration/GAMGAgglomerateLduAddressing.C, GAMGPreconditioner.C.
+//
+// The agglomeration is sequential and order dependent in the reference (greedy matching in
+// cell order), so it stays a host algorithm run once per addressing ("cacheAgglomeration");
+// everything executed per solve or per cycle runs on the device.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ldu_internal.hpp"
+
+static const int kMaxLevels = 50;   // GAMGAgglomeration.C:75
+static const double kSmall = 1e-20;
+
+struct GamgLevel {
+    ldu_addr* addr = nullptr;
+    ldu_matrix* mat = nullptr;
+    int nFineCells = 0, nFineFaces = 0;
+    std::vector<int> restrictAddr;       // fine (orig) -> coarse (orig)
+    std::vector<int> faceRestrictAddr;   // fine face -> coarse face | -(coarse cell)-1
+    // device maps, NEW numbering (V-cycle transfers)
+    int* d_childStart = nullptr;
+    int* d_child = nullptr;
+    int* d_mapNew = nullptr;
+    // device maps, ORIGINAL numbering (coefficient agglomeration)
+    int* d_cfStart = nullptr;
+    int* d_cfFine = nullptr;
+    unsigned char* d_cfFlip = nullptr;
+    int* d_ccStart = nullptr;
+    int* d_ccFine = nullptr;
+    int* d_childStartO = nullptr;
+    int* d_childO = nullptr;
+    double* d_corr = nullptr;
+    double* d_src = nullptr;
+};
+
+struct GamgHierarchy {
+    std::vector<GamgLevel> levels;
+    int nCellsInCoarsestLevel = -1, mergeLevels = -1, agglomerator = -1;
+    uint64_t coeffEpoch = ~0ull;
+    double* d_Apsi = nullptr;
+    double* d_finestCorr = nullptr;
+    double* d_finestRes = nullptr;
+};
+
+template <class T>
+static int up(T** dst, const std::vector<T>& src)
+{
+    size_t n = src.size() ? src.size() : 1;
+    LDU_CHECK_HIP(hipMalloc((void**)dst, n * sizeof(T)));
+    if (src.size())
+        LDU_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void gamg_free(GamgHierarchy* g)
+{
+    if (!g) return;
+    for (auto& L : g->levels)
+    {
+        void* ptrs[] = {L.d_childStart, L.d_child, L.d_mapNew, L.d_cfStart, L.d_cfFine, L.d_cfFlip,
+                        L.d_ccStart, L.d_ccFine, L.d_childStartO, L.d_childO, L.d_corr, L.d_src};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (L.mat) matrix_free(L.mat);
+        if (L.addr) { plan_free(L.addr); delete L.addr; }
+    }
+    if (g->d_Apsi) (void)hipFree(g->d_Apsi);
+    if (g->d_finestCorr) (void)hipFree(g->d_finestCorr);
+    if (g->d_finestRes) (void)hipFree(g->d_finestRes);
+    delete g;
+}
+
+// ---------------------------------------------------------------- pair agglomeration (host)
+
+// One pairing pass (pairGAMGAgglomerate.C:31-198).  cellFaces order = faces where the cell is
+// the upper (neighbour) side first, then owned faces, both ascending (:70-88) - i.e. exactly the
+// losort / ownerStart row order.
+static void pair_level(int nCells, int nFaces, const int* lower, const int* upper,
+                       const std::vector<double>& weight, std::vector<int>& coarseMap, int& nCoarse)
+{
+    std::vector<int> nbrStart(nCells + 1, 0), ownStart(nCells + 1, 0), nbrFaces(nFaces);
+    for (int f = 0; f < nFaces; f++) { nbrStart[upper[f] + 1]++; ownStart[lower[f] + 1]++; }
+    for (int c = 0; c < nCells; c++) { nbrStart[c + 1] += nbrStart[c]; ownStart[c + 1] += ownStart[c]; }
+    {
+        std::vector<int> pos(nbrStart.begin(), nbrStart.end() - 1);
+        for (int f = 0; f < nFaces; f++) nbrFaces[pos[upper[f]]++] = f;
+    }
+    coarseMap.assign(nCells, -1);
+    nCoarse = 0;
+    const double negGreat = -1e20;
+    for (int c = 0; c < nCells; c++)
+    {
+        if (coarseMap[c] >= 0) continue;
+        int match = -1;
+        double best = negGreat;
+        auto tryFace = [&](int f) {
+            if (coarseMap[upper[f]] < 0 && coarseMap[lower[f]] < 0 && weight[f] > best)
+            {
+                match = f;
+                best = weight[f];
+            }
+        };
+        for (int t = nbrStart[c]; t < nbrStart[c + 1]; t++) tryFace(nbrFaces[t]);
+        for (int f = ownStart[c]; f < ownStart[c + 1]; f++) tryFace(f);
+        if (match >= 0)
+        {
+            coarseMap[upper[match]] = nCoarse;
+            coarseMap[lower[match]] = nCoarse;
+            nCoarse++;
+            continue;
+        }
+        // no free neighbour: join the neighbouring cluster across the heaviest face (:138-170)
+        int cm = -1;
+        double cbest = negGreat;
+        auto tryCluster = [&](int f) {
+            if (weight[f] > cbest) { cm = f; cbest = weight[f]; }
+        };
+        for (int t = nbrStart[c]; t < nbrStart[c + 1]; t++) tryCluster(nbrFaces[t]);
+        for (int f = ownStart[c]; f < ownStart[c + 1]; f++) tryCluster(f);
+        if (cm >= 0) coarseMap[c] = std::max(coarseMap[upper[cm]], coarseMap[lower[cm]]);
+    }
+    for (int c = 0; c < nCells; c++)
+        if (coarseMap[c] < 0) coarseMap[c] = nCoarse++;   // singletons (:177-184)
+    for (int c = 0; c < nCells; c++) coarseMap[c] = nCoarse - 1 - coarseMap[c];   // reversal (:186-195)
+}
+
+// Coarse addressing (GAMGAgglomerateLduAddressing.C:91-198): coarse faces de-duplicated per
+// (owner, neighbour) pair, numbered owner by owner in order of first discovery.
+static void coarse_addressing(int nFineFaces, const int* lower, const int* upper,
+                              const std::vector<int>& rmap, int nCoarse, std::vector<int>& faceRestrict,
+                              std::vector<int>& cLower, std::vector<int>& cUpper)
+{
+    faceRestrict.assign(nFineFaces, 0);
+    std::vector<int> cap(nCoarse + 1, 0);
+    for (int f = 0; f < nFineFaces; f++)
+    {
+        int a = rmap[upper[f]], b = rmap[lower[f]];
+        if (a != b) cap[std::min(a, b) + 1]++;
+    }
+    for (int c = 0; c < nCoarse; c++) cap[c + 1] += cap[c];
+    std::vector<int> nbrOf(cap[nCoarse]), idOf(cap[nCoarse]), cnt(nCoarse, 0);
+    int nTmp = 0;
+    for (int f = 0; f < nFineFaces; f++)
+    {
+        int a = rmap[upper[f]], b = rmap[lower[f]];
+        if (a == b) { faceRestrict[f] = -(a + 1); continue; }
+        int own = std::min(a, b), nei = std::max(a, b);
+        int base = cap[own], found = -1;
+        for (int i = 0; i < cnt[own]; i++)
+            if (nbrOf[base + i] == nei) { found = idOf[base + i]; break; }
+        if (found < 0)
+        {
+            nbrOf[base + cnt[own]] = nei;
+            idOf[base + cnt[own]] = nTmp;
+            cnt[own]++;
+            found = nTmp++;
+        }
+        faceRestrict[f] = found;
+    }
+    std::vector<int> renum(nTmp);
+    cLower.resize(nTmp);
+    cUpper.resize(nTmp);
+    int k = 0;
+    for (int c = 0; c < nCoarse; c++)
+        for (int i = 0; i < cnt[c]; i++)
+        {
+            cLower[k] = c;
+            cUpper[k] = nbrOf[cap[c] + i];
+            renum[idOf[cap[c] + i]] = k++;
+        }
+    for (int f = 0; f < nFineFaces; f++)
+        if (faceRestrict[f] >= 0) faceRestrict[f] = renum[faceRestrict[f]];
+}
+
+struct HostLevel {
+    int nCells = 0;
+    std::vector<int> restrictAddr, faceRestrictAddr, lower, upper;
+};
+
+// pairGAMGAgglomerate.C:201-292
+static void agglomerate_all(const ldu_addr* fine, const std::vector<double>& fineWeights,
+                            int nCellsInCoarsestLevel, int mergeLevels, std::vector<HostLevel>& out)
+{
+    out.clear();
+    std::vector<double> w = fineWeights;
+    int nPairLevels = 0;
+    while ((int)out.size() < kMaxLevels - 1)
+    {
+        const bool top = out.empty();
+        const int nC = top ? fine->nCells : out.back().nCells;
+        const std::vector<int>& lo = top ? fine->l : out.back().lower;
+        const std::vector<int>& up_ = top ? fine->u : out.back().upper;
+        const int nF = (int)lo.size();
+        HostLevel L;
+        pair_level(nC, nF, lo.data(), up_.data(), w, L.restrictAddr, L.nCells);
+        if (!(L.nCells >= nCellsInCoarsestLevel)) break;   // continueAgglomerating (GAMGAgglomeration.C:53-62)
+        coarse_addressing(nF, lo.data(), up_.data(), L.restrictAddr, L.nCells, L.faceRestrictAddr,
+                          L.lower, L.upper);
+        // restrictFaceField of the weights (GAMGAgglomerationTemplates.C:63-83)
+        std::vector<double> cw(L.lower.size(), 0.0);
+        for (int f = 0; f < nF; f++)
+            if (L.faceRestrictAddr[f] >= 0) cw[L.faceRestrictAddr[f]] += w[f];
+        w.swap(cw);
+        if (nPairLevels % mergeLevels)
+        {
+            // combineLevels (pairGAMGAgglomerationCombineLevels.C:32-95)
+            HostLevel& P = out.back();
+            for (size_t i = 0; i < P.faceRestrictAddr.size(); i++)
+            {
+                int v = P.faceRestrictAddr[i];
+                P.faceRestrictAddr[i] = v >= 0 ? L.faceRestrictAddr[v] : -L.restrictAddr[-v - 1] - 1;
+            }
+            for (size_t i = 0; i < P.restrictAddr.size(); i++) P.restrictAddr[i] = L.restrictAddr[P.restrictAddr[i]];
+            P.nCells = L.nCells;
+            P.lower.swap(L.lower);
+            P.upper.swap(L.upper);
+        }
+        else
+        {
+            out.push_back(std::move(L));
+        }
+        nPairLevels++;
+    }
+}
+
+// ---------------------------------------------------------------- hierarchy construction
+
+static int build_level_maps(GamgLevel& L, const ldu_addr* fineA)
+{
+    const ldu_addr* cA = L.addr;
+    const int nFC = L.nFineCells, nFF = L.nFineFaces, nCC = cA->nCells, nCF = cA->nFaces;
+    // children per coarse cell, ascending original fine index
+    std::vector<int> childStartO(nCC + 1, 0), childO(nFC);
+    for (int i = 0; i < nFC; i++) childStartO[L.restrictAddr[i] + 1]++;
+    for (int c = 0; c < nCC; c++) childStartO[c + 1] += childStartO[c];
+    {
+        std::vector<int> pos(childStartO.begin(), childStartO.end() - 1);
+        for (int i = 0; i < nFC; i++) childO[pos[L.restrictAddr[i]]++] = i;
+    }
+    // the same in NEW numbering of both levels (order of summation unchanged)
+    std::vector<int> childStart(nCC + 1, 0), child(nFC), mapNew(nFC);
+    for (int cn = 0; cn < nCC; cn++)
+    {
+        int co = cA->perm[cn];
+        childStart[cn + 1] = childStart[cn] + (childStartO[co + 1] - childStartO[co]);
+    }
+    for (int cn = 0; cn < nCC; cn++)
+    {
+        int co = cA->perm[cn];
+        int k = childStart[cn];
+        for (int t = childStartO[co]; t < childStartO[co + 1]; t++) child[k++] = fineA->iperm[childO[t]];
+    }
+    for (int fn = 0; fn < nFC; fn++) mapNew[fn] = cA->iperm[L.restrictAddr[fineA->perm[fn]]];
+
+    // coefficient agglomeration lists (ascending fine face): GAMGSolverAgglomerateMatrix.C:148-205
+    std::vector<int> cfStart(nCF + 1, 0), cfFine, ccStart(nCC + 1, 0), ccFine;
+    std::vector<unsigned char> cfFlip;
+    for (int f = 0; f < nFF; f++)
+    {
+        int v = L.faceRestrictAddr[f];
+        if (v >= 0) cfStart[v + 1]++;
+        else ccStart[-1 - v + 1]++;
+    }
+    for (int c = 0; c < nCF; c++) cfStart[c + 1] += cfStart[c];
+    for (int c = 0; c < nCC; c++) ccStart[c + 1] += ccStart[c];
+    cfFine.resize(cfStart[nCF]);
+    cfFlip.resize(cfStart[nCF] ? cfStart[nCF] : 1);
+    ccFine.resize(ccStart[nCC]);
+    {
+        std::vector<int> p1(cfStart.begin(), cfStart.end() - 1), p2(ccStart.begin(), ccStart.end() - 1);
+        for (int f = 0; f < nFF; f++)
+        {
+            int v = L.faceRestrictAddr[f];
+            if (v >= 0)
+            {
+                int k = p1[v]++;
+                cfFine[k] = f;
+                // orientation test against restrictAddr[l[f]] (:158-171)
+                int rl = L.restrictAddr[fineA->l[f]];
+                if (cA->l[v] == rl) cfFlip[k] = 0;
+                else if (cA->u[v] == rl) cfFlip[k] = 1;
+                else { ldu_set_error("GAMG: inconsistent addressing between fine and coarse grids"); return -5; }
+            }
+            else ccFine[p2[-1 - v]++] = f;
+        }
+    }
+    if (up(&L.d_childStart, childStart) || up(&L.d_child, child) || up(&L.d_mapNew, mapNew)
+        || up(&L.d_cfStart, cfStart) || up(&L.d_cfFine, cfFine) || up(&L.d_cfFlip, cfFlip)
+        || up(&L.d_ccStart, ccStart) || up(&L.d_ccFine, ccFine) || up(&L.d_childStartO, childStartO)
+        || up(&L.d_childO, childO))
+        return -1;
+    LDU_CHECK_HIP(hipMalloc((void**)&L.d_corr, sizeof(double) * (size_t)(nCC + 1)));
+    LDU_CHECK_HIP(hipMalloc((void**)&L.d_src, sizeof(double) * (size_t)(nCC + 1)));
+    return 0;
+}
+
+static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
+{
+    ldu_addr* a = m->a;
+    if (a->nPatchFaces)
+    {
+        ldu_set_error("GAMG with coupled (processor) patches is not implemented yet");
+        return -6;
+    }
+    GamgHierarchy* g = m->gamg;
+    const bool reuse = g && c->cacheAgglomeration && g->nCellsInCoarsestLevel == c->nCellsInCoarsestLevel
+                       && g->mergeLevels == c->mergeLevels && g->agglomerator == c->agglomerator
+                       && c->agglomerator == LDU_AGG_FACEAREAPAIR;
+    if (!reuse)
+    {
+        if (g) { gamg_free(g); m->gamg = nullptr; }
+        g = new GamgHierarchy();
+        g->nCellsInCoarsestLevel = c->nCellsInCoarsestLevel;
+        g->mergeLevels = c->mergeLevels;
+        g->agglomerator = c->agglomerator;
+        std::vector<double> w(a->nFaces);
+        if (c->agglomerator == LDU_AGG_ALGEBRAICPAIR)
+        {
+            // algebraicPairGAMGAgglomeration.C:55: mag(matrix.upper())
+            if (a->nFaces)
+                LDU_CHECK_HIP(hipMemcpy(w.data(), m->d_upperO, sizeof(double) * a->nFaces, hipMemcpyDeviceToHost));
+            for (auto& x : w) x = std::fabs(x);
+        }
+        else
+        {
+            if ((int)a->faceWeights.size() != a->nFaces)
+            {
+                ldu_set_error("faceAreaPair agglomeration needs ldu_addr_set_face_weights()");
+                delete g;
+                return -7;
+            }
+            w = a->faceWeights;
+        }
+        std::vector<HostLevel> hl;
+        agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl);
+        if (hl.empty())
+        {
+            // GAMGSolver.C:108-126
+            ldu_set_error("No coarse levels created, either matrix too small for GAMG or "
+                          "nCellsInCoarsestLevel too large.");
+            delete g;
+            return -8;
+        }
+        g->levels.resize(hl.size());
+        const ldu_addr* fineA = a;
+        for (size_t i = 0; i < hl.size(); i++)
+        {
+            GamgLevel& L = g->levels[i];
+            L.nFineCells = fineA->nCells;
+            L.nFineFaces = fineA->nFaces;
+            L.restrictAddr.swap(hl[i].restrictAddr);
+            L.faceRestrictAddr.swap(hl[i].faceRestrictAddr);
+            if (addr_create_internal(a->ctx, &L.addr, hl[i].nCells, (int)hl[i].lower.size(),
+                                     hl[i].lower.data(), hl[i].upper.data()))
+                return -1;
+            if (matrix_alloc(L.addr, &L.mat)) return -1;
+            if (build_level_maps(L, fineA)) return -1;
+            fineA = L.addr;
+        }
+        const size_t n = (size_t)a->nCells + 1;
+        LDU_CHECK_HIP(hipMalloc((void**)&g->d_Apsi, sizeof(double) * n));
+        LDU_CHECK_HIP(hipMalloc((void**)&g->d_finestCorr, sizeof(double) * n));
+        LDU_CHECK_HIP(hipMalloc((void**)&g->d_finestRes, sizeof(double) * n));
+        m->gamg = g;
+    }
+    // level coefficients: rebuilt from the fine matrix whenever the coefficients changed
+    // (GAMGSolver.C:86-89 runs agglomerateMatrix for every level in every solver construction)
+    if (g->coeffEpoch != m->coeffEpoch)
+    {
+        hipStream_t s = a->ctx->stream;
+        const ldu_matrix* fm = m;
+        for (auto& L : g->levels)
+        {
+            ldu_matrix* cm = L.mat;
+            cm->sym = m->sym;
+            if (!cm->sym && cm->d_lowerO == cm->d_upperO)
+            {
+                LDU_CHECK_HIP(hipMalloc((void**)&cm->d_lowerO, sizeof(double) * (size_t)(L.addr->nFaces + 1)));
+            }
+            if (k_agglomerate_coeffs(L.addr->nFaces, L.d_cfStart, L.d_cfFine, L.d_cfFlip, L.addr->nCells,
+                                     L.d_ccStart, L.d_ccFine, L.d_childStartO, L.d_childO, fm->d_diagO,
+                                     fm->d_upperO, fm->d_lowerO, cm->d_diagO, cm->d_upperO, cm->d_lowerO,
+                                     m->sym, s))
+                return -1;
+            if (matrix_refresh_layout(cm)) return -1;
+            fm = cm;
+        }
+        g->coeffEpoch = m->coeffEpoch;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- V-cycle
+
+// GAMGSolverScale.C:31-75
+static int gamg_scale(ldu_matrix* A, double* field, double* Acf, const double* source)
+{
+    ldu_ctx* ctx = A->a->ctx;
+    hipStream_t s = ctx->stream;
+    const int n = A->a->nCells;
+    if (dev_amul(A, Acf, field, false)) return -1;
+    // (source.field , Acf.field) fused, one 2-double all-reduce (:54-61)
+    if (k_reduce(ctx, n, RED_DOT2, source, field, Acf, nullptr, S_SCALE_NUM, s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_SCALE_NUM, 2, s)) return -1;
+    return k_gamg_scale_update(n, field, source, Acf, A->d_diag, ctx->S(), s);
+}
+
+// GAMGSolverInterpolate.C:30-83
+static int gamg_interpolate(ldu_matrix* A, double* psi, double* Apsi)
+{
+    hipStream_t s = A->a->ctx->stream;
+    if (k_offdiag(A, Apsi, psi, 2, s)) return -1;
+    return k_neg_div(A->a->nCells, psi, Apsi, A->d_diag, s);
+}
+
+// coarsest level: ICCG / BICCG with the outer tolerances (GAMGSolverSolve.C:430-487, ICCG.C:46)
+static int solve_coarsest(ldu_matrix* A, const ldu_controls* c, double* corr, const double* src)
+{
+    hipStream_t s = A->a->ctx->stream;
+    if (k_ew(A->a->nCells, EW_ZERO, corr, nullptr, nullptr, s)) return -1;
+    ldu_controls cc;
+    ldu_default_controls(&cc);
+    cc.tolerance = c->tolerance;
+    cc.relTol = c->relTol;
+    cc.historyCapacity = 0;
+    if (A->sym) { cc.solver = LDU_SOLVER_PCG; cc.preconditioner = LDU_PRE_DIC; }
+    else { cc.solver = LDU_SOLVER_PBICG; cc.preconditioner = LDU_PRE_DILU; }
+    ldu_perf p;
+    memset(&p, 0, sizeof(p));
+    ldu_ctx* ctx = A->a->ctx;
+    if (ctx->sb + 2 * S_BANK > S_NSLOTS) { ldu_set_error("scalar bank overflow"); return -1; }
+    ctx->sb += S_BANK;   // nested solve: own scalar bank
+    int rc = dev_solve(A, &cc, corr, src, &p, nullptr);
+    ctx->sb -= S_BANK;
+    return rc;
+}
+
+// GAMGSolverSolve.C:120-364
+static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, double* Apsi,
+                  double* finestCorrection, double* finestResidual)
+{
+    GamgHierarchy* g = m->gamg;
+    ldu_ctx* ctx = m->a->ctx;
+    hipStream_t s = ctx->stream;
+    const int coarsestLevel = (int)g->levels.size() - 1;
+    const int scaleCorrection = c->scaleCorrection < 0 ? (m->sym ? 1 : 0) : c->scaleCorrection;
+    auto& Lv = g->levels;
+
+    if (k_restrict(Lv[0].addr->nCells, Lv[0].d_childStart, Lv[0].d_child, finestResidual, Lv[0].d_src, s))
+        return -1;
+
+    for (int leveli = 0; leveli < coarsestLevel; leveli++)
+    {
+        GamgLevel& L = Lv[leveli];
+        const int n = L.addr->nCells;
+        if (c->nPreSweeps)
+        {
+            if (k_ew(n, EW_ZERO, L.d_corr, nullptr, nullptr, s)) return -1;
+            if (dev_smooth(L.mat, c->smoother, L.d_corr, L.d_src,
+                           std::min(c->nPreSweeps + c->preSweepsLevelMultiplier * leveli, c->maxPreSweeps)))
+                return -1;
+            double* ACf = Apsi;
+            if (scaleCorrection && leveli < coarsestLevel - 1)
+                if (gamg_scale(L.mat, L.d_corr, ACf, L.d_src)) return -1;
+            if (dev_amul(L.mat, ACf, L.d_corr, false)) return -1;
+            if (k_ew(n, EW_SUB_INPLACE, L.d_src, ACf, nullptr, s)) return -1;
+        }
+        GamgLevel& C = Lv[leveli + 1];
+        if (k_restrict(C.addr->nCells, C.d_childStart, C.d_child, L.d_src, C.d_src, s)) return -1;
+    }
+
+    if (solve_coarsest(Lv[coarsestLevel].mat, c, Lv[coarsestLevel].d_corr, Lv[coarsestLevel].d_src)) return -1;
+
+    for (int leveli = coarsestLevel - 1; leveli >= 0; leveli--)
+    {
+        GamgLevel& L = Lv[leveli];
+        GamgLevel& C = Lv[leveli + 1];
+        const int n = L.addr->nCells;
+        double* preSmoothed = finestCorrection;
+        if (c->nPreSweeps)
+            if (k_ew(n, EW_COPY, preSmoothed, L.d_corr, nullptr, s)) return -1;
+        if (k_prolong(n, C.d_mapNew, C.d_corr, L.d_corr, s)) return -1;
+        double* ACf = Apsi;
+        if (c->interpolateCorrection)
+            if (gamg_interpolate(L.mat, L.d_corr, ACf)) return -1;
+        if (scaleCorrection && leveli < coarsestLevel - 1)
+            if (gamg_scale(L.mat, L.d_corr, ACf, L.d_src)) return -1;
+        if (c->nPreSweeps)
+            if (k_ew(n, EW_ADD_INPLACE, L.d_corr, preSmoothed, nullptr, s)) return -1;
+        if (dev_smooth(L.mat, c->smoother, L.d_corr, L.d_src,
+                       std::min(c->nPostSweeps + c->postSweepsLevelMultiplier * leveli, c->maxPostSweeps)))
+            return -1;
+    }
+
+    const int n0 = m->a->nCells;
+    if (k_prolong(n0, Lv[0].d_mapNew, Lv[0].d_corr, finestCorrection, s)) return -1;
+    if (c->interpolateCorrection)
+        if (gamg_interpolate(m, finestCorrection, Apsi)) return -1;
+    if (scaleCorrection)
+        if (gamg_scale(m, finestCorrection, Apsi, finestResidual)) return -1;
+    if (k_ew(n0, EW_ADD_INPLACE, psi, finestCorrection, nullptr, s)) return -1;
+    return dev_smooth(m, c->smoother, psi, source, c->nFinestSweeps);
+}
+
+static bool check_convergence(ldu_perf* p, double tol, double relTol)
+{
+    p->converged = (p->finalResidual < tol
+                    || (relTol > kSmall && p->finalResidual < relTol * p->initialResidual)) ? 1 : 0;
+    return p->converged != 0;
+}
+
+// GAMGSolverSolve.C:34-117
+int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
+               double* hist)
+{
+    if (ensure_hierarchy(m, c)) return -1;
+    GamgHierarchy* g = m->gamg;
+    ldu_ctx* ctx = m->a->ctx;
+    hipStream_t s = ctx->stream;
+    const int n = m->a->nCells;
+    double* Apsi = g->d_Apsi;
+    double* finestCorrection = g->d_finestCorr;
+    double* finestResidual = g->d_finestRes;
+
+    if (dev_amul(m, Apsi, psi, false)) return -1;
+    // normFactor uses finestCorrection as its temporary (:46-50)
+    {
+        if (dev_sumA(m, finestCorrection)) return -1;
+        if (k_reduce(ctx, n, RED_SUM, psi, nullptr, nullptr, nullptr, S_SUMPSI, s)) return -1;
+        const double cnt = (double)n;
+        LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_COUNT, &cnt, sizeof(double), hipMemcpyHostToDevice, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+        if (comm_allreduce_scalars(ctx, S_SUMPSI, 1, s)) return -1;
+        if (comm_allreduce_scalars(ctx, S_COUNT, 1, s)) return -1;
+        if (k_reduce(ctx, n, RED_NORMFACTOR, Apsi, source, finestCorrection, nullptr, S_NORM, s)) return -1;
+        if (comm_allreduce_scalars(ctx, S_NORM, 1, s)) return -1;
+    }
+    if (k_ew(n, EW_SUB, finestResidual, source, Apsi, s)) return -1;
+    if (k_reduce(ctx, n, RED_SUMMAG, finestResidual, nullptr, nullptr, nullptr, S_RES, s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_RES, 1, s)) return -1;
+    double v[2];
+    if (dev_read_scalars(ctx, S_RES, 2, v)) return -1;
+    const double normFactor = v[1] + kSmall;
+    perf->normFactor = normFactor;
+    perf->initialResidual = v[0] / normFactor;
+    perf->finalResidual = perf->initialResidual;
+    if (hist && perf->nHistory < c->historyCapacity) hist[perf->nHistory] = perf->finalResidual;
+    perf->nHistory++;
+
+    if (!check_convergence(perf, c->tolerance, c->relTol))
+    {
+        do
+        {
+            if (vcycle(m, c, psi, source, Apsi, finestCorrection, finestResidual)) return -1;
+            if (dev_amul(m, Apsi, psi, false)) return -1;
+            // finestResidual = source; finestResidual -= Apsi (:96-98)
+            if (k_ew(n, EW_SUB, finestResidual, source, Apsi, s)) return -1;
+            if (k_reduce(ctx, n, RED_SUMMAG, finestResidual, nullptr, nullptr, nullptr, S_RES, s)) return -1;
+            if (comm_allreduce_scalars(ctx, S_RES, 1, s)) return -1;
+            double r;
+            if (dev_read_scalars(ctx, S_RES, 1, &r)) return -1;
+            perf->finalResidual = r / normFactor;
+            if (hist && perf->nHistory < c->historyCapacity) hist[perf->nHistory] = perf->finalResidual;
+            perf->nHistory++;
+        } while (++perf->nIterations < c->maxIter && !check_convergence(perf, c->tolerance, c->relTol));
+    }
+    return 0;
+}
+
+// GAMGPreconditioner.C:44-128
+int gamg_precondition_setup(ldu_matrix* m, const ldu_controls* c) { return ensure_hierarchy(m, c); }
+
+int gamg_precondition(ldu_matrix* m, const ldu_controls* c, double* wA, const double* rA)
+{
+    GamgHierarchy* g = m->gamg;
+    hipStream_t s = m->a->ctx->stream;
+    const int n = m->a->nCells;
+    double* AwA = g->d_Apsi;
+    if (k_ew(n, EW_ZERO, wA, nullptr, nullptr, s)) return -1;
+    if (k_ew(n, EW_COPY, g->d_finestRes, rA, nullptr, s)) return -1;
+    for (int cycle = 0; cycle < c->nVcycles; cycle++)
+    {
+        if (vcycle(m, c, wA, rA, AwA, g->d_finestCorr, g->d_finestRes)) return -1;
+        if (cycle < c->nVcycles - 1)
+        {
+            if (dev_amul(m, AwA, wA, false)) return -1;
+            if (k_ew(n, EW_SUB, g->d_finestRes, rA, AwA, s)) return -1;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- introspection (tests)
+
+int gamg_build_for_query(ldu_matrix* m, const ldu_controls* c) { return ensure_hierarchy(m, c); }
+
+int gamg_query(ldu_matrix* m, int32_t* nLevels, int32_t* nCells, int32_t* nFaces)
+{
+    GamgHierarchy* g = m->gamg;
+    if (!g) { ldu_set_error("no GAMG hierarchy"); return -9; }
+    *nLevels = (int)g->levels.size();
+    for (size_t i = 0; i < g->levels.size(); i++)
+    {
+        nCells[i] = g->levels[i].addr->nCells;
+        nFaces[i] = g->levels[i].addr->nFaces;
+    }
+    return 0;
+}
+
+int gamg_level_data(ldu_matrix* m, int level, int32_t* restrictAddr, double* diag, double* upper,
+                    double* lower)
+{
+    GamgHierarchy* g = m->gamg;
+    if (!g || level < 0 || level >= (int)g->levels.size()) { ldu_set_error("bad GAMG level"); return -9; }
+    GamgLevel& L = g->levels[level];
+    LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+    if (restrictAddr) memcpy(restrictAddr, L.restrictAddr.data(), sizeof(int) * L.restrictAddr.size());
+    if (diag) LDU_CHECK_HIP(hipMemcpy(diag, L.mat->d_diagO, sizeof(double) * L.addr->nCells, hipMemcpyDeviceToHost));
+    if (upper && L.addr->nFaces)
+        LDU_CHECK_HIP(hipMemcpy(upper, L.mat->d_upperO, sizeof(double) * L.addr->nFaces, hipMemcpyDeviceToHost));
+    if (lower && L.addr->nFaces)
+        LDU_CHECK_HIP(hipMemcpy(lower, L.mat->d_lowerO, sizeof(double) * L.addr->nFaces, hipMemcpyDeviceToHost));
+    return 0;
+}

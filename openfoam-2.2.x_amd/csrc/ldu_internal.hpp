@@ -1,0 +1,288 @@
+// Internal structures of libldugpu (not part of the C ABI).
+//
+// Data layout in HBM:
+//   * cells are renumbered into DEPENDENCY-LEVEL order of the lower-triangular DAG
+//     (level(c) = 1 + max level of lower neighbours); rows of one level are contiguous,
+//     so every triangular sweep (DIC/DILU/GaussSeidel) is a sequence of fully parallel,
+//     fully coalesced level kernels that reproduce the reference's sequential result
+//     bit-for-bit (per-row accumulation order = the reference's face order);
+//   * rows are cut into slices of <= 64 rows (one wavefront) that never straddle a level;
+//     a slice stores its off-diagonal entries column-major (entry k of lane i at
+//     ent + k*64 + i) = sliced ELL, so each wave-instruction reads 64 consecutive values;
+//   * per entry: int32 column (new numbering) + f64 coefficient; entries of a row are in the
+//     reference's accumulation order: lower-neighbour faces ascending, then owned faces
+//     ascending (lduMatrixATmul.C:75-79).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ldugpu.h"
+
+#define LDU_WAVE 64
+
+void ldu_set_error(const std::string& msg);
+#define LDU_CHECK_HIP(expr)                                                        \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            ldu_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+            return -1;                                                             \
+        }                                                                          \
+    } while (0)
+
+struct ldu_comm_impl;  // RCCL wrapper (ldu_comm.cpp)
+
+// scalar slots on the device
+enum {
+    S_WARA0 = 0, S_WARA1 = 1, S_WAPA = 2, S_RES = 3, S_NORM = 4, S_SINGULAR = 5, S_SUMPSI = 6,
+    S_TMP0 = 7, S_TMP1 = 8, S_SCALE_NUM = 9, S_SCALE_DEN = 10, S_COUNT = 11, S_BANK = 16, S_NSLOTS = 128
+};
+
+struct ldu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second stream (PBiCG transpose system, halo overlap)
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    double* d_partials = nullptr;    // reduction scratch [2 * maxBlocks]
+    int maxRedBlocks = 1024;
+    double* d_scalars = nullptr;     // [S_NSLOTS] = banks of S_BANK slots
+    double* h_scalars = nullptr;     // pinned mirror
+    int sb = 0;                      // current bank offset (nested solves push a new bank)
+    double* S() const { return d_scalars + sb; }
+    bool useGraphs = true;
+    int fuseRows = 4096;             // levels up to this many rows are fused into one-block chains
+    // communicator
+    int rank = 0, nRanks = 1;
+    ldu_comm_impl* comm = nullptr;
+};
+
+struct Segment {
+    int levelBegin, levelEnd;   // [begin, end) levels
+    int sliceBegin, sliceEnd;   // [begin, end) slices
+    bool fused;                 // one block walks the levels with __syncthreads()
+};
+
+struct Patch {
+    int n = 0;
+    int nbrRank = -1;
+    std::vector<int> faceCells;   // original numbering
+    int* d_faceCells = nullptr;   // new numbering
+    double* d_send = nullptr;
+    double* d_recv = nullptr;
+    int offset = 0;               // offset of this patch in the concatenated patch-face arrays
+};
+
+struct ldu_addr {
+    ldu_ctx* ctx = nullptr;
+    int nCells = 0, nFaces = 0;
+    // host addressing (original numbering)
+    std::vector<int> l, u, losort, ownerStart, losortStart;
+    std::vector<int> perm, iperm;          // perm[new] = old ; iperm[old] = new
+    std::vector<int> level;                // per old cell
+    int nLevels = 0;
+    std::vector<int> levelStart;           // rows (new numbering), size nLevels+1
+    std::vector<int> levelSliceStart;      // size nLevels+1
+    int nSlices = 0;
+    long nEntries = 0;                     // padded entry count
+    std::vector<Segment> segs;
+    std::vector<double> faceWeights;
+    bool finalized = false;
+
+    // device
+    int* d_perm = nullptr;
+    int* d_iperm = nullptr;
+    int* d_sliceRow = nullptr;             // [nSlices+1] first row of slice (rows of slice s = [r[s], r[s]+cnt))
+    int* d_sliceCnt = nullptr;             // [nSlices] rows in slice (<= 64)
+    int* d_sliceEnt = nullptr;             // [nSlices] first entry
+    int* d_sliceW = nullptr;               // [nSlices] width (max nL+nU)
+    int* d_levelSliceStart = nullptr;      // [nLevels+1]
+    unsigned char* d_nL = nullptr;         // [nCells] lower-part entries per row (new numbering)
+    unsigned char* d_nU = nullptr;         // [nCells]
+    int* d_col = nullptr;                  // [nEntries]
+    int* d_face = nullptr;                 // [nEntries] original face index (-1 padding)
+    int* d_l = nullptr;                    // [nFaces] original lowerAddr
+    int* d_u = nullptr;                    // [nFaces]
+    int* d_losort = nullptr;               // [nFaces]
+    int* d_ownerStart = nullptr;           // [nCells+1]
+    int* d_losortStart = nullptr;          // [nCells+1]
+
+    // coupled patches
+    std::vector<Patch> patches;
+    int nPatchFaces = 0;
+    // boundary rows: for every cell touched by a coupled patch, its (patch-face) list in
+    // the reference's update order (patch ascending, face ascending)
+    int nBRows = 0;
+    int* d_bRow = nullptr;                 // [nBRows] row (new numbering)
+    int* d_bStart = nullptr;               // [nBRows+1]
+    int* d_bFace = nullptr;                // [nPatchFaces] index into concatenated patch-face arrays
+    int* d_pfCell = nullptr;               // [nPatchFaces] faceCells (new numbering), concatenated
+    double* d_sendAll = nullptr;           // [nPatchFaces]
+    double* d_recvAll = nullptr;           // [nPatchFaces]
+
+    // cached graphs of level-scheduled sweeps, keyed by (mode, pointer arguments)
+    std::map<std::string, hipGraphExec_t> graphs;
+
+    // scratch vectors (new numbering), reused by the C-ABI vector entry points
+    std::vector<double*> scratch;
+    double* scratchVec(int i);
+};
+
+struct GamgHierarchy;  // ldu_gamg.cpp
+
+struct ldu_matrix {
+    ldu_addr* a = nullptr;
+    bool sym = true;
+    bool haveCoeffs = false;
+    // LDU-space coefficients, original order (device)
+    double* d_diagO = nullptr;
+    double* d_upperO = nullptr;
+    double* d_lowerO = nullptr;     // == d_upperO when symmetric
+    bool ownsLdu = true;            // coarse GAMG levels own theirs as well
+    // compute layout
+    double* d_diag = nullptr;       // [nCells] new numbering
+    double* d_valA = nullptr;       // [nEntries] lower part = lower[f], upper part = upper[f]
+    double* d_valT = nullptr;       // transpose coefficients (== d_valA when symmetric)
+    // coupled patch coefficients, concatenated in patch order
+    double* d_bou = nullptr;        // [nPatchFaces]
+    double* d_int = nullptr;
+    // preconditioner / smoother factor cache (valid for the current coefficients)
+    int rDKind = -1;                // LDU_PRE_DIC / LDU_PRE_DILU
+    double* d_rD = nullptr;
+    double* d_valP = nullptr;       // rD[row]*valA
+    double* d_valPT = nullptr;      // rD[row]*valT
+    double* d_rDiag = nullptr;      // 1/diag (diagonal preconditioner)
+    bool rDiagValid = false;
+    // GAMG hierarchy (addressing part cached when cacheAgglomeration)
+    GamgHierarchy* gamg = nullptr;
+    // work vectors
+    std::vector<double*> work;
+    double* workVec(int i);
+    uint64_t coeffEpoch = 0;
+};
+
+// ---------------------------------------------------------------- kernels (ldu_kernels.hip)
+enum SweepMode {
+    SW_TRI_FWD = 0,   // w = rD*rhs - sum_lower valP*w[col]            (DIC/DILU forward)
+    SW_TRI_BWD = 1,   // w -= sum_upper(desc) valP*w[col]              (DIC/DILU backward)
+    SW_RD = 2,        // rD = diag - sum_lower (valT*valA)/rD[col]     (calcReciprocalD, unreciprocated)
+    SW_GS_FWD = 3,    // GaussSeidel forward (optionally stores bPrime)
+    SW_GS_BWD = 4     // symGaussSeidel reverse sweep from the stored bPrime
+};
+
+struct SweepArgs {
+    int mode;
+    double* w;            // output / in-place vector (w, rD or psi)
+    const double* rhs;    // rhs (TRI_FWD), source/bPrime (GS_FWD), stored bPrime (GS_BWD)
+    const double* scale;  // rD (TRI_FWD) or diag (RD, GS_*)
+    const double* val;    // valP / valA
+    const double* val2;   // valT for SW_RD
+    double* aux;          // bPrime store (GS_FWD when non-null)
+};
+
+int k_sweep(ldu_addr* a, const SweepArgs& args);
+
+int k_fill_sell(ldu_addr* a, const double* lowerO, const double* upperO, double* val, hipStream_t s);
+int k_permute_in(ldu_addr* a, double* dstNew, const double* srcOld, hipStream_t s);   // dst[new] = src[perm[new]]
+int k_permute_out(ldu_addr* a, double* dstOld, const double* srcNew, hipStream_t s);  // dst[perm[new]] = src[new]
+int k_scale_rows(ldu_addr* a, double* valOut, const double* valIn, const double* rowScale, hipStream_t s);
+int k_reciprocal(int n, double* x, hipStream_t s);
+int k_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStream_t s);
+int k_residual_rows(ldu_matrix* m, double* r, const double* x, const double* b, hipStream_t s);
+int k_sumA_rows(ldu_matrix* m, double* sumA, hipStream_t s);
+int k_offdiag(ldu_matrix* m, double* y, const double* x, int mode, hipStream_t s);  // H (0), H1 (1), interpolate (2)
+int k_faceH(ldu_matrix* m, double* faceH, const double* xOld, hipStream_t s);
+
+// interfaces: pack psi[faceCells] -> send buffers; apply result[row] -= sign*coeff*recv
+int k_pack_patches(ldu_addr* a, const double* x, hipStream_t s);
+int k_apply_patches(ldu_addr* a, double* result, const double* coeffs, double sign, hipStream_t s);
+int k_sumA_patches(ldu_addr* a, double* sumA, const double* bou, hipStream_t s);
+
+// elementwise
+enum EwOp {
+    EW_COPY = 0,        // y = a
+    EW_SUB = 1,         // y = a - b
+    EW_ADD_INPLACE = 2, // y += a
+    EW_MUL_INPLACE = 3, // y *= a
+    EW_ZERO = 4,        // y = 0
+    EW_DIV = 5,         // y = a / b
+    EW_MUL = 6,         // y = a * b
+    EW_SUB_INPLACE = 7  // y -= a
+};
+int k_ew(int n, int op, double* y, const double* a, const double* b, hipStream_t s);
+int k_pcg_update_p(int n, double* pA, const double* wA, const double* scalars, int cur, int prev,
+                   int first, hipStream_t s);
+int k_pbicg_update_p(int n, double* pA, const double* wA, double* pT, const double* wT,
+                     const double* scalars, int cur, int prev, int first, hipStream_t s);
+// psi += alpha pA ; rA -= alpha wA ; (rT -= alpha wT) ; partial sum |rA| ; singular test on device
+int k_pcg_update_xr(ldu_ctx* ctx, int n, double* psi, double* rA, const double* pA, const double* wA,
+                    double* rT, const double* wT, int cur, hipStream_t s);
+int k_gamg_scale_update(int n, double* field, const double* source, const double* Acf,
+                        const double* diag, const double* scalars, hipStream_t s);
+int k_neg_div(int n, double* psi, const double* Apsi, const double* diag, hipStream_t s);
+
+// reductions -> ctx->d_scalars[slot] (deterministic two-stage tree)
+enum RedOp { RED_DOT = 0, RED_SUMMAG = 1, RED_SUM = 2, RED_NORMFACTOR = 3, RED_DOT2 = 4 };
+int k_reduce(ldu_ctx* ctx, int n, int op, const double* a, const double* b, const double* c,
+             const double* d, int slot, hipStream_t s);
+
+// GAMG transfer
+int k_restrict(int nCoarse, const int* childStart, const int* child, const double* fine,
+               double* coarse, hipStream_t s);
+int k_prolong(int nFine, const int* map, const double* coarse, double* fine, hipStream_t s);
+int k_agglomerate_coeffs(int nCoarseFaces, const int* cfStart, const int* cfFine, const unsigned char* cfFlip,
+                         int nCoarseCells, const int* ccStart, const int* ccFine,
+                         const int* childStartO, const int* childO,
+                         const double* fineDiag, const double* fineUpper, const double* fineLower,
+                         double* coarseDiag, double* coarseUpper, double* coarseLower, bool sym,
+                         hipStream_t s);
+
+// fv stencils (face loops) on the original numbering
+int k_fv_interpolate(ldu_addr* a, int nComp, const double* lambdas, const double* vf, double* sf, hipStream_t s);
+int k_fv_surfaceIntegrate(ldu_addr* a, int nComp, const double* ssf, const double* sfVec, const double* V,
+                          double* out, hipStream_t s);
+int k_fv_snGrad(ldu_addr* a, const double* delta, const double* vf, double* ssf, hipStream_t s);
+int k_fv_negSumDiag(ldu_addr* a, const double* lower, const double* upper, double* diag, hipStream_t s);
+int k_fv_laplacian_coeffs(int nFaces, const double* delta, const double* gammaMagSf, double* upper, hipStream_t s);
+int k_fv_div_coeffs(int nFaces, const double* w, const double* phi, double* lower, double* upper, hipStream_t s);
+
+// ---------------------------------------------------------------- host pieces
+int plan_build(ldu_addr* a);                              // ldu_plan.cpp
+int plan_finalize_patches(ldu_addr* a);
+void plan_free(ldu_addr* a);
+
+int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s);   // ldu_comm.cpp
+int comm_exchange(ldu_addr* a, hipStream_t s);                                   // halo send/recv
+void comm_destroy(ldu_ctx* ctx);
+
+// solvers (ldu_solvers.cpp): all vectors device, new numbering
+int matrix_ensure_rD(ldu_matrix* m, int kind);
+int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose);
+int dev_residual(ldu_matrix* m, double* r, const double* x, const double* b);
+int dev_sumA(ldu_matrix* m, double* sumA);
+int dev_precondition(ldu_matrix* m, int kind, double* w, const double* r, bool transpose, hipStream_t s);
+int dev_smooth(ldu_matrix* m, int smoother, double* psi, const double* source, int nSweeps);
+int dev_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
+              double* hist);
+int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out);
+
+// GAMG (ldu_gamg.cpp)
+int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
+               double* hist);
+int gamg_precondition_setup(ldu_matrix* m, const ldu_controls* c);
+int gamg_precondition(ldu_matrix* m, const ldu_controls* c, double* wA, const double* rA);
+void gamg_free(GamgHierarchy* g);
+int gamg_build_for_query(ldu_matrix* m, const ldu_controls* c);
+int gamg_query(ldu_matrix* m, int32_t* nLevels, int32_t* nCells, int32_t* nFaces);
+int gamg_level_data(ldu_matrix* m, int level, int32_t* restrictAddr, double* diag, double* upper,
+                    double* lower);
+
+// matrix helpers (ldu_capi.cpp)
+int matrix_alloc(ldu_addr* a, ldu_matrix** out);
+int matrix_refresh_layout(ldu_matrix* m);   // LDU-space device coefficients -> compute layout
+void matrix_free(ldu_matrix* m);
+int addr_create_internal(ldu_ctx* ctx, ldu_addr** out, int nCells, int nFaces, const int* l, const int* u);

@@ -1,0 +1,991 @@
+// HIP kernels of the lduMatrix hot path for gfx950 (CDNA4, wave64).
+//
+// Everything here is HBM-bandwidth- or dependency-latency-bound f64 work with int32
+// indirection: no MFMA.  Rules followed (cdna_hip_programming.md section 6):
+//   * one wavefront (64 lanes) owns one slice of <= 64 consecutive rows; entry k of the
+//     slice is read as 64 consecutive int32 / f64 values (fully coalesced sliced-ELL);
+//   * reductions: per-lane accumulation -> wave shuffle tree -> LDS across the 4 waves of a
+//     block -> one partial per block -> single-block final pass (deterministic, no atomics);
+//   * compiled with -ffp-contract=off: a*b+c is never contracted, so every row reproduces
+//     the reference's rounding exactly (SURVEY.md Appendix B last bullet).
+#include "ldu_internal.hpp"
+
+#define BLK 256
+#define WPB (BLK / LDU_WAVE)   // waves per block
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- layout kernels
+
+__global__ void fill_sell_kernel(int nSlices, const int* __restrict__ sliceRow,
+                                 const int* __restrict__ sliceCnt, const int* __restrict__ sliceEnt,
+                                 const int* __restrict__ sliceW, const unsigned char* __restrict__ nL,
+                                 const int* __restrict__ face, const double* __restrict__ lowerO,
+                                 const double* __restrict__ upperO, double* __restrict__ val)
+{
+    const int s = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (s >= nSlices) return;
+    const int lane = threadIdx.x & 63;
+    const int cnt = sliceCnt[s];
+    const int r = sliceRow[s] + lane;
+    const int nl = lane < cnt ? nL[r] : 0;
+    const long ent = (long)sliceEnt[s] + lane;
+    const int W = sliceW[s];
+    for (int k = 0; k < W; k++)
+    {
+        const long e = ent + (long)k * LDU_WAVE;
+        const int f = face[e];
+        double v = 0.0;
+        if (f >= 0) v = (k < nl) ? lowerO[f] : upperO[f];
+        val[e] = v;
+    }
+}
+
+int k_fill_sell(ldu_addr* a, const double* lowerO, const double* upperO, double* val, hipStream_t s)
+{
+    if (a->nSlices == 0) return 0;
+    fill_sell_kernel<<<cdiv(a->nSlices, WPB), BLK, 0, s>>>(a->nSlices, a->d_sliceRow, a->d_sliceCnt,
+        a->d_sliceEnt, a->d_sliceW, a->d_nL, a->d_face, lowerO, upperO, val);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void scale_rows_kernel(int nSlices, const int* __restrict__ sliceRow,
+                                  const int* __restrict__ sliceCnt, const int* __restrict__ sliceEnt,
+                                  const int* __restrict__ sliceW, const double* __restrict__ valIn,
+                                  const double* __restrict__ rowScale, double* __restrict__ valOut)
+{
+    const int s = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (s >= nSlices) return;
+    const int lane = threadIdx.x & 63;
+    const int cnt = sliceCnt[s];
+    const int r = sliceRow[s] + lane;
+    const double sc = lane < cnt ? rowScale[r] : 0.0;
+    const long ent = (long)sliceEnt[s] + lane;
+    const int W = sliceW[s];
+    for (int k = 0; k < W; k++)
+    {
+        const long e = ent + (long)k * LDU_WAVE;
+        valOut[e] = sc * valIn[e];
+    }
+}
+
+int k_scale_rows(ldu_addr* a, double* valOut, const double* valIn, const double* rowScale, hipStream_t s)
+{
+    if (a->nSlices == 0) return 0;
+    scale_rows_kernel<<<cdiv(a->nSlices, WPB), BLK, 0, s>>>(a->nSlices, a->d_sliceRow, a->d_sliceCnt,
+        a->d_sliceEnt, a->d_sliceW, valIn, rowScale, valOut);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void permute_in_kernel(int n, const int* __restrict__ perm, const double* __restrict__ src,
+                                  double* __restrict__ dst)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) dst[i] = src[perm[i]];
+}
+__global__ void permute_out_kernel(int n, const int* __restrict__ perm, const double* __restrict__ src,
+                                   double* __restrict__ dst)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) dst[perm[i]] = src[i];
+}
+
+static inline int ewGrid(long n) { int g = cdiv(n, BLK); return g < 1 ? 1 : (g > 4096 ? 4096 : g); }
+
+int k_permute_in(ldu_addr* a, double* dstNew, const double* srcOld, hipStream_t s)
+{
+    permute_in_kernel<<<ewGrid(a->nCells), BLK, 0, s>>>(a->nCells, a->d_perm, srcOld, dstNew);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int k_permute_out(ldu_addr* a, double* dstOld, const double* srcNew, hipStream_t s)
+{
+    permute_out_kernel<<<ewGrid(a->nCells), BLK, 0, s>>>(a->nCells, a->d_perm, srcNew, dstOld);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void reciprocal_kernel(int n, double* x)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) x[i] = 1.0 / x[i];
+}
+int k_reciprocal(int n, double* x, hipStream_t s)
+{
+    reciprocal_kernel<<<ewGrid(n), BLK, 0, s>>>(n, x);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- row kernels (Amul family)
+// MODE 0: y = diag*x + sum val*x[col]                 (Amul / Tmul, lduMatrixATmul.C:34-151)
+// MODE 1: y = b - diag*x - sum val*x[col]             (residual, :203-280)
+// MODE 2: y = diag + sum val                          (sumA, :154-200)
+// MODE 3: y = - sum val*x[col]                        (H, lduMatrixTemplates.C:34-65)
+// MODE 4: y = - sum val                               (H1, lduMatrixATmul.C:298-327)
+// MODE 5: y = + sum val*x[col]                        (GAMG interpolate, GAMGSolverInterpolate.C:61-66)
+template <int MODE>
+__global__ void __launch_bounds__(BLK)
+row_kernel(int nSlices, const int* __restrict__ sliceRow, const int* __restrict__ sliceCnt,
+           const int* __restrict__ sliceEnt, const int* __restrict__ sliceW,
+           const unsigned char* __restrict__ nL, const unsigned char* __restrict__ nU,
+           const int* __restrict__ col, const double* __restrict__ val,
+           const double* __restrict__ diag, const double* __restrict__ x,
+           const double* __restrict__ b, double* __restrict__ y)
+{
+    const int s = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (s >= nSlices) return;
+    const int lane = threadIdx.x & 63;
+    const int cnt = sliceCnt[s];
+    if (lane >= cnt) return;
+    const int r = sliceRow[s] + lane;
+    const int n = (int)nL[r] + (int)nU[r];
+    const long ent = (long)sliceEnt[s] + lane;
+    double acc;
+    if (MODE == 0) acc = diag[r] * x[r];
+    else if (MODE == 1) acc = b[r] - diag[r] * x[r];
+    else if (MODE == 2) acc = diag[r];
+    else acc = 0.0;
+    for (int k = 0; k < n; k++)
+    {
+        const long e = ent + (long)k * LDU_WAVE;
+        const double v = val[e];
+        if (MODE == 0 || MODE == 5) acc += v * x[col[e]];
+        else if (MODE == 1 || MODE == 3) acc -= v * x[col[e]];
+        else if (MODE == 2) acc += v;
+        else acc -= v;
+    }
+    y[r] = acc;
+}
+
+template <int MODE>
+static int launch_row(ldu_matrix* m, double* y, const double* x, const double* b, const double* val,
+                      hipStream_t s)
+{
+    ldu_addr* a = m->a;
+    if (a->nSlices == 0) return 0;
+    row_kernel<MODE><<<cdiv(a->nSlices, WPB), BLK, 0, s>>>(a->nSlices, a->d_sliceRow, a->d_sliceCnt,
+        a->d_sliceEnt, a->d_sliceW, a->d_nL, a->d_nU, a->d_col, val, m->d_diag, x, b, y);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int k_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStream_t s)
+{
+    return launch_row<0>(m, y, x, nullptr, transpose ? m->d_valT : m->d_valA, s);
+}
+int k_residual_rows(ldu_matrix* m, double* r, const double* x, const double* b, hipStream_t s)
+{
+    return launch_row<1>(m, r, x, b, m->d_valA, s);
+}
+int k_sumA_rows(ldu_matrix* m, double* sumA, hipStream_t s)
+{
+    return launch_row<2>(m, sumA, nullptr, nullptr, m->d_valA, s);
+}
+int k_offdiag(ldu_matrix* m, double* y, const double* x, int mode, hipStream_t s)
+{
+    if (mode == 0) return launch_row<3>(m, y, x, nullptr, m->d_valA, s);
+    if (mode == 1) return launch_row<4>(m, y, nullptr, nullptr, m->d_valA, s);
+    return launch_row<5>(m, y, x, nullptr, m->d_valA, s);
+}
+
+// faceH (lduMatrixTemplates.C:78-110) on the original numbering: x in ORIGINAL order
+__global__ void faceH_kernel(int nFaces, const int* __restrict__ l, const int* __restrict__ u,
+                             const double* __restrict__ lower, const double* __restrict__ upper,
+                             const double* __restrict__ x, double* __restrict__ out)
+{
+    for (int f = blockIdx.x * BLK + threadIdx.x; f < nFaces; f += gridDim.x * BLK)
+        out[f] = upper[f] * x[u[f]] - lower[f] * x[l[f]];
+}
+int k_faceH(ldu_matrix* m, double* faceH, const double* xOld, hipStream_t s)
+{
+    ldu_addr* a = m->a;
+    if (a->nFaces == 0) return 0;
+    faceH_kernel<<<ewGrid(a->nFaces), BLK, 0, s>>>(a->nFaces, a->d_l, a->d_u, m->d_lowerO, m->d_upperO,
+                                                   xOld, faceH);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- level-scheduled sweeps
+
+struct SliceTab {
+    const int* sliceRow; const int* sliceCnt; const int* sliceEnt;
+    const unsigned char* nL; const unsigned char* nU; const int* col;
+};
+
+template <int MODE>
+__device__ __forceinline__ void sweep_slice(const SliceTab& T, int s, int lane, double* __restrict__ w,
+                                            const double* __restrict__ rhs,
+                                            const double* __restrict__ scale,
+                                            const double* __restrict__ val,
+                                            const double* __restrict__ val2, double* __restrict__ aux)
+{
+    const int cnt = T.sliceCnt[s];
+    if (lane >= cnt) return;
+    const int r = T.sliceRow[s] + lane;
+    const int nl = T.nL[r];
+    const int nu = T.nU[r];
+    const long ent = (long)T.sliceEnt[s] + lane;
+    if (MODE == SW_TRI_FWD)
+    {
+        // DICPreconditioner.C:109-117 / DILUPreconditioner.C:113-128 with valP = rD[row]*coeff
+        double acc = scale[r] * rhs[r];
+        for (int k = 0; k < nl; k++)
+        {
+            const long e = ent + (long)k * LDU_WAVE;
+            acc -= val[e] * w[T.col[e]];
+        }
+        w[r] = acc;
+    }
+    else if (MODE == SW_TRI_BWD)
+    {
+        // DICPreconditioner.C:119-122: owned faces in DEscending order
+        double acc = w[r];
+        for (int k = nl + nu - 1; k >= nl; k--)
+        {
+            const long e = ent + (long)k * LDU_WAVE;
+            acc -= val[e] * w[T.col[e]];
+        }
+        w[r] = acc;
+    }
+    else if (MODE == SW_RD)
+    {
+        // DICPreconditioner.C:71-74 / DILUPreconditioner.C:72-75 (before the reciprocal)
+        double acc = scale[r];
+        for (int k = 0; k < nl; k++)
+        {
+            const long e = ent + (long)k * LDU_WAVE;
+            acc -= (val2[e] * val[e]) / w[T.col[e]];
+        }
+        w[r] = acc;
+    }
+    else if (MODE == SW_GS_FWD)
+    {
+        // GaussSeidelSmoother.C:151-176 as a row gather
+        double acc = rhs[r];
+        for (int k = 0; k < nl; k++)
+        {
+            const long e = ent + (long)k * LDU_WAVE;
+            acc -= val[e] * w[T.col[e]];
+        }
+        if (aux) aux[r] = acc;
+        for (int k = nl; k < nl + nu; k++)
+        {
+            const long e = ent + (long)k * LDU_WAVE;
+            acc -= val[e] * w[T.col[e]];
+        }
+        w[r] = acc / scale[r];
+    }
+    else   // SW_GS_BWD: symGaussSeidelSmoother.C:178-205
+    {
+        double acc = rhs[r];
+        for (int k = nl; k < nl + nu; k++)
+        {
+            const long e = ent + (long)k * LDU_WAVE;
+            acc -= val[e] * w[T.col[e]];
+        }
+        w[r] = acc / scale[r];
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(BLK)
+sweep_level_kernel(SliceTab T, int sliceBegin, int sliceEnd, double* w, const double* rhs,
+                   const double* scale, const double* val, const double* val2, double* aux)
+{
+    const int s = sliceBegin + blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (s >= sliceEnd) return;
+    sweep_slice<MODE>(T, s, threadIdx.x & 63, w, rhs, scale, val, val2, aux);
+}
+
+#define FUSED_THREADS 1024
+// One block walks a run of small levels; __syncthreads() orders the levels (same-CU
+// visibility of global stores is all that is needed).
+template <int MODE, bool DESC>
+__global__ void __launch_bounds__(FUSED_THREADS)
+sweep_fused_kernel(SliceTab T, const int* __restrict__ levelSliceStart, int levelBegin, int levelEnd,
+                   double* w, const double* rhs, const double* scale, const double* val,
+                   const double* val2, double* aux)
+{
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int nW = FUSED_THREADS / LDU_WAVE;
+    if (!DESC)
+    {
+        for (int L = levelBegin; L < levelEnd; L++)
+        {
+            const int s1 = levelSliceStart[L + 1];
+            for (int s = levelSliceStart[L] + wave; s < s1; s += nW)
+                sweep_slice<MODE>(T, s, lane, w, rhs, scale, val, val2, aux);
+            __syncthreads();
+        }
+    }
+    else
+    {
+        for (int L = levelEnd - 1; L >= levelBegin; L--)
+        {
+            const int s1 = levelSliceStart[L + 1];
+            for (int s = levelSliceStart[L] + wave; s < s1; s += nW)
+                sweep_slice<MODE>(T, s, lane, w, rhs, scale, val, val2, aux);
+            __syncthreads();
+        }
+    }
+}
+
+template <int MODE, bool DESC>
+static int launch_sweep_segments(ldu_addr* a, const SweepArgs& g, hipStream_t s)
+{
+    SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    const int nSeg = (int)a->segs.size();
+    for (int i = 0; i < nSeg; i++)
+    {
+        const Segment& sg = a->segs[DESC ? nSeg - 1 - i : i];
+        if (sg.sliceEnd == sg.sliceBegin) continue;
+        if (sg.fused)
+            sweep_fused_kernel<MODE, DESC><<<1, FUSED_THREADS, 0, s>>>(T, a->d_levelSliceStart,
+                sg.levelBegin, sg.levelEnd, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+        else
+            sweep_level_kernel<MODE><<<cdiv(sg.sliceEnd - sg.sliceBegin, WPB), BLK, 0, s>>>(
+                T, sg.sliceBegin, sg.sliceEnd, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+    }
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_sweep(ldu_addr* a, const SweepArgs& g, hipStream_t s)
+{
+    switch (g.mode)
+    {
+    case SW_TRI_FWD: return launch_sweep_segments<SW_TRI_FWD, false>(a, g, s);
+    case SW_TRI_BWD: return launch_sweep_segments<SW_TRI_BWD, true>(a, g, s);
+    case SW_RD:      return launch_sweep_segments<SW_RD, false>(a, g, s);
+    case SW_GS_FWD:  return launch_sweep_segments<SW_GS_FWD, false>(a, g, s);
+    case SW_GS_BWD:  return launch_sweep_segments<SW_GS_BWD, true>(a, g, s);
+    }
+    return -1;
+}
+
+// A sweep is hundreds of dependent launches: capture once per (mode, pointers) into a
+// hipGraph and replay (launch-bound inner loop -> graph, per the MI355X playbook).
+int k_sweep(ldu_addr* a, const SweepArgs& g)
+{
+    ldu_ctx* ctx = a->ctx;
+    hipStream_t s = ctx->stream;
+    if (a->nCells == 0) return 0;
+    if (!ctx->useGraphs || a->segs.size() <= 2) return launch_sweep(a, g, s);
+
+    char key[256];
+    snprintf(key, sizeof(key), "%d|%p|%p|%p|%p|%p|%p", g.mode, (void*)g.w, (const void*)g.rhs,
+             (const void*)g.scale, (const void*)g.val, (const void*)g.val2, (void*)g.aux);
+    auto it = a->graphs.find(key);
+    if (it == a->graphs.end())
+    {
+        hipGraph_t graph = nullptr;
+        LDU_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = launch_sweep(a, g, s);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc || e != hipSuccess)
+        {
+            ldu_set_error("sweep graph capture failed");
+            return -1;
+        }
+        hipGraphExec_t exec = nullptr;
+        LDU_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (a->graphs.size() > 64)
+        {
+            for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
+            a->graphs.clear();
+        }
+        it = a->graphs.emplace(key, exec).first;
+    }
+    LDU_CHECK_HIP(hipGraphLaunch(it->second, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------- coupled patches
+
+__global__ void pack_kernel(int n, const int* __restrict__ pfCell, const double* __restrict__ x,
+                            double* __restrict__ send)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) send[i] = x[pfCell[i]];
+}
+int k_pack_patches(ldu_addr* a, const double* x, hipStream_t s)
+{
+    if (!a->nPatchFaces) return 0;
+    pack_kernel<<<ewGrid(a->nPatchFaces), BLK, 0, s>>>(a->nPatchFaces, a->d_pfCell, x, a->d_sendAll);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// processorFvPatchScalarField.C:125-128: result[faceCells[i]] -= coeffs[i]*pnf[i], applied per
+// boundary row in (patch, face) order; sign<0 = negated coefficients (residual / smoothers).
+__global__ void apply_patches_kernel(int nBRows, const int* __restrict__ bRow,
+                                     const int* __restrict__ bStart, const int* __restrict__ bFace,
+                                     const double* __restrict__ coeffs, const double* __restrict__ recv,
+                                     double sign, double* __restrict__ result)
+{
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < nBRows; j += gridDim.x * BLK)
+    {
+        const int r = bRow[j];
+        double acc = result[r];
+        for (int t = bStart[j]; t < bStart[j + 1]; t++)
+        {
+            const int i = bFace[t];
+            const double c = sign < 0 ? -coeffs[i] : coeffs[i];
+            acc -= c * recv[i];
+        }
+        result[r] = acc;
+    }
+}
+int k_apply_patches(ldu_addr* a, double* result, const double* coeffs, double sign, hipStream_t s)
+{
+    if (!a->nPatchFaces) return 0;
+    apply_patches_kernel<<<ewGrid(a->nBRows), BLK, 0, s>>>(a->nBRows, a->d_bRow, a->d_bStart, a->d_bFace,
+                                                          coeffs, a->d_recvAll, sign, result);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// sumA: sumA[pa[face]] -= pCoeffs[face] (lduMatrixATmul.C:187-199)
+__global__ void sumA_patches_kernel(int nBRows, const int* __restrict__ bRow,
+                                    const int* __restrict__ bStart, const int* __restrict__ bFace,
+                                    const double* __restrict__ bou, double* __restrict__ sumA)
+{
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < nBRows; j += gridDim.x * BLK)
+    {
+        const int r = bRow[j];
+        double acc = sumA[r];
+        for (int t = bStart[j]; t < bStart[j + 1]; t++) acc -= bou[bFace[t]];
+        sumA[r] = acc;
+    }
+}
+int k_sumA_patches(ldu_addr* a, double* sumA, const double* bou, hipStream_t s)
+{
+    if (!a->nPatchFaces) return 0;
+    sumA_patches_kernel<<<ewGrid(a->nBRows), BLK, 0, s>>>(a->nBRows, a->d_bRow, a->d_bStart, a->d_bFace,
+                                                         bou, sumA);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- elementwise
+
+__global__ void ew_kernel(int n, int op, double* __restrict__ y, const double* __restrict__ a,
+                          const double* __restrict__ b)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+    {
+        switch (op)
+        {
+        case EW_COPY: y[i] = a[i]; break;
+        case EW_SUB: y[i] = a[i] - b[i]; break;
+        case EW_ADD_INPLACE: y[i] += a[i]; break;
+        case EW_MUL_INPLACE: y[i] *= a[i]; break;
+        case EW_ZERO: y[i] = 0.0; break;
+        case EW_DIV: y[i] = a[i] / b[i]; break;
+        case EW_MUL: y[i] = a[i] * b[i]; break;
+        case EW_SUB_INPLACE: y[i] -= a[i]; break;
+        }
+    }
+}
+int k_ew(int n, int op, double* y, const double* a, const double* b, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    ew_kernel<<<ewGrid(n), BLK, 0, s>>>(n, op, y, a, b);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// PCG.C:134-149: pA = wA (first) or pA = wA + beta*pA, beta = wArA/wArAold (device scalars)
+__global__ void pcg_update_p_kernel(int n, double* __restrict__ pA, const double* __restrict__ wA,
+                                    const double* __restrict__ S, int cur, int prev, int first)
+{
+    if (first)
+    {
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) pA[i] = wA[i];
+    }
+    else
+    {
+        const double beta = S[cur] / S[prev];
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+            pA[i] = wA[i] + beta * pA[i];
+    }
+}
+int k_pcg_update_p(int n, double* pA, const double* wA, const double* scalars, int cur, int prev,
+                   int first, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    pcg_update_p_kernel<<<ewGrid(n), BLK, 0, s>>>(n, pA, wA, scalars, cur, prev, first);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// PBiCG.C:144-162
+__global__ void pbicg_update_p_kernel(int n, double* __restrict__ pA, const double* __restrict__ wA,
+                                      double* __restrict__ pT, const double* __restrict__ wT,
+                                      const double* __restrict__ S, int cur, int prev, int first)
+{
+    if (first)
+    {
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+        {
+            pA[i] = wA[i];
+            pT[i] = wT[i];
+        }
+    }
+    else
+    {
+        const double beta = S[cur] / S[prev];
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+        {
+            pA[i] = wA[i] + beta * pA[i];
+            pT[i] = wT[i] + beta * pT[i];
+        }
+    }
+}
+int k_pbicg_update_p(int n, double* pA, const double* wA, double* pT, const double* wT,
+                     const double* scalars, int cur, int prev, int first, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    pbicg_update_p_kernel<<<ewGrid(n), BLK, 0, s>>>(n, pA, wA, pT, wT, scalars, cur, prev, first);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- reductions
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void block_partial(double acc, double* partials)
+{
+    __shared__ double lds[WPB];
+    acc = wave_sum(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double t = lds[0];
+        for (int i = 1; i < WPB; i++) t += lds[i];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// RED_NORMFACTOR: sum |a - t| + |b - t|, t = c[i]*avg (lduMatrixSolver.C:187-192), avg from scalars
+template <int OP>
+__global__ void __launch_bounds__(BLK)
+reduce_partial_kernel(int n, const double* __restrict__ a, const double* __restrict__ b,
+                      const double* __restrict__ c, const double* __restrict__ S,
+                      double* __restrict__ partials)
+{
+    double acc = 0.0;
+    double avg = 0.0;
+    if (OP == RED_NORMFACTOR) avg = S[S_SUMPSI] / S[S_COUNT];
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+    {
+        if (OP == RED_DOT) acc += a[i] * b[i];
+        else if (OP == RED_SUMMAG) acc += fabs(a[i]);
+        else if (OP == RED_SUM) acc += a[i];
+        else if (OP == RED_NORMFACTOR)
+        {
+            const double t = c[i] * avg;
+            acc += fabs(a[i] - t) + fabs(b[i] - t);
+        }
+    }
+    block_partial(acc, partials);
+}
+
+// two dot products at once: (a.b , c.b)  -> GAMG scale (GAMGSolverScale.C:54-58)
+__global__ void __launch_bounds__(BLK)
+reduce_dot2_kernel(int n, const double* __restrict__ a, const double* __restrict__ b,
+                   const double* __restrict__ c, double* __restrict__ partials, int stride)
+{
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+    {
+        acc0 += a[i] * b[i];
+        acc1 += c[i] * b[i];
+    }
+    __shared__ double lds[2 * WPB];
+    acc0 = wave_sum(acc0);
+    acc1 = wave_sum(acc1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { lds[wave] = acc0; lds[WPB + wave] = acc1; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double t0 = lds[0], t1 = lds[WPB];
+        for (int i = 1; i < WPB; i++) { t0 += lds[i]; t1 += lds[WPB + i]; }
+        partials[blockIdx.x] = t0;
+        partials[stride + blockIdx.x] = t1;
+    }
+}
+
+__global__ void __launch_bounds__(BLK)
+reduce_final_kernel(const double* __restrict__ partials, int nBlocks, double* __restrict__ S, int slot,
+                    double addend, int nOut, int stride)
+{
+    __shared__ double lds[BLK];
+    for (int o = 0; o < nOut; o++)
+    {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nBlocks; i += BLK) acc += partials[o * stride + i];
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = BLK / 2; w > 0; w >>= 1)
+        {
+            if (threadIdx.x < w) lds[threadIdx.x] += lds[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) S[slot + o] = lds[0] + addend;
+        __syncthreads();
+    }
+}
+
+static inline int redGrid(ldu_ctx* ctx, long n)
+{
+    int g = cdiv(n, BLK * 4);
+    if (g < 1) g = 1;
+    if (g > ctx->maxRedBlocks) g = ctx->maxRedBlocks;
+    return g;
+}
+
+int k_reduce(ldu_ctx* ctx, int n, int op, const double* a, const double* b, const double* c,
+             const double* d, int slot, hipStream_t s)
+{
+    (void)d;
+    const int g = redGrid(ctx, n);
+    const double* S = ctx->S();
+    switch (op)
+    {
+    case RED_DOT: reduce_partial_kernel<RED_DOT><<<g, BLK, 0, s>>>(n, a, b, c, S, ctx->d_partials); break;
+    case RED_SUMMAG: reduce_partial_kernel<RED_SUMMAG><<<g, BLK, 0, s>>>(n, a, b, c, S, ctx->d_partials); break;
+    case RED_SUM: reduce_partial_kernel<RED_SUM><<<g, BLK, 0, s>>>(n, a, b, c, S, ctx->d_partials); break;
+    case RED_NORMFACTOR:
+        reduce_partial_kernel<RED_NORMFACTOR><<<g, BLK, 0, s>>>(n, a, b, c, S, ctx->d_partials); break;
+    case RED_DOT2:
+        reduce_dot2_kernel<<<g, BLK, 0, s>>>(n, a, b, c, ctx->d_partials, ctx->maxRedBlocks); break;
+    default: return -1;
+    }
+    reduce_final_kernel<<<1, BLK, 0, s>>>(ctx->d_partials, g, ctx->S(), slot, 0.0,
+                                         op == RED_DOT2 ? 2 : 1, ctx->maxRedBlocks);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// PCG.C:159-172 / PBiCG.C:170-188: singular test, psi += alpha pA, rA -= alpha wA (rT -= alpha wT),
+// and the partial sums of |rA| for the residual - one pass.
+__global__ void __launch_bounds__(BLK)
+pcg_update_xr_kernel(int n, double* __restrict__ psi, double* __restrict__ rA,
+                     const double* __restrict__ pA, const double* __restrict__ wA,
+                     double* __restrict__ rT, const double* __restrict__ wT, double* __restrict__ S,
+                     int cur, double* __restrict__ partials)
+{
+    const double wApA = S[S_WAPA];
+    const bool singular = fabs(wApA) / S[S_NORM] < 1e-300;   // solverPerformance::vsmall_
+    double acc = 0.0;
+    if (singular)
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) S[S_SINGULAR] = 1.0;
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) acc += fabs(rA[i]);
+    }
+    else
+    {
+        const double alpha = S[cur] / wApA;
+        for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+        {
+            psi[i] += alpha * pA[i];
+            const double r = rA[i] - alpha * wA[i];
+            rA[i] = r;
+            if (rT) rT[i] -= alpha * wT[i];
+            acc += fabs(r);
+        }
+    }
+    block_partial(acc, partials);
+}
+
+int k_pcg_update_xr(ldu_ctx* ctx, int n, double* psi, double* rA, const double* pA, const double* wA,
+                    double* rT, const double* wT, int cur, hipStream_t s)
+{
+    const int g = redGrid(ctx, n);
+    pcg_update_xr_kernel<<<g, BLK, 0, s>>>(n, psi, rA, pA, wA, rT, wT, ctx->S(), cur,
+                                           ctx->d_partials);
+    reduce_final_kernel<<<1, BLK, 0, s>>>(ctx->d_partials, g, ctx->S(), S_RES, 0.0, 1,
+                                         ctx->maxRedBlocks);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// GAMGSolverScale.C:62-74: sf = num/stabilise(den, VSMALL); field = sf*field + (source - sf*Acf)/D
+__global__ void gamg_scale_update_kernel(int n, double* __restrict__ field,
+                                         const double* __restrict__ source,
+                                         const double* __restrict__ Acf, const double* __restrict__ diag,
+                                         const double* __restrict__ S)
+{
+    const double den = S[S_SCALE_DEN];
+    const double sf = S[S_SCALE_NUM] / (den >= 0 ? den + 1e-300 : den - 1e-300);
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+        field[i] = sf * field[i] + (source[i] - sf * Acf[i]) / diag[i];
+}
+int k_gamg_scale_update(int n, double* field, const double* source, const double* Acf,
+                        const double* diag, const double* scalars, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    gamg_scale_update_kernel<<<ewGrid(n), BLK, 0, s>>>(n, field, source, Acf, diag, scalars);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// GAMGSolverInterpolate.C:78-82: psi = -Apsi/diag
+__global__ void neg_div_kernel(int n, double* __restrict__ psi, const double* __restrict__ Apsi,
+                               const double* __restrict__ diag)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) psi[i] = -Apsi[i] / diag[i];
+}
+int k_neg_div(int n, double* psi, const double* Apsi, const double* diag, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    neg_div_kernel<<<ewGrid(n), BLK, 0, s>>>(n, psi, Apsi, diag);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- GAMG transfer
+
+// GAMGAgglomerationTemplates.C:31-59: cf = 0; cf[map[i]] += ff[i] in ascending fine index ->
+// per coarse cell: children (ascending ORIGINAL fine index) summed left to right.
+__global__ void restrict_kernel(int nCoarse, const int* __restrict__ childStart,
+                                const int* __restrict__ child, const double* __restrict__ fine,
+                                double* __restrict__ coarse)
+{
+    for (int c = blockIdx.x * BLK + threadIdx.x; c < nCoarse; c += gridDim.x * BLK)
+    {
+        double acc = 0.0;
+        for (int t = childStart[c]; t < childStart[c + 1]; t++) acc += fine[child[t]];
+        coarse[c] = acc;
+    }
+}
+int k_restrict(int nCoarse, const int* childStart, const int* child, const double* fine, double* coarse,
+               hipStream_t s)
+{
+    if (nCoarse <= 0) return 0;
+    restrict_kernel<<<ewGrid(nCoarse), BLK, 0, s>>>(nCoarse, childStart, child, fine, coarse);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// GAMGAgglomerationTemplates.C:87-100: ff[i] = cf[map[i]]
+__global__ void prolong_kernel(int nFine, const int* __restrict__ map, const double* __restrict__ coarse,
+                               double* __restrict__ fine)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < nFine; i += gridDim.x * BLK) fine[i] = coarse[map[i]];
+}
+int k_prolong(int nFine, const int* map, const double* coarse, double* fine, hipStream_t s)
+{
+    if (nFine <= 0) return 0;
+    prolong_kernel<<<ewGrid(nFine), BLK, 0, s>>>(nFine, map, coarse, fine);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// GAMGSolverAgglomerateMatrix.C:148-205 as gathers in ascending fine-face order (all arrays in
+// ORIGINAL numbering of their level).
+__global__ void agg_faces_kernel(int nCoarseFaces, const int* __restrict__ cfStart,
+                                 const int* __restrict__ cfFine, const unsigned char* __restrict__ cfFlip,
+                                 const double* __restrict__ fineUpper, const double* __restrict__ fineLower,
+                                 double* __restrict__ coarseUpper, double* __restrict__ coarseLower,
+                                 bool sym)
+{
+    for (int c = blockIdx.x * BLK + threadIdx.x; c < nCoarseFaces; c += gridDim.x * BLK)
+    {
+        double up = 0.0, lo = 0.0;
+        for (int t = cfStart[c]; t < cfStart[c + 1]; t++)
+        {
+            const int f = cfFine[t];
+            if (sym) up += fineUpper[f];
+            else if (!cfFlip[t]) { up += fineUpper[f]; lo += fineLower[f]; }
+            else { up += fineLower[f]; lo += fineUpper[f]; }
+        }
+        coarseUpper[c] = up;
+        if (!sym) coarseLower[c] = lo;
+    }
+}
+__global__ void agg_diag_kernel(int nCoarseCells, const int* __restrict__ childStartO,
+                                const int* __restrict__ childO, const int* __restrict__ ccStart,
+                                const int* __restrict__ ccFine, const double* __restrict__ fineDiag,
+                                const double* __restrict__ fineUpper, const double* __restrict__ fineLower,
+                                double* __restrict__ coarseDiag, bool sym)
+{
+    for (int c = blockIdx.x * BLK + threadIdx.x; c < nCoarseCells; c += gridDim.x * BLK)
+    {
+        double acc = 0.0;
+        for (int t = childStartO[c]; t < childStartO[c + 1]; t++) acc += fineDiag[childO[t]];
+        for (int t = ccStart[c]; t < ccStart[c + 1]; t++)
+        {
+            const int f = ccFine[t];
+            if (sym) acc += 2 * fineUpper[f];
+            else acc += fineUpper[f] + fineLower[f];
+        }
+        coarseDiag[c] = acc;
+    }
+}
+int k_agglomerate_coeffs(int nCoarseFaces, const int* cfStart, const int* cfFine, const unsigned char* cfFlip,
+                         int nCoarseCells, const int* ccStart, const int* ccFine,
+                         const int* childStartO, const int* childO,
+                         const double* fineDiag, const double* fineUpper, const double* fineLower,
+                         double* coarseDiag, double* coarseUpper, double* coarseLower, bool sym,
+                         hipStream_t s)
+{
+    if (nCoarseFaces > 0)
+        agg_faces_kernel<<<ewGrid(nCoarseFaces), BLK, 0, s>>>(nCoarseFaces, cfStart, cfFine, cfFlip,
+            fineUpper, fineLower, coarseUpper, coarseLower, sym);
+    if (nCoarseCells > 0)
+        agg_diag_kernel<<<ewGrid(nCoarseCells), BLK, 0, s>>>(nCoarseCells, childStartO, childO, ccStart,
+            ccFine, fineDiag, fineUpper, fineLower, coarseDiag, sym);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- fv stencils (original numbering)
+
+// surfaceInterpolationScheme.C:293-296: sf = lambda*(vf[P]-vf[N]) + vf[N]
+__global__ void fv_interpolate_kernel(int nFaces, int nComp, const int* __restrict__ P,
+                                      const int* __restrict__ N, const double* __restrict__ lambda,
+                                      const double* __restrict__ vf, double* __restrict__ sf)
+{
+    for (int f = blockIdx.x * BLK + threadIdx.x; f < nFaces; f += gridDim.x * BLK)
+    {
+        const int p = P[f], q = N[f];
+        const double lam = lambda[f];
+        for (int c = 0; c < nComp; c++)
+        {
+            const double a = vf[(long)p * nComp + c], b = vf[(long)q * nComp + c];
+            sf[(long)f * nComp + c] = lam * (a - b) + b;
+        }
+    }
+}
+int k_fv_interpolate(ldu_addr* a, int nComp, const double* lambdas, const double* vf, double* sf,
+                     hipStream_t s)
+{
+    if (a->nFaces == 0) return 0;
+    fv_interpolate_kernel<<<ewGrid(a->nFaces), BLK, 0, s>>>(a->nFaces, nComp, a->d_l, a->d_u, lambdas, vf, sf);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// fvcSurfaceIntegrate.C:56-60,75 / gaussGrad.C:82-88,105 as a cell gather in the reference's
+// face order: a cell receives -= from faces where it is the neighbour and += from owned faces,
+// interleaved by ascending face index == (neighbour faces ascending) then (owned faces ascending).
+// sfVec != NULL: contribution = Sf[f]*ssf[f] (gaussGrad, nComp = 3, ssf scalar per face)
+__global__ void fv_surfaceIntegrate_kernel(int nCells, int nComp, const int* __restrict__ losortStart,
+                                           const int* __restrict__ losort,
+                                           const int* __restrict__ ownerStart,
+                                           const double* __restrict__ ssf,
+                                           const double* __restrict__ sfVec,
+                                           const double* __restrict__ V, double* __restrict__ out)
+{
+    for (int c = blockIdx.x * BLK + threadIdx.x; c < nCells; c += gridDim.x * BLK)
+    {
+        for (int k = 0; k < nComp; k++)
+        {
+            double acc = 0.0;
+            for (int t = losortStart[c]; t < losortStart[c + 1]; t++)
+            {
+                const int f = losort[t];
+                acc -= sfVec ? sfVec[(long)f * 3 + k] * ssf[f] : ssf[(long)f * nComp + k];
+            }
+            for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+                acc += sfVec ? sfVec[(long)f * 3 + k] * ssf[f] : ssf[(long)f * nComp + k];
+            out[(long)c * nComp + k] = acc / V[c];
+        }
+    }
+}
+int k_fv_surfaceIntegrate(ldu_addr* a, int nComp, const double* ssf, const double* sfVec, const double* V,
+                          double* out, hipStream_t s)
+{
+    if (a->nCells == 0) return 0;
+    fv_surfaceIntegrate_kernel<<<ewGrid(a->nCells), BLK, 0, s>>>(a->nCells, nComp, a->d_losortStart,
+        a->d_losort, a->d_ownerStart, ssf, sfVec, V, out);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// snGradScheme.C:139-143
+__global__ void fv_snGrad_kernel(int nFaces, const int* __restrict__ own, const int* __restrict__ nei,
+                                 const double* __restrict__ delta, const double* __restrict__ vf,
+                                 double* __restrict__ ssf)
+{
+    for (int f = blockIdx.x * BLK + threadIdx.x; f < nFaces; f += gridDim.x * BLK)
+        ssf[f] = delta[f] * (vf[nei[f]] - vf[own[f]]);
+}
+int k_fv_snGrad(ldu_addr* a, const double* delta, const double* vf, double* ssf, hipStream_t s)
+{
+    if (a->nFaces == 0) return 0;
+    fv_snGrad_kernel<<<ewGrid(a->nFaces), BLK, 0, s>>>(a->nFaces, a->d_l, a->d_u, delta, vf, ssf);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// lduMatrix::negSumDiag (lduMatrixOperations.C:50-64): diag[l] -= lower; diag[u] -= upper in face
+// order, from a zero diagonal: row gather (neighbour faces asc. then owned faces asc.)
+__global__ void fv_negSumDiag_kernel(int nCells, const int* __restrict__ losortStart,
+                                     const int* __restrict__ losort, const int* __restrict__ ownerStart,
+                                     const double* __restrict__ lower, const double* __restrict__ upper,
+                                     double* __restrict__ diag)
+{
+    for (int c = blockIdx.x * BLK + threadIdx.x; c < nCells; c += gridDim.x * BLK)
+    {
+        double acc = 0.0;
+        for (int t = losortStart[c]; t < losortStart[c + 1]; t++) acc -= upper[losort[t]];
+        for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++) acc -= lower[f];
+        diag[c] = acc;
+    }
+}
+int k_fv_negSumDiag(ldu_addr* a, const double* lower, const double* upper, double* diag, hipStream_t s)
+{
+    if (a->nCells == 0) return 0;
+    fv_negSumDiag_kernel<<<ewGrid(a->nCells), BLK, 0, s>>>(a->nCells, a->d_losortStart, a->d_losort,
+        a->d_ownerStart, lower, upper, diag);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// gaussLaplacianScheme.C:63: upper = deltaCoeffs*gammaMagSf
+__global__ void fv_lap_kernel(int n, const double* __restrict__ delta, const double* __restrict__ g,
+                              double* __restrict__ upper)
+{
+    for (int f = blockIdx.x * BLK + threadIdx.x; f < n; f += gridDim.x * BLK) upper[f] = delta[f] * g[f];
+}
+int k_fv_laplacian_coeffs(int nFaces, const double* delta, const double* gammaMagSf, double* upper,
+                          hipStream_t s)
+{
+    if (nFaces == 0) return 0;
+    fv_lap_kernel<<<ewGrid(nFaces), BLK, 0, s>>>(nFaces, delta, gammaMagSf, upper);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// gaussConvectionScheme.C:87-88: lower = -w*phi; upper = lower + phi
+__global__ void fv_div_kernel(int n, const double* __restrict__ w, const double* __restrict__ phi,
+                              double* __restrict__ lower, double* __restrict__ upper)
+{
+    for (int f = blockIdx.x * BLK + threadIdx.x; f < n; f += gridDim.x * BLK)
+    {
+        const double lo = -w[f] * phi[f];
+        lower[f] = lo;
+        upper[f] = lo + phi[f];
+    }
+}
+int k_fv_div_coeffs(int nFaces, const double* w, const double* phi, double* lower, double* upper,
+                    hipStream_t s)
+{
+    if (nFaces == 0) return 0;
+    fv_div_kernel<<<ewGrid(nFaces), BLK, 0, s>>>(nFaces, w, phi, lower, upper);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}

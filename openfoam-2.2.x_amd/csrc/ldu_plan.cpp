@@ -1,0 +1,275 @@
+// Device "plan" of one lduAddressing: dependency levels, level-ordered renumbering,
+// sliced-ELL entry layout and the sweep schedule.  Built once per addressing
+// (the reference builds losort/ownerStart lazily once per mesh: lduAddressing.C:31-169).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "ldu_internal.hpp"
+
+template <class T>
+static int upload(T** dst, const std::vector<T>& src)
+{
+    size_t n = src.size() ? src.size() : 1;
+    LDU_CHECK_HIP(hipMalloc((void**)dst, n * sizeof(T)));
+    if (src.size())
+        LDU_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+double* ldu_addr::scratchVec(int i)
+{
+    while ((int)scratch.size() <= i) scratch.push_back(nullptr);
+    if (!scratch[i])
+    {
+        size_t n = (size_t)std::max(nCells, std::max(nFaces, 1)) * 3 + 64;
+        if (hipMalloc((void**)&scratch[i], n * sizeof(double)) != hipSuccess) return nullptr;
+    }
+    return scratch[i];
+}
+
+int plan_build(ldu_addr* a)
+{
+    const int nC = a->nCells, nF = a->nFaces;
+    const std::vector<int>& l = a->l;
+    const std::vector<int>& u = a->u;
+
+    // validate: upper-triangular order by owner (lduAddressing.H:36-63)
+    for (int f = 0; f < nF; f++)
+    {
+        if (l[f] < 0 || u[f] >= nC || l[f] >= u[f])
+        {
+            ldu_set_error("ldu_addr_create: face " + std::to_string(f) + " violates lower < upper < nCells");
+            return -2;
+        }
+        if (f && l[f] < l[f - 1])
+        {
+            ldu_set_error("ldu_addr_create: faces must be sorted by owner (upper-triangular order)");
+            return -2;
+        }
+    }
+
+    // losort / ownerStart / losortStart (lduAddressing.C:31-169)
+    a->losort.assign(nF, 0);
+    a->ownerStart.assign(nC + 1, 0);
+    a->losortStart.assign(nC + 1, 0);
+    {
+        std::vector<int> cnt(nC + 1, 0);
+        for (int f = 0; f < nF; f++) cnt[u[f] + 1]++;
+        for (int c = 0; c < nC; c++) cnt[c + 1] += cnt[c];
+        for (int c = 0; c <= nC; c++) a->losortStart[c] = cnt[c];
+        for (int f = 0; f < nF; f++) a->losort[cnt[u[f]]++] = f;
+        std::vector<int> oc(nC + 1, 0);
+        for (int f = 0; f < nF; f++) oc[l[f] + 1]++;
+        for (int c = 0; c < nC; c++) oc[c + 1] += oc[c];
+        a->ownerStart = oc;
+    }
+
+    // dependency levels of the lower-triangular DAG: one pass in face order is enough
+    // because every face into cell k (owner < k) precedes the faces owned by k.
+    a->level.assign(nC, 0);
+    for (int f = 0; f < nF; f++)
+        a->level[u[f]] = std::max(a->level[u[f]], a->level[l[f]] + 1);
+    int nLevels = 0;
+    for (int c = 0; c < nC; c++) nLevels = std::max(nLevels, a->level[c] + 1);
+    a->nLevels = nLevels;
+    a->levelStart.assign(nLevels + 1, 0);
+    for (int c = 0; c < nC; c++) a->levelStart[a->level[c] + 1]++;
+    for (int L = 0; L < nLevels; L++) a->levelStart[L + 1] += a->levelStart[L];
+    a->perm.assign(nC, 0);
+    a->iperm.assign(nC, 0);
+    {
+        std::vector<int> pos(a->levelStart.begin(), a->levelStart.end() - 1);
+        for (int c = 0; c < nC; c++)   // stable: original order inside a level
+        {
+            int r = pos[a->level[c]]++;
+            a->perm[r] = c;
+            a->iperm[c] = r;
+        }
+    }
+
+    // slices (<= 64 rows, never straddling a level)
+    std::vector<int> sliceRow, sliceCnt, sliceEnt, sliceW;
+    a->levelSliceStart.assign(nLevels + 1, 0);
+    std::vector<unsigned char> nL(nC), nU(nC);
+    for (int r = 0; r < nC; r++)
+    {
+        int c = a->perm[r];
+        int cl = a->losortStart[c + 1] - a->losortStart[c];
+        int cu = a->ownerStart[c + 1] - a->ownerStart[c];
+        if (cl > 255 || cu > 255)
+        {
+            ldu_set_error("ldu_addr_create: more than 255 lower or upper neighbours in one row");
+            return -2;
+        }
+        nL[r] = (unsigned char)cl;
+        nU[r] = (unsigned char)cu;
+    }
+    long ent = 0;
+    for (int L = 0; L < nLevels; L++)
+    {
+        a->levelSliceStart[L] = (int)sliceRow.size();
+        for (int r0 = a->levelStart[L]; r0 < a->levelStart[L + 1]; r0 += LDU_WAVE)
+        {
+            int cnt = std::min(LDU_WAVE, a->levelStart[L + 1] - r0);
+            int W = 0;
+            for (int i = 0; i < cnt; i++) W = std::max(W, (int)nL[r0 + i] + (int)nU[r0 + i]);
+            sliceRow.push_back(r0);
+            sliceCnt.push_back(cnt);
+            sliceEnt.push_back((int)ent);
+            sliceW.push_back(W);
+            ent += (long)W * LDU_WAVE;
+            if (ent > 2000000000L)
+            {
+                ldu_set_error("ldu_addr_create: entry count exceeds int32 addressing");
+                return -2;
+            }
+        }
+    }
+    a->levelSliceStart[nLevels] = (int)sliceRow.size();
+    a->nSlices = (int)sliceRow.size();
+    a->nEntries = ent;
+    sliceRow.push_back(nC);
+
+    std::vector<int> col((size_t)ent, 0), face((size_t)ent, -1);
+    for (int s = 0; s < a->nSlices; s++)
+    {
+        for (int i = 0; i < sliceCnt[s]; i++)
+        {
+            int r = sliceRow[s] + i;
+            int c = a->perm[r];
+            long base = (long)sliceEnt[s] + i;
+            int k = 0;
+            for (int j = a->losortStart[c]; j < a->losortStart[c + 1]; j++, k++)
+            {
+                int f = a->losort[j];
+                col[base + (long)k * LDU_WAVE] = a->iperm[l[f]];
+                face[base + (long)k * LDU_WAVE] = f;
+            }
+            for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++, k++)
+            {
+                col[base + (long)k * LDU_WAVE] = a->iperm[u[f]];
+                face[base + (long)k * LDU_WAVE] = f;
+            }
+            // padding columns point at the row itself (never dereferenced: k < nL+nU guards)
+            for (; k < sliceW[s]; k++) col[base + (long)k * LDU_WAVE] = r;
+        }
+        for (int i = sliceCnt[s]; i < LDU_WAVE; i++)
+            for (int k = 0; k < sliceW[s]; k++)
+                col[(long)sliceEnt[s] + i + (long)k * LDU_WAVE] = sliceRow[s];
+    }
+
+    // sweep schedule: runs of small levels are fused into single-block chains
+    a->segs.clear();
+    {
+        const int fuseRows = a->ctx->fuseRows;
+        int L = 0;
+        while (L < nLevels)
+        {
+            int rows = a->levelStart[L + 1] - a->levelStart[L];
+            Segment sg;
+            sg.levelBegin = L;
+            if (rows <= fuseRows)
+            {
+                int E = L;
+                while (E < nLevels && (a->levelStart[E + 1] - a->levelStart[E]) <= fuseRows) E++;
+                sg.levelEnd = E;
+                sg.fused = true;
+            }
+            else
+            {
+                sg.levelEnd = L + 1;
+                sg.fused = false;
+            }
+            sg.sliceBegin = a->levelSliceStart[sg.levelBegin];
+            sg.sliceEnd = a->levelSliceStart[sg.levelEnd];
+            a->segs.push_back(sg);
+            L = sg.levelEnd;
+        }
+    }
+
+    if (upload(&a->d_perm, a->perm)) return -1;
+    if (upload(&a->d_iperm, a->iperm)) return -1;
+    if (upload(&a->d_sliceRow, sliceRow)) return -1;
+    if (upload(&a->d_sliceCnt, sliceCnt)) return -1;
+    if (upload(&a->d_sliceEnt, sliceEnt)) return -1;
+    if (upload(&a->d_sliceW, sliceW)) return -1;
+    if (upload(&a->d_levelSliceStart, a->levelSliceStart)) return -1;
+    if (upload(&a->d_nL, nL)) return -1;
+    if (upload(&a->d_nU, nU)) return -1;
+    if (upload(&a->d_col, col)) return -1;
+    if (upload(&a->d_face, face)) return -1;
+    if (upload(&a->d_l, a->l)) return -1;
+    if (upload(&a->d_u, a->u)) return -1;
+    if (upload(&a->d_losort, a->losort)) return -1;
+    if (upload(&a->d_ownerStart, a->ownerStart)) return -1;
+    if (upload(&a->d_losortStart, a->losortStart)) return -1;
+    return 0;
+}
+
+// Coupled patches: boundary-row lists in the reference's update order
+// (lduMatrixUpdateMatrixInterfaces.C:96-266: patch by patch, face by face).
+int plan_finalize_patches(ldu_addr* a)
+{
+    int off = 0;
+    for (auto& p : a->patches) { p.offset = off; off += p.n; }
+    a->nPatchFaces = off;
+    if (off == 0) { a->finalized = true; return 0; }
+
+    std::vector<int> pfCell(off);
+    std::vector<std::vector<int>> perRow;   // by new row index -> list of patch-face ids
+    std::map<int, int> rowSlot;
+    std::vector<int> bRow;
+    for (auto& p : a->patches)
+    {
+        for (int i = 0; i < p.n; i++)
+        {
+            int r = a->iperm[p.faceCells[i]];
+            pfCell[p.offset + i] = r;
+            auto it = rowSlot.find(r);
+            if (it == rowSlot.end())
+            {
+                rowSlot[r] = (int)bRow.size();
+                bRow.push_back(r);
+                perRow.emplace_back();
+                it = rowSlot.find(r);
+            }
+            perRow[it->second].push_back(p.offset + i);   // ascending (patch, face) by construction
+        }
+    }
+    std::vector<int> bStart(bRow.size() + 1, 0), bFace;
+    for (size_t i = 0; i < bRow.size(); i++)
+    {
+        bStart[i + 1] = bStart[i] + (int)perRow[i].size();
+        bFace.insert(bFace.end(), perRow[i].begin(), perRow[i].end());
+    }
+    a->nBRows = (int)bRow.size();
+    if (upload(&a->d_bRow, bRow)) return -1;
+    if (upload(&a->d_bStart, bStart)) return -1;
+    if (upload(&a->d_bFace, bFace)) return -1;
+    if (upload(&a->d_pfCell, pfCell)) return -1;
+    LDU_CHECK_HIP(hipMalloc((void**)&a->d_sendAll, sizeof(double) * (size_t)off));
+    LDU_CHECK_HIP(hipMalloc((void**)&a->d_recvAll, sizeof(double) * (size_t)off));
+    LDU_CHECK_HIP(hipMemset(a->d_recvAll, 0, sizeof(double) * (size_t)off));
+    for (auto& p : a->patches)
+    {
+        p.d_send = a->d_sendAll + p.offset;
+        p.d_recv = a->d_recvAll + p.offset;
+        p.d_faceCells = a->d_pfCell + p.offset;
+    }
+    a->finalized = true;
+    return 0;
+}
+
+void plan_free(ldu_addr* a)
+{
+    for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
+    a->graphs.clear();
+    void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW,
+                    a->d_levelSliceStart, a->d_nL, a->d_nU, a->d_col, a->d_face, a->d_l, a->d_u,
+                    a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,
+                    a->d_pfCell, a->d_sendAll, a->d_recvAll};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (double* p : a->scratch) if (p) (void)hipFree(p);
+    a->scratch.clear();
+}

@@ -1,0 +1,441 @@
+// Host-side solver loops driving the HIP kernels: PCG (PCG.C:65-182), PBiCG (PBiCG.C:65-198),
+// smoothSolver (smoothSolver.C:77-180), diagonalSolver, the preconditioners and smoothers.
+// All vectors are device arrays in the level-ordered numbering.  Scalars (wArA, wApA, ...)
+// stay on the device; the host reads back only the residual it needs for checkConvergence.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "ldu_internal.hpp"
+
+static const double kGreat = 1e20;    // SolverPerformance.H:269-275
+static const double kSmall = 1e-20;
+
+double* ldu_matrix::workVec(int i)
+{
+    while ((int)work.size() <= i) work.push_back(nullptr);
+    if (!work[i])
+    {
+        size_t n = (size_t)(a->nCells > 0 ? a->nCells : 1) + 64;
+        if (hipMalloc((void**)&work[i], n * sizeof(double)) != hipSuccess) return nullptr;
+    }
+    return work[i];
+}
+
+int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
+{
+    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars + ctx->sb + slot, ctx->S() + slot, sizeof(double) * count,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < count; i++) out[i] = ctx->h_scalars[ctx->sb + slot + i];
+    return 0;
+}
+
+static int dev_write_scalar(ldu_ctx* ctx, int slot, double v)
+{
+    // stream-ordered write through a tiny staging slot in pinned memory is racy if reused
+    // before the copy ran; use a blocking small copy instead (rare: once per solve).
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    LDU_CHECK_HIP(hipMemcpy(ctx->S() + slot, &v, sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---------------------------------------------------------------- interface-aware matrix ops
+// initMatrixInterfaces -> pack + exchange ; interior rows ; updateMatrixInterfaces -> apply
+// (lduMatrixUpdateMatrixInterfaces.C:30-266)
+
+static int halo_start(ldu_matrix* m, const double* x)
+{
+    ldu_addr* a = m->a;
+    if (!a->nPatchFaces) return 0;
+    if (k_pack_patches(a, x, a->ctx->stream)) return -1;
+    return comm_exchange(a, a->ctx->stream);
+}
+
+int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose)
+{
+    hipStream_t s = m->a->ctx->stream;
+    if (halo_start(m, x)) return -1;
+    if (k_amul(m, y, x, transpose, s)) return -1;
+    if (m->a->nPatchFaces) return k_apply_patches(m->a, y, transpose ? m->d_int : m->d_bou, 1.0, s);
+    return 0;
+}
+
+int dev_residual(ldu_matrix* m, double* r, const double* x, const double* b)
+{
+    hipStream_t s = m->a->ctx->stream;
+    if (halo_start(m, x)) return -1;
+    if (k_residual_rows(m, r, x, b, s)) return -1;
+    if (m->a->nPatchFaces) return k_apply_patches(m->a, r, m->d_bou, -1.0, s);
+    return 0;
+}
+
+int dev_sumA(ldu_matrix* m, double* sumA)
+{
+    hipStream_t s = m->a->ctx->stream;
+    if (k_sumA_rows(m, sumA, s)) return -1;
+    if (m->a->nPatchFaces) return k_sumA_patches(m->a, sumA, m->d_bou, s);
+    return 0;
+}
+
+// ---------------------------------------------------------------- preconditioners
+
+int matrix_ensure_rD(ldu_matrix* m, int kind)
+{
+    ldu_addr* a = m->a;
+    hipStream_t s = a->ctx->stream;
+    if (kind == LDU_PRE_FDIC) kind = LDU_PRE_DIC;   // FDIC == DIC with precomputed rD*upper
+    if (kind == LDU_PRE_DIAGONAL)
+    {
+        if (m->rDiagValid) return 0;
+        if (!m->d_rDiag) LDU_CHECK_HIP(hipMalloc((void**)&m->d_rDiag, sizeof(double) * (size_t)(a->nCells + 1)));
+        if (k_ew(a->nCells, EW_COPY, m->d_rDiag, m->d_diag, nullptr, s)) return -1;
+        if (k_reciprocal(a->nCells, m->d_rDiag, s)) return -1;   // diagonalPreconditioner.C:62-68
+        m->rDiagValid = true;
+        return 0;
+    }
+    if (m->rDKind == kind) return 0;
+    const size_t nE = (size_t)(a->nEntries > 0 ? a->nEntries : 1);
+    if (!m->d_rD) LDU_CHECK_HIP(hipMalloc((void**)&m->d_rD, sizeof(double) * (size_t)(a->nCells + 1)));
+    if (!m->d_valP) LDU_CHECK_HIP(hipMalloc((void**)&m->d_valP, sizeof(double) * nE));
+    // calcReciprocalD (DICPreconditioner.C:57-84 / DILUPreconditioner.C:57-85)
+    SweepArgs g{};
+    g.mode = SW_RD;
+    g.w = m->d_rD;
+    g.scale = m->d_diag;
+    g.val = m->d_valA;
+    g.val2 = m->d_valT;
+    if (k_sweep(a, g)) return -1;
+    if (k_reciprocal(a->nCells, m->d_rD, s)) return -1;
+    // rD[row]*coeff, the products the sweeps use (identical rounding: FDICPreconditioner.C:79-83)
+    if (k_scale_rows(a, m->d_valP, m->d_valA, m->d_rD, s)) return -1;
+    if (!m->sym)
+    {
+        if (!m->d_valPT) LDU_CHECK_HIP(hipMalloc((void**)&m->d_valPT, sizeof(double) * nE));
+        if (k_scale_rows(a, m->d_valPT, m->d_valT, m->d_rD, s)) return -1;
+    }
+    m->rDKind = kind;
+    return 0;
+}
+
+int dev_precondition(ldu_matrix* m, int kind, double* w, const double* r, bool transpose, hipStream_t s)
+{
+    ldu_addr* a = m->a;
+    (void)s;
+    switch (kind)
+    {
+    case LDU_PRE_NONE:       // noPreconditioner.C:58-74
+        return k_ew(a->nCells, EW_COPY, w, r, nullptr, a->ctx->stream);
+    case LDU_PRE_DIAGONAL:   // diagonalPreconditioner.C:72-87
+        if (matrix_ensure_rD(m, kind)) return -1;
+        return k_ew(a->nCells, EW_MUL, w, m->d_rDiag, r, a->ctx->stream);
+    case LDU_PRE_DIC:
+    case LDU_PRE_FDIC:
+    case LDU_PRE_DILU:
+    {
+        if (matrix_ensure_rD(m, kind)) return -1;
+        // precondition : forward uses lower[] on the neighbour rows, backward upper[] on owned rows
+        // preconditionT: forward uses upper[], backward lower[]  (DILUPreconditioner.C:138-185)
+        const double* vp = (transpose && !m->sym) ? m->d_valPT : m->d_valP;
+        SweepArgs f{};
+        f.mode = SW_TRI_FWD; f.w = w; f.rhs = r; f.scale = m->d_rD; f.val = vp;
+        if (k_sweep(a, f)) return -1;
+        SweepArgs b{};
+        b.mode = SW_TRI_BWD; b.w = w; b.val = vp;
+        return k_sweep(a, b);
+    }
+    }
+    ldu_set_error("unknown preconditioner");
+    return -3;
+}
+
+// ---------------------------------------------------------------- smoothers
+
+static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSweeps, bool sym)
+{
+    ldu_addr* a = m->a;
+    hipStream_t s = a->ctx->stream;
+    double* bPrime = nullptr;
+    if (a->nPatchFaces || sym) bPrime = m->workVec(12);
+    for (int sweep = 0; sweep < nSweeps; sweep++)
+    {
+        const double* rhs = source;
+        if (a->nPatchFaces)
+        {
+            // bPrime = source; coupled boundaries Jacobi-style with negated coefficients
+            // (GaussSeidelSmoother.C:98-145)
+            if (halo_start(m, psi)) return -1;
+            if (k_ew(a->nCells, EW_COPY, bPrime, source, nullptr, s)) return -1;
+            if (k_apply_patches(a, bPrime, m->d_bou, -1.0, s)) return -1;
+            rhs = bPrime;
+        }
+        SweepArgs g{};
+        g.mode = SW_GS_FWD; g.w = psi; g.rhs = rhs; g.scale = m->d_diag; g.val = m->d_valA;
+        g.aux = sym ? bPrime : nullptr;
+        if (k_sweep(a, g)) return -1;
+        if (sym)
+        {
+            SweepArgs b{};
+            b.mode = SW_GS_BWD; b.w = psi; b.rhs = bPrime; b.scale = m->d_diag; b.val = m->d_valA;
+            if (k_sweep(a, b)) return -1;
+        }
+    }
+    return 0;
+}
+
+// DICSmoother.C:67-116, DILUSmoother.C:67-119, FDICSmoother.C:98-146
+static int smooth_dic(ldu_matrix* m, int kind, double* psi, const double* source, int nSweeps)
+{
+    ldu_addr* a = m->a;
+    hipStream_t s = a->ctx->stream;
+    if (matrix_ensure_rD(m, kind)) return -1;
+    double* rA = m->workVec(13);
+    double* w = m->workVec(14);
+    for (int sweep = 0; sweep < nSweeps; sweep++)
+    {
+        if (dev_residual(m, rA, psi, source)) return -1;
+        SweepArgs f{};
+        f.mode = SW_TRI_FWD; f.w = w; f.rhs = rA; f.scale = m->d_rD; f.val = m->d_valP;
+        if (k_sweep(a, f)) return -1;
+        SweepArgs b{};
+        b.mode = SW_TRI_BWD; b.w = w; b.val = m->d_valP;
+        if (k_sweep(a, b)) return -1;
+        if (k_ew(a->nCells, EW_ADD_INPLACE, psi, w, nullptr, s)) return -1;
+    }
+    return 0;
+}
+
+int dev_smooth(ldu_matrix* m, int smoother, double* psi, const double* source, int nSweeps)
+{
+    switch (smoother)
+    {
+    case LDU_SM_GAUSSSEIDEL:    return smooth_gs(m, psi, source, nSweeps, false);
+    case LDU_SM_SYMGAUSSSEIDEL: return smooth_gs(m, psi, source, nSweeps, true);
+    case LDU_SM_DIC:
+    case LDU_SM_FDIC:           return smooth_dic(m, LDU_PRE_DIC, psi, source, nSweeps);
+    case LDU_SM_DILU:           return smooth_dic(m, LDU_PRE_DILU, psi, source, nSweeps);
+    case LDU_SM_DICGAUSSSEIDEL:   // DICGaussSeidelSmoother.C:79-89
+        if (smooth_dic(m, LDU_PRE_DIC, psi, source, nSweeps)) return -1;
+        return smooth_gs(m, psi, source, nSweeps, false);
+    case LDU_SM_DILUGAUSSSEIDEL:
+        if (smooth_dic(m, LDU_PRE_DILU, psi, source, nSweeps)) return -1;
+        return smooth_gs(m, psi, source, nSweeps, false);
+    }
+    ldu_set_error("unknown smoother");
+    return -3;
+}
+
+// ---------------------------------------------------------------- convergence helpers
+
+// SolverPerformance.C:59-91
+static bool check_convergence(ldu_perf* p, double tol, double relTol)
+{
+    p->converged = (p->finalResidual < tol
+                    || (relTol > kSmall && p->finalResidual < relTol * p->initialResidual)) ? 1 : 0;
+    return p->converged != 0;
+}
+
+static void hist_push(ldu_perf* p, const ldu_controls* c, double* hist)
+{
+    if (hist && p->nHistory < c->historyCapacity) hist[p->nHistory] = p->finalResidual;
+    p->nHistory++;
+}
+
+// normFactor (lduMatrixSolver.C:179-197) -> device scalar S_NORM; leaves sumA*avg nowhere
+// (computed on the fly).  tmp receives sumA.
+static int dev_normFactor(ldu_matrix* m, const double* psi, const double* source, const double* Apsi,
+                          double* tmp)
+{
+    ldu_addr* a = m->a;
+    ldu_ctx* ctx = a->ctx;
+    hipStream_t s = ctx->stream;
+    if (dev_sumA(m, tmp)) return -1;
+    // gAverage(psi) = allreduce(sum)/allreduce(n) (FieldFunctions.C:514-533)
+    if (k_reduce(ctx, a->nCells, RED_SUM, psi, nullptr, nullptr, nullptr, S_SUMPSI, s)) return -1;
+    {
+        const double cnt = (double)a->nCells;
+        LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_COUNT, &cnt, sizeof(double), hipMemcpyHostToDevice, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    if (comm_allreduce_scalars(ctx, S_SUMPSI, 1, s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_COUNT, 1, s)) return -1;
+    if (k_reduce(ctx, a->nCells, RED_NORMFACTOR, Apsi, source, tmp, nullptr, S_NORM, s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_NORM, 1, s)) return -1;
+    // + solverPerformance::small_
+    double nf;
+    if (dev_read_scalars(ctx, S_NORM, 1, &nf)) return -1;
+    nf += kSmall;
+    return dev_write_scalar(ctx, S_NORM, nf);
+}
+
+// ---------------------------------------------------------------- PCG / PBiCG
+
+static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source,
+                        ldu_perf* perf, double* hist, bool bi)
+{
+    ldu_addr* a = m->a;
+    ldu_ctx* ctx = a->ctx;
+    hipStream_t s = ctx->stream;
+    const int n = a->nCells;
+    double* pA = m->workVec(0);
+    double* wA = m->workVec(1);
+    double* rA = m->workVec(2);
+    double *pT = nullptr, *wT = nullptr, *rT = nullptr;
+    if (bi) { pT = m->workVec(3); wT = m->workVec(4); rT = m->workVec(5); }
+
+    // --- A.psi, initial residual, normalisation factor (PCG.C:93-108)
+    if (dev_amul(m, wA, psi, false)) return -1;
+    if (k_ew(n, EW_SUB, rA, source, wA, s)) return -1;
+    if (bi)
+    {
+        if (dev_amul(m, wT, psi, true)) return -1;
+        if (k_ew(n, EW_SUB, rT, source, wT, s)) return -1;
+        if (k_ew(n, EW_ZERO, pT, nullptr, nullptr, s)) return -1;
+    }
+    if (dev_normFactor(m, psi, source, wA, pA)) return -1;
+    if (k_reduce(ctx, n, RED_SUMMAG, rA, nullptr, nullptr, nullptr, S_RES, s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_RES, 1, s)) return -1;
+    {
+        double z = 0.0;
+        LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_SINGULAR, &z, sizeof(double), hipMemcpyHostToDevice, s));
+        double g[2] = {kGreat, kGreat};   // wArA = great_ (PCG.C:89)
+        LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_WARA0, g, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    double v[2];
+    if (dev_read_scalars(ctx, S_RES, 2, v)) return -1;   // S_RES, S_NORM adjacent
+    const double normFactor = v[1];
+    perf->normFactor = normFactor;
+    perf->initialResidual = v[0] / normFactor;
+    perf->finalResidual = perf->initialResidual;
+    hist_push(perf, c, hist);
+
+    if (!check_convergence(perf, c->tolerance, c->relTol))
+    {
+        const int pre = c->preconditioner;
+        if (pre == LDU_PRE_GAMG)
+        {
+            if (gamg_precondition_setup(m, c)) return -1;
+        }
+        else if (pre != LDU_PRE_NONE)
+        {
+            if (matrix_ensure_rD(m, pre)) return -1;
+        }
+        int cur = S_WARA0, prev = S_WARA1;
+        do
+        {
+            // wArAold = wArA (slot swap)
+            { int t = cur; cur = prev; prev = t; }
+            // --- precondition (PCG.C:129 / PBiCG.C:138-139)
+            if (pre == LDU_PRE_GAMG)
+            {
+                if (gamg_precondition(m, c, wA, rA)) return -1;
+            }
+            else
+            {
+                if (dev_precondition(m, pre, wA, rA, false, s)) return -1;
+                if (bi && dev_precondition(m, pre, wT, rT, true, s)) return -1;
+            }
+            // --- wArA = gSumProd(wA, rA) / wArT = gSumProd(wA, rT)
+            if (k_reduce(ctx, n, RED_DOT, wA, bi ? rT : rA, nullptr, nullptr, cur, s)) return -1;
+            if (comm_allreduce_scalars(ctx, cur, 1, s)) return -1;
+            // --- search directions
+            const int first = perf->nIterations == 0;
+            if (bi)
+            {
+                if (k_pbicg_update_p(n, pA, wA, pT, wT, ctx->S(), cur, prev, first, s)) return -1;
+            }
+            else if (k_pcg_update_p(n, pA, wA, ctx->S(), cur, prev, first, s)) return -1;
+            // --- wA = A pA (wT = T pT)
+            if (dev_amul(m, wA, pA, false)) return -1;
+            if (bi && dev_amul(m, wT, pT, true)) return -1;
+            // --- wApA = gSumProd(wA, pA) / wApT = gSumProd(wA, pT)
+            if (k_reduce(ctx, n, RED_DOT, wA, bi ? pT : pA, nullptr, nullptr, S_WAPA, s)) return -1;
+            if (comm_allreduce_scalars(ctx, S_WAPA, 1, s)) return -1;
+            // --- singularity test + psi/rA update + |rA| partial sums, one pass
+            if (k_pcg_update_xr(ctx, n, psi, rA, pA, wA, rT, wT, cur, s)) return -1;
+            if (comm_allreduce_scalars(ctx, S_RES, 1, s)) return -1;
+            double rs[3];
+            if (dev_read_scalars(ctx, S_RES, 3, rs)) return -1;   // S_RES, S_NORM, S_SINGULAR
+            if (rs[2] != 0.0) { perf->singular = 1; break; }
+            perf->finalResidual = rs[0] / normFactor;
+            hist_push(perf, c, hist);
+        } while (perf->nIterations++ < c->maxIter && !check_convergence(perf, c->tolerance, c->relTol));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- smoothSolver
+
+static int solve_smooth(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source,
+                        ldu_perf* perf, double* hist)
+{
+    ldu_addr* a = m->a;
+    ldu_ctx* ctx = a->ctx;
+    hipStream_t s = ctx->stream;
+    const int n = a->nCells;
+    if (c->nSweeps < 0)
+    {
+        if (dev_smooth(m, c->smoother, psi, source, -c->nSweeps)) return -1;
+        perf->nIterations -= c->nSweeps;
+        return 0;
+    }
+    double* Apsi = m->workVec(0);
+    double* temp = m->workVec(1);
+    if (dev_amul(m, Apsi, psi, false)) return -1;
+    if (dev_normFactor(m, psi, source, Apsi, temp)) return -1;
+    if (k_ew(n, EW_SUB, temp, source, Apsi, s)) return -1;
+    if (k_reduce(ctx, n, RED_SUMMAG, temp, nullptr, nullptr, nullptr, S_RES, s)) return -1;
+    if (comm_allreduce_scalars(ctx, S_RES, 1, s)) return -1;
+    double v[2];
+    if (dev_read_scalars(ctx, S_RES, 2, v)) return -1;
+    const double normFactor = v[1];
+    perf->normFactor = normFactor;
+    perf->initialResidual = v[0] / normFactor;
+    perf->finalResidual = perf->initialResidual;
+    hist_push(perf, c, hist);
+    if (!check_convergence(perf, c->tolerance, c->relTol))
+    {
+        do
+        {
+            if (dev_smooth(m, c->smoother, psi, source, c->nSweeps)) return -1;
+            if (dev_residual(m, temp, psi, source)) return -1;
+            if (k_reduce(ctx, n, RED_SUMMAG, temp, nullptr, nullptr, nullptr, S_RES, s)) return -1;
+            if (comm_allreduce_scalars(ctx, S_RES, 1, s)) return -1;
+            double r;
+            if (dev_read_scalars(ctx, S_RES, 1, &r)) return -1;
+            perf->finalResidual = r / normFactor;
+            hist_push(perf, c, hist);
+        } while ((perf->nIterations += c->nSweeps) < c->maxIter
+                 && !check_convergence(perf, c->tolerance, c->relTol));
+    }
+    return 0;
+}
+
+int dev_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
+              double* hist)
+{
+    ldu_addr* a = m->a;
+    switch (c->solver)
+    {
+    case LDU_SOLVER_PCG:
+        if (!m->sym && c->preconditioner != LDU_PRE_NONE && c->preconditioner != LDU_PRE_DIAGONAL
+            && c->preconditioner != LDU_PRE_GAMG)
+        {
+            // the reference has no DIC for asymmetric matrices (lduMatrixPreconditioner.C:98-124)
+        }
+        return solve_krylov(m, c, psi, source, perf, hist, false);
+    case LDU_SOLVER_PBICG:
+        return solve_krylov(m, c, psi, source, perf, hist, true);
+    case LDU_SOLVER_SMOOTH:
+        return solve_smooth(m, c, psi, source, perf, hist);
+    case LDU_SOLVER_GAMG:
+        return gamg_solve(m, c, psi, source, perf, hist);
+    case LDU_SOLVER_DIAGONAL:   // diagonalSolver.C:62-81
+        if (k_ew(a->nCells, EW_DIV, psi, source, m->d_diag, a->ctx->stream)) return -1;
+        perf->converged = 1;
+        return 0;
+    }
+    ldu_set_error("unknown solver");
+    return -3;
+}
