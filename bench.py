@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py - GAMG / PCG iterations per second and achieved HBM GB/s of the 10 M-cell p-solve.
+
+Workload (BASELINE.json configs[2]): the synthetic stand-in for the motorBike
+pressure matrix - structured 216^3 hex box (10 077 696 cells, 30 093 120 faces), variable-
+coefficient 7-point Laplacian (seed 12345), solved with the motorBike tutorial's GAMG block
+(tolerance 1e-7, relTol 0.01, GaussSeidel, nPostSweeps 2, faceAreaPair, nCellsInCoarsestLevel 10,
+mergeLevels 1, cacheAgglomeration on).
+
+A step = one complete p-solve: coefficients (already resident in HBM) handed to the solver
+(ldu_matrix_set_coeffs: layout + level-matrix agglomeration, as the reference rebuilds them in
+every solver construction), psi reset to 0, then lduMatrix::solver::solve.  One-time addressing
+work (dependency levels, agglomeration maps) happens before the timed region, like the
+reference's cached lduAddressing / cacheAgglomeration.
+
+value = V-cycles (the reference's nIterations) of all timed steps / wall time.
+N > 1: the same matrix decomposed into N sub-domains (strong scaling), one rank per GPU, halo
+exchange + scalar all-reduces on RCCL.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+GAMG_CONTROLS = dict(solver="GAMG", tolerance=1e-7, relTol=0.01, smoother="GaussSeidel",
+                     nPreSweeps=0, nPostSweeps=2, nFinestSweeps=2, cacheAgglomeration=1,
+                     agglomerator="faceAreaPair", nCellsInCoarsestLevel=10, mergeLevels=1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-n", type=int, default=0, help="box edge of the CPU sample (0 = same)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the lduMatrix HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    entry.load_package()
+    from openfoam_amd import capi, cases, decompose
+
+    n = args.n
+    t_gen = time.perf_counter()
+    p = cases.box3d(n)
+    t_gen = time.perf_counter() - t_gen
+    nC_total, nF_total = p["nCells"], int(p["lowerAddr"].size)
+
+    if world > 1:
+        # 2x2x2 blocks at 8 ranks, slabs/blocks otherwise
+        shape = {2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(world, (1, 1, world))
+        cell_rank = decompose.block_ranks(n, n, n, *shape)
+        subs, cell_maps = decompose.decompose(p, cell_rank, world)
+        lp = subs[rank]
+        del subs
+    else:
+        lp = p
+
+    ctx = capi.Context(local_rank)
+    if world > 1:
+        uid = [capi.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, world, uid[0])
+
+    t0 = time.perf_counter()
+    addr = capi.Addressing(ctx, lp["nCells"], lp["lowerAddr"], lp["upperAddr"], lp.get("faceWeights"),
+                           patches=lp.get("patches_dev", ()))
+    mat = capi.Matrix(addr)
+    t_addr = time.perf_counter() - t0
+    info = addr.info()
+
+    # inputs resident in HBM before the timed region
+    d_diag = torch.from_numpy(lp["diag"]).to(dev)
+    d_upper = torch.from_numpy(lp["upper"]).to(dev)
+    d_source = torch.from_numpy(lp["source"]).to(dev)
+    d_psi = torch.zeros(lp["nCells"], dtype=torch.float64, device=dev)
+    d_patch = []
+    for i, q in enumerate(lp.get("patches", [])):
+        d_patch.append((torch.from_numpy(q["bouCoeffs"]).to(dev), torch.from_numpy(q["intCoeffs"]).to(dev)))
+    torch.cuda.synchronize()
+
+    def step(controls):
+        d_psi.zero_()
+        torch.cuda.synchronize()
+        mat.set_coeffs(d_diag, d_upper)
+        for i, (b, c) in enumerate(d_patch):
+            mat.set_patch_coeffs(i, b, c)
+        _, perf = mat.solve(d_psi, d_source, history=True, **controls)
+        return perf
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # first solve also builds the cached agglomeration (one-time, reported separately)
+    t0 = time.perf_counter()
+    perf0 = step(GAMG_CONTROLS)
+    barrier()
+    t_first = time.perf_counter() - t0
+    for _ in range(max(0, args.warmup - 1)):
+        step(GAMG_CONTROLS)
+
+    barrier()
+    mat.profile_begin()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        perf = step(GAMG_CONTROLS)
+        iters += perf["nIterations"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = mat.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    nC, nF = lp["nCells"], int(lp["lowerAddr"].size)
+    # algorithmic bytes: GaussSeidel sweep sym 60 nC + 12 nF ; Amul sym 24 nC + 16 nF
+    gs_bytes = 60.0 * nC + 12.0 * nF
+    amul_bytes = 24.0 * nC + 16.0 * nF
+    roof = None
+    if "gs_sweep" in prof and prof["gs_sweep"]["count"]:
+        ms = prof["gs_sweep"]["ms"] / prof["gs_sweep"]["count"]
+        ach = gs_bytes / (ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel="GaussSeidel sweep (finest level; one graph launch of "
+                    "%d dependency-level kernels)" % info["nLevels"], achieved=round(ach, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                    avg_launch_ms=round(ms, 4), bytes_per_launch=gs_bytes,
+                    launches=prof["gs_sweep"]["count"])
+    amul = None
+    if "amul" in prof and prof["amul"]["count"]:
+        ms = prof["amul"]["ms"] / prof["amul"]["count"]
+        ach = amul_bytes / (ms * 1e-3) / 1e9
+        amul = dict(kernel="row_kernel<0> (Amul)", achieved=round(ach, 1), unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), avg_launch_ms=round(ms, 4),
+                    bytes_per_launch=amul_bytes, launches=prof["amul"]["count"])
+
+    # extra: PCG+DIC iterations/s on the same matrix (fixed 40 iterations)
+    extra = {}
+    try:
+        d_psi.zero_()
+        torch.cuda.synchronize()
+        mat.profile_begin()
+        t0 = time.perf_counter()
+        _, pp = mat.solve(d_psi, d_source, history=False, solver="PCG", preconditioner="DIC",
+                          tolerance=0.0, relTol=0.0, maxIter=39)
+        barrier()
+        tp = time.perf_counter() - t0
+        pprof = mat.profile_end()
+        nit = pp["nIterations"]
+        extra["pcg_dic_iterations_per_s"] = round(nit / tp, 2)
+        extra["pcg_dic_GBs_algorithmic"] = round((160.0 * nC + 48.0 * nF) * nit / tp / 1e9, 1)
+        if "tri_sweep" in pprof:
+            extra["dic_sweep_avg_ms"] = round(pprof["tri_sweep"]["ms"] / pprof["tri_sweep"]["count"], 4)
+    except Exception as e:  # pragma: no cover
+        extra["pcg_error"] = str(e)
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py
+        cn = args.cpu_n or n
+        cp = p if cn == n else cases.box3d(cn)
+        S = oracle_py.System(cp)
+        okw = dict(smoother="GaussSeidel", nCellsInCoarsestLevel=10, mergeLevels=1,
+                   agglomerator="faceAreaPair", tolerance=1e-7, relTol=0.01)
+        secs, setup = S.time_gamg_vcycles(cp["source"], nVcycles=2, **okw)
+        scale = (cn ** 3) / float(n ** 3)
+        cpu = dict(value=round(2.0 / secs * scale, 4), unit="V-cycles/s", cores=1, kind="port",
+                   sample="oracle (C restatement, gcc -O2, 1 thread): 2 GAMG V-cycles on the %d^3 box "
+                          "(%.1f s; agglomeration %.1f s excluded, cached like cacheAgglomeration)"
+                          % (cn, secs, setup) + ("" if cn == n else "; scaled by cell count to %d^3" % n))
+
+    if rank == 0:
+        out = {
+            "metric": "GAMG p-solve iterations/sec (V-cycles/s) + achieved HBM GB/s, 10M-cell motorBike stand-in",
+            "value": round(iters / elapsed, 3),
+            "unit": "V-cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "simpleFoam motorBike ~10M-cell p-solve stand-in: %d^3 hex box "
+                                   "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
+                                   "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total),
+                       "parallelism": "domain decomposition x%d" % world,
+                       "vcycles_per_solve": perf["nIterations"],
+                       "dependency_levels_finest": info["nLevels"]},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "amul": amul,
+            "extra": dict(extra, first_solve_s=round(t_first, 3), addressing_setup_s=round(t_addr, 3),
+                          problem_generation_s=round(t_gen, 3),
+                          initial_residual=perf["initialResidual"], final_residual=perf["finalResidual"],
+                          residual_history=[float("%.6e" % h) for h in perf["history"]]),
+        }
+        print(json.dumps(out))
+    mat.close()
+    addr.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,18 @@ int ldu_gamg_levels(ldu_matrix* m, const ldu_controls* controls, int32_t* nLevel
 int ldu_gamg_level_data(ldu_matrix* m, int32_t level, int32_t* restrictAddr /* fine nCells */,
                         double* diag, double* upper, double* lower /* may be NULL */);
 
+/* ---- measurement: HIP-event timing of kernel classes on the library's compute stream -----
+ * (the stream is private to the library, so an outside torch.cuda.Event cannot see it).
+ * Only operations on the addressing of `m` (the finest level) are recorded. */
+enum { LDU_PROF_AMUL = 0,      /* Amul/Tmul row kernel: one launch each                      */
+       LDU_PROF_GS_SWEEP = 1,  /* one GaussSeidel sweep = one graph launch of level kernels   */
+       LDU_PROF_TRI_SWEEP = 2, /* one DIC/DILU forward or backward sweep (graph launch)       */
+       LDU_PROF_RESIDUAL = 3,  /* residual row kernel                                         */
+       LDU_PROF_NCATS = 8 };
+int ldu_profile_begin(ldu_matrix* m);
+/* ms[c] = total milliseconds, counts[c] = recorded launches of class c since begin */
+int ldu_profile_end(ldu_matrix* m, double ms[8], int64_t counts[8]);
+
 /* ---- finite-volume stencils feeding the matrix ------------- */
 typedef struct ldu_mesh_geom {
     /* internal faces */

@@ -26,7 +26,7 @@ EXPORTS = [
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
     "ldu_gSumProd", "ldu_gSumMag", "ldu_precondition", "ldu_smooth", "ldu_solve", "ldu_gamg_levels",
     "ldu_gamg_level_data", "ldu_fv_interpolate", "ldu_fvc_surfaceIntegrate", "ldu_fvc_gaussGrad",
-    "ldu_fvc_snGrad", "ldu_fvm_laplacian", "ldu_fvm_div",
+    "ldu_fvc_snGrad", "ldu_fvm_laplacian", "ldu_fvm_div", "ldu_profile_begin", "ldu_profile_end",
 ]
 
 
@@ -299,6 +299,16 @@ class Matrix:
                        normFactor=perf.normFactor, nIterations=perf.nIterations,
                        converged=bool(perf.converged), singular=bool(perf.singular),
                        history=hist[:n].copy(), solveSeconds=perf.solveSeconds)
+
+    def profile_begin(self):
+        _chk(lib().ldu_profile_begin(self.h))
+
+    def profile_end(self):
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        _chk(lib().ldu_profile_end(self.h, ms, cnt))
+        names = ["amul", "gs_sweep", "tri_sweep", "residual", "c4", "c5", "c6", "rd_sweep"]
+        return {n: dict(ms=ms[i], count=cnt[i]) for i, n in enumerate(names) if cnt[i]}
 
     def gamg_levels(self, **controls):
         c = make_controls(**controls)

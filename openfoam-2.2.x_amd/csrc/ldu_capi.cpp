@@ -26,6 +26,29 @@ static bool is_device_ptr(const void* p)
     return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
+void ldu_ctx::profStart(const ldu_addr* a, int cat)
+{
+    if (!profOn || a != profAddr) return;
+    ProfCat& P = prof[cat];
+    if (P.used + 2 > 16384) return;
+    while (P.ev.size() < P.used + 2)
+    {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        P.ev.push_back(e);
+    }
+    (void)hipEventRecord(P.ev[P.used], stream);
+}
+
+void ldu_ctx::profStop(const ldu_addr* a, int cat)
+{
+    if (!profOn || a != profAddr) return;
+    ProfCat& P = prof[cat];
+    if (P.used + 2 > 16384 || P.ev.size() < P.used + 2) return;
+    (void)hipEventRecord(P.ev[P.used + 1], stream);
+    P.used += 2;
+}
+
 extern "C" {
 
 const char* ldu_last_error(void) { return g_err.c_str(); }
@@ -515,6 +538,36 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
     perf->solveSeconds = now_s() - t0;
     if (rc) return rc;
     return S.out(psi, x);
+}
+
+int ldu_profile_begin(ldu_matrix* m)
+{
+    ldu_ctx* ctx = m->a->ctx;
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& c : ctx->prof) { c.used = 0; c.launches = 0; }
+    ctx->profAddr = m->a;
+    ctx->profOn = true;
+    return 0;
+}
+
+int ldu_profile_end(ldu_matrix* m, double ms[8], int64_t counts[8])
+{
+    ldu_ctx* ctx = m->a->ctx;
+    ctx->profOn = false;
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < LDU_PROF_NCAT; c++)
+    {
+        double tot = 0;
+        auto& P = ctx->prof[c];
+        for (size_t i = 0; i + 1 < P.used; i += 2)
+        {
+            float t = 0;
+            if (hipEventElapsedTime(&t, P.ev[i], P.ev[i + 1]) == hipSuccess) tot += t;
+        }
+        ms[c] = tot;
+        counts[c] = (int64_t)(P.used / 2);
+    }
+    return 0;
 }
 
 int ldu_gamg_levels(ldu_matrix* m, const ldu_controls* c, int32_t* nLevels, int32_t* nCells, int32_t* nFaces)

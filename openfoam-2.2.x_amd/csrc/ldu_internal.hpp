@@ -36,6 +36,7 @@ void ldu_set_error(const std::string& msg);
     } while (0)
 
 struct ldu_comm_impl;  // RCCL wrapper (ldu_comm.cpp)
+#define LDU_PROF_NCAT 8
 
 // scalar slots on the device
 enum {
@@ -59,6 +60,13 @@ struct ldu_ctx {
     // communicator
     int rank = 0, nRanks = 1;
     ldu_comm_impl* comm = nullptr;
+    // per-kernel-class timing with HIP events on the compute stream (bench.py roofline)
+    bool profOn = false;
+    const struct ldu_addr* profAddr = nullptr;
+    struct ProfCat { std::vector<hipEvent_t> ev; size_t used = 0; long launches = 0; };
+    ProfCat prof[LDU_PROF_NCAT];
+    void profStart(const struct ldu_addr* a, int cat);
+    void profStop(const struct ldu_addr* a, int cat);
 };
 
 struct Segment {

@@ -171,11 +171,17 @@ static int launch_row(ldu_matrix* m, double* y, const double* x, const double* b
 
 int k_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStream_t s)
 {
-    return launch_row<0>(m, y, x, nullptr, transpose ? m->d_valT : m->d_valA, s);
+    m->a->ctx->profStart(m->a, LDU_PROF_AMUL);
+    int rc = launch_row<0>(m, y, x, nullptr, transpose ? m->d_valT : m->d_valA, s);
+    m->a->ctx->profStop(m->a, LDU_PROF_AMUL);
+    return rc;
 }
 int k_residual_rows(ldu_matrix* m, double* r, const double* x, const double* b, hipStream_t s)
 {
-    return launch_row<1>(m, r, x, b, m->d_valA, s);
+    m->a->ctx->profStart(m->a, LDU_PROF_RESIDUAL);
+    int rc = launch_row<1>(m, r, x, b, m->d_valA, s);
+    m->a->ctx->profStop(m->a, LDU_PROF_RESIDUAL);
+    return rc;
 }
 int k_sumA_rows(ldu_matrix* m, double* sumA, hipStream_t s)
 {
@@ -372,7 +378,15 @@ int k_sweep(ldu_addr* a, const SweepArgs& g)
     ldu_ctx* ctx = a->ctx;
     hipStream_t s = ctx->stream;
     if (a->nCells == 0) return 0;
-    if (!ctx->useGraphs || a->segs.size() <= 2) return launch_sweep(a, g, s);
+    const int cat = (g.mode == SW_GS_FWD || g.mode == SW_GS_BWD) ? LDU_PROF_GS_SWEEP
+                    : (g.mode == SW_RD ? 7 : LDU_PROF_TRI_SWEEP);
+    if (!ctx->useGraphs || a->segs.size() <= 2)
+    {
+        ctx->profStart(a, cat);
+        int rc = launch_sweep(a, g, s);
+        ctx->profStop(a, cat);
+        return rc;
+    }
 
     char key[256];
     snprintf(key, sizeof(key), "%d|%p|%p|%p|%p|%p|%p", g.mode, (void*)g.w, (const void*)g.rhs,
@@ -399,7 +413,9 @@ int k_sweep(ldu_addr* a, const SweepArgs& g)
         }
         it = a->graphs.emplace(key, exec).first;
     }
+    ctx->profStart(a, cat);
     LDU_CHECK_HIP(hipGraphLaunch(it->second, s));
+    ctx->profStop(a, cat);
     return 0;
 }
 

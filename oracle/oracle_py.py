@@ -237,6 +237,24 @@ class System:
                        converged=bool(perf.converged), singular=bool(perf.singular),
                        history=hist[:perf.nHist].copy())
 
+    def time_gamg_vcycles(self, rA, nVcycles=2, **optkw):
+        """CPU baseline helper: build the hierarchy once (cacheAgglomeration), then time
+        nVcycles V-cycles (GAMGPreconditioner-style application).  Returns (seconds, setup_s)."""
+        import time
+        o = make_opts(nVcycles=nVcycles, **optkw)
+        fw = self.face_weights()
+        L = lib()
+        L.orc_gamg_pre_new.restype = C.c_void_p
+        t0 = time.perf_counter()
+        g = C.c_void_p(L.orc_gamg_pre_new(C.byref(self.sys), C.byref(o), _p(fw)))
+        t1 = time.perf_counter()
+        w = self._vec()
+        r = self._vec(rA)
+        L.orc_gamg_pre_apply(g, _p(w), _p(r))
+        t2 = time.perf_counter()
+        L.orc_gamg_pre_free(g)
+        return t2 - t1, t1 - t0
+
     def gamg_levels(self, **optkw):
         o = make_opts(**optkw)
         fw = self.face_weights()
