@@ -102,7 +102,20 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * S_NSLOTS));
     LDU_CHECK_HIP(hipMemset(c->d_scalars, 0, sizeof(double) * S_NSLOTS));
     LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * S_NSLOTS, hipHostMallocDefault));
-    const char* e = getenv("LDU_NO_GRAPH");
+    LDU_CHECK_HIP(hipMalloc((void**)&c->d_abort, sizeof(int)));
+    LDU_CHECK_HIP(hipMemset(c->d_abort, 0, sizeof(int)));
+    LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_abort, sizeof(int), hipHostMallocDefault));
+    *c->h_abort = 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->numCUs = prop.multiProcessorCount;
+    }
+    const char* e = getenv("LDU_SWEEP");
+    if (e && !strcmp(e, "levels")) c->sweepP2P = 0;
+    e = getenv("LDU_P2P_BPC");
+    if (e && atoi(e) > 0) c->p2pBlocksPerCU = atoi(e);
+    e = getenv("LDU_NO_GRAPH");
     if (e && atoi(e)) c->useGraphs = false;
     e = getenv("LDU_FUSE_ROWS");
     if (e) c->fuseRows = atoi(e);
@@ -119,6 +132,8 @@ int ldu_ctx_destroy(ldu_ctx* c)
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_scalars);
     (void)hipHostFree(c->h_scalars);
+    (void)hipFree(c->d_abort);
+    (void)hipHostFree(c->h_abort);
     (void)hipEventDestroy(c->evFork);
     (void)hipEventDestroy(c->evJoin);
     (void)hipStreamDestroy(c->stream);
@@ -359,7 +374,14 @@ struct Stager {
     int out(double* user, const double* devNew)
     {
         if (!a->nCells) return 0;
-        if (is_device_ptr(user)) return k_permute_out(a, user, devNew, s);
+        if (is_device_ptr(user))
+        {
+            // blocking like the reference's solve(): the caller may touch `user` from any
+            // stream as soon as we return
+            if (k_permute_out(a, user, devNew, s)) return -1;
+            LDU_CHECK_HIP(hipStreamSynchronize(s));
+            return 0;
+        }
         double* st = a->scratchVec(nextScratch++);
         if (!st) return -1;
         if (k_permute_out(a, st, devNew, s)) return -1;

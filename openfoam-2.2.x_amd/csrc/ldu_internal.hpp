@@ -57,6 +57,13 @@ struct ldu_ctx {
     double* S() const { return d_scalars + sb; }
     bool useGraphs = true;
     int fuseRows = 4096;             // levels up to this many rows are fused into one-block chains
+    // sweep engine: 1 = persistent point-to-point kernel (default), 0 = one kernel per level
+    int sweepP2P = 1;
+    int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
+    int numCUs = 256;
+    int* d_abort = nullptr;          // set by a sweep whose bounded spin expired
+    int* h_abort = nullptr;          // pinned mirror
+    int p2pGen = 0;                  // bumped when a sweep aborted: addressings reset their tickets
     // communicator
     int rank = 0, nRanks = 1;
     ldu_comm_impl* comm = nullptr;
@@ -131,6 +138,14 @@ struct ldu_addr {
     int* d_pfCell = nullptr;               // [nPatchFaces] faceCells (new numbering), concatenated
     double* d_sendAll = nullptr;           // [nPatchFaces]
     double* d_recvAll = nullptr;           // [nPatchFaces]
+
+    // point-to-point sweep state: one 16-byte {value lo, tag, value hi, tag} granule per row,
+    // a chunk ticket counter and the launch epoch (= tag; never 0)
+    uint4* d_granule = nullptr;            // [nCells]
+    unsigned* d_ticket = nullptr;          // [1]
+    unsigned ticketBase = 0;
+    unsigned epoch = 0;
+    int p2pGen = 0;
 
     // cached graphs of level-scheduled sweeps, keyed by (mode, pointer arguments)
     std::map<std::string, hipGraphExec_t> graphs;

@@ -371,8 +371,270 @@ static int launch_sweep(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     return -1;
 }
 
-// A sweep is hundreds of dependent launches: capture once per (mode, pointers) into a
-// hipGraph and replay (launch-bound inner loop -> graph, per the MI355X playbook).
+// ---------------------------------------------------------------- persistent point-to-point sweep
+//
+// One launch per sweep.  Slices are taken in dependency-level order through a chunk ticket
+// (atomicAdd, one per CHUNK slices), so every slice a wave can wait for has already been taken
+// by a RUNNING workgroup: forward progress without any co-residency assumption.
+// A finished row publishes {value, tag = launch epoch} as two 8-byte agent-scope (sc1,
+// write-through) granules {v_lo, tag}, {v_hi, tag}; a consumer polls the 16 bytes with sc1 loads
+// (L2/fabric served, never the stale per-CU L1) until both tags match - no flags, no fences, no
+// reset pass (MI355X_MICROARCH.md "handoff-1to1", cdna_hip_programming.md G16 form R2).
+// Everything a row needs that does not depend on other rows of this sweep (coefficients,
+// columns, rhs) is loaded before the wait, so the critical path per dependency level is one
+// cross-CU hand-off instead of a kernel boundary plus a chain of dependent HBM loads.
+// Spins are bounded: on expiry the sweep sets *abortFlag and every wave drains.
+
+#define P2P_CHUNK WPB          // slices per ticket: one per wave of the workgroup
+#define P2P_SPIN_LIMIT (1u << 22)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void granule_store(uint4* G, int row, double v, unsigned tag)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    u32x4 d;
+    d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
+    uint4* p = G + row;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+}
+
+// four granule loads in flight, one wait
+__device__ __forceinline__ void granule_load4(const uint4* p0, const uint4* p1, const uint4* p2,
+                                              const uint4* p3, u32x4& g0, u32x4& g1, u32x4& g2,
+                                              u32x4& g3)
+{
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+}
+
+__device__ __forceinline__ double granule_value(const u32x4& g)
+{
+    return __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
+}
+
+// acc -= sum_{i=0..n-1} val[e(i)] * (value of row col[e(i)] published in THIS sweep), in order;
+// entry index k(i) = first + i*step.  OP = 0: acc -= v*x ; OP = 1: acc -= (v2*v)/x  (SW_RD)
+template <int OP>
+__device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restrict__ G, unsigned tag,
+                                               const int* __restrict__ col,
+                                               const double* __restrict__ val,
+                                               const double* __restrict__ val2, long ent, int first,
+                                               int step, int n, int selfRow, volatile int* abortFlag)
+{
+    for (int i0 = 0; i0 < n; i0 += 4)
+    {
+        int c[4];
+        double v[4], v2[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const bool need = i0 + j < n;
+            const long e = ent + (long)(first + (i0 + j) * step) * LDU_WAVE;
+            c[j] = need ? col[e] : selfRow;
+            v[j] = need ? val[e] : 0.0;
+            v2[j] = (OP == 1 && need) ? val2[e] : 0.0;
+        }
+        u32x4 g0, g1, g2, g3;
+        unsigned spins = 0;
+        for (;;)
+        {
+            granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
+            bool ok = true;
+            if (i0 + 0 < n) ok &= (g0.y == tag) & (g0.w == tag);
+            if (i0 + 1 < n) ok &= (g1.y == tag) & (g1.w == tag);
+            if (i0 + 2 < n) ok &= (g2.y == tag) & (g2.w == tag);
+            if (i0 + 3 < n) ok &= (g3.y == tag) & (g3.w == tag);
+            if (ok) break;
+            if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
+            {
+                *abortFlag = 1;
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const double x0 = granule_value(g0), x1 = granule_value(g1), x2 = granule_value(g2),
+                     x3 = granule_value(g3);
+        if (OP == 0)
+        {
+            if (i0 + 0 < n) acc -= v[0] * x0;
+            if (i0 + 1 < n) acc -= v[1] * x1;
+            if (i0 + 2 < n) acc -= v[2] * x2;
+            if (i0 + 3 < n) acc -= v[3] * x3;
+        }
+        else
+        {
+            if (i0 + 0 < n) acc -= (v2[0] * v[0]) / x0;
+            if (i0 + 1 < n) acc -= (v2[1] * v[1]) / x1;
+            if (i0 + 2 < n) acc -= (v2[2] * v[2]) / x2;
+            if (i0 + 3 < n) acc -= (v2[3] * v[3]) / x3;
+        }
+    }
+    return true;
+}
+
+template <int MODE>
+__device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, uint4* __restrict__ G,
+                                          unsigned tag, volatile int* abortFlag, double* __restrict__ w,
+                                          const double* __restrict__ rhs,
+                                          const double* __restrict__ scale,
+                                          const double* __restrict__ val,
+                                          const double* __restrict__ val2, double* __restrict__ aux)
+{
+    const int cnt = T.sliceCnt[s];
+    if (lane >= cnt) return true;
+    const int r = T.sliceRow[s] + lane;
+    const int nl = T.nL[r];
+    const int nu = T.nU[r];
+    const long ent = (long)T.sliceEnt[s] + lane;
+    double out;
+    if (MODE == SW_TRI_FWD)
+    {
+        double acc = scale[r] * rhs[r];
+        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag)) return false;
+        out = acc;
+    }
+    else if (MODE == SW_TRI_BWD)
+    {
+        double acc = w[r];
+        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, nl + nu - 1, -1, nu, r, abortFlag)) return false;
+        out = acc;
+    }
+    else if (MODE == SW_RD)
+    {
+        double acc = scale[r];
+        if (!p2p_accumulate<1>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag)) return false;
+        out = acc;
+    }
+    else if (MODE == SW_GS_FWD)
+    {
+        // old values of the upper neighbours: plain loads, issued before the wait
+        double acc = rhs[r];
+        const double d = scale[r];
+        double xu[8];
+        double vu[8];
+        const int nuFast = nu <= 8 ? nu : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+            if (j < nuFast)
+            {
+                const long e = ent + (long)(nl + j) * LDU_WAVE;
+                vu[j] = val[e];
+                xu[j] = w[T.col[e]];
+            }
+        }
+        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag)) return false;
+        if (aux) aux[r] = acc;
+        if (nuFast)
+        {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j < nuFast) acc -= vu[j] * xu[j];
+        }
+        else
+        {
+            for (int k = nl; k < nl + nu; k++)
+            {
+                const long e = ent + (long)k * LDU_WAVE;
+                acc -= val[e] * w[T.col[e]];
+            }
+        }
+        out = acc / d;
+    }
+    else   // SW_GS_BWD
+    {
+        double acc = rhs[r];
+        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, nl, 1, nu, r, abortFlag)) return false;
+        out = acc / scale[r];
+    }
+    w[r] = out;
+    granule_store(G, r, out, tag);
+    return true;
+}
+
+template <int MODE, bool DESC>
+__global__ void __launch_bounds__(BLK)
+sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, uint4* G,
+                 unsigned tag, int* abortFlag, double* w, const double* rhs, const double* scale,
+                 const double* val, const double* val2, double* aux)
+{
+    __shared__ int s_chunk[2];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // thread 0 keeps one ticket in flight ahead of the one being processed
+    int nextT = 0;
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    for (int it = 0;; it++)
+    {
+        if (threadIdx.x == 0)
+        {
+            // an expired spin anywhere drains the whole grid (uniform per workgroup)
+            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            s_chunk[it & 1] = t;
+            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+        }
+        __syncthreads();
+        const int chunk = s_chunk[it & 1];
+        if (chunk >= nChunks) return;
+        const int si = chunk * P2P_CHUNK + wave;
+        if (si < nSlices)
+        {
+            const int s = DESC ? nSlices - 1 - si : si;
+            p2p_slice<MODE>(T, s, lane, G, tag, abortFlag, w, rhs, scale, val, val2, aux);
+        }
+    }
+}
+
+template <int MODE, bool DESC>
+static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
+{
+    ldu_ctx* ctx = a->ctx;
+    SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    const int nChunks = cdiv(a->nSlices, P2P_CHUNK);
+    int grid = ctx->numCUs * ctx->p2pBlocksPerCU;
+    if (grid > nChunks) grid = nChunks;
+    if (grid < 1) grid = 1;
+    if (a->p2pGen != ctx->p2pGen)
+    {
+        // a previous sweep aborted somewhere: ticket counters are no longer in step
+        LDU_CHECK_HIP(hipMemsetAsync(a->d_ticket, 0, sizeof(unsigned), s));
+        a->ticketBase = 0;
+        a->p2pGen = ctx->p2pGen;
+    }
+    a->epoch++;
+    if (a->epoch == 0) a->epoch = 1;   // tag 0 = never published
+    sweep_p2p_kernel<MODE, DESC><<<grid, BLK, 0, s>>>(T, a->nSlices, nChunks, a->d_ticket, a->ticketBase,
+        a->d_granule, a->epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+    // every workgroup overshoots the ticket exactly once
+    a->ticketBase += (unsigned)(nChunks + grid);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_sweep_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
+{
+    switch (g.mode)
+    {
+    case SW_TRI_FWD: return launch_p2p<SW_TRI_FWD, false>(a, g, s);
+    case SW_TRI_BWD: return launch_p2p<SW_TRI_BWD, true>(a, g, s);
+    case SW_RD:      return launch_p2p<SW_RD, false>(a, g, s);
+    case SW_GS_FWD:  return launch_p2p<SW_GS_FWD, false>(a, g, s);
+    case SW_GS_BWD:  return launch_p2p<SW_GS_BWD, true>(a, g, s);
+    }
+    return -1;
+}
+
+// Level-kernel engine: a sweep is hundreds of dependent launches: capture once per (mode,
+// pointers) into a hipGraph and replay.  Kept as the fallback / cross-check of the
+// point-to-point engine (LDU_SWEEP=levels).
 int k_sweep(ldu_addr* a, const SweepArgs& g)
 {
     ldu_ctx* ctx = a->ctx;
@@ -380,6 +642,13 @@ int k_sweep(ldu_addr* a, const SweepArgs& g)
     if (a->nCells == 0) return 0;
     const int cat = (g.mode == SW_GS_FWD || g.mode == SW_GS_BWD) ? LDU_PROF_GS_SWEEP
                     : (g.mode == SW_RD ? 7 : LDU_PROF_TRI_SWEEP);
+    if (ctx->sweepP2P)
+    {
+        ctx->profStart(a, cat);
+        int rc = launch_sweep_p2p(a, g, s);
+        ctx->profStop(a, cat);
+        return rc;
+    }
     if (!ctx->useGraphs || a->segs.size() <= 2)
     {
         ctx->profStart(a, cat);

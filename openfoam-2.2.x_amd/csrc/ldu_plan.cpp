@@ -204,6 +204,13 @@ int plan_build(ldu_addr* a)
     if (upload(&a->d_losort, a->losort)) return -1;
     if (upload(&a->d_ownerStart, a->ownerStart)) return -1;
     if (upload(&a->d_losortStart, a->losortStart)) return -1;
+    // point-to-point sweep state (tags start at 0 = never published)
+    LDU_CHECK_HIP(hipMalloc((void**)&a->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
+    LDU_CHECK_HIP(hipMemset(a->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
+    LDU_CHECK_HIP(hipMalloc((void**)&a->d_ticket, sizeof(unsigned)));
+    LDU_CHECK_HIP(hipMemset(a->d_ticket, 0, sizeof(unsigned)));
+    a->ticketBase = 0;
+    a->epoch = 0;
     return 0;
 }
 
@@ -268,7 +275,7 @@ void plan_free(ldu_addr* a)
     void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW,
                     a->d_levelSliceStart, a->d_nL, a->d_nU, a->d_col, a->d_face, a->d_l, a->d_u,
                     a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,
-                    a->d_pfCell, a->d_sendAll, a->d_recvAll};
+                    a->d_pfCell, a->d_sendAll, a->d_recvAll, a->d_granule, a->d_ticket};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : a->scratch) if (p) (void)hipFree(p);
     a->scratch.clear();

@@ -26,8 +26,17 @@ int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
 {
     LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars + ctx->sb + slot, ctx->S() + slot, sizeof(double) * count,
                                  hipMemcpyDeviceToHost, ctx->stream));
+    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_abort, ctx->d_abort, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < count; i++) out[i] = ctx->h_scalars[ctx->sb + slot + i];
+    if (*ctx->h_abort)
+    {
+        // a point-to-point sweep gave up waiting (bounded spin): fail loudly, never hang
+        (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), ctx->stream);
+        ctx->p2pGen++;
+        ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
+        return -20;
+    }
     return 0;
 }
 
