@@ -115,6 +115,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && !strcmp(e, "levels")) c->sweepP2P = 0;
     e = getenv("LDU_P2P_BPC");
     if (e && atoi(e) > 0) c->p2pBlocksPerCU = atoi(e);
+    e = getenv("LDU_P2P_SLEEP");
+    if (e) k_set_p2p_sleep(atoi(e));
     e = getenv("LDU_NO_GRAPH");
     if (e && atoi(e)) c->useGraphs = false;
     e = getenv("LDU_FUSE_ROWS");

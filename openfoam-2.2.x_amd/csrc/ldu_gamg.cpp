@@ -360,6 +360,9 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 return -1;
             if (matrix_alloc(L.addr, &L.mat)) return -1;
             if (build_level_maps(L, fineA)) return -1;
+            if (getenv("LDU_VERBOSE"))
+                fprintf(stderr, "[ldugpu] GAMG level %2zu: %9d cells %9d faces  %5d dependency levels  %7d slices\n",
+                        i + 1, L.addr->nCells, L.addr->nFaces, L.addr->nLevels, L.addr->nSlices);
             fineA = L.addr;
         }
         const size_t n = (size_t)a->nCells + 1;

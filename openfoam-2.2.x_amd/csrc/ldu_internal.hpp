@@ -208,6 +208,7 @@ struct SweepArgs {
 };
 
 int k_sweep(ldu_addr* a, const SweepArgs& args);
+int k_set_p2p_sleep(int n);
 
 int k_fill_sell(ldu_addr* a, const double* lowerO, const double* upperO, double* val, hipStream_t s);
 int k_permute_in(ldu_addr* a, double* dstNew, const double* srcOld, hipStream_t s);   // dst[new] = src[perm[new]]

@@ -390,6 +390,14 @@ static int launch_sweep(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// poll back-off between two granule polls, in units of s_sleep(1) (64 clocks); tunable (LDU_P2P_SLEEP)
+__device__ int g_p2p_sleep = 2;
+int k_set_p2p_sleep(int n)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_sleep), &n, sizeof(int)));
+    return 0;
+}
+
 __device__ __forceinline__ void granule_store(uint4* G, int row, double v, unsigned tag)
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -444,6 +452,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
         }
         u32x4 g0, g1, g2, g3;
         unsigned spins = 0;
+        const int sleepN = g_p2p_sleep;
         for (;;)
         {
             granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
@@ -458,7 +467,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
                 *abortFlag = 1;
                 return false;
             }
-            __builtin_amdgcn_s_sleep(2);
+            for (int q = 0; q < sleepN; q++) __builtin_amdgcn_s_sleep(1);
         }
         const double x0 = granule_value(g0), x1 = granule_value(g1), x2 = granule_value(g2),
                      x3 = granule_value(g3);
