@@ -79,6 +79,9 @@ int ldu_ctx_sync(ldu_ctx* ctx);
  * (replaces UPstream::init / MPI_COMM_WORLD, src/Pstream/mpi/UPstream.C). */
 int ldu_comm_unique_id(uint8_t id[128]);
 int ldu_ctx_comm_init(ldu_ctx* ctx, int rank, int nRanks, const uint8_t id[128]);
+/* Test facility for 1-GPU boxes: nRanks contexts of ONE process (one host thread each) form a
+ * local group that exchanges halos / reductions through device copies instead of RCCL. */
+int ldu_ctx_comm_init_local(ldu_ctx* ctx, int rank, int nRanks, int groupId);
 
 /* ---- addressing (lduAddressing.H:111-199, lduPrimitiveMesh.H:83-99) ------------ */
 /* lower/upper = lowerAddr()/upperAddr(), upper-triangular order (sorted by owner).  */

@@ -20,7 +20,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
-    "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_addr_create", "ldu_addr_add_patch",
+    "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
@@ -121,6 +121,10 @@ class Context:
     def comm_init(self, rank, n_ranks, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         _chk(lib().ldu_ctx_comm_init(self.h, int(rank), int(n_ranks), buf))
+
+    def comm_init_local(self, rank, n_ranks, group_id):
+        """Test facility: ranks = threads of this process sharing one GPU (no RCCL)."""
+        _chk(lib().ldu_ctx_comm_init_local(self.h, int(rank), int(n_ranks), int(group_id)))
 
     @staticmethod
     def unique_id():

@@ -340,6 +340,7 @@ int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bou
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_bou + p.offset, bou, sizeof(double) * p.n, hipMemcpyDefault, s));
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_int + p.offset, intc, sizeof(double) * p.n, hipMemcpyDefault, s));
     }
+    m->coeffEpoch++;   // coarse-level interface coefficients follow
     return 0;
 }
 

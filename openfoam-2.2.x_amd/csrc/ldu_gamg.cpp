@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 
 #include "ldu_internal.hpp"
 
@@ -37,6 +38,8 @@ struct GamgLevel {
     int* d_childO = nullptr;
     double* d_corr = nullptr;
     double* d_src = nullptr;
+    int* d_pcStart = nullptr;            // coarse patch face -> fine patch faces (concatenated, asc.)
+    int* d_pcFine = nullptr;
 };
 
 struct GamgHierarchy {
@@ -64,7 +67,8 @@ void gamg_free(GamgHierarchy* g)
     for (auto& L : g->levels)
     {
         void* ptrs[] = {L.d_childStart, L.d_child, L.d_mapNew, L.d_cfStart, L.d_cfFine, L.d_cfFlip,
-                        L.d_ccStart, L.d_ccFine, L.d_childStartO, L.d_childO, L.d_corr, L.d_src};
+                        L.d_ccStart, L.d_ccFine, L.d_childStartO, L.d_childO, L.d_corr, L.d_src,
+                        L.d_pcStart, L.d_pcFine};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (L.mat) matrix_free(L.mat);
         if (L.addr) { plan_free(L.addr); delete L.addr; }
@@ -177,15 +181,26 @@ static void coarse_addressing(int nFineFaces, const int* lower, const int* upper
         if (faceRestrict[f] >= 0) faceRestrict[f] = renum[faceRestrict[f]];
 }
 
+// coarse image of one processor patch (processorGAMGInterface.C:47-126)
+struct HostPatch {
+    int nbrRank = -1;
+    std::vector<int> faceCells;   // coarse cell per coarse patch face
+    std::vector<int> fra;         // faceRestrictAddressing: fine patch face -> coarse patch face
+};
+
 struct HostLevel {
     int nCells = 0;
     std::vector<int> restrictAddr, faceRestrictAddr, lower, upper;
+    std::vector<HostPatch> patches;
 };
 
-// pairGAMGAgglomerate.C:201-292
-static void agglomerate_all(const ldu_addr* fine, const std::vector<double>& fineWeights,
-                            int nCellsInCoarsestLevel, int mergeLevels, std::vector<HostLevel>& out)
+// pairGAMGAgglomerate.C:201-292.  Every rank runs this loop in lock-step: the stop criterion is
+// and-reduced over the ranks and the restrict maps are exchanged across the processor patches
+// at every pair level (GAMGAgglomerateLduAddressing.C:201-268).
+static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fineWeights,
+                           int nCellsInCoarsestLevel, int mergeLevels, std::vector<HostLevel>& out)
 {
+    ldu_ctx* ctx = fine->ctx;
     out.clear();
     std::vector<double> w = fineWeights;
     int nPairLevels = 0;
@@ -198,7 +213,10 @@ static void agglomerate_all(const ldu_addr* fine, const std::vector<double>& fin
         const int nF = (int)lo.size();
         HostLevel L;
         pair_level(nC, nF, lo.data(), up_.data(), w, L.restrictAddr, L.nCells);
-        if (!(L.nCells >= nCellsInCoarsestLevel)) break;   // continueAgglomerating (GAMGAgglomeration.C:53-62)
+        // continueAgglomerating (GAMGAgglomeration.C:53-62): and-reduce over the ranks
+        int cont = (L.nCells >= nCellsInCoarsestLevel) ? 1 : 0;
+        if (comm_allreduce_min_int(ctx, &cont)) return -1;
+        if (!cont) break;
         coarse_addressing(nF, lo.data(), up_.data(), L.restrictAddr, L.nCells, L.faceRestrictAddr,
                           L.lower, L.upper);
         // restrictFaceField of the weights (GAMGAgglomerationTemplates.C:63-83)
@@ -206,9 +224,47 @@ static void agglomerate_all(const ldu_addr* fine, const std::vector<double>& fin
         for (int f = 0; f < nF; f++)
             if (L.faceRestrictAddr[f] >= 0) cw[L.faceRestrictAddr[f]] += w[f];
         w.swap(cw);
+
+        // coarse processor interfaces: coarse faces = unique (master cell, slave cell) pairs in
+        // order of first occurrence - both ranks scan the same faces in the same order
+        const size_t nP = fine->patches.size();
+        if (nP)
+        {
+            std::vector<std::vector<int>> send(nP), recv;
+            std::vector<const std::vector<int>*> fineFC(nP);
+            for (size_t p = 0; p < nP; p++)
+            {
+                fineFC[p] = top ? &fine->patches[p].faceCells : &out.back().patches[p].faceCells;
+                send[p].resize(fineFC[p]->size());
+                for (size_t i = 0; i < send[p].size(); i++) send[p][i] = L.restrictAddr[(*fineFC[p])[i]];
+            }
+            if (comm_exchange_ints(ctx, fine->patches, send, recv)) return -1;
+            L.patches.resize(nP);
+            for (size_t p = 0; p < nP; p++)
+            {
+                HostPatch& HP = L.patches[p];
+                HP.nbrRank = fine->patches[p].nbrRank;
+                const bool master = ctx->rank < HP.nbrRank;
+                std::map<std::pair<int, int>, int> seen;
+                HP.fra.resize(send[p].size());
+                for (size_t ffi = 0; ffi < send[p].size(); ffi++)
+                {
+                    const int loc = send[p][ffi], nbr = recv[p][ffi];
+                    const std::pair<int, int> key = master ? std::make_pair(loc, nbr) : std::make_pair(nbr, loc);
+                    auto it = seen.find(key);
+                    if (it == seen.end())
+                    {
+                        it = seen.emplace(key, (int)HP.faceCells.size()).first;
+                        HP.faceCells.push_back(loc);
+                    }
+                    HP.fra[ffi] = it->second;
+                }
+            }
+        }
+
         if (nPairLevels % mergeLevels)
         {
-            // combineLevels (pairGAMGAgglomerationCombineLevels.C:32-95)
+            // combineLevels (pairGAMGAgglomerationCombineLevels.C:32-95, GAMGInterface.C:36-49)
             HostLevel& P = out.back();
             for (size_t i = 0; i < P.faceRestrictAddr.size(); i++)
             {
@@ -219,6 +275,11 @@ static void agglomerate_all(const ldu_addr* fine, const std::vector<double>& fin
             P.nCells = L.nCells;
             P.lower.swap(L.lower);
             P.upper.swap(L.upper);
+            for (size_t p = 0; p < P.patches.size(); p++)
+            {
+                for (auto& v : P.patches[p].fra) v = L.patches[p].fra[v];
+                P.patches[p].faceCells.swap(L.patches[p].faceCells);
+            }
         }
         else
         {
@@ -226,6 +287,7 @@ static void agglomerate_all(const ldu_addr* fine, const std::vector<double>& fin
         }
         nPairLevels++;
     }
+    return 0;
 }
 
 // ---------------------------------------------------------------- hierarchy construction
@@ -302,11 +364,6 @@ static int build_level_maps(GamgLevel& L, const ldu_addr* fineA)
 static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
 {
     ldu_addr* a = m->a;
-    if (a->nPatchFaces)
-    {
-        ldu_set_error("GAMG with coupled (processor) patches is not implemented yet");
-        return -6;
-    }
     GamgHierarchy* g = m->gamg;
     const bool reuse = g && c->cacheAgglomeration && g->nCellsInCoarsestLevel == c->nCellsInCoarsestLevel
                        && g->mergeLevels == c->mergeLevels && g->agglomerator == c->agglomerator
@@ -337,7 +394,11 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             w = a->faceWeights;
         }
         std::vector<HostLevel> hl;
-        agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl);
+        if (agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl))
+        {
+            delete g;
+            return -1;
+        }
         if (hl.empty())
         {
             // GAMGSolver.C:108-126
@@ -358,6 +419,30 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             if (addr_create_internal(a->ctx, &L.addr, hl[i].nCells, (int)hl[i].lower.size(),
                                      hl[i].lower.data(), hl[i].upper.data()))
                 return -1;
+            // coarse processor patches + the lists that agglomerate their coefficients
+            // (GAMGInterface::agglomerateCoeffs, GAMGInterface.C:61-75) in ascending fine-face order
+            if (!hl[i].patches.empty())
+            {
+                for (auto& hp : hl[i].patches)
+                {
+                    Patch P;
+                    P.n = (int)hp.faceCells.size();
+                    P.nbrRank = hp.nbrRank;
+                    P.faceCells = hp.faceCells;
+                    L.addr->patches.push_back(P);
+                }
+                if (plan_finalize_patches(L.addr)) return -1;
+                std::vector<int> pcStart(L.addr->nPatchFaces + 1, 0), pcFine(fineA->nPatchFaces);
+                for (size_t p = 0; p < hl[i].patches.size(); p++)
+                    for (int v : hl[i].patches[p].fra) pcStart[L.addr->patches[p].offset + v + 1]++;
+                for (int k = 0; k < L.addr->nPatchFaces; k++) pcStart[k + 1] += pcStart[k];
+                std::vector<int> pos(pcStart.begin(), pcStart.end() - 1);
+                for (size_t p = 0; p < hl[i].patches.size(); p++)
+                    for (size_t ffi = 0; ffi < hl[i].patches[p].fra.size(); ffi++)
+                        pcFine[pos[L.addr->patches[p].offset + hl[i].patches[p].fra[ffi]]++] =
+                            fineA->patches[p].offset + (int)ffi;
+                if (up(&L.d_pcStart, pcStart) || up(&L.d_pcFine, pcFine)) return -1;
+            }
             if (matrix_alloc(L.addr, &L.mat)) return -1;
             if (build_level_maps(L, fineA)) return -1;
             if (getenv("LDU_VERBOSE"))
@@ -390,6 +475,10 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                                      fm->d_upperO, fm->d_lowerO, cm->d_diagO, cm->d_upperO, cm->d_lowerO,
                                      m->sym, s))
                 return -1;
+            if (L.addr->nPatchFaces)
+                if (k_patch_agglomerate(L.addr->nPatchFaces, L.d_pcStart, L.d_pcFine, fm->d_bou, fm->d_int,
+                                        cm->d_bou, cm->d_int, s))
+                    return -1;
             if (matrix_refresh_layout(cm)) return -1;
             fm = cm;
         }

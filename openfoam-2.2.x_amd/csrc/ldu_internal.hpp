@@ -281,6 +281,11 @@ void plan_free(ldu_addr* a);
 
 int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s);   // ldu_comm.cpp
 int comm_exchange(ldu_addr* a, hipStream_t s);                                   // halo send/recv
+int comm_allreduce_min_int(ldu_ctx* ctx, int* v);
+int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
+                       const std::vector<std::vector<int>>& send, std::vector<std::vector<int>>& recv);
+int k_patch_agglomerate(int nCoarse, const int* start, const int* fine, const double* fBou,
+                        const double* fInt, double* cBou, double* cInt, hipStream_t s);
 void comm_destroy(ldu_ctx* ctx);
 
 // solvers (ldu_solvers.cpp): all vectors device, new numbering

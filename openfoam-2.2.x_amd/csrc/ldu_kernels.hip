@@ -1145,6 +1145,33 @@ int k_agglomerate_coeffs(int nCoarseFaces, const int* cfStart, const int* cfFine
     return 0;
 }
 
+// GAMGInterface::agglomerateCoeffs (GAMGInterface.C:61-75): coarse[fra[ffi]] += fine[ffi] in
+// ascending ffi, as a gather per coarse patch face
+__global__ void patch_agg_kernel(int nCoarse, const int* __restrict__ start, const int* __restrict__ fine,
+                                 const double* __restrict__ fBou, const double* __restrict__ fInt,
+                                 double* __restrict__ cBou, double* __restrict__ cInt)
+{
+    for (int c = blockIdx.x * BLK + threadIdx.x; c < nCoarse; c += gridDim.x * BLK)
+    {
+        double b = 0.0, i = 0.0;
+        for (int t = start[c]; t < start[c + 1]; t++)
+        {
+            b += fBou[fine[t]];
+            i += fInt[fine[t]];
+        }
+        cBou[c] = b;
+        cInt[c] = i;
+    }
+}
+int k_patch_agglomerate(int nCoarse, const int* start, const int* fine, const double* fBou,
+                        const double* fInt, double* cBou, double* cInt, hipStream_t s)
+{
+    if (nCoarse <= 0) return 0;
+    patch_agg_kernel<<<ewGrid(nCoarse), BLK, 0, s>>>(nCoarse, start, fine, fBou, fInt, cBou, cInt);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------- fv stencils (original numbering)
 
 // surfaceInterpolationScheme.C:293-296: sf = lambda*(vf[P]-vf[N]) + vf[N]

@@ -16,6 +16,16 @@
 #define ORC_VSMALL 1e-300
 #define ORC_MAXLEVELS 50 /* GAMGAgglomerations/GAMGAgglomeration/GAMGAgglomeration.C:75 */
 
+/* Coarse image of one processor patch (processorGAMGInterface.C:47-126). */
+typedef struct lvl_patch {
+    int n;          /* coarse patch faces */
+    int nFine;      /* faces of the fine patch it was built from */
+    int* faceCells; /* [n] coarse cell of each coarse patch face */
+    int* fra;       /* [nFine] faceRestrictAddressing: fine patch face -> coarse patch face */
+    double* bou;    /* [n] agglomerated interfaceBouCoeffs */
+    double* intc;   /* [n] agglomerated interfaceIntCoeffs */
+} lvl_patch;
+
 /* One coarse level: owns its addressing, maps and coefficients, per domain. */
 typedef struct dom_level {
     int nFineCells, nFineFaces;
@@ -28,6 +38,8 @@ typedef struct dom_level {
     double* upper;
     double* lower;         /* NULL when symmetric */
     orc_patch* patches;    /* coarse coupled patches (owned) */
+    int nPatches;
+    lvl_patch* lp;         /* [nPatches] */
 } dom_level;
 
 typedef struct level_t {
@@ -236,6 +248,11 @@ static void agglomerate_addressing(dom_level* L, const int* lowerAddr, const int
 
 static void free_dom_level_addr(dom_level* L)
 {
+    for (int p = 0; p < L->nPatches; p++)
+    {
+        free(L->lp[p].faceCells); free(L->lp[p].fra); free(L->lp[p].bou); free(L->lp[p].intc);
+    }
+    free(L->lp);
     free(L->restrictAddr); free(L->faceRestrictAddr); free(L->l); free(L->u);
     free(L->diag); free(L->upper); free(L->lower); free(L->patches);
     memset(L, 0, sizeof(*L));
@@ -253,6 +270,16 @@ static void combine_levels(dom_level* prev, dom_level* cur)
     }
     for (int i = 0; i < prev->nFineCells; i++)
         prev->restrictAddr[i] = cur->restrictAddr[prev->restrictAddr[i]];
+    /* GAMGInterface::combine (GAMGInterface.C:36-49) */
+    for (int p = 0; p < prev->nPatches; p++)
+    {
+        lvl_patch* P = &prev->lp[p];
+        lvl_patch* C = &cur->lp[p];
+        for (int i = 0; i < P->nFine; i++) P->fra[i] = C->fra[P->fra[i]];
+        free(P->faceCells);
+        P->faceCells = C->faceCells; C->faceCells = 0;
+        P->n = C->n;
+    }
     prev->nCells = cur->nCells;
     prev->nFaces = cur->nFaces;
     free(prev->l); free(prev->u);
@@ -325,12 +352,6 @@ orc_gamg* orc_gamg_build(const orc_sys* s, const orc_opts* o, const double* face
     for (int d = 0; d < s->nDom; d++)
     {
         if (s->dom[d].lower != s->dom[d].upper) g->sym = 0;
-        if (s->dom[d].nPatches)
-        {
-            fprintf(stderr, "orc_gamg_build: coupled patches not supported by the oracle GAMG yet\n");
-            free(g);
-            return 0;
-        }
     }
     const int nDom = s->nDom;
 
@@ -402,6 +423,59 @@ orc_gamg* orc_gamg_build(const orc_sys* s, const orc_opts* o, const double* face
             free(w[d]);
             w[d] = aw;
         }
+        /* coarse processor interfaces (GAMGAgglomerateLduAddressing.C:201-268 +
+         * processorGAMGInterface.C:47-126): coarse patch faces = unique (master cell, slave cell)
+         * pairs in order of first occurrence, so both ranks number them identically */
+        for (int d = 0; d < nDom; d++)
+        {
+            dom_level* L = &Lv->dl[d];
+            const int nP = s->dom[d].nPatches;
+            L->nPatches = nP;
+            L->lp = (lvl_patch*)calloc((size_t)nP + 1, sizeof(lvl_patch));
+            for (int p = 0; p < nP; p++)
+            {
+                const int q = s->dom[d].patches[p].nbrDom;
+                const int pq = s->dom[d].patches[p].nbrPatch;
+                const int* Fd; const int* Fq; int nFine;
+                if (nCreatedLevels == 0)
+                {
+                    Fd = s->dom[d].patches[p].faceCells; Fq = s->dom[q].patches[pq].faceCells;
+                    nFine = s->dom[d].patches[p].n;
+                }
+                else
+                {
+                    Fd = g->lev[nCreatedLevels - 1].dl[d].lp[p].faceCells;
+                    Fq = g->lev[nCreatedLevels - 1].dl[q].lp[pq].faceCells;
+                    nFine = g->lev[nCreatedLevels - 1].dl[d].lp[p].n;
+                }
+                const int* rd = L->restrictAddr;
+                const int* rq = Lv->dl[q].restrictAddr;
+                lvl_patch* P = &L->lp[p];
+                P->nFine = nFine;
+                P->fra = (int*)malloc(sizeof(int) * (size_t)(nFine + 1));
+                P->faceCells = (int*)malloc(sizeof(int) * (size_t)(nFine + 1));
+                int* pairA = (int*)malloc(sizeof(int) * (size_t)(nFine + 1));
+                int* pairB = (int*)malloc(sizeof(int) * (size_t)(nFine + 1));
+                int nc = 0;
+                for (int ffi = 0; ffi < nFine; ffi++)
+                {
+                    const int loc = rd[Fd[ffi]], nbr = rq[Fq[ffi]];
+                    const int a = d < q ? loc : nbr;   /* master side first */
+                    const int b = d < q ? nbr : loc;
+                    int found = -1;
+                    for (int c = 0; c < nc; c++) if (pairA[c] == a && pairB[c] == b) { found = c; break; }
+                    if (found < 0)
+                    {
+                        pairA[nc] = a; pairB[nc] = b;
+                        P->faceCells[nc] = loc;
+                        found = nc++;
+                    }
+                    P->fra[ffi] = found;
+                }
+                P->n = nc;
+                free(pairA); free(pairB);
+            }
+        }
         if (nPairLevels % o->mergeLevels)
         {
             for (int d = 0; d < nDom; d++)
@@ -435,7 +509,28 @@ orc_gamg* orc_gamg_build(const orc_sys* s, const orc_opts* o, const double* face
             C->l = L->l; C->u = L->u;
             C->diag = L->diag; C->upper = L->upper;
             C->lower = L->lower ? L->lower : L->upper;
-            C->nPatches = 0; C->patches = 0;
+            /* GAMGInterface::agglomerateCoeffs (GAMGInterface.C:61-75) */
+            C->nPatches = L->nPatches;
+            L->patches = (orc_patch*)calloc((size_t)L->nPatches + 1, sizeof(orc_patch));
+            for (int p = 0; p < L->nPatches; p++)
+            {
+                lvl_patch* P = &L->lp[p];
+                const orc_patch* FP = &F->patches[p];
+                P->bou = (double*)calloc((size_t)P->n + 1, sizeof(double));
+                P->intc = (double*)calloc((size_t)P->n + 1, sizeof(double));
+                for (int ffi = 0; ffi < P->nFine; ffi++)
+                {
+                    P->bou[P->fra[ffi]] += FP->bouCoeffs[ffi];
+                    P->intc[P->fra[ffi]] += FP->intCoeffs[ffi];
+                }
+                L->patches[p].n = P->n;
+                L->patches[p].faceCells = P->faceCells;
+                L->patches[p].bouCoeffs = P->bou;
+                L->patches[p].intCoeffs = P->intc;
+                L->patches[p].nbrDom = FP->nbrDom;
+                L->patches[p].nbrPatch = FP->nbrPatch;
+            }
+            C->patches = L->patches;
         }
         orc_sys_finalize(&Lv->sys);
     }

@@ -1,0 +1,127 @@
+"""GPU, multi-rank path on ONE GPU (-m gpu): N ranks = N host threads with their own contexts in
+a 'local' communicator group (ldu_ctx_comm_init_local), checked against the oracle's serial
+emulation of the same N-rank algorithm (rank-local DIC/DILU/GaussSeidel/agglomeration, processor
+patches, rank-ordered reductions).  The RCCL backend shares every call site with this one."""
+import threading
+
+import numpy as np
+import pytest
+
+from openfoam_amd import capi, cases, decompose
+
+pytestmark = pytest.mark.gpu
+_GROUP = [100]
+
+
+def run_ranks(subs, fn):
+    """fn(rank, ctx, addr, mat) in one thread per rank; returns list of results."""
+    n = len(subs)
+    _GROUP[0] += 1
+    gid = _GROUP[0]
+    out = [None] * n
+    err = [None] * n
+
+    def worker(r):
+        try:
+            ctx = capi.Context(0)
+            ctx.comm_init_local(r, n, gid)
+            sp = subs[r]
+            a = capi.Addressing(ctx, sp["nCells"], sp["lowerAddr"], sp["upperAddr"], sp.get("faceWeights"),
+                                patches=sp["patches_dev"])
+            m = capi.Matrix(a)
+            m.set_coeffs(sp["diag"], sp["upper"], sp.get("lower"))
+            for i, q in enumerate(sp["patches"]):
+                m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+            out[r] = fn(r, ctx, a, m)
+            m.close(); a.close(); ctx.close()
+        except Exception as e:  # pragma: no cover
+            err[r] = e
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def _case(n, asym=False, size=10):
+    p = cases.box3d(size, asym=asym)
+    shape = {2: (1, 1, 2), 3: (1, 1, 3), 4: (1, 2, 2), 8: (2, 2, 2)}[n]
+    cr = decompose.block_ranks(size, size, size, *shape)
+    subs, maps = decompose.decompose(p, cr, n)
+    return p, subs, maps
+
+
+@pytest.mark.parametrize("n,asym", [(2, False), (4, False), (3, True), (8, False)])
+def test_ops_bitexact(oracle, n, asym):
+    p, subs, maps = _case(n, asym)
+    rng = np.random.RandomState(5)
+    xs = [rng.randn(s["nCells"]) for s in subs]
+    bs = [rng.randn(s["nCells"]) for s in subs]
+    S = oracle.System(subs)
+    X, B = np.concatenate(xs), np.concatenate(bs)
+    sm = "GaussSeidel"
+
+    def fn(r, ctx, a, m):
+        return dict(Amul=m.Amul(xs[r]), Tmul=m.Tmul(xs[r]), sumA=m.sumA(), res=m.residual(xs[r], bs[r]),
+                    gs=m.smooth(sm, xs[r], bs[r], 2), sgs=m.smooth("symGaussSeidel", xs[r], bs[r], 1),
+                    dot=m.gSumProd(xs[r], bs[r]))
+    res = run_ranks(subs, fn)
+    cat = lambda k: np.concatenate([r[k] for r in res])
+    assert np.array_equal(cat("Amul"), S.Amul(X))
+    assert np.array_equal(cat("Tmul"), S.Tmul(X))
+    assert np.array_equal(cat("sumA"), S.sumA())
+    assert np.array_equal(cat("res"), S.residual(X, B))
+    assert np.array_equal(cat("gs"), S.smooth(sm, X, B, 2))
+    assert np.array_equal(cat("sgs"), S.smooth("symGaussSeidel", X, B, 1))
+    assert abs(res[0]["dot"] - S.gSumProd(X, B)) < 1e-10
+
+
+SOLVES = [
+    (dict(solver="PCG", preconditioner="DIC", tolerance=1e-9, relTol=0), False),
+    (dict(solver="PBiCG", preconditioner="DILU", tolerance=1e-9, relTol=0), True),
+    (dict(solver="smoothSolver", smoother="GaussSeidel", nSweeps=2, tolerance=1e-6, relTol=0, maxIter=200), False),
+    (dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4), False),
+    (dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4,
+          mergeLevels=2, nPreSweeps=1), False),
+    (dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-8, relTol=0, nCellsInCoarsestLevel=4), True),
+]
+
+
+@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("case", SOLVES, ids=["%s%d" % (c[0]["solver"], i) for i, c in enumerate(SOLVES)])
+def test_solve_history(oracle, n, case):
+    kw, asym = case
+    p, subs, maps = _case(n, asym)
+    okw = dict(kw)
+    if "preconditioner" in okw:
+        okw["precond"] = okw.pop("preconditioner")
+    X0 = np.concatenate([s["psi"] for s in subs]); B = np.concatenate([s["source"] for s in subs])
+    xo, po = oracle.System(subs).solve(X0, B, **okw)
+
+    def fn(r, ctx, a, m):
+        return m.solve(subs[r]["psi"], subs[r]["source"], **kw)
+    res = run_ranks(subs, fn)
+    for x, perf in res:
+        assert perf["nIterations"] == po["nIterations"]
+        np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+    x = np.concatenate([r[0] for r in res])
+    assert np.max(np.abs(x - xo)) <= 1e-8 * np.max(np.abs(xo))
+
+
+def test_rccl_backend_single_rank(oracle, monkeypatch):
+    """RCCL communicator on one rank with LDU_FORCE_COMM=1: every scalar reduction of a PCG solve
+    goes through ncclAllReduce on the compute stream (the multi-GPU code path, world size 1)."""
+    monkeypatch.setenv("LDU_FORCE_COMM", "1")
+    p = cases.box3d(10)
+    ctx = capi.Context(0)
+    ctx.comm_init(0, 1, capi.Context.unique_id())
+    a, m = capi.from_problem(ctx, p)
+    x, perf = m.solve(p["psi"], p["source"], solver="PCG", preconditioner="DIC", tolerance=1e-9, relTol=0)
+    xo, po = oracle.System(p).solve(p["psi"], p["source"], solver="PCG", precond="DIC", tolerance=1e-9, relTol=0)
+    assert perf["nIterations"] == po["nIterations"]
+    np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+    m.close(); a.close(); ctx.close()
