@@ -77,7 +77,7 @@ def main():
         # 2x2x2 blocks at 8 ranks, slabs/blocks otherwise
         shape = {2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(world, (1, 1, world))
         cell_rank = decompose.block_ranks(n, n, n, *shape)
-        subs, cell_maps = decompose.decompose(p, cell_rank, world)
+        subs, cell_maps = decompose.decompose(p, cell_rank, world, only_rank=rank)
         lp = subs[rank]
         del subs
     else:

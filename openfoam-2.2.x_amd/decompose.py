@@ -29,8 +29,8 @@ def block_ranks(nx, ny, nz, px, py, pz):
     return (bi + px * (bj + py * bk)).astype(np.int64)
 
 
-def decompose(p, cell_rank, n_ranks):
-    """Split problem dict p.  Returns (subs, cell_maps): subs[r] is a problem dict with
+def decompose(p, cell_rank, n_ranks, only_rank=None):
+    """Split problem dict p (only_rank: build just that rank's sub-domain; the others are None).  Returns (subs, cell_maps): subs[r] is a problem dict with
     'patches' (oracle form: faceCells/bouCoeffs/intCoeffs/nbrDom/nbrPatch) and
     'patches_dev' (device form: faceCells/nbrRank); cell_maps[r] = global cell ids of rank r
     in local order (ascending global id, preserving the upper-triangular face order)."""
@@ -48,6 +48,9 @@ def decompose(p, cell_rank, n_ranks):
     subs = []
     cut = rl != ru
     for r in range(n_ranks):
+        if only_rank is not None and r != only_rank:
+            subs.append(None)
+            continue
         ids = cell_maps[r]
         inner = (rl == r) & (ru == r)
         sp = dict(nCells=int(ids.size), lowerAddr=local_id[l[inner]].astype(np.int32),
@@ -76,6 +79,12 @@ def decompose(p, cell_rank, n_ranks):
         subs.append(sp)
     # pair patches: patch (r -> nb) matches patch (nb -> r); both list the same global faces
     for r in range(n_ranks):
+        if subs[r] is None:
+            continue
+        if only_rank is not None:
+            subs[r]["patches_dev"] = [dict(faceCells=q["faceCells"], nbrRank=q["nbrRank"])
+                                      for q in subs[r]["patches"]]
+            continue
         for q in subs[r]["patches"]:
             nb = q["nbrDom"]
             for j, q2 in enumerate(subs[nb]["patches"]):
