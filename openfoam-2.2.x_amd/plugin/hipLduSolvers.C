@@ -1,0 +1,446 @@
+/*---------------------------------------------------------------------------*\
+  hipLduSolvers - OpenFOAM-2.2.x plugin that puts the MI355X lduMatrix hot path
+  (libldugpu.so, include/ldugpu.h) behind OpenFOAM's own run-time selection:
+
+      system/controlDict:   libs ("libhipLduSolvers.so");
+
+  After the library is loaded, `solver PCG; / PBiCG; / GAMG; / smoothSolver;`
+  in system/fvSolution resolve to the classes below (registered with
+  addRemovable...ConstructorToTable, which REPLACES the stock table entry:
+  runTimeSelectionTables.H:102-133); the same classes are also reachable as
+  hipPCG / hipPBiCG / hipGAMG / hipSmoothSolver.  No solver application changes.
+
+  This file is the ONLY code that sees OpenFOAM types: it marshals the raw
+  arrays the reference hands to its solvers into the C ABI.
+  Built against the reference headers by plugin/build_plugin.sh.
+\*---------------------------------------------------------------------------*/
+
+#include "lduMatrix.H"
+#include "processorLduInterface.H"
+#include "addToRunTimeSelectionTable.H"
+#include "Pstream.H"
+#include "Switch.H"
+#include "labelList.H"
+
+#include <cstring>
+#include <cstdlib>
+
+#include "ldugpu.h"
+
+#include <map>
+#include <vector>
+
+namespace Foam
+{
+
+// ------------------------------------------------------------------ device registry
+
+struct hipLduEntry
+{
+    ldu_addr* addr;
+    ldu_matrix* mat;
+    label nCells, nFaces;
+    bool weightsSet;
+};
+
+static ldu_ctx* hipCtx_ = NULL;
+static std::map<const lduAddressing*, hipLduEntry> hipEntries_;
+static std::vector<double> hipFaceWeights_;
+
+static void hipCheck(int rc, const char* where)
+{
+    if (rc)
+    {
+        FatalErrorIn(where) << "libldugpu: " << ldu_last_error() << exit(FatalError);
+    }
+}
+
+static ldu_ctx* hipContext()
+{
+    if (!hipCtx_)
+    {
+        // one rank per GPU: device = rank within the node
+        int dev = Pstream::parRun() ? Pstream::myProcNo() % 8 : 0;
+        hipCheck(ldu_ctx_create(&hipCtx_, dev), "hipContext()");
+        if (Pstream::parRun())
+        {
+            // RCCL communicator bootstrapped over the existing Pstream (replaces MPI on the hot path)
+            labelList id(128/sizeof(label), 0);      // 128-byte ncclUniqueId as labels
+            uint8_t raw[128];
+            if (Pstream::master())
+            {
+                hipCheck(ldu_comm_unique_id(raw), "hipContext()");
+                std::memcpy(id.begin(), raw, 128);
+            }
+            Pstream::scatter(id);
+            std::memcpy(raw, id.begin(), 128);
+            hipCheck
+            (
+                ldu_ctx_comm_init(hipCtx_, Pstream::myProcNo(), Pstream::nProcs(), raw),
+                "hipContext()"
+            );
+        }
+    }
+    return hipCtx_;
+}
+
+// Device image of (lduAddressing, coupled patches), built once per addressing like the
+// reference's lazily built losort/ownerStart.
+static hipLduEntry& hipLookup
+(
+    const lduMatrix& matrix,
+    const lduInterfaceFieldPtrsList& interfaces
+)
+{
+    const lduAddressing& la = matrix.lduAddr();
+    std::map<const lduAddressing*, hipLduEntry>::iterator it = hipEntries_.find(&la);
+    const label nCells = la.size();
+    const label nFaces = la.lowerAddr().size();
+    if (it != hipEntries_.end() && (it->second.nCells != nCells || it->second.nFaces != nFaces))
+    {
+        ldu_matrix_destroy(it->second.mat);
+        ldu_addr_destroy(it->second.addr);
+        hipEntries_.erase(it);
+        it = hipEntries_.end();
+    }
+    if (it == hipEntries_.end())
+    {
+        hipLduEntry e;
+        e.nCells = nCells;
+        e.nFaces = nFaces;
+        e.weightsSet = false;
+        hipCheck
+        (
+            ldu_addr_create
+            (
+                hipContext(), &e.addr, nCells, nFaces,
+                la.lowerAddr().begin(), la.upperAddr().begin()
+            ),
+            "hipLookup"
+        );
+        bool any = false;
+        forAll(interfaces, patchi)
+        {
+            if (interfaces.set(patchi))
+            {
+                const processorLduInterface* pp =
+                    dynamic_cast<const processorLduInterface*>(&interfaces[patchi].interface());
+                if (!pp)
+                {
+                    FatalErrorIn("hipLookup")
+                        << "only processor coupled patches are supported on the GPU path, patch "
+                        << patchi << " is " << interfaces[patchi].interface().type()
+                        << exit(FatalError);
+                }
+                const labelUList& fc = la.patchAddr(patchi);
+                hipCheck(ldu_addr_add_patch(e.addr, fc.size(), fc.begin(), pp->neighbProcNo()), "hipLookup");
+                any = true;
+            }
+        }
+        if (any) hipCheck(ldu_addr_finalize(e.addr), "hipLookup");
+        hipCheck(ldu_matrix_create(e.addr, &e.mat), "hipLookup");
+        it = hipEntries_.insert(std::make_pair(&la, e)).first;
+    }
+    if (!it->second.weightsSet && label(hipFaceWeights_.size()) == nFaces && nFaces)
+    {
+        hipCheck(ldu_addr_set_face_weights(it->second.addr, &hipFaceWeights_[0]), "hipLookup");
+        it->second.weightsSet = true;
+    }
+    return it->second;
+}
+
+// Coefficients are re-read every solve (fvScalarMatrix.C:152-174 changes diag around the call).
+static void hipSetCoeffs
+(
+    hipLduEntry& e,
+    const lduMatrix& matrix,
+    const FieldField<Field, scalar>& bouCoeffs,
+    const FieldField<Field, scalar>& intCoeffs,
+    const lduInterfaceFieldPtrsList& interfaces
+)
+{
+    hipCheck
+    (
+        ldu_matrix_set_coeffs
+        (
+            e.mat, matrix.diag().begin(), matrix.upper().begin(),
+            matrix.asymmetric() ? matrix.lower().begin() : NULL
+        ),
+        "hipSetCoeffs"
+    );
+    label k = 0;
+    forAll(interfaces, patchi)
+    {
+        if (interfaces.set(patchi))
+        {
+            hipCheck
+            (
+                ldu_matrix_set_patch_coeffs(e.mat, k++, bouCoeffs[patchi].begin(), intCoeffs[patchi].begin()),
+                "hipSetCoeffs"
+            );
+        }
+    }
+}
+
+static int hipPreconditionerKind(const word& n)
+{
+    if (n == "none") return LDU_PRE_NONE;
+    if (n == "diagonal") return LDU_PRE_DIAGONAL;
+    if (n == "DIC" || n == "hipDIC") return LDU_PRE_DIC;
+    if (n == "FDIC") return LDU_PRE_FDIC;
+    if (n == "DILU" || n == "hipDILU") return LDU_PRE_DILU;
+    if (n == "GAMG") return LDU_PRE_GAMG;
+    FatalErrorIn("hipPreconditionerKind") << "preconditioner " << n << " has no GPU implementation"
+        << exit(FatalError);
+    return -1;
+}
+
+static int hipSmootherKind(const word& n)
+{
+    if (n == "GaussSeidel" || n == "hipGaussSeidel") return LDU_SM_GAUSSSEIDEL;
+    if (n == "symGaussSeidel") return LDU_SM_SYMGAUSSSEIDEL;
+    if (n == "DIC") return LDU_SM_DIC;
+    if (n == "DILU") return LDU_SM_DILU;
+    if (n == "FDIC") return LDU_SM_FDIC;
+    if (n == "DICGaussSeidel") return LDU_SM_DICGAUSSSEIDEL;
+    if (n == "DILUGaussSeidel") return LDU_SM_DILUGAUSSSEIDEL;
+    FatalErrorIn("hipSmootherKind") << "smoother " << n << " has no GPU implementation"
+        << exit(FatalError);
+    return -1;
+}
+
+// The keys the reference reads (lduMatrixSolver.C:164-169, smoothSolver.C:73, GAMGSolver.C:157-181,
+// GAMGAgglomeration.C:79, pairGAMGAgglomeration.C:45, GAMGPreconditioner.C:77); preconditioner /
+// smoother may be a word or a sub-dictionary (lduMatrixPreconditioner.C:70-81).
+static void hipReadControls(const dictionary& dict, int solverKind, ldu_controls& c)
+{
+    ldu_default_controls(&c);
+    c.solver = solverKind;
+    c.maxIter = dict.lookupOrDefault<label>("maxIter", 1000);
+    c.tolerance = dict.lookupOrDefault<scalar>("tolerance", 1e-6);
+    c.relTol = dict.lookupOrDefault<scalar>("relTol", 0);
+    c.nSweeps = dict.lookupOrDefault<label>("nSweeps", 1);
+    const dictionary* gd = &dict;
+    if (dict.found("preconditioner"))
+    {
+        c.preconditioner = hipPreconditionerKind(lduMatrix::preconditioner::getName(dict));
+        if (dict.isDict("preconditioner")) gd = &dict.subDict("preconditioner");
+    }
+    if (gd->found("smoother"))
+    {
+        c.smoother = hipSmootherKind(lduMatrix::smoother::getName(*gd));
+    }
+    Switch sw(false);
+    if (gd->readIfPresent("cacheAgglomeration", sw)) c.cacheAgglomeration = sw;
+    label l;
+    if (gd->readIfPresent("nPreSweeps", l)) c.nPreSweeps = l;
+    if (gd->readIfPresent("preSweepsLevelMultiplier", l)) c.preSweepsLevelMultiplier = l;
+    if (gd->readIfPresent("maxPreSweeps", l)) c.maxPreSweeps = l;
+    if (gd->readIfPresent("nPostSweeps", l)) c.nPostSweeps = l;
+    if (gd->readIfPresent("postSweepsLevelMultiplier", l)) c.postSweepsLevelMultiplier = l;
+    if (gd->readIfPresent("maxPostSweeps", l)) c.maxPostSweeps = l;
+    if (gd->readIfPresent("nFinestSweeps", l)) c.nFinestSweeps = l;
+    if (gd->readIfPresent("interpolateCorrection", sw)) c.interpolateCorrection = sw;
+    if (gd->readIfPresent("scaleCorrection", sw)) c.scaleCorrection = sw;
+    if (gd->readIfPresent("directSolveCoarsest", sw)) c.directSolveCoarsest = sw;
+    if (gd->readIfPresent("nCellsInCoarsestLevel", l)) c.nCellsInCoarsestLevel = l;
+    if (gd->readIfPresent("mergeLevels", l)) c.mergeLevels = l;
+    if (gd->readIfPresent("nVcycles", l)) c.nVcycles = l;
+    if (gd->found("agglomerator"))
+    {
+        const word ag(gd->lookup("agglomerator"));
+        c.agglomerator = (ag == "algebraicPair") ? LDU_AGG_ALGEBRAICPAIR : LDU_AGG_FACEAREAPAIR;
+    }
+}
+
+
+// ------------------------------------------------------------------ solvers
+
+template<int SolverKind>
+class hipLduSolver
+:
+    public lduMatrix::solver
+{
+public:
+
+    static const word typeName;
+    virtual const word& type() const { return typeName; }
+
+    hipLduSolver
+    (
+        const word& fieldName,
+        const lduMatrix& matrix,
+        const FieldField<Field, scalar>& interfaceBouCoeffs,
+        const FieldField<Field, scalar>& interfaceIntCoeffs,
+        const lduInterfaceFieldPtrsList& interfaces,
+        const dictionary& solverControls
+    )
+    :
+        lduMatrix::solver
+        (
+            fieldName, matrix, interfaceBouCoeffs, interfaceIntCoeffs, interfaces, solverControls
+        )
+    {}
+
+    virtual ~hipLduSolver() {}
+
+    virtual solverPerformance solve
+    (
+        scalarField& psi,
+        const scalarField& source,
+        const direction cmpt = 0
+    ) const
+    {
+        ldu_controls c;
+        hipReadControls(controlDict_, SolverKind, c);
+
+        // the log name the reference prints (PCG.C:73-77, GAMGSolverSolve.C:42, smoothSolver.C:85)
+        word name(typeName);
+        if (SolverKind == LDU_SOLVER_PCG || SolverKind == LDU_SOLVER_PBICG)
+        {
+            name = lduMatrix::preconditioner::getName(controlDict_) + typeName;
+        }
+
+        hipLduEntry& e = hipLookup(matrix_, interfaces_);
+        hipSetCoeffs(e, matrix_, interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_);
+
+        ldu_perf perf;
+        hipCheck(ldu_solve(e.mat, &c, psi.begin(), source.begin(), &perf, NULL), "hipLduSolver::solve");
+        if (getenv("LDU_VERBOSE"))
+        {
+            Info<< "[hipLduSolvers] " << name << " for " << fieldName_ << " solved on the GPU in "
+                << perf.solveSeconds << " s" << endl;
+        }
+
+        return solverPerformance
+        (
+            name, fieldName_, perf.initialResidual, perf.finalResidual, perf.nIterations,
+            perf.converged, perf.singular
+        );
+    }
+};
+
+template<> const word hipLduSolver<LDU_SOLVER_PCG>::typeName("PCG");
+template<> const word hipLduSolver<LDU_SOLVER_PBICG>::typeName("PBiCG");
+template<> const word hipLduSolver<LDU_SOLVER_GAMG>::typeName("GAMG");
+template<> const word hipLduSolver<LDU_SOLVER_SMOOTH>::typeName("smoothSolver");
+
+typedef hipLduSolver<LDU_SOLVER_PCG> hipPCG;
+typedef hipLduSolver<LDU_SOLVER_PBICG> hipPBiCG;
+typedef hipLduSolver<LDU_SOLVER_GAMG> hipGAMG;
+typedef hipLduSolver<LDU_SOLVER_SMOOTH> hipSmoothSolver;
+
+// registration: stock names are overridden (set), hip* names added alongside
+static const word nPCG("PCG"), nHipPCG("hipPCG"), nPBiCG("PBiCG"), nHipPBiCG("hipPBiCG"),
+    nGAMG("GAMG"), nHipGAMG("hipGAMG"), nSmooth("smoothSolver"), nHipSmooth("hipSmoothSolver");
+
+lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipPCG> addHipPCGSym_(nPCG);
+lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipPCG> addHipPCGSym2_(nHipPCG);
+lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipPBiCG> addHipPBiCGAsym_(nPBiCG);
+lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipPBiCG> addHipPBiCGAsym2_(nHipPBiCG);
+lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipGAMG> addHipGAMGSym_(nGAMG);
+lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipGAMG> addHipGAMGAsym_(nGAMG);
+lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipGAMG> addHipGAMGSym2_(nHipGAMG);
+lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipGAMG> addHipGAMGAsym2_(nHipGAMG);
+lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipSmoothSolver> addHipSmoothSym_(nSmooth);
+lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipSmoothSolver> addHipSmoothAsym_(nSmooth);
+lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipSmoothSolver> addHipSmoothSym2_(nHipSmooth);
+lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipSmoothSolver> addHipSmoothAsym2_(nHipSmooth);
+
+
+// ------------------------------------------------------------------ preconditioners (hipDIC, hipDILU)
+
+template<int Kind>
+class hipLduPreconditioner
+:
+    public lduMatrix::preconditioner
+{
+public:
+
+    static const word typeName;
+    virtual const word& type() const { return typeName; }
+
+    hipLduPreconditioner(const lduMatrix::solver& sol, const dictionary&)
+    :
+        lduMatrix::preconditioner(sol)
+    {
+        hipLduEntry& e = hipLookup(sol.matrix(), sol.interfaces());
+        hipSetCoeffs(e, sol.matrix(), sol.interfaceBouCoeffs(), sol.interfaceIntCoeffs(), sol.interfaces());
+    }
+
+    virtual void precondition(scalarField& wA, const scalarField& rA, const direction = 0) const
+    {
+        hipLduEntry& e = hipLookup(solver_.matrix(), solver_.interfaces());
+        hipCheck(ldu_precondition(e.mat, Kind, wA.begin(), rA.begin(), 0), "hipLduPreconditioner");
+    }
+
+    virtual void preconditionT(scalarField& wT, const scalarField& rT, const direction = 0) const
+    {
+        hipLduEntry& e = hipLookup(solver_.matrix(), solver_.interfaces());
+        hipCheck(ldu_precondition(e.mat, Kind, wT.begin(), rT.begin(), 1), "hipLduPreconditioner");
+    }
+};
+
+template<> const word hipLduPreconditioner<LDU_PRE_DIC>::typeName("hipDIC");
+template<> const word hipLduPreconditioner<LDU_PRE_DILU>::typeName("hipDILU");
+typedef hipLduPreconditioner<LDU_PRE_DIC> hipDICPreconditioner;
+typedef hipLduPreconditioner<LDU_PRE_DILU> hipDILUPreconditioner;
+
+lduMatrix::preconditioner::addRemovablesymMatrixConstructorToTable<hipDICPreconditioner> addHipDIC_;
+lduMatrix::preconditioner::addRemovableasymMatrixConstructorToTable<hipDILUPreconditioner> addHipDILU_;
+
+
+// ------------------------------------------------------------------ smoother (hipGaussSeidel)
+
+class hipGaussSeidelSmoother
+:
+    public lduMatrix::smoother
+{
+public:
+
+    static const word typeName;
+    virtual const word& type() const { return typeName; }
+
+    hipGaussSeidelSmoother
+    (
+        const word& fieldName,
+        const lduMatrix& matrix,
+        const FieldField<Field, scalar>& interfaceBouCoeffs,
+        const FieldField<Field, scalar>& interfaceIntCoeffs,
+        const lduInterfaceFieldPtrsList& interfaces
+    )
+    :
+        lduMatrix::smoother(fieldName, matrix, interfaceBouCoeffs, interfaceIntCoeffs, interfaces)
+    {
+        hipLduEntry& e = hipLookup(matrix_, interfaces_);
+        hipSetCoeffs(e, matrix_, interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_);
+    }
+
+    virtual void smooth
+    (
+        scalarField& psi,
+        const scalarField& source,
+        const direction,
+        const label nSweeps
+    ) const
+    {
+        hipLduEntry& e = hipLookup(matrix_, interfaces_);
+        hipCheck(ldu_smooth(e.mat, LDU_SM_GAUSSSEIDEL, psi.begin(), source.begin(), nSweeps),
+                 "hipGaussSeidelSmoother");
+    }
+};
+
+const word hipGaussSeidelSmoother::typeName("hipGaussSeidel");
+lduMatrix::smoother::addRemovablesymMatrixConstructorToTable<hipGaussSeidelSmoother> addHipGSSym_;
+lduMatrix::smoother::addRemovableasymMatrixConstructorToTable<hipGaussSeidelSmoother> addHipGSAsym_;
+
+} // End namespace Foam
+
+
+// Geometric agglomeration weights: faceAreaPairGAMGAgglomeration (libfiniteVolume) computes
+// mag(cmptMultiply(Sf/sqrt(magSf), (1,1.01,1.02))) from fvMesh::Sf(); a finiteVolume-aware
+// caller hands them over here once per mesh.
+extern "C" void hipLduSetFaceWeights(const double* w, int n)
+{
+    Foam::hipFaceWeights_.assign(w, w + n);
+}

@@ -30,6 +30,8 @@
 #include "OSspecific.H"
 
 #include <cstdio>
+#include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <map>
 #include <string>
@@ -174,6 +176,9 @@ int main(int argc, char* argv[])
             "deltaT 1; writeControl timeStep; writeInterval 1000000; writeFormat ascii;\n"
             "writePrecision 17; writeCompression off; timeFormat general; timePrecision 6;\n"
             "runTimeModifiable false;\n");
+        // optional plugin (the product's OpenFOAM shim): loaded by the reference's own
+        // dlLibraryTable exactly like `libs (...)` in a user's system/controlDict (Time.C:343)
+        if (getenv("LDU_PLUGIN_LIB")) fprintf(f, "libs (\"%s\");\n", getenv("LDU_PLUGIN_LIB"));
         fclose(f);
     }
     Time runTime(Time::controlDictName, caseDir.path(), caseDir.name(), "system", "constant", false);
@@ -214,6 +219,14 @@ int main(int argc, char* argv[])
 
     FieldField<Field, scalar> bc(0), ic(0);
     lduInterfaceFieldPtrsList ifs(0);
+
+    if (getenv("LDU_PLUGIN_LIB") && suppliedWeights)
+    {
+        // hand the geometric agglomeration weights to the plugin
+        typedef void (*setw_t)(const double*, int);
+        setw_t fn = (setw_t)dlsym(RTLD_DEFAULT, "hipLduSetFaceWeights");
+        if (fn) fn(weights.begin(), weights.size());
+    }
 
     if (mode == "solve")
     {
