@@ -153,6 +153,11 @@ int ldu_profile_begin(ldu_matrix* m);
 /* ms[c] = total milliseconds, counts[c] = recorded launches of class c since begin */
 int ldu_profile_end(ldu_matrix* m, double ms[8], int64_t counts[8]);
 
+/* Debug: per-slice trace of the point-to-point sweep engine (8 x u64 per slice of the addressing of
+ * m: tTicket, tWaitStart, tReady, tDone [shader clocks], polls, XCC id, workgroup, ticket).
+ * buf = device memory of nSlices*64 bytes, or NULL to switch tracing off. */
+int ldu_debug_p2p_trace(ldu_matrix* m, void* buf);
+
 /* ---- finite-volume stencils feeding the matrix ------------- */
 typedef struct ldu_mesh_geom {
     /* internal faces */

@@ -311,7 +311,7 @@ class Matrix:
         ms = (C.c_double * 8)()
         cnt = (C.c_int64 * 8)()
         _chk(lib().ldu_profile_end(self.h, ms, cnt))
-        names = ["amul", "gs_sweep", "tri_sweep", "residual", "c4", "c5", "c6", "rd_sweep"]
+        names = ["amul", "gs_sweep", "tri_sweep", "residual", "gs_multi", "c5", "c6", "rd_sweep"]
         return {n: dict(ms=ms[i], count=cnt[i]) for i, n in enumerate(names) if cnt[i]}
 
     def gamg_levels(self, **controls):

@@ -113,6 +113,12 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     }
     const char* e = getenv("LDU_SWEEP");
     if (e && !strcmp(e, "levels")) c->sweepP2P = 0;
+    e = getenv("LDU_P2P_MAXBPC");
+    if (e && atoi(e) > 0) c->p2pMaxBlocksPerCU = atoi(e);
+    e = getenv("LDU_P2P_GATE");
+    if (e) c->p2pGate = atoi(e);
+    e = getenv("LDU_GS_PIPELINE");
+    if (e) c->gsPipeline = atoi(e);
     e = getenv("LDU_P2P_BPC");
     if (e && atoi(e) > 0) c->p2pBlocksPerCU = atoi(e);
     e = getenv("LDU_P2P_SLEEP");
@@ -563,6 +569,13 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
     perf->solveSeconds = now_s() - t0;
     if (rc) return rc;
     return S.out(psi, x);
+}
+
+int ldu_debug_p2p_trace(ldu_matrix* m, void* buf)
+{
+    LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+    m->a->ctx->p2pTrace = buf != nullptr;
+    return k_set_p2p_trace((unsigned long long*)buf);
 }
 
 int ldu_profile_begin(ldu_matrix* m)

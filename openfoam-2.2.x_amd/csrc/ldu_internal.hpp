@@ -59,8 +59,12 @@ struct ldu_ctx {
     int fuseRows = 4096;             // levels up to this many rows are fused into one-block chains
     // sweep engine: 1 = persistent point-to-point kernel (default), 0 = one kernel per level
     int sweepP2P = 1;
+    int p2pGate = 0;                 // slice-completion gate before granule polling (measured slower: off)
+    int p2pTrace = 0;                // diagnostic kernels with per-slice tracing
+    int gsPipeline = 1;              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
     int numCUs = 256;
+    int p2pMaxBlocksPerCU = 5;       // register-limited residency of the sweep kernels
     int* d_abort = nullptr;          // set by a sweep whose bounded spin expired
     int* h_abort = nullptr;          // pinned mirror
     int p2pGen = 0;                  // bumped when a sweep aborted: addressings reset their tickets
@@ -143,9 +147,16 @@ struct ldu_addr {
     // a chunk ticket counter and the launch epoch (= tag; never 0)
     uint4* d_granule = nullptr;            // [nCells]
     unsigned* d_ticket = nullptr;          // [1]
+    int* d_gateF = nullptr;                // [nSlices] gate slice of forward sweeps (-1 none)
+    int* d_gateB = nullptr;                // [nSlices] gate slice of backward sweeps
+    unsigned* d_sliceDone = nullptr;       // [nSlices] completion tags (hint for the gate)
     unsigned ticketBase = 0;
     unsigned epoch = 0;
     int p2pGen = 0;
+
+    // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
+    struct GsTasks { int* d_tasks = nullptr; int n = 0; };
+    std::map<int, GsTasks> gsTasks;
 
     // cached graphs of level-scheduled sweeps, keyed by (mode, pointer arguments)
     std::map<std::string, hipGraphExec_t> graphs;
@@ -209,6 +220,9 @@ struct SweepArgs {
 
 int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
+int k_set_p2p_trace(unsigned long long* buf);
+int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
+                     const double* val);
 
 int k_fill_sell(ldu_addr* a, const double* lowerO, const double* upperO, double* val, hipStream_t s);
 int k_permute_in(ldu_addr* a, double* dstNew, const double* srcOld, hipStream_t s);   // dst[new] = src[perm[new]]

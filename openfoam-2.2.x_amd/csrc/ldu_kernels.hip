@@ -217,6 +217,8 @@ int k_faceH(ldu_matrix* m, double* faceH, const double* xOld, hipStream_t s)
 struct SliceTab {
     const int* sliceRow; const int* sliceCnt; const int* sliceEnt;
     const unsigned char* nL; const unsigned char* nU; const int* col;
+    const int* gate = nullptr;        // per slice: slice whose completion opens the polling gate (-1: none)
+    unsigned* sliceDone = nullptr;    // per slice: tag of the last sweep that completed it (hint only)
 };
 
 template <int MODE>
@@ -385,10 +387,22 @@ static int launch_sweep(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 // cross-CU hand-off instead of a kernel boundary plus a chain of dependent HBM loads.
 // Spins are bounded: on expiry the sweep sets *abortFlag and every wave drains.
 
-#define P2P_CHUNK WPB          // slices per ticket: one per wave of the workgroup
+#ifndef P2P_BLK
+#define P2P_BLK 256
+#endif
+#define P2P_CHUNK (P2P_BLK / LDU_WAVE)   // slices per ticket: one per wave of the workgroup
 #define P2P_SPIN_LIMIT (1u << 22)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// optional per-slice trace (LDU_P2P_TRACE): {tTicket, tWait, tReady, tDone, polls, xcc, slice, 0}
+struct P2PStat { long long tWait, tReady; unsigned polls; int gateSlice; const unsigned* sliceDone; };
+__device__ unsigned long long* g_p2p_trace = nullptr;
+int k_set_p2p_trace(unsigned long long* buf)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_trace), &buf, sizeof(buf)));
+    return 0;
+}
 
 // poll back-off between two granule polls, in units of s_sleep(1) (64 clocks); tunable (LDU_P2P_SLEEP)
 __device__ int g_p2p_sleep = 2;
@@ -430,13 +444,17 @@ __device__ __forceinline__ double granule_value(const u32x4& g)
 
 // acc -= sum_{i=0..n-1} val[e(i)] * (value of row col[e(i)] published in THIS sweep), in order;
 // entry index k(i) = first + i*step.  OP = 0: acc -= v*x ; OP = 1: acc -= (v2*v)/x  (SW_RD)
-template <int OP>
+template <int OP, bool DIAG = false>
 __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restrict__ G, unsigned tag,
                                                const int* __restrict__ col,
                                                const double* __restrict__ val,
                                                const double* __restrict__ val2, long ent, int first,
-                                               int step, int n, int selfRow, volatile int* abortFlag)
+                                               int step, int n, int selfRow, volatile int* abortFlag,
+                                               P2PStat& waitEst)
 {
+    // (An adaptive pre-sleep before the first poll was tried and measured 2-6x SLOWER: the wait
+    //  shrinks quickly while the levels grow, so any history-based nap oversleeps at the front.)
+    if (DIAG && g_p2p_trace) waitEst.tWait = wall_clock64();
     for (int i0 = 0; i0 < n; i0 += 4)
     {
         int c[4];
@@ -450,10 +468,28 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             v[j] = need ? val[e] : 0.0;
             v2[j] = (OP == 1 && need) ? val2[e] : 0.0;
         }
+        if (DIAG && i0 == 0 && waitEst.gateSlice >= 0)
+        {
+            // Cheap gate before the expensive granule polling (4 x 16 B x 64 lanes per poll):
+            // ONE lane polls ONE word - the completion tag of a slice about one dependency level
+            // BEFORE the slices this one really waits for.  It is only a hint that the front is
+            // near (never used for correctness), so the wave wakes up ~one level early and the
+            // fine-grained polling below runs for ~1 hand-off instead of the whole look-ahead.
+            const unsigned* gp = waitEst.sliceDone + waitEst.gateSlice;
+            unsigned gspins = 0;
+            for (;;)
+            {
+                const unsigned gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(gv - tag) >= 0) break;
+                if (++gspins > P2P_SPIN_LIMIT || ((gspins & 255u) == 0 && *abortFlag)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            waitEst.gateSlice = -1;
+        }
         u32x4 g0, g1, g2, g3;
         unsigned spins = 0;
         const int sleepN = g_p2p_sleep;
-        for (;;)
+        for (;; waitEst.polls += DIAG ? 1u : 0u)
         {
             granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
             bool ok = true;
@@ -486,16 +522,18 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             if (i0 + 3 < n) acc -= (v2[3] * v[3]) / x3;
         }
     }
+    if (DIAG && g_p2p_trace) waitEst.tReady = wall_clock64();
     return true;
 }
 
-template <int MODE>
+template <int MODE, bool DIAG = false>
 __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, uint4* __restrict__ G,
                                           unsigned tag, volatile int* abortFlag, double* __restrict__ w,
                                           const double* __restrict__ rhs,
                                           const double* __restrict__ scale,
                                           const double* __restrict__ val,
-                                          const double* __restrict__ val2, double* __restrict__ aux)
+                                          const double* __restrict__ val2, double* __restrict__ aux,
+                                          P2PStat& waitEst)
 {
     const int cnt = T.sliceCnt[s];
     if (lane >= cnt) return true;
@@ -507,19 +545,19 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
     if (MODE == SW_TRI_FWD)
     {
         double acc = scale[r] * rhs[r];
-        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag)) return false;
+        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         out = acc;
     }
     else if (MODE == SW_TRI_BWD)
     {
         double acc = w[r];
-        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, nl + nu - 1, -1, nu, r, abortFlag)) return false;
+        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, nl + nu - 1, -1, nu, r, abortFlag, waitEst)) return false;
         out = acc;
     }
     else if (MODE == SW_RD)
     {
         double acc = scale[r];
-        if (!p2p_accumulate<1>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag)) return false;
+        if (!p2p_accumulate<1, DIAG>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         out = acc;
     }
     else if (MODE == SW_GS_FWD)
@@ -540,7 +578,7 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
                 xu[j] = w[T.col[e]];
             }
         }
-        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag)) return false;
+        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         if (aux) aux[r] = acc;
         if (nuFast)
         {
@@ -561,7 +599,7 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
     else   // SW_GS_BWD
     {
         double acc = rhs[r];
-        if (!p2p_accumulate<0>(acc, G, tag, T.col, val, val2, ent, nl, 1, nu, r, abortFlag)) return false;
+        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, nl, 1, nu, r, abortFlag, waitEst)) return false;
         out = acc / scale[r];
     }
     w[r] = out;
@@ -569,8 +607,8 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
     return true;
 }
 
-template <int MODE, bool DESC>
-__global__ void __launch_bounds__(BLK)
+template <int MODE, bool DESC, bool DIAG>
+__global__ void __launch_bounds__(P2P_BLK)
 sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, uint4* G,
                  unsigned tag, int* abortFlag, double* w, const double* rhs, const double* scale,
                  const double* val, const double* val2, double* aux)
@@ -578,6 +616,7 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
     __shared__ int s_chunk[2];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
+    P2PStat waitEst = {0, 0, 0, -1, nullptr};   // gate + timestamps / poll count of the current slice
     // thread 0 keeps one ticket in flight ahead of the one being processed
     int nextT = 0;
     if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
@@ -597,7 +636,25 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
         if (si < nSlices)
         {
             const int s = DESC ? nSlices - 1 - si : si;
-            p2p_slice<MODE>(T, s, lane, G, tag, abortFlag, w, rhs, scale, val, val2, aux);
+            const long long tT = (DIAG && g_p2p_trace) ? wall_clock64() : 0;
+            if (DIAG)
+            {
+                waitEst.polls = 0;
+                waitEst.gateSlice = T.gate ? T.gate[s] : -1;
+                waitEst.sliceDone = T.sliceDone;
+            }
+            p2p_slice<MODE, DIAG>(T, s, lane, G, tag, abortFlag, w, rhs, scale, val, val2, aux, waitEst);
+            if (DIAG && T.sliceDone && lane == 0)
+                __hip_atomic_store(T.sliceDone + s, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (DIAG && g_p2p_trace && lane == 0)
+            {
+                unsigned long long* rec = g_p2p_trace + (size_t)s * 8;
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                rec[0] = (unsigned long long)tT; rec[1] = (unsigned long long)waitEst.tWait;
+                rec[2] = (unsigned long long)waitEst.tReady; rec[3] = (unsigned long long)wall_clock64();
+                rec[4] = waitEst.polls; rec[5] = xcc & 0xf; rec[6] = (unsigned long long)blockIdx.x; rec[7] = chunk;
+            }
         }
     }
 }
@@ -607,8 +664,13 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    if (ctx->p2pGate)
+    {
+        T.gate = DESC ? a->d_gateB : a->d_gateF;
+        T.sliceDone = a->d_sliceDone;
+    }
     const int nChunks = cdiv(a->nSlices, P2P_CHUNK);
-    int grid = ctx->numCUs * ctx->p2pBlocksPerCU;
+    int grid = ctx->numCUs * ctx->p2pBlocksPerCU * 256 / P2P_BLK;   // p2pBlocksPerCU counts 256-thread units
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
     if (a->p2pGen != ctx->p2pGen)
@@ -620,9 +682,250 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     }
     a->epoch++;
     if (a->epoch == 0) a->epoch = 1;   // tag 0 = never published
-    sweep_p2p_kernel<MODE, DESC><<<grid, BLK, 0, s>>>(T, a->nSlices, nChunks, a->d_ticket, a->ticketBase,
-        a->d_granule, a->epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+    if (ctx->p2pGate || ctx->p2pTrace)
+        sweep_p2p_kernel<MODE, DESC, true><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, a->d_ticket,
+            a->ticketBase, a->d_granule, a->epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+    else
+        sweep_p2p_kernel<MODE, DESC, false><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, a->d_ticket,
+            a->ticketBase, a->d_granule, a->epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
     // every workgroup overshoots the ticket exactly once
+    a->ticketBase += (unsigned)(nChunks + grid);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------- pipelined Gauss-Seidel sweeps
+// four "old" (previous sweep) neighbour values xu[BASE..BASE+3] of a row, static indices only
+template <int BASE>
+__device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* __restrict__ G, unsigned t,
+                                               const double* __restrict__ val, long ent, int nl, int nu,
+                                               int selfRow, volatile int* abortFlag, double (&xu)[8],
+                                               double (&vu)[8])
+{
+    int c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const bool need = BASE + q < nu;
+        const long e = ent + (long)(nl + BASE + q) * LDU_WAVE;
+        c[q] = need ? T.col[e] : selfRow;
+        vu[BASE + q] = need ? val[e] : 0.0;
+    }
+    u32x4 g0, g1, g2, g3;
+    unsigned spins = 0;
+    for (;;)
+    {
+        granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
+        bool ok = true;
+        if (BASE + 0 < nu) ok &= (g0.y == t) & (g0.w == t);
+        if (BASE + 1 < nu) ok &= (g1.y == t) & (g1.w == t);
+        if (BASE + 2 < nu) ok &= (g2.y == t) & (g2.w == t);
+        if (BASE + 3 < nu) ok &= (g3.y == t) & (g3.w == t);
+        if (ok) break;
+        if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
+        {
+            *abortFlag = 1;
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    xu[BASE + 0] = granule_value(g0);
+    xu[BASE + 1] = granule_value(g1);
+    xu[BASE + 2] = granule_value(g2);
+    xu[BASE + 3] = granule_value(g3);
+    return true;
+}
+
+
+// k consecutive GaussSeidel sweeps of the SAME matrix in ONE launch.  Sweep j+1 of a row only needs
+// sweep j's values of its UPPER neighbours (its "old" values) and sweep j+1's values of its LOWER
+// neighbours, so sweep j+1 can trail sweep j by the level distance to the upper neighbours: the
+// whole smoothing takes (nLevels + skew*(k-1)) hand-offs instead of k*nLevels.  Arithmetic per row
+// is untouched (GaussSeidelSmoother.C:151-176), so the result is bit-identical to k separate sweeps.
+// Tasks (sweep, slice) are ticketed in a host-built topological order (plan_gs_tasks); tag E+j marks
+// "value of sweep j".  Only the last sweep writes psi (earlier values live in the granules).
+template <int DUMMY>
+__device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int k, int lane,
+                                            uint4* __restrict__ G, unsigned tag0,
+                                            volatile int* abortFlag, double* __restrict__ psi,
+                                            const double* __restrict__ rhs,
+                                            const double* __restrict__ diag,
+                                            const double* __restrict__ val, P2PStat& waitEst)
+{
+    const int cnt = T.sliceCnt[s];
+    if (lane >= cnt) return;
+    const int r = T.sliceRow[s] + lane;
+    const int nl = T.nL[r];
+    const int nu = T.nU[r];
+    const long ent = (long)T.sliceEnt[s] + lane;
+    double acc = rhs[r];
+    const double d = diag[r];
+    const unsigned tagNew = tag0 + (unsigned)j;
+    // 1. "old" values of the upper neighbours: before the kernel (sweep 0) or sweep j-1's granules,
+    //    which are long published (that sweep runs ahead of this one)
+    double xu[8], vu[8];
+    const int nuFast = nu <= 8 ? nu : -1;
+    if (nuFast >= 0)
+    {
+        if (j == 0)
+        {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (q < nuFast)
+                {
+                    const long e = ent + (long)(nl + q) * LDU_WAVE;
+                    vu[q] = val[e];
+                    xu[q] = psi[T.col[e]];
+                }
+        }
+        else
+        {
+            if (!gs_gather_old4<0>(T, G, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+            if (nuFast > 4)
+                if (!gs_gather_old4<4>(T, G, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+        }
+    }
+    // 2. new values of the lower neighbours (the critical path)
+    if (!p2p_accumulate<0>(acc, G, tagNew, T.col, val, nullptr, ent, 0, 1, nl, r, abortFlag, waitEst)) return;
+    // 3. upper part, in face order
+    if (nuFast >= 0)
+    {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (q < nuFast) acc -= vu[q] * xu[q];
+    }
+    else if (j == 0)
+    {
+        for (int q = nl; q < nl + nu; q++)
+        {
+            const long e = ent + (long)q * LDU_WAVE;
+            acc -= val[e] * psi[T.col[e]];
+        }
+    }
+    else
+    {
+        if (!p2p_accumulate<0>(acc, G, tagNew - 1u, T.col, val, nullptr, ent, nl, 1, nu, r, abortFlag, waitEst)) return;
+    }
+    const double out = acc / d;
+    if (j == k - 1) psi[r] = out;
+    granule_store(G, r, out, tagNew);
+}
+
+__global__ void __launch_bounds__(P2P_BLK)
+sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
+                          unsigned* ticket, unsigned ticketBase, uint4* G, unsigned tag0, int* abortFlag,
+                          double* psi, const double* rhs, const double* diag, const double* val)
+{
+    __shared__ int s_chunk[2];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    P2PStat waitEst = {0, 0, 0, -1, nullptr};
+    int nextT = 0;
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    for (int it = 0;; it++)
+    {
+        if (threadIdx.x == 0)
+        {
+            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            s_chunk[it & 1] = t;
+            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+        }
+        __syncthreads();
+        const int chunk = s_chunk[it & 1];
+        if (chunk >= nChunks) return;
+        const int ti = chunk * P2P_CHUNK + wave;
+        if (ti < nTasks)
+        {
+            const int task = tasks[ti];
+            if (task >= 0)
+            {
+                const int sl = task & 0x0fffffff;
+                p2p_gs_task<0>(T, sl, task >> 28, k, lane, G, tag0, abortFlag, psi, rhs, diag, val, waitEst);
+            }
+        }
+    }
+}
+
+// Host side: topological task order for k pipelined sweeps (cached per k in the addressing).
+int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
+                     const double* val)
+{
+    ldu_ctx* ctx = a->ctx;
+    hipStream_t s = ctx->stream;
+    if (a->nCells == 0 || k <= 0) return 0;
+    auto it = a->gsTasks.find(k);
+    if (it == a->gsTasks.end())
+    {
+        // M[L] = running max over levels <= L of the highest level holding an upper neighbour
+        const int nLev = a->nLevels;
+        std::vector<int> M(nLev, 0);
+        for (int f = 0; f < a->nFaces; f++)
+        {
+            const int Ll = a->level[a->l[f]], Lu = a->level[a->u[f]];
+            if (Lu > M[Ll]) M[Ll] = Lu;
+        }
+        for (int L = 0; L < nLev; L++)
+        {
+            if (M[L] < L) M[L] = L;
+            if (L && M[L] < M[L - 1]) M[L] = M[L - 1];
+        }
+        std::vector<int> tasks;
+        tasks.reserve((size_t)k * a->nSlices + 4 * (size_t)nLev * k);
+        std::vector<int> next(k, 0);   // next level to emit per sweep
+        bool progress = true;
+        while (progress)
+        {
+            progress = false;
+            for (int j = 0; j < k; j++)
+            {
+                const int L = next[j];
+                if (L >= nLev) continue;
+                // sweep j may take level L once sweep j-1 has emitted every level <= M[L]
+                if (j > 0 && next[j - 1] <= M[L]) continue;
+                for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++)
+                    tasks.push_back((j << 28) | sl);
+                next[j]++;
+                progress = true;
+            }
+        }
+        ldu_addr::GsTasks gt;
+        gt.n = (int)tasks.size();
+        LDU_CHECK_HIP(hipMalloc((void**)&gt.d_tasks, sizeof(int) * (tasks.size() + 1)));
+        LDU_CHECK_HIP(hipMemcpy(gt.d_tasks, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice));
+        it = a->gsTasks.emplace(k, gt).first;
+    }
+    SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    if (ctx->p2pGate)
+    {
+        T.gate = a->d_gateF;
+        T.sliceDone = a->d_sliceDone;
+    }
+    const int nTasks = it->second.n;
+    const int nChunks = cdiv(nTasks, P2P_CHUNK);
+    // k sweeps are in flight at once: keep the same look-ahead (in levels) as a single sweep
+    int bpc = ctx->p2pBlocksPerCU * k;
+    if (bpc > ctx->p2pMaxBlocksPerCU) bpc = ctx->p2pMaxBlocksPerCU;
+    int grid = ctx->numCUs * bpc * 256 / P2P_BLK;
+    if (grid > nChunks) grid = nChunks;
+    if (grid < 1) grid = 1;
+    if (a->p2pGen != ctx->p2pGen)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(a->d_ticket, 0, sizeof(unsigned), s));
+        a->ticketBase = 0;
+        a->p2pGen = ctx->p2pGen;
+    }
+    // tags tag0 .. tag0+k-1; keep them away from 0 and from wrapping inside one launch
+    if (a->epoch > 0xffffff00u)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(a->d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
+        a->epoch = 0;
+    }
+    const unsigned tag0 = a->epoch + 1;
+    a->epoch += (unsigned)k;
+    ctx->profStart(a, 4);   // "gs_multi": one launch = k pipelined sweeps
+    sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, a->d_ticket,
+        a->ticketBase, a->d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+    ctx->profStop(a, 4);
     a->ticketBase += (unsigned)(nChunks + grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;

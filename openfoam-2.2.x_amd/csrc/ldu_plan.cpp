@@ -159,6 +159,44 @@ int plan_build(ldu_addr* a)
                 col[(long)sliceEnt[s] + i + (long)k * LDU_WAVE] = sliceRow[s];
     }
 
+    // polling gates of the point-to-point sweeps: the slice one dependency level before the
+    // latest-scheduled slice this one depends on (forward: lower neighbours; backward: upper)
+    std::vector<int> gateF(a->nSlices, -1), gateB(a->nSlices, -1);
+    {
+        std::vector<int> rowSlice(nC), sliceLevel(a->nSlices);
+        for (int L = 0; L < nLevels; L++)
+            for (int s = a->levelSliceStart[L]; s < a->levelSliceStart[L + 1]; s++)
+            {
+                sliceLevel[s] = L;
+                for (int i = 0; i < sliceCnt[s]; i++) rowSlice[sliceRow[s] + i] = s;
+            }
+        for (int s = 0; s < a->nSlices; s++)
+        {
+            int depF = -1, depB = a->nSlices;
+            for (int i = 0; i < sliceCnt[s]; i++)
+            {
+                const int r = sliceRow[s] + i;
+                const long base = (long)sliceEnt[s] + i;
+                for (int k = 0; k < nL[r]; k++)
+                    depF = std::max(depF, rowSlice[col[base + (long)k * LDU_WAVE]]);
+                for (int k = nL[r]; k < nL[r] + nU[r]; k++)
+                    depB = std::min(depB, rowSlice[col[base + (long)k * LDU_WAVE]]);
+            }
+            if (depF >= 0)
+            {
+                const int L = sliceLevel[depF];
+                const int g = depF - (a->levelSliceStart[L + 1] - a->levelSliceStart[L]);
+                gateF[s] = g >= 0 ? g : -1;
+            }
+            if (depB < a->nSlices)
+            {
+                const int L = sliceLevel[depB];
+                const int g = depB + (a->levelSliceStart[L + 1] - a->levelSliceStart[L]);
+                gateB[s] = g < a->nSlices ? g : -1;
+            }
+        }
+    }
+
     // sweep schedule: runs of small levels are fused into single-block chains
     a->segs.clear();
     {
@@ -207,6 +245,10 @@ int plan_build(ldu_addr* a)
     // point-to-point sweep state (tags start at 0 = never published)
     LDU_CHECK_HIP(hipMalloc((void**)&a->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
     LDU_CHECK_HIP(hipMemset(a->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
+    if (upload(&a->d_gateF, gateF)) return -1;
+    if (upload(&a->d_gateB, gateB)) return -1;
+    LDU_CHECK_HIP(hipMalloc((void**)&a->d_sliceDone, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
+    LDU_CHECK_HIP(hipMemset(a->d_sliceDone, 0, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
     LDU_CHECK_HIP(hipMalloc((void**)&a->d_ticket, sizeof(unsigned)));
     LDU_CHECK_HIP(hipMemset(a->d_ticket, 0, sizeof(unsigned)));
     a->ticketBase = 0;
@@ -272,10 +314,13 @@ void plan_free(ldu_addr* a)
 {
     for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
     a->graphs.clear();
+    for (auto& kv : a->gsTasks) if (kv.second.d_tasks) (void)hipFree(kv.second.d_tasks);
+    a->gsTasks.clear();
     void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW,
                     a->d_levelSliceStart, a->d_nL, a->d_nU, a->d_col, a->d_face, a->d_l, a->d_u,
                     a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,
-                    a->d_pfCell, a->d_sendAll, a->d_recvAll, a->d_granule, a->d_ticket};
+                    a->d_pfCell, a->d_sendAll, a->d_recvAll, a->d_granule, a->d_ticket, a->d_gateF, a->d_gateB,
+                    a->d_sliceDone};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : a->scratch) if (p) (void)hipFree(p);
     a->scratch.clear();

@@ -166,6 +166,18 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     hipStream_t s = a->ctx->stream;
     double* bPrime = nullptr;
     if (a->nPatchFaces || sym) bPrime = m->workVec(12);
+    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && a->ctx->gsPipeline && nSweeps >= 2)
+    {
+        // consecutive sweeps pipelined inside one launch (bit-identical to separate sweeps)
+        int left = nSweeps;
+        while (left > 0)
+        {
+            const int k = left > 4 ? 4 : left;
+            if (k_sweep_gs_multi(a, k, psi, source, m->d_diag, m->d_valA)) return -1;
+            left -= k;
+        }
+        return 0;
+    }
     for (int sweep = 0; sweep < nSweeps; sweep++)
     {
         const double* rhs = source;
