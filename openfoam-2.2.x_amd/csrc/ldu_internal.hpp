@@ -61,6 +61,7 @@ struct ldu_ctx {
     int sweepP2P = 1;
     int p2pGate = 0;                 // slice-completion gate before granule polling (measured slower: off)
     int p2pTrace = 0;                // diagnostic kernels with per-slice tracing
+    int gsFast = 0;                  // software-pipelined GaussSeidel task engine (measured: no gain, off)
     int gsPipeline = 1;              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
     int numCUs = 256;

@@ -128,10 +128,12 @@ int plan_build(ldu_addr* a)
     }
     a->levelSliceStart[nLevels] = (int)sliceRow.size();
     a->nSlices = (int)sliceRow.size();
-    a->nEntries = ent;
+    // 512 padding entries: the fast GaussSeidel path reads 8 entries per row unconditionally
+    const long entPad = ent + 512;
+    a->nEntries = entPad;
     sliceRow.push_back(nC);
 
-    std::vector<int> col((size_t)ent, 0), face((size_t)ent, -1);
+    std::vector<int> col((size_t)entPad, 0), face((size_t)entPad, -1);
     for (int s = 0; s < a->nSlices; s++)
     {
         for (int i = 0; i < sliceCnt[s]; i++)
