@@ -150,14 +150,16 @@ def main():
     gs_bytes = 60.0 * nC + 12.0 * nF
     amul_bytes = 24.0 * nC + 16.0 * nF
     roof = None
-    if "gs_sweep" in prof and prof["gs_sweep"]["count"]:
-        ms = prof["gs_sweep"]["ms"] / prof["gs_sweep"]["count"]
-        ach = gs_bytes / (ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel="GaussSeidel sweep (finest level; one graph launch of "
-                    "%d dependency-level kernels)" % info["nLevels"], achieved=round(ach, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
-                    avg_launch_ms=round(ms, 4), bytes_per_launch=gs_bytes,
-                    launches=prof["gs_sweep"]["count"])
+    key, per_launch = ("gs_multi", GAMG_CONTROLS["nFinestSweeps"]) if "gs_multi" in prof else ("gs_sweep", 1)
+    if key in prof and prof[key]["count"]:
+        ms = prof[key]["ms"] / prof[key]["count"]
+        ach = per_launch * gs_bytes / (ms * 1e-3) / 1e9
+        kname = ("sweep_p2p_gs_multi_kernel: %d pipelined GaussSeidel sweeps of the finest level per launch"
+                 % per_launch) if key == "gs_multi" else "sweep_p2p_kernel<SW_GS_FWD>: one GaussSeidel sweep"
+        roof = dict(bound="hbm", kernel=kname + " (%d dependency levels)" % info["nLevels"],
+                    achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                    traffic=None, avg_launch_ms=round(ms, 4), bytes_per_launch=per_launch * gs_bytes,
+                    launches=prof[key]["count"])
     amul = None
     if "amul" in prof and prof["amul"]["count"]:
         ms = prof["amul"]["ms"] / prof["amul"]["count"]
