@@ -156,9 +156,16 @@ def main():
         ach = per_launch * gs_bytes / (ms * 1e-3) / 1e9
         kname = ("sweep_p2p_gs_multi_kernel: %d pipelined GaussSeidel sweeps of the finest level per launch"
                  % per_launch) if key == "gs_multi" else "sweep_p2p_kernel<SW_GS_FWD>: one GaussSeidel sweep"
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if key == "gs_multi" and n == 216 and world == 1:
+                traffic = pj["bytes_per_launch"]   # separate rocprofv3 --pmc passes, see profiles/r01_pmc_traffic.md
+        except Exception:
+            pass
         roof = dict(bound="hbm", kernel=kname + " (%d dependency levels)" % info["nLevels"],
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                    traffic=None, avg_launch_ms=round(ms, 4), bytes_per_launch=per_launch * gs_bytes,
+                    traffic=traffic, avg_launch_ms=round(ms, 4), bytes_per_launch=per_launch * gs_bytes,
                     launches=prof[key]["count"])
     amul = None
     if "amul" in prof and prof["amul"]["count"]:
