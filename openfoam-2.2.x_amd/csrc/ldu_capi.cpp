@@ -117,6 +117,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e) > 0) c->p2pMaxBlocksPerCU = atoi(e);
     e = getenv("LDU_P2P_GATE");
     if (e) c->p2pGate = atoi(e);
+    e = getenv("LDU_DUAL_STREAM");
+    if (e) c->dualStream = atoi(e);
     e = getenv("LDU_GS_FAST");
     if (e) c->gsFast = atoi(e);
     e = getenv("LDU_GS_PIPELINE");

@@ -62,6 +62,7 @@ struct ldu_ctx {
     int p2pGate = 0;                 // slice-completion gate before granule polling (measured slower: off)
     int p2pTrace = 0;                // diagnostic kernels with per-slice tracing
     int gsFast = 0;                  // software-pipelined GaussSeidel task engine (measured: no gain, off)
+    int dualStream = 1;              // PBiCG: A system and transposed system on two streams
     int gsPipeline = 1;              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
     int numCUs = 256;
@@ -146,14 +147,20 @@ struct ldu_addr {
 
     // point-to-point sweep state: one 16-byte {value lo, tag, value hi, tag} granule per row,
     // a chunk ticket counter and the launch epoch (= tag; never 0)
-    uint4* d_granule = nullptr;            // [nCells]
-    unsigned* d_ticket = nullptr;          // [1]
+    // two independent lanes so that two sweeps of the same addressing can run concurrently on
+    // two streams (PBiCG: the A system and the transposed system)
+    struct P2PLane {
+        uint4* d_granule = nullptr;        // [nCells]
+        unsigned* d_ticket = nullptr;      // [1]
+        unsigned ticketBase = 0;
+        unsigned epoch = 0;
+        int gen = 0;
+    };
+    P2PLane p2p[2];
+    P2PLane* lane(int i);                  // lazily allocates lane 1
     int* d_gateF = nullptr;                // [nSlices] gate slice of forward sweeps (-1 none)
     int* d_gateB = nullptr;                // [nSlices] gate slice of backward sweeps
     unsigned* d_sliceDone = nullptr;       // [nSlices] completion tags (hint for the gate)
-    unsigned ticketBase = 0;
-    unsigned epoch = 0;
-    int p2pGen = 0;
 
     // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
     struct GsTasks { int* d_tasks = nullptr; int n = 0; };
@@ -217,6 +224,8 @@ struct SweepArgs {
     const double* val;    // valP / valA
     const double* val2;   // valT for SW_RD
     double* aux;          // bPrime store (GS_FWD when non-null)
+    int lane;             // P2P state lane (0 default; 1 = second concurrent sweep)
+    hipStream_t stream;   // nullptr = the context's compute stream
 };
 
 int k_sweep(ldu_addr* a, const SweepArgs& args);
@@ -305,7 +314,7 @@ void comm_destroy(ldu_ctx* ctx);
 
 // solvers (ldu_solvers.cpp): all vectors device, new numbering
 int matrix_ensure_rD(ldu_matrix* m, int kind);
-int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose);
+int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStream_t s = nullptr);
 int dev_residual(ldu_matrix* m, double* r, const double* x, const double* b);
 int dev_sumA(ldu_matrix* m, double* sumA);
 int dev_precondition(ldu_matrix* m, int kind, double* w, const double* r, bool transpose, hipStream_t s);

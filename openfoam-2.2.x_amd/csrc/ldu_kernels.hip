@@ -664,6 +664,9 @@ template <int MODE, bool DESC>
 static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
+    ldu_addr::P2PLane* Pp = a->lane(g.lane);
+    if (!Pp) { ldu_set_error("p2p lane allocation failed"); return -1; }
+    ldu_addr::P2PLane& P = *Pp;
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
     if (ctx->p2pGate)
     {
@@ -674,23 +677,23 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     int grid = ctx->numCUs * ctx->p2pBlocksPerCU * 256 / P2P_BLK;   // p2pBlocksPerCU counts 256-thread units
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
-    if (a->p2pGen != ctx->p2pGen)
+    if (P.gen != ctx->p2pGen)
     {
         // a previous sweep aborted somewhere: ticket counters are no longer in step
-        LDU_CHECK_HIP(hipMemsetAsync(a->d_ticket, 0, sizeof(unsigned), s));
-        a->ticketBase = 0;
-        a->p2pGen = ctx->p2pGen;
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
+        P.ticketBase = 0;
+        P.gen = ctx->p2pGen;
     }
-    a->epoch++;
-    if (a->epoch == 0) a->epoch = 1;   // tag 0 = never published
+    P.epoch++;
+    if (P.epoch == 0) P.epoch = 1;   // tag 0 = never published
     if (ctx->p2pGate || ctx->p2pTrace)
-        sweep_p2p_kernel<MODE, DESC, true><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, a->d_ticket,
-            a->ticketBase, a->d_granule, a->epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+        sweep_p2p_kernel<MODE, DESC, true><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, P.d_ticket,
+            P.ticketBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
     else
-        sweep_p2p_kernel<MODE, DESC, false><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, a->d_ticket,
-            a->ticketBase, a->d_granule, a->epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+        sweep_p2p_kernel<MODE, DESC, false><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, P.d_ticket,
+            P.ticketBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
     // every workgroup overshoots the ticket exactly once
-    a->ticketBase += (unsigned)(nChunks + grid);
+    P.ticketBase += (unsigned)(nChunks + grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1039,6 +1042,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
                      const double* val)
 {
     ldu_ctx* ctx = a->ctx;
+    ldu_addr::P2PLane& P = *a->lane(0);
     hipStream_t s = ctx->stream;
     if (a->nCells == 0 || k <= 0) return 0;
     auto it = a->gsTasks.find(k);
@@ -1096,30 +1100,30 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     int grid = ctx->numCUs * bpc * 256 / P2P_BLK;
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
-    if (a->p2pGen != ctx->p2pGen)
+    if (P.gen != ctx->p2pGen)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(a->d_ticket, 0, sizeof(unsigned), s));
-        a->ticketBase = 0;
-        a->p2pGen = ctx->p2pGen;
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
+        P.ticketBase = 0;
+        P.gen = ctx->p2pGen;
     }
     // tags tag0 .. tag0+k-1; keep them away from 0 and from wrapping inside one launch
-    if (a->epoch > 0xffffff00u)
+    if (P.epoch > 0xffffff00u)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(a->d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
-        a->epoch = 0;
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
+        P.epoch = 0;
     }
-    const unsigned tag0 = a->epoch + 1;
-    a->epoch += (unsigned)k;
+    const unsigned tag0 = P.epoch + 1;
+    P.epoch += (unsigned)k;
     ctx->profStart(a, 4);   // "gs_multi": one launch = k pipelined sweeps
     T.sliceW = a->d_sliceW;
     if (ctx->gsFast)
-        sweep_p2p_gs_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, a->d_ticket,
-            a->ticketBase, a->d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+        sweep_p2p_gs_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
+            P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     else
-        sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, a->d_ticket,
-            a->ticketBase, a->d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+        sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
+            P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     ctx->profStop(a, 4);
-    a->ticketBase += (unsigned)(nChunks + grid);
+    P.ticketBase += (unsigned)(nChunks + grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1143,22 +1147,22 @@ static int launch_sweep_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 int k_sweep(ldu_addr* a, const SweepArgs& g)
 {
     ldu_ctx* ctx = a->ctx;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = g.stream ? g.stream : ctx->stream;
     if (a->nCells == 0) return 0;
     const int cat = (g.mode == SW_GS_FWD || g.mode == SW_GS_BWD) ? LDU_PROF_GS_SWEEP
                     : (g.mode == SW_RD ? 7 : LDU_PROF_TRI_SWEEP);
     if (ctx->sweepP2P)
     {
-        ctx->profStart(a, cat);
+        if (s == ctx->stream) ctx->profStart(a, cat);
         int rc = launch_sweep_p2p(a, g, s);
-        ctx->profStop(a, cat);
+        if (s == ctx->stream) ctx->profStop(a, cat);
         return rc;
     }
     if (!ctx->useGraphs || a->segs.size() <= 2)
     {
-        ctx->profStart(a, cat);
+        if (s == ctx->stream) ctx->profStart(a, cat);
         int rc = launch_sweep(a, g, s);
-        ctx->profStop(a, cat);
+        if (s == ctx->stream) ctx->profStop(a, cat);
         return rc;
     }
 
@@ -1187,9 +1191,9 @@ int k_sweep(ldu_addr* a, const SweepArgs& g)
         }
         it = a->graphs.emplace(key, exec).first;
     }
-    ctx->profStart(a, cat);
+    if (s == ctx->stream) ctx->profStart(a, cat);
     LDU_CHECK_HIP(hipGraphLaunch(it->second, s));
-    ctx->profStop(a, cat);
+    if (s == ctx->stream) ctx->profStop(a, cat);
     return 0;
 }
 

@@ -17,6 +17,23 @@ static int upload(T** dst, const std::vector<T>& src)
     return 0;
 }
 
+ldu_addr::P2PLane* ldu_addr::lane(int i)
+{
+    P2PLane& P = p2p[i];
+    if (!P.d_granule)
+    {
+        // tags start at 0 = never published
+        if (hipMalloc((void**)&P.d_granule, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
+        if (hipMemset(P.d_granule, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&P.d_ticket, sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(P.d_ticket, 0, sizeof(unsigned)) != hipSuccess) return nullptr;
+        P.ticketBase = 0;
+        P.epoch = 0;
+        P.gen = ctx->p2pGen;
+    }
+    return &P;
+}
+
 double* ldu_addr::scratchVec(int i)
 {
     while ((int)scratch.size() <= i) scratch.push_back(nullptr);
@@ -245,16 +262,11 @@ int plan_build(ldu_addr* a)
     if (upload(&a->d_ownerStart, a->ownerStart)) return -1;
     if (upload(&a->d_losortStart, a->losortStart)) return -1;
     // point-to-point sweep state (tags start at 0 = never published)
-    LDU_CHECK_HIP(hipMalloc((void**)&a->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
-    LDU_CHECK_HIP(hipMemset(a->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
+    if (!a->lane(0)) return -1;
     if (upload(&a->d_gateF, gateF)) return -1;
     if (upload(&a->d_gateB, gateB)) return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&a->d_sliceDone, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
     LDU_CHECK_HIP(hipMemset(a->d_sliceDone, 0, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
-    LDU_CHECK_HIP(hipMalloc((void**)&a->d_ticket, sizeof(unsigned)));
-    LDU_CHECK_HIP(hipMemset(a->d_ticket, 0, sizeof(unsigned)));
-    a->ticketBase = 0;
-    a->epoch = 0;
     return 0;
 }
 
@@ -321,7 +333,8 @@ void plan_free(ldu_addr* a)
     void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW,
                     a->d_levelSliceStart, a->d_nL, a->d_nU, a->d_col, a->d_face, a->d_l, a->d_u,
                     a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,
-                    a->d_pfCell, a->d_sendAll, a->d_recvAll, a->d_granule, a->d_ticket, a->d_gateF, a->d_gateB,
+                    a->d_pfCell, a->d_sendAll, a->d_recvAll, a->p2p[0].d_granule, a->p2p[0].d_ticket,
+                    a->p2p[1].d_granule, a->p2p[1].d_ticket, a->d_gateF, a->d_gateB,
                     a->d_sliceDone};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : a->scratch) if (p) (void)hipFree(p);

@@ -61,9 +61,9 @@ static int halo_start(ldu_matrix* m, const double* x)
     return comm_exchange(a, a->ctx->stream);
 }
 
-int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose)
+int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStream_t s2)
 {
-    hipStream_t s = m->a->ctx->stream;
+    hipStream_t s = s2 ? s2 : m->a->ctx->stream;
     if (halo_start(m, x)) return -1;
     if (k_amul(m, y, x, transpose, s)) return -1;
     if (m->a->nPatchFaces) return k_apply_patches(m->a, y, transpose ? m->d_int : m->d_bou, 1.0, s);
@@ -130,14 +130,15 @@ int matrix_ensure_rD(ldu_matrix* m, int kind)
 int dev_precondition(ldu_matrix* m, int kind, double* w, const double* r, bool transpose, hipStream_t s)
 {
     ldu_addr* a = m->a;
-    (void)s;
+    if (!s) s = a->ctx->stream;
+    const int lane = (s == a->ctx->stream2) ? 1 : 0;   // second concurrent sweep: own P2P state
     switch (kind)
     {
     case LDU_PRE_NONE:       // noPreconditioner.C:58-74
-        return k_ew(a->nCells, EW_COPY, w, r, nullptr, a->ctx->stream);
+        return k_ew(a->nCells, EW_COPY, w, r, nullptr, s);
     case LDU_PRE_DIAGONAL:   // diagonalPreconditioner.C:72-87
         if (matrix_ensure_rD(m, kind)) return -1;
-        return k_ew(a->nCells, EW_MUL, w, m->d_rDiag, r, a->ctx->stream);
+        return k_ew(a->nCells, EW_MUL, w, m->d_rDiag, r, s);
     case LDU_PRE_DIC:
     case LDU_PRE_FDIC:
     case LDU_PRE_DILU:
@@ -148,9 +149,11 @@ int dev_precondition(ldu_matrix* m, int kind, double* w, const double* r, bool t
         const double* vp = (transpose && !m->sym) ? m->d_valPT : m->d_valP;
         SweepArgs f{};
         f.mode = SW_TRI_FWD; f.w = w; f.rhs = r; f.scale = m->d_rD; f.val = vp;
+        f.lane = lane; f.stream = s;
         if (k_sweep(a, f)) return -1;
         SweepArgs b{};
         b.mode = SW_TRI_BWD; b.w = w; b.val = vp;
+        b.lane = lane; b.stream = s;
         return k_sweep(a, b);
     }
     }
@@ -343,6 +346,7 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
             if (matrix_ensure_rD(m, pre)) return -1;
         }
         int cur = S_WARA0, prev = S_WARA1;
+        const bool dual = bi && !a->nPatchFaces && ctx->dualStream && pre != LDU_PRE_GAMG;
         do
         {
             // wArAold = wArA (slot swap)
@@ -354,8 +358,18 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
             }
             else
             {
+                // PBiCG: the transposed system is independent until the dot product -> second
+                // stream, own point-to-point lane (both are latency-bound: they overlap fully)
+                if (dual)
+                {
+                    LDU_CHECK_HIP(hipEventRecord(ctx->evFork, s));
+                    LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+                    if (dev_precondition(m, pre, wT, rT, true, ctx->stream2)) return -1;
+                    LDU_CHECK_HIP(hipEventRecord(ctx->evJoin, ctx->stream2));
+                }
                 if (dev_precondition(m, pre, wA, rA, false, s)) return -1;
-                if (bi && dev_precondition(m, pre, wT, rT, true, s)) return -1;
+                if (bi && !dual && dev_precondition(m, pre, wT, rT, true, s)) return -1;
+                if (dual) LDU_CHECK_HIP(hipStreamWaitEvent(s, ctx->evJoin, 0));
             }
             // --- wArA = gSumProd(wA, rA) / wArT = gSumProd(wA, rT)
             if (k_reduce(ctx, n, RED_DOT, wA, bi ? rT : rA, nullptr, nullptr, cur, s)) return -1;
@@ -368,8 +382,16 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
             }
             else if (k_pcg_update_p(n, pA, wA, ctx->S(), cur, prev, first, s)) return -1;
             // --- wA = A pA (wT = T pT)
+            if (dual)
+            {
+                LDU_CHECK_HIP(hipEventRecord(ctx->evFork, s));
+                LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+                if (dev_amul(m, wT, pT, true, ctx->stream2)) return -1;
+                LDU_CHECK_HIP(hipEventRecord(ctx->evJoin, ctx->stream2));
+            }
             if (dev_amul(m, wA, pA, false)) return -1;
-            if (bi && dev_amul(m, wT, pT, true)) return -1;
+            if (bi && !dual && dev_amul(m, wT, pT, true)) return -1;
+            if (dual) LDU_CHECK_HIP(hipStreamWaitEvent(s, ctx->evJoin, 0));
             // --- wApA = gSumProd(wA, pA) / wApT = gSumProd(wA, pT)
             if (k_reduce(ctx, n, RED_DOT, wA, bi ? pT : pA, nullptr, nullptr, S_WAPA, s)) return -1;
             if (comm_allreduce_scalars(ctx, S_WAPA, 1, s)) return -1;
