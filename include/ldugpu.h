@@ -157,6 +157,8 @@ int ldu_profile_end(ldu_matrix* m, double ms[8], int64_t counts[8]);
  * m: tTicket, tWaitStart, tReady, tDone [shader clocks], polls, XCC id, workgroup, ticket).
  * buf = device memory of nSlices*64 bytes, or NULL to switch tracing off. */
 int ldu_debug_p2p_trace(ldu_matrix* m, void* buf);
+/* Debug: the first dependency wait that expired in an aborted sweep (row, tag, columns, seen tags). */
+int ldu_debug_p2p_stuck(ldu_matrix* m, int32_t out[16]);
 
 /* ---- finite-volume stencils feeding the matrix ------------- */
 typedef struct ldu_mesh_geom {

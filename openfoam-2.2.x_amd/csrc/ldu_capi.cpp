@@ -121,10 +121,14 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->dualStream = atoi(e);
     e = getenv("LDU_GS_FAST");
     if (e) c->gsFast = atoi(e);
+    e = getenv("LDU_GS_MAXSKEW");
+    if (e) c->gsPipelineMaxSkew = atoi(e);
     e = getenv("LDU_GS_PIPELINE");
     if (e) c->gsPipeline = atoi(e);
     e = getenv("LDU_P2P_BPC");
     if (e && atoi(e) > 0) c->p2pBlocksPerCU = atoi(e);
+    e = getenv("LDU_P2P_BACKOFF");
+    if (e) k_set_p2p_backoff((unsigned)atoi(e));
     e = getenv("LDU_P2P_SLEEP");
     if (e) k_set_p2p_sleep(atoi(e));
     e = getenv("LDU_NO_GRAPH");
@@ -538,6 +542,7 @@ int ldu_precondition(ldu_matrix* m, int32_t pre, double* wA, const double* rA, i
     double* w = S.tmp();
     if (!r || !w) return -1;
     if (dev_precondition(m, pre, w, r, transpose != 0, S.s)) return -1;
+    if (int rc = dev_check_abort(m->a->ctx)) return rc;
     return S.out(wA, w);
 }
 
@@ -549,6 +554,7 @@ int ldu_smooth(ldu_matrix* m, int32_t smoother, double* psi, const double* sourc
     double* b = S.in(source);
     if (!x || !b) return -1;
     if (dev_smooth(m, smoother, x, b, nSweeps)) return -1;
+    if (int rc = dev_check_abort(m->a->ctx)) return rc;
     return S.out(psi, x);
 }
 
@@ -572,7 +578,30 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
     LDU_CHECK_HIP(hipStreamSynchronize(S.s));
     perf->solveSeconds = now_s() - t0;
     if (rc) return rc;
+    if (int rc2 = dev_check_abort(m->a->ctx)) return rc2;
     return S.out(psi, x);
+}
+
+int ldu_debug_granule_tags(ldu_matrix* m, int32_t* tags /* nCells, level order */, int32_t* perm)
+{
+    ldu_addr* a = m->a;
+    LDU_CHECK_HIP(hipStreamSynchronize(a->ctx->stream));
+    std::vector<uint4> g(a->nCells);
+    LDU_CHECK_HIP(hipMemcpy(g.data(), a->p2p[0].d_granule, sizeof(uint4) * a->nCells, hipMemcpyDeviceToHost));
+    for (int i = 0; i < a->nCells; i++) { tags[i] = (int)g[i].y; perm[i] = a->level[a->perm[i]]; }
+    return 0;
+}
+
+int ldu_debug_p2p_records(ldu_matrix* m, int32_t* out /* 1 + 512 */)
+{
+    LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+    return k_read_p2p_dbg_records(out);
+}
+
+int ldu_debug_p2p_stuck(ldu_matrix* m, int32_t out[16])
+{
+    LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+    return k_read_p2p_dbg(out);
 }
 
 int ldu_debug_p2p_trace(ldu_matrix* m, void* buf)

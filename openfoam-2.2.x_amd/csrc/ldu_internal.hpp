@@ -63,7 +63,8 @@ struct ldu_ctx {
     int p2pTrace = 0;                // diagnostic kernels with per-slice tracing
     int gsFast = 0;                  // software-pipelined GaussSeidel task engine (measured: no gain, off)
     int dualStream = 1;              // PBiCG: A system and transposed system on two streams
-    int gsPipeline = 1;              // pipeline consecutive GaussSeidel sweeps in one launch
+    int gsPipeline = 1;
+    int gsPipelineMaxSkew = 4;       // pipeline sweeps only if upper neighbours are <= this many levels ahead              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
     int numCUs = 256;
     int p2pMaxBlocksPerCU = 5;       // register-limited residency of the sweep kernels
@@ -230,6 +231,9 @@ struct SweepArgs {
 
 int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
+int k_set_p2p_backoff(unsigned n);
+int k_read_p2p_dbg(int* out);
+int k_read_p2p_dbg_records(int* out);
 int k_set_p2p_trace(unsigned long long* buf);
 int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
                      const double* val);
@@ -322,6 +326,7 @@ int dev_smooth(ldu_matrix* m, int smoother, double* psi, const double* source, i
 int dev_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
               double* hist);
 int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out);
+int dev_check_abort(ldu_ctx* ctx);
 
 // GAMG (ldu_gamg.cpp)
 int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,

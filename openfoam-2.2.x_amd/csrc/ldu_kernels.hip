@@ -405,8 +405,37 @@ int k_set_p2p_trace(unsigned long long* buf)
     return 0;
 }
 
+// first expired wait of a sweep: {claimed, selfRow, expected tag, col0..3, seen tags of col0..3}
+__device__ int g_p2p_dbg[16] = {0};
+__device__ int g_p2p_dbgN = 0;
+__device__ int g_p2p_dbgRec[64 * 8] = {0};   // {kind, row, expected tag, col, seen tag y, seen tag w, sweep/aux, 0}
+int k_read_p2p_dbg_records(int* out /* 1 + 64*8 */)
+{
+    LDU_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2p_dbgN), sizeof(int)));
+    LDU_CHECK_HIP(hipMemcpyFromSymbol(out + 1, HIP_SYMBOL(g_p2p_dbgRec), sizeof(int) * 64 * 8));
+    int z[64 * 8] = {0};
+    int zero = 0;
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_dbgN), &zero, sizeof(int)));
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_dbgRec), z, sizeof(int) * 64 * 8));
+    return 0;
+}
+
+int k_read_p2p_dbg(int* out)
+{
+    LDU_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2p_dbg), sizeof(int) * 16));
+    int z[16] = {0};
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_dbg), z, sizeof(int) * 16));
+    return 0;
+}
+
 // poll back-off between two granule polls, in units of s_sleep(1) (64 clocks); tunable (LDU_P2P_SLEEP)
 __device__ int g_p2p_sleep = 2;
+__device__ unsigned g_p2p_backoff = 4096u;   // polls before a waiting wave backs off (0 = never)
+int k_set_p2p_backoff(unsigned n)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_backoff), &n, sizeof(unsigned)));
+    return 0;
+}
 int k_set_p2p_sleep(int n)
 {
     LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_sleep), &n, sizeof(int)));
@@ -731,6 +760,8 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
             *abortFlag = 1;
             return false;
         }
+        // never on the critical path (the previous sweep runs ahead): back off quickly so that
+        // thousands of waiting waves do not starve the waves of the sweep they wait for
         __builtin_amdgcn_s_sleep(1);
     }
     xu[BASE + 0] = granule_value(g0);
@@ -1046,6 +1077,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     hipStream_t s = ctx->stream;
     if (a->nCells == 0 || k <= 0) return 0;
     auto it = a->gsTasks.find(k);
+    if (it != a->gsTasks.end() && it->second.n < 0) return 1;   // not pipelinable (see below)
     if (it == a->gsTasks.end())
     {
         // M[L] = running max over levels <= L of the highest level holding an upper neighbour
@@ -1056,10 +1088,27 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
             const int Ll = a->level[a->l[f]], Lu = a->level[a->u[f]];
             if (Lu > M[Ll]) M[Ll] = Lu;
         }
+        int maxSkew = 0;
         for (int L = 0; L < nLev; L++)
         {
             if (M[L] < L) M[L] = L;
             if (L && M[L] < M[L - 1]) M[L] = M[L - 1];
+            if (M[L] - L > maxSkew) maxSkew = M[L] - L;
+        }
+        if (getenv("LDU_VERBOSE"))
+            fprintf(stderr, "[ldugpu] GS pipeline plan: %d cells, %d levels, max upper-neighbour skew %d levels\n",
+                    a->nCells, nLev, maxSkew);
+        // Pipelining pays when sweep j+1 can follow sweep j closely.  On irregular DAGs the upper
+        // neighbours can sit dozens of levels ahead: the trailing sweep's waves would then wait (and
+        // poll) for a long time and starve the leading sweep (measured: spin-bound aborts on a random
+        // graph with skew ~70).  Such addressings run their sweeps one after the other.
+        // (small addressings cannot starve anything: few waiting waves)
+        if (maxSkew > ctx->gsPipelineMaxSkew && a->nSlices > 512)
+        {
+            ldu_addr::GsTasks none;
+            none.n = -1;
+            it = a->gsTasks.emplace(k, none).first;
+            return 1;
         }
         std::vector<int> tasks;
         tasks.reserve((size_t)k * a->nSlices + 4 * (size_t)nLev * k);

@@ -40,6 +40,21 @@ int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
     return 0;
 }
 
+// Surface an aborted point-to-point sweep to callers that do not read scalars (ldu_smooth, ...).
+int dev_check_abort(ldu_ctx* ctx)
+{
+    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_abort, ctx->d_abort, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (*ctx->h_abort)
+    {
+        (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), ctx->stream);
+        ctx->p2pGen++;
+        ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
+        return -20;
+    }
+    return 0;
+}
+
 static int dev_write_scalar(ldu_ctx* ctx, int slot, double v)
 {
     // stream-ordered write through a tiny staging slot in pinned memory is racy if reused
@@ -173,13 +188,18 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     {
         // consecutive sweeps pipelined inside one launch (bit-identical to separate sweeps)
         int left = nSweeps;
+        bool pipelined = true;
         while (left > 0)
         {
             const int k = left > 4 ? 4 : left;
-            if (k_sweep_gs_multi(a, k, psi, source, m->d_diag, m->d_valA)) return -1;
+            if (k == 1) break;   // a single remaining sweep: the plain engine below
+            const int rc = k_sweep_gs_multi(a, k, psi, source, m->d_diag, m->d_valA);
+            if (rc < 0) return -1;
+            if (rc > 0) { pipelined = false; break; }   // DAG too skewed: sweep by sweep
             left -= k;
         }
-        return 0;
+        if (pipelined && left == 0) return 0;
+        nSweeps = left;
     }
     for (int sweep = 0; sweep < nSweeps; sweep++)
     {
