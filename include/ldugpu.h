@@ -34,7 +34,8 @@ enum { LDU_SOLVER_PCG = 0, LDU_SOLVER_PBICG = 1, LDU_SOLVER_SMOOTH = 2, LDU_SOLV
 enum { LDU_PRE_NONE = 0, LDU_PRE_DIAGONAL = 1, LDU_PRE_DIC = 2, LDU_PRE_FDIC = 3, LDU_PRE_DILU = 4,
        LDU_PRE_GAMG = 5 };
 enum { LDU_SM_GAUSSSEIDEL = 0, LDU_SM_SYMGAUSSSEIDEL = 1, LDU_SM_DIC = 2, LDU_SM_DILU = 3,
-       LDU_SM_DICGAUSSSEIDEL = 4, LDU_SM_DILUGAUSSSEIDEL = 5, LDU_SM_FDIC = 6 };
+       LDU_SM_DICGAUSSSEIDEL = 4, LDU_SM_DILUGAUSSSEIDEL = 5, LDU_SM_FDIC = 6,
+       LDU_SM_NONBLOCKINGGAUSSSEIDEL = 7 /* == GaussSeidel bit-for-bit when no coupled patch is present */ };
 enum { LDU_AGG_FACEAREAPAIR = 0, LDU_AGG_ALGEBRAICPAIR = 1 };
 
 /* Solver controls = the keys the reference reads from the fvSolution sub-dictionary:

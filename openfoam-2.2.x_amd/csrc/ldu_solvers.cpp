@@ -254,6 +254,17 @@ int dev_smooth(ldu_matrix* m, int smoother, double* psi, const double* source, i
     switch (smoother)
     {
     case LDU_SM_GAUSSSEIDEL:    return smooth_gs(m, psi, source, nSweeps, false);
+    case LDU_SM_NONBLOCKINGGAUSSSEIDEL:
+        // nonBlockingGaussSeidelSmoother.C:46-240 sweeps the cells below blockStart_ before the halo
+        // arrives and the rest after it.  Without coupled patches there is nothing to wait for and the
+        // cell loop is the GaussSeidel loop, operation for operation.  With coupled patches the halo
+        // term enters bPrime between the two blocks (a different rounding order): not implemented.
+        if (m->a->nPatchFaces)
+        {
+            ldu_set_error("nonBlockingGaussSeidel with coupled patches is not implemented; use GaussSeidel");
+            return -3;
+        }
+        return smooth_gs(m, psi, source, nSweeps, false);
     case LDU_SM_SYMGAUSSSEIDEL: return smooth_gs(m, psi, source, nSweeps, true);
     case LDU_SM_DIC:
     case LDU_SM_FDIC:           return smooth_dic(m, LDU_PRE_DIC, psi, source, nSweeps);

@@ -199,6 +199,7 @@ static int hipSmootherKind(const word& n)
 {
     if (n == "GaussSeidel" || n == "hipGaussSeidel") return LDU_SM_GAUSSSEIDEL;
     if (n == "symGaussSeidel") return LDU_SM_SYMGAUSSSEIDEL;
+    if (n == "nonBlockingGaussSeidel") return LDU_SM_NONBLOCKINGGAUSSSEIDEL;
     if (n == "DIC") return LDU_SM_DIC;
     if (n == "DILU") return LDU_SM_DILU;
     if (n == "FDIC") return LDU_SM_FDIC;

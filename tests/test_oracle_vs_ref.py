@@ -171,3 +171,15 @@ def test_gamg_preconditioned_pcg(oracle):
                       tolerance=1e-9, relTol=0, nVcycles=2)
     assert perf["nIterations"] == int(ref["perf"][2])
     np.testing.assert_allclose(x, ref["psi"], rtol=1e-9, atol=1e-12)
+
+
+def test_nonblocking_gs_equals_gs_serially(oracle):
+    """nonBlockingGaussSeidelSmoother.C: without coupled patches its cell loop is GaussSeidel's;
+    the product maps the name to the GaussSeidel kernels on that ground - checked on the reference."""
+    p = cases.box3d(9)
+    rng = np.random.RandomState(4)
+    p["psi"] = rng.randn(p["nCells"]); p["source"] = rng.randn(p["nCells"])
+    kw = dict(solver="smoothSolver", nSweeps=2, tolerance=1e-12, relTol=0, maxIter=6)
+    a, _ = oracle.run_ref("solve", p, oracle.dict_string(smoother="GaussSeidel", **kw))
+    b, _ = oracle.run_ref("solve", p, oracle.dict_string(smoother="nonBlockingGaussSeidel", **kw))
+    assert np.array_equal(a["psi"], b["psi"]) and np.array_equal(a["perf"], b["perf"])
