@@ -126,7 +126,7 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     e = getenv("LDU_GS_PIPELINE");
     if (e) c->gsPipeline = atoi(e);
     e = getenv("LDU_P2P_BPC");
-    if (e && atoi(e) > 0) c->p2pBlocksPerCU = atoi(e);
+    if (e && atoi(e) > 0) { c->p2pBlocksPerCU = atoi(e); c->p2pBpcForced = 1; }
     e = getenv("LDU_P2P_BACKOFF");
     if (e) k_set_p2p_backoff((unsigned)atoi(e));
     e = getenv("LDU_P2P_SLEEP");
@@ -135,6 +135,11 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e)) c->useGraphs = false;
     e = getenv("LDU_FUSE_ROWS");
     if (e) c->fuseRows = atoi(e);
+    e = getenv("LDU_P2P_PROXY");
+    if (e) k_set_p2p_proxy(atoi(e));
+    e = getenv("LDU_P2P_SLABS");
+    if (e) c->p2pSlabs = atoi(e);
+    if (c->sweepP2P && c->p2pSlabs != 0 && k_xcd_census(c)) return -1;
     *out = c;
     return 0;
 }
@@ -226,6 +231,9 @@ int ldu_addr_destroy(ldu_addr* a)
 int ldu_addr_info(const ldu_addr* a, int32_t* nLevels, int32_t* nSlices, int64_t* nEntriesPadded)
 {
     if (nLevels) *nLevels = a->nLevels;
+    if (getenv("LDU_VERBOSE"))
+        fprintf(stderr, "[ldugpu] addressing: %d cells, %d levels, %d slices, %d XCD slabs\n", a->nCells,
+                a->nLevels, a->nSlices, a->nSlabs);
     if (nSlices) *nSlices = a->nSlices;
     if (nEntriesPadded) *nEntriesPadded = a->nEntries;
     return 0;

@@ -584,9 +584,25 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
             if (gamg_scale(L.mat, L.d_corr, ACf, L.d_src)) return -1;
         if (c->nPreSweeps)
             if (k_ew(n, EW_ADD_INPLACE, L.d_corr, preSmoothed, nullptr, s)) return -1;
-        if (dev_smooth(L.mat, c->smoother, L.d_corr, L.d_src,
-                       std::min(c->nPostSweeps + c->postSweepsLevelMultiplier * leveli, c->maxPostSweeps)))
-            return -1;
+        static const bool timeLevels = getenv("LDU_GAMG_TIME") != nullptr;   // diagnostic: per-level smoothing time
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timeLevels)
+        {
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, s);
+        }
+        const int nPost = std::min(c->nPostSweeps + c->postSweepsLevelMultiplier * leveli, c->maxPostSweeps);
+        if (dev_smooth(L.mat, c->smoother, L.d_corr, L.d_src, nPost)) return -1;
+        if (timeLevels)
+        {
+            float ms = 0;
+            (void)hipEventRecord(e1, s);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            fprintf(stderr, "[ldugpu] level %2d: %9d cells %5d dag-levels %d slabs width %.1f: %d sweeps %.3f ms\n",
+                    leveli + 1, n, L.addr->nLevels, L.addr->nSlabs, L.addr->slabWidth, nPost, ms);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
     }
 
     const int n0 = m->a->nCells;

@@ -66,8 +66,12 @@ struct ldu_ctx {
     int gsPipeline = 1;
     int gsPipelineMaxSkew = 4;       // pipeline sweeps only if upper neighbours are <= this many levels ahead              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
+    int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
     int p2pMaxBlocksPerCU = 5;       // register-limited residency of the sweep kernels
+    // XCD-slab sweep engine: -1 = choose per addressing, 0 = chip-wide engine only, 1..8 = forced
+    int p2pSlabs = -1;
+    int nXcd = 0;                    // XCDs seen by the placement census (0 = census failed: no slabs)
     int* d_abort = nullptr;          // set by a sweep whose bounded spin expired
     int* h_abort = nullptr;          // pinned mirror
     int p2pGen = 0;                  // bumped when a sweep aborted: addressings reset their tickets
@@ -151,6 +155,9 @@ struct ldu_addr {
     // two independent lanes so that two sweeps of the same addressing can run concurrently on
     // two streams (PBiCG: the A system and the transposed system)
     struct P2PLane {
+        uint4* d_X = nullptr;              // [nCells] write-through copies of exported rows (slab engine)
+        unsigned* d_ctl = nullptr;         // [2][8] per-slab chunk tickets, double-buffered by launch parity
+        unsigned par = 0;
         uint4* d_granule = nullptr;        // [nCells]
         unsigned* d_ticket = nullptr;      // [1]
         unsigned ticketBase = 0;
@@ -163,8 +170,18 @@ struct ldu_addr {
     int* d_gateB = nullptr;                // [nSlices] gate slice of backward sweeps
     unsigned* d_sliceDone = nullptr;       // [nSlices] completion tags (hint for the gate)
 
+    // XCD slabs: contiguous ranges of the ORIGINAL cell numbering (dependencies only run from lower to
+    // higher slabs), one per XCD; slices never straddle a slab; slabList = each slab's slices in
+    // level order; colX = col with bit 31 set where the column lives in another slab
+    int nSlabs = 0;                        // 0 = chip-wide engine
+    double slabWidth = 0;                  // average slices per level per slab (sizes the grid)
+    int slabStart[9] = {0};                // offsets into slabList
+    int* d_slabList = nullptr;             // [nSlices]
+    int* d_colX = nullptr;                 // [nEntries]
+    unsigned char* d_xflag = nullptr;      // [nCells] 1 = has a neighbour in another slab
+
     // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
-    struct GsTasks { int* d_tasks = nullptr; int n = 0; };
+    struct GsTasks { int* d_tasks = nullptr; int n = 0; int* d_slabTasks = nullptr; int slabStart[9] = {0}; };
     std::map<int, GsTasks> gsTasks;
 
     // cached graphs of level-scheduled sweeps, keyed by (mode, pointer arguments)
@@ -231,6 +248,8 @@ struct SweepArgs {
 
 int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
+int k_xcd_census(ldu_ctx* ctx);
+int k_set_p2p_proxy(int n);
 int k_set_p2p_backoff(unsigned n);
 int k_read_p2p_dbg(int* out);
 int k_read_p2p_dbg_records(int* out);

@@ -8,6 +8,9 @@
 //     block -> one partial per block -> single-block final pass (deterministic, no atomics);
 //   * compiled with -ffp-contract=off: a*b+c is never contracted, so every row reproduces
 //     the reference's rounding exactly (SURVEY.md Appendix B last bullet).
+#include <cmath>
+#include <algorithm>
+
 #include "ldu_internal.hpp"
 
 #define BLK 256
@@ -451,6 +454,24 @@ __device__ __forceinline__ void granule_store(uint4* G, int row, double v, unsig
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
 }
 
+// XCD-slab engine (see "XCD slabs" below): the granule stays in the producing XCD's L2 (plain store:
+// same-XCD consumers hit it there with their L1-bypassing sc1 loads); rows with a neighbour in
+// another slab also publish a write-through copy for the other XCDs.
+__device__ __forceinline__ void granule_store_slab(uint4* G, uint4* X, int row, double v, unsigned tag,
+                                                   bool exported)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    u32x4 d;
+    d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
+    uint4* p = G + row;
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(d) : "memory");
+    if (exported)
+    {
+        uint4* q = X + row;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(q), "v"(d) : "memory");
+    }
+}
+
 // four granule loads in flight, one wait
 __device__ __forceinline__ void granule_load4(const uint4* p0, const uint4* p1, const uint4* p2,
                                               const uint4* p3, u32x4& g0, u32x4& g1, u32x4& g2,
@@ -472,10 +493,40 @@ __device__ __forceinline__ double granule_value(const u32x4& g)
     return __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
 }
 
+// Slab engine: same-XCD polls are L2 hits, so hundreds of waiting waves polling 4 KB each per round
+// saturate the XCD's L2 request bandwidth and slow the very hand-offs they wait for.  A waiting
+// wave therefore first watches ONE granule with ONE lane (its rows' dependencies sit in the same
+// level and complete within about one hand-off of each other) and only then polls all of them.
+__device__ int g_p2p_proxy = 0;   // measured: one extra L2 round trip per level, no gain (off)
+int k_set_p2p_proxy(int n)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_proxy), &n, sizeof(int)));
+    return 0;
+}
+__device__ __forceinline__ void proxy_wait(const uint4* p, unsigned tag, bool has, volatile int* abortFlag)
+{
+    const unsigned long long m = __ballot(has);
+    if (!m || !g_p2p_proxy) return;
+    const int leader = __ffsll((long long)m) - 1;
+    if ((int)(threadIdx.x & 63) == leader)
+    {
+        unsigned spins = 0;
+        for (;;)
+        {
+            u32x4 g;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+            if (g.y == tag && g.w == tag) break;
+            if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) break;   // the full poll reports it
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
 // acc -= sum_{i=0..n-1} val[e(i)] * (value of row col[e(i)] published in THIS sweep), in order;
 // entry index k(i) = first + i*step.  OP = 0: acc -= v*x ; OP = 1: acc -= (v2*v)/x  (SW_RD)
-template <int OP, bool DIAG = false>
-__device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restrict__ G, unsigned tag,
+template <int OP, bool DIAG = false, bool SLAB = false>
+__device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restrict__ G,
+                                               const uint4* __restrict__ X, unsigned tag,
                                                const int* __restrict__ col,
                                                const double* __restrict__ val,
                                                const double* __restrict__ val2, long ent, int first,
@@ -489,6 +540,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
     {
         int c[4];
         double v[4], v2[4];
+        const uint4* gp[4];   // SLAB: same-slab columns from G (this XCD's L2), others from X
 #pragma unroll
         for (int j = 0; j < 4; j++)
         {
@@ -497,6 +549,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             c[j] = need ? col[e] : selfRow;
             v[j] = need ? val[e] : 0.0;
             v2[j] = (OP == 1 && need) ? val2[e] : 0.0;
+            if (SLAB) gp[j] = (c[j] < 0 ? X : G) + (c[j] & 0x7fffffff);
         }
         if (DIAG && i0 == 0 && waitEst.gateSlice >= 0)
         {
@@ -516,12 +569,14 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             }
             waitEst.gateSlice = -1;
         }
+        if (SLAB && i0 == 0) proxy_wait(gp[0], tag, n > 0, abortFlag);
         u32x4 g0, g1, g2, g3;
         unsigned spins = 0;
         const int sleepN = g_p2p_sleep;
         for (;; waitEst.polls += DIAG ? 1u : 0u)
         {
-            granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
+            if (SLAB) granule_load4(gp[0], gp[1], gp[2], gp[3], g0, g1, g2, g3);
+            else granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
             bool ok = true;
             if (i0 + 0 < n) ok &= (g0.y == tag) & (g0.w == tag);
             if (i0 + 1 < n) ok &= (g1.y == tag) & (g1.w == tag);
@@ -556,8 +611,9 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
     return true;
 }
 
-template <int MODE, bool DIAG = false>
+template <int MODE, bool DIAG = false, bool SLAB = false>
 __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, uint4* __restrict__ G,
+                                          uint4* __restrict__ X, const unsigned char* __restrict__ xflag,
                                           unsigned tag, volatile int* abortFlag, double* __restrict__ w,
                                           const double* __restrict__ rhs,
                                           const double* __restrict__ scale,
@@ -571,23 +627,24 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
     const int nl = T.nL[r];
     const int nu = T.nU[r];
     const long ent = (long)T.sliceEnt[s] + lane;
+    const bool exported = SLAB ? xflag[r] != 0 : false;
     double out;
     if (MODE == SW_TRI_FWD)
     {
         double acc = scale[r] * rhs[r];
-        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
+        if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         out = acc;
     }
     else if (MODE == SW_TRI_BWD)
     {
         double acc = w[r];
-        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, nl + nu - 1, -1, nu, r, abortFlag, waitEst)) return false;
+        if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, nl + nu - 1, -1, nu, r, abortFlag, waitEst)) return false;
         out = acc;
     }
     else if (MODE == SW_RD)
     {
         double acc = scale[r];
-        if (!p2p_accumulate<1, DIAG>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
+        if (!p2p_accumulate<1, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         out = acc;
     }
     else if (MODE == SW_GS_FWD)
@@ -605,10 +662,10 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
             {
                 const long e = ent + (long)(nl + j) * LDU_WAVE;
                 vu[j] = val[e];
-                xu[j] = w[T.col[e]];
+                xu[j] = w[T.col[e] & 0x7fffffff];
             }
         }
-        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
+        if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         if (aux) aux[r] = acc;
         if (nuFast)
         {
@@ -621,7 +678,7 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
             for (int k = nl; k < nl + nu; k++)
             {
                 const long e = ent + (long)k * LDU_WAVE;
-                acc -= val[e] * w[T.col[e]];
+                acc -= val[e] * w[T.col[e] & 0x7fffffff];
             }
         }
         out = acc / d;
@@ -629,12 +686,77 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
     else   // SW_GS_BWD
     {
         double acc = rhs[r];
-        if (!p2p_accumulate<0, DIAG>(acc, G, tag, T.col, val, val2, ent, nl, 1, nu, r, abortFlag, waitEst)) return false;
+        if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, nl, 1, nu, r, abortFlag, waitEst)) return false;
         out = acc / scale[r];
     }
     w[r] = out;
-    granule_store(G, r, out, tag);
+    if (SLAB) granule_store_slab(G, X, r, out, tag, exported);
+    else granule_store(G, r, out, tag);
     return true;
+}
+
+// XCD slabs: what a workgroup needs to find its slab's queue
+struct SlabCtl {
+    int nSlabs;
+    int start[9];                    // slab s owns list[start[s] .. start[s+1])
+    const int* list;                 // slices (or GaussSeidel tasks) of every slab in schedule order
+    unsigned* tick;                  // [8] this launch's chunk tickets, one per slab (zero at launch)
+    unsigned* tickNext;              // [8] the next launch's: zeroed by this one
+    uint4* X;                        // write-through granule copies of exported rows
+    const unsigned char* xflag;      // per row: exported
+};
+
+__device__ __forceinline__ int xcc_id()
+{
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return (int)(xcc & 0xf);
+}
+
+// One sweep on the XCD-slab engine: the workgroups that landed on XCD x serve slab x's queue (slices
+// in level order; reversed for backward sweeps) - everything else is sweep_p2p_kernel.  Progress:
+// the queues are restrictions of ONE global topological order and every workgroup of the grid is
+// resident, so the globally first unfinished slice is always held by a running wave.
+template <int MODE, bool DESC>
+__global__ void __launch_bounds__(P2P_BLK)
+sweep_slab_kernel(SliceTab T, SlabCtl C, uint4* G, unsigned tag, int* abortFlag, double* w,
+                  const double* rhs, const double* scale, const double* val, const double* val2, double* aux)
+{
+    __shared__ int s_chunk[2];
+    const int slab = xcc_id();
+    if (slab >= C.nSlabs) return;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int first = C.start[slab];
+    const int nSl = C.start[slab + 1] - first;
+    const int nChunks = (nSl + P2P_CHUNK - 1) / P2P_CHUNK;
+    unsigned* ticket = C.tick + slab;
+    P2PStat waitEst = {0, 0, 0, -1, nullptr};
+    int nextT = 0;
+    if (threadIdx.x == 0)
+    {
+        __hip_atomic_store(C.tickNext + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nextT = (int)atomicAdd(ticket, 1u);
+    }
+    for (int it = 0;; it++)
+    {
+        if (threadIdx.x == 0)
+        {
+            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            s_chunk[it & 1] = t;
+            if (t < nChunks) nextT = (int)atomicAdd(ticket, 1u);
+        }
+        __syncthreads();
+        const int chunk = s_chunk[it & 1];
+        if (chunk >= nChunks) return;
+        const int si = chunk * P2P_CHUNK + wave;
+        if (si < nSl)
+        {
+            const int s = C.list[first + (DESC ? nSl - 1 - si : si)];
+            p2p_slice<MODE, false, true>(T, s, lane, G, C.X, C.xflag, tag, abortFlag, w, rhs, scale, val, val2,
+                                         aux, waitEst);
+        }
+    }
 }
 
 template <int MODE, bool DESC, bool DIAG>
@@ -673,7 +795,8 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
                 waitEst.gateSlice = T.gate ? T.gate[s] : -1;
                 waitEst.sliceDone = T.sliceDone;
             }
-            p2p_slice<MODE, DIAG>(T, s, lane, G, tag, abortFlag, w, rhs, scale, val, val2, aux, waitEst);
+            p2p_slice<MODE, DIAG, false>(T, s, lane, G, nullptr, nullptr, tag, abortFlag, w, rhs, scale, val, val2,
+                                         aux, waitEst);
             if (DIAG && T.sliceDone && lane == 0)
                 __hip_atomic_store(T.sliceDone + s, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (DIAG && g_p2p_trace && lane == 0)
@@ -689,6 +812,82 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
     }
 }
 
+// Placement census: the slab engine needs workgroups of one launch on every XCD it assigns a slab to
+// and HW_REG_XCC_ID values 0..n-1.  HIP promises neither, so it is checked once per context with the
+// sweep kernels' own geometry; a failed census leaves the chip-wide engine in charge.
+__global__ void __launch_bounds__(P2P_BLK) xcc_census_kernel(int* out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+
+int k_xcd_census(ldu_ctx* ctx)
+{
+    const int grid = ctx->numCUs * ctx->p2pBlocksPerCU;
+    int* d = nullptr;
+    LDU_CHECK_HIP(hipMalloc((void**)&d, sizeof(int) * (size_t)grid));
+    xcc_census_kernel<<<grid, P2P_BLK, 0, ctx->stream>>>(d);
+    std::vector<int> h(grid);
+    LDU_CHECK_HIP(hipMemcpyAsync(h.data(), d, sizeof(int) * (size_t)grid, hipMemcpyDeviceToHost, ctx->stream));
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    int cnt[16] = {0};
+    for (int v : h) cnt[v & 15]++;
+    int n = 0;
+    while (n < 16 && cnt[n] > 0) n++;
+    bool ok = n >= 1 && n <= 8;
+    for (int i = n; i < 16; i++) ok = ok && cnt[i] == 0;
+    for (int i = 0; i < n; i++) ok = ok && cnt[i] * n * 2 >= grid;   // at least half its fair share
+    ctx->nXcd = ok ? n : 0;
+    if (getenv("LDU_VERBOSE"))
+        fprintf(stderr, "[ldugpu] XCD census: %d workgroups on %d XCDs -> slab engine %s\n", grid, n,
+                ok ? "available" : "disabled");
+    return 0;
+}
+
+// Workgroups per CU of a slab-engine launch with k sweeps in flight.  Every waiting wave slows the
+// hand-offs of its CU (measured: 0.86 us per level at 1 workgroup per CU, 1.0 at 2, 1.1 at 3), but
+// too few waves cannot cover the several dependent loads a slice needs before it can wait: about
+// 8 levels of look-ahead are needed (tools/det_probe.py).
+static int slab_bpc(const ldu_addr* a, int k)
+{
+    const ldu_ctx* ctx = a->ctx;
+    if (ctx->p2pBpcForced) return std::min(ctx->p2pBlocksPerCU * k, ctx->p2pMaxBlocksPerCU);
+    const double wavesPerXcdPerBpc = std::max(1, ctx->numCUs / std::max(1, ctx->nXcd)) * 4.0;
+    int bpc = (int)std::ceil(8.0 * k * a->slabWidth / wavesPerXcdPerBpc);
+    return std::max(1, std::min(bpc, std::min(4, ctx->p2pMaxBlocksPerCU)));
+}
+
+// Which engine runs a sweep.  The slab engine's hand-off is faster (same-XCD L2), but on wide
+// levels both engines are bound by the CUs' memory queues (the streaming loads of the rows ahead
+// delay the polls of the rows at the front) and the slab engine's fixed slab->XCD binding balances
+// worse: measured break-even widths (average slices per level per slab), tools/det_probe.py.
+// kind: 0 = triangular sweeps, 1 = one GaussSeidel sweep, 2 = k pipelined GaussSeidel sweeps
+// (k sweeps in flight multiply the width; with k > 2 the chip-wide engine's 8x larger pool of
+//  waves wins except on one-XCD-sized matrices: per-level table of the 216^3 GAMG hierarchy in
+//  profiles/r01_xcd_slab_probe.md)
+static bool use_slab(const ldu_addr* a, int kind, int k = 1)
+{
+    const ldu_ctx* ctx = a->ctx;
+    if (a->nSlabs <= 0 || ctx->p2pTrace) return false;
+    if (ctx->p2pSlabs > 0) return true;   // forced
+    if (kind == 0) return a->slabWidth <= 24.0;
+    if (kind == 1) return a->slabWidth <= 16.0;
+    if (k <= 2) return k * a->slabWidth <= 14.0;
+    return a->nSlabs == 1 && k * a->slabWidth <= 10.0;
+}
+
+// per-launch part of SlabCtl: flips the ticket parity (this launch's counters were zeroed by the
+// previous launch on this lane, or by the allocation)
+static void slab_ctl(ldu_addr* a, ldu_addr::P2PLane& P, SlabCtl& C)
+{
+    C.nSlabs = a->nSlabs;
+    C.tick = P.d_ctl + 8 * P.par;
+    C.tickNext = P.d_ctl + 8 * (P.par ^ 1u);
+    P.par ^= 1u;
+    C.X = P.d_X;
+    C.xflag = a->d_xflag;
+}
+
 template <int MODE, bool DESC>
 static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 {
@@ -696,6 +895,21 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     ldu_addr::P2PLane* Pp = a->lane(g.lane);
     if (!Pp) { ldu_set_error("p2p lane allocation failed"); return -1; }
     ldu_addr::P2PLane& P = *Pp;
+    if (use_slab(a, (MODE == SW_GS_FWD || MODE == SW_GS_BWD) ? 1 : 0))
+    {
+        SliceTab TS{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_colX};
+        SlabCtl C;
+        slab_ctl(a, P, C);
+        C.list = a->d_slabList;
+        for (int i = 0; i <= 8; i++) C.start[i] = a->slabStart[i];
+        P.epoch++;
+        if (P.epoch == 0) P.epoch = 1;
+        const int grid = ctx->numCUs * slab_bpc(a, 1);
+        sweep_slab_kernel<MODE, DESC><<<grid, P2P_BLK, 0, s>>>(TS, C, P.d_granule, P.epoch, ctx->d_abort, g.w,
+            g.rhs, g.scale, g.val, g.val2, g.aux);
+        LDU_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
     if (ctx->p2pGate)
     {
@@ -729,8 +943,9 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 
 // ---------------------------------------------------------------- pipelined Gauss-Seidel sweeps
 // four "old" (previous sweep) neighbour values xu[BASE..BASE+3] of a row, static indices only
-template <int BASE>
-__device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* __restrict__ G, unsigned t,
+template <int BASE, bool SLAB = false>
+__device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* __restrict__ G,
+                                               const uint4* __restrict__ X, unsigned t,
                                                const double* __restrict__ val, long ent, int nl, int nu,
                                                int selfRow, volatile int* abortFlag, double (&xu)[8],
                                                double (&vu)[8])
@@ -744,11 +959,15 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
         c[q] = need ? T.col[e] : selfRow;
         vu[BASE + q] = need ? val[e] : 0.0;
     }
+    const uint4* gp[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
+    if (SLAB && BASE == 0) proxy_wait(gp[0], t, nu > 0, abortFlag);
     u32x4 g0, g1, g2, g3;
     unsigned spins = 0;
     for (;;)
     {
-        granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
+        granule_load4(gp[0], gp[1], gp[2], gp[3], g0, g1, g2, g3);
         bool ok = true;
         if (BASE + 0 < nu) ok &= (g0.y == t) & (g0.w == t);
         if (BASE + 1 < nu) ok &= (g1.y == t) & (g1.w == t);
@@ -779,9 +998,10 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
 // is untouched (GaussSeidelSmoother.C:151-176), so the result is bit-identical to k separate sweeps.
 // Tasks (sweep, slice) are ticketed in a host-built topological order (plan_gs_tasks); tag E+j marks
 // "value of sweep j".  Only the last sweep writes psi (earlier values live in the granules).
-template <int DUMMY>
+template <bool SLAB>
 __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int k, int lane,
-                                            uint4* __restrict__ G, unsigned tag0,
+                                            uint4* __restrict__ G, uint4* __restrict__ X,
+                                            const unsigned char* __restrict__ xflag, unsigned tag0,
                                             volatile int* abortFlag, double* __restrict__ psi,
                                             const double* __restrict__ rhs,
                                             const double* __restrict__ diag,
@@ -793,6 +1013,7 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
     const int nl = T.nL[r];
     const int nu = T.nU[r];
     const long ent = (long)T.sliceEnt[s] + lane;
+    const bool exported = SLAB ? xflag[r] != 0 : false;
     double acc = rhs[r];
     const double d = diag[r];
     const unsigned tagNew = tag0 + (unsigned)j;
@@ -810,18 +1031,18 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
                 {
                     const long e = ent + (long)(nl + q) * LDU_WAVE;
                     vu[q] = val[e];
-                    xu[q] = psi[T.col[e]];
+                    xu[q] = psi[T.col[e] & 0x7fffffff];
                 }
         }
         else
         {
-            if (!gs_gather_old4<0>(T, G, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+            if (!gs_gather_old4<0, SLAB>(T, G, X, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
             if (nuFast > 4)
-                if (!gs_gather_old4<4>(T, G, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+                if (!gs_gather_old4<4, SLAB>(T, G, X, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
         }
     }
     // 2. new values of the lower neighbours (the critical path)
-    if (!p2p_accumulate<0>(acc, G, tagNew, T.col, val, nullptr, ent, 0, 1, nl, r, abortFlag, waitEst)) return;
+    if (!p2p_accumulate<0, false, SLAB>(acc, G, X, tagNew, T.col, val, nullptr, ent, 0, 1, nl, r, abortFlag, waitEst)) return;
     // 3. upper part, in face order
     if (nuFast >= 0)
     {
@@ -834,16 +1055,17 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
         for (int q = nl; q < nl + nu; q++)
         {
             const long e = ent + (long)q * LDU_WAVE;
-            acc -= val[e] * psi[T.col[e]];
+            acc -= val[e] * psi[T.col[e] & 0x7fffffff];
         }
     }
     else
     {
-        if (!p2p_accumulate<0>(acc, G, tagNew - 1u, T.col, val, nullptr, ent, nl, 1, nu, r, abortFlag, waitEst)) return;
+        if (!p2p_accumulate<0, false, SLAB>(acc, G, X, tagNew - 1u, T.col, val, nullptr, ent, nl, 1, nu, r, abortFlag, waitEst)) return;
     }
     const double out = acc / d;
     if (j == k - 1) psi[r] = out;
-    granule_store(G, r, out, tagNew);
+    if (SLAB) granule_store_slab(G, X, r, out, tagNew, exported);
+    else granule_store(G, r, out, tagNew);
 }
 
 __global__ void __launch_bounds__(P2P_BLK)
@@ -875,12 +1097,54 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
             if (task >= 0)
             {
                 const int sl = task & 0x0fffffff;
-                p2p_gs_task<0>(T, sl, task >> 28, k, lane, G, tag0, abortFlag, psi, rhs, diag, val, waitEst);
+                p2p_gs_task<false>(T, sl, task >> 28, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst);
             }
         }
     }
 }
 
+
+// (slab engine twin of sweep_p2p_gs_multi_kernel: per-slab task queues)
+__global__ void __launch_bounds__(P2P_BLK)
+sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0, int* abortFlag, double* psi,
+                           const double* rhs, const double* diag, const double* val)
+{
+    __shared__ int s_chunk[2];
+    const int slab = xcc_id();
+    if (slab >= C.nSlabs) return;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int first = C.start[slab];
+    const int nT = C.start[slab + 1] - first;
+    const int nChunks = (nT + P2P_CHUNK - 1) / P2P_CHUNK;
+    unsigned* ticket = C.tick + slab;
+    P2PStat waitEst = {0, 0, 0, -1, nullptr};
+    int nextT = 0;
+    if (threadIdx.x == 0)
+    {
+        __hip_atomic_store(C.tickNext + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nextT = (int)atomicAdd(ticket, 1u);
+    }
+    for (int it = 0;; it++)
+    {
+        if (threadIdx.x == 0)
+        {
+            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            s_chunk[it & 1] = t;
+            if (t < nChunks) nextT = (int)atomicAdd(ticket, 1u);
+        }
+        __syncthreads();
+        const int chunk = s_chunk[it & 1];
+        if (chunk >= nChunks) return;
+        const int ti = chunk * P2P_CHUNK + wave;
+        if (ti < nT)
+        {
+            const int task = C.list[first + ti];
+            p2p_gs_task<true>(T, task & 0x0fffffff, task >> 28, k, lane, G, C.X, C.xflag, tag0, abortFlag, psi,
+                              rhs, diag, val, waitEst);
+        }
+    }
+}
 
 // ---- fast path: software-pipelined GaussSeidel task engine ------------------------------------
 // Trace of the generic engine (tools/p2p_trace.py, 216^3): a wave spends 2.9 us per slice in three
@@ -1060,7 +1324,7 @@ sweep_p2p_gs_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int n
             if (M.W <= 8 && __all(fits))
                 gs_task_fast(T, M, j, k, lane, G, tag0, abortFlag, psi, rhs, diag, val);
             else
-                p2p_gs_task<0>(T, s, j, k, lane, G, tag0, abortFlag, psi, rhs, diag, val, waitEst);
+                p2p_gs_task<false>(T, s, j, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst);
         }
         cur = nxt;
         task = taskN;
@@ -1133,6 +1397,29 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         gt.n = (int)tasks.size();
         LDU_CHECK_HIP(hipMalloc((void**)&gt.d_tasks, sizeof(int) * (tasks.size() + 1)));
         LDU_CHECK_HIP(hipMemcpy(gt.d_tasks, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice));
+        if (a->nSlabs > 0)
+        {
+            // per-slab queues = the global topological order restricted to each slab
+            std::vector<int> sliceSlab(a->nSlices, 0), slabTasks;
+            {
+                std::vector<int> list(a->nSlices);
+                LDU_CHECK_HIP(hipMemcpy(list.data(), a->d_slabList, sizeof(int) * (size_t)a->nSlices,
+                                        hipMemcpyDeviceToHost));
+                for (int sl = 0; sl < a->nSlabs; sl++)
+                    for (int i = a->slabStart[sl]; i < a->slabStart[sl + 1]; i++) sliceSlab[list[i]] = sl;
+            }
+            slabTasks.reserve(tasks.size());
+            for (int sl = 0; sl < a->nSlabs; sl++)
+            {
+                gt.slabStart[sl] = (int)slabTasks.size();
+                for (int t : tasks)
+                    if (sliceSlab[t & 0x0fffffff] == sl) slabTasks.push_back(t);
+            }
+            for (int sl = a->nSlabs; sl <= 8; sl++) gt.slabStart[sl] = (int)slabTasks.size();
+            LDU_CHECK_HIP(hipMalloc((void**)&gt.d_slabTasks, sizeof(int) * (slabTasks.size() + 1)));
+            LDU_CHECK_HIP(hipMemcpy(gt.d_slabTasks, slabTasks.data(), sizeof(int) * slabTasks.size(),
+                                    hipMemcpyHostToDevice));
+        }
         it = a->gsTasks.emplace(k, gt).first;
     }
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
@@ -1159,12 +1446,26 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     if (P.epoch > 0xffffff00u)
     {
         LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
+        if (P.d_X) LDU_CHECK_HIP(hipMemsetAsync(P.d_X, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
         P.epoch = 0;
     }
     const unsigned tag0 = P.epoch + 1;
     P.epoch += (unsigned)k;
     ctx->profStart(a, 4);   // "gs_multi": one launch = k pipelined sweeps
     T.sliceW = a->d_sliceW;
+    if (it->second.d_slabTasks && use_slab(a, 2, k))
+    {
+        SliceTab TS{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_colX};
+        SlabCtl C;
+        slab_ctl(a, P, C);
+        C.list = it->second.d_slabTasks;
+        for (int i = 0; i <= 8; i++) C.start[i] = it->second.slabStart[i];
+        sweep_slab_gs_multi_kernel<<<ctx->numCUs * slab_bpc(a, k), P2P_BLK, 0, s>>>(TS, C, k, P.d_granule, tag0,
+            ctx->d_abort, psi, rhs, diag, val);
+        ctx->profStop(a, 4);
+        LDU_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (ctx->gsFast)
         sweep_p2p_gs_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
             P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);

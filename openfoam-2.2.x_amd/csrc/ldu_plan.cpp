@@ -27,6 +27,14 @@ ldu_addr::P2PLane* ldu_addr::lane(int i)
         if (hipMemset(P.d_granule, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
         if (hipMalloc((void**)&P.d_ticket, sizeof(unsigned)) != hipSuccess) return nullptr;
         if (hipMemset(P.d_ticket, 0, sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (nSlabs > 0)
+        {
+            if (hipMalloc((void**)&P.d_X, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
+            if (hipMemset(P.d_X, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
+            if (hipMalloc((void**)&P.d_ctl, sizeof(unsigned) * 16) != hipSuccess) return nullptr;
+            if (hipMemset(P.d_ctl, 0, sizeof(unsigned) * 16) != hipSuccess) return nullptr;
+            P.par = 0;
+        }
         P.ticketBase = 0;
         P.epoch = 0;
         P.gen = ctx->p2pGen;
@@ -43,6 +51,65 @@ double* ldu_addr::scratchVec(int i)
         if (hipMalloc((void**)&scratch[i], n * sizeof(double)) != hipSuccess) return nullptr;
     }
     return scratch[i];
+}
+
+// XCD slabs.  A hand-off between two workgroups of the SAME XCD can stay in that XCD's L2 (plain
+// granule store, L1-bypassing load): measured 1.0 us per dependency level against 1.4 us for the
+// chip-wide write-through hand-off (profiles/r01_xcd_slab_probe.md).  The cells are therefore cut
+// into up to 8 contiguous ranges of the ORIGINAL numbering, one per XCD.  lower < upper for every
+// face, so dependencies between slabs only run from a lower to a higher slab (forward sweeps; the
+// reverse for backward sweeps): the slabs form a one-directional pipeline in which the slower
+// cross-XCD hand-off is a start-up delay, not a per-level cost.
+// Returns the slab count (0 = keep the chip-wide engine) and the slab boundaries (cell index).
+static int choose_slabs(const ldu_addr* a, std::vector<int>& slabCell)
+{
+    const ldu_ctx* ctx = a->ctx;
+    const int nC = a->nCells;
+    slabCell.clear();
+    if (!ctx->sweepP2P || ctx->p2pSlabs == 0 || ctx->nXcd <= 0 || ctx->p2pGate || ctx->gsFast || nC == 0)
+        return 0;
+    const int wavesPerXcd = std::max(1, ctx->numCUs / ctx->nXcd) * ctx->p2pBlocksPerCU * 4;
+    int S;
+    if (ctx->p2pSlabs > 0)
+        S = std::min(ctx->p2pSlabs, ctx->nXcd);
+    else
+    {
+        // measured (tools/det_probe.py, profiles/r01_xcd_slab_probe.md): one XCD up to ~150k cells,
+        // all of them above; intermediate counts never won
+        S = nC <= 150000 ? 1 : ctx->nXcd;
+    }
+    // equal shares of the entries
+    slabCell.assign(S + 1, nC);
+    slabCell[0] = 0;
+    {
+        const long total = (long)nC + 2L * a->nFaces;
+        long acc = 0;
+        int s = 1;
+        for (int c = 0; c < nC && s < S; c++)
+        {
+            acc += 1 + (a->losortStart[c + 1] - a->losortStart[c]) + (a->ownerStart[c + 1] - a->ownerStart[c]);
+            if (acc * S >= total * s) slabCell[s++] = c + 1;
+        }
+    }
+    const_cast<ldu_addr*>(a)->slabWidth = (double)nC / LDU_WAVE / std::max(1, a->nLevels) / S;
+    if (ctx->p2pSlabs > 0) return S;
+    // cost model, in hand-offs: a level costs one round per wavesPerXcd slices of its busiest slab
+    // (slab engine) against 1.4 x one round per chip-load of slices (chip-wide engine).  Rejects
+    // numberings whose index ranges follow the levels (then the slabs run one after the other).
+    std::vector<int> w((size_t)a->nLevels * S, 0);
+    for (int s = 0; s < S; s++)
+        for (int c = slabCell[s]; c < slabCell[s + 1]; c++) w[(size_t)a->level[c] * S + s]++;
+    double roundsSlab = 0, roundsChip = 0;
+    for (int L = 0; L < a->nLevels; L++)
+    {
+        int mx = 0, tot = 0;
+        for (int s = 0; s < S; s++) { mx = std::max(mx, w[(size_t)L * S + s]); tot += w[(size_t)L * S + s]; }
+        const int slS = (mx + LDU_WAVE - 1) / LDU_WAVE, slC = (tot + LDU_WAVE - 1) / LDU_WAVE;
+        roundsSlab += std::max(1, (slS + wavesPerXcd - 1) / wavesPerXcd);
+        roundsChip += 1.4 * std::max(1, (slC + wavesPerXcd * ctx->nXcd - 1) / (wavesPerXcd * ctx->nXcd));
+    }
+    if (roundsSlab > roundsChip) { slabCell.clear(); return 0; }
+    return S;
 }
 
 int plan_build(ldu_addr* a)
@@ -105,8 +172,18 @@ int plan_build(ldu_addr* a)
         }
     }
 
-    // slices (<= 64 rows, never straddling a level)
-    std::vector<int> sliceRow, sliceCnt, sliceEnt, sliceW;
+    // XCD slabs (see choose_slabs); rowSlab is monotone in the original cell index, hence
+    // non-decreasing inside a level
+    std::vector<int> slabCell;
+    const int S = choose_slabs(a, slabCell);
+    a->nSlabs = S;
+    std::vector<unsigned char> rowSlab(nC, 0);
+    if (S > 1)
+        for (int s = 0; s < S; s++)
+            for (int c = slabCell[s]; c < slabCell[s + 1]; c++) rowSlab[a->iperm[c]] = (unsigned char)s;
+
+    // slices (<= 64 rows, never straddling a level or a slab)
+    std::vector<int> sliceRow, sliceCnt, sliceEnt, sliceW, sliceSlab;
     a->levelSliceStart.assign(nLevels + 1, 0);
     std::vector<unsigned char> nL(nC), nU(nC);
     for (int r = 0; r < nC; r++)
@@ -126,9 +203,11 @@ int plan_build(ldu_addr* a)
     for (int L = 0; L < nLevels; L++)
     {
         a->levelSliceStart[L] = (int)sliceRow.size();
-        for (int r0 = a->levelStart[L]; r0 < a->levelStart[L + 1]; r0 += LDU_WAVE)
+        for (int r0 = a->levelStart[L], cnt = 0; r0 < a->levelStart[L + 1]; r0 += cnt)
         {
-            int cnt = std::min(LDU_WAVE, a->levelStart[L + 1] - r0);
+            cnt = 1;
+            while (cnt < LDU_WAVE && r0 + cnt < a->levelStart[L + 1] && rowSlab[r0 + cnt] == rowSlab[r0]) cnt++;
+            sliceSlab.push_back(rowSlab[r0]);
             int W = 0;
             for (int i = 0; i < cnt; i++) W = std::max(W, (int)nL[r0 + i] + (int)nU[r0 + i]);
             sliceRow.push_back(r0);
@@ -176,6 +255,40 @@ int plan_build(ldu_addr* a)
         for (int i = sliceCnt[s]; i < LDU_WAVE; i++)
             for (int k = 0; k < sliceW[s]; k++)
                 col[(long)sliceEnt[s] + i + (long)k * LDU_WAVE] = sliceRow[s];
+    }
+
+    // slab engine tables
+    std::vector<int> slabList, colX;
+    std::vector<unsigned char> xflag;
+    if (S > 0)
+    {
+        slabList.reserve(a->nSlices);
+        for (int sl = 0; sl < S; sl++)
+        {
+            a->slabStart[sl] = (int)slabList.size();
+            for (int s = 0; s < a->nSlices; s++)
+                if (sliceSlab[s] == sl) slabList.push_back(s);
+        }
+        for (int sl = S; sl <= 8; sl++) a->slabStart[sl] = (int)slabList.size();
+        colX = col;
+        xflag.assign(nC, 0);
+        if (S > 1)
+            for (int s = 0; s < a->nSlices; s++)
+                for (int i = 0; i < sliceCnt[s]; i++)
+                {
+                    const int r = sliceRow[s] + i;
+                    for (int k = 0; k < (int)nL[r] + (int)nU[r]; k++)
+                    {
+                        const long e = (long)sliceEnt[s] + i + (long)k * LDU_WAVE;
+                        const int q = col[e];
+                        if (rowSlab[q] != rowSlab[r])
+                        {
+                            colX[e] = (int)((unsigned)q | 0x80000000u);
+                            xflag[r] = 1;
+                            xflag[q] = 1;
+                        }
+                    }
+                }
     }
 
     // polling gates of the point-to-point sweeps: the slice one dependency level before the
@@ -261,6 +374,12 @@ int plan_build(ldu_addr* a)
     if (upload(&a->d_losort, a->losort)) return -1;
     if (upload(&a->d_ownerStart, a->ownerStart)) return -1;
     if (upload(&a->d_losortStart, a->losortStart)) return -1;
+    if (S > 0)
+    {
+        if (upload(&a->d_slabList, slabList)) return -1;
+        if (upload(&a->d_colX, colX)) return -1;
+        if (upload(&a->d_xflag, xflag)) return -1;
+    }
     // point-to-point sweep state (tags start at 0 = never published)
     if (!a->lane(0)) return -1;
     if (upload(&a->d_gateF, gateF)) return -1;
@@ -328,14 +447,19 @@ void plan_free(ldu_addr* a)
 {
     for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
     a->graphs.clear();
-    for (auto& kv : a->gsTasks) if (kv.second.d_tasks) (void)hipFree(kv.second.d_tasks);
+    for (auto& kv : a->gsTasks)
+    {
+        if (kv.second.d_tasks) (void)hipFree(kv.second.d_tasks);
+        if (kv.second.d_slabTasks) (void)hipFree(kv.second.d_slabTasks);
+    }
     a->gsTasks.clear();
     void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW,
                     a->d_levelSliceStart, a->d_nL, a->d_nU, a->d_col, a->d_face, a->d_l, a->d_u,
                     a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,
                     a->d_pfCell, a->d_sendAll, a->d_recvAll, a->p2p[0].d_granule, a->p2p[0].d_ticket,
                     a->p2p[1].d_granule, a->p2p[1].d_ticket, a->d_gateF, a->d_gateB,
-                    a->d_sliceDone};
+                    a->d_sliceDone, a->d_slabList, a->d_colX, a->d_xflag, a->p2p[0].d_X, a->p2p[0].d_ctl,
+                    a->p2p[1].d_X, a->p2p[1].d_ctl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : a->scratch) if (p) (void)hipFree(p);
     a->scratch.clear();
