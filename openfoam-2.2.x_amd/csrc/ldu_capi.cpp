@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
+
 #include "ldu_internal.hpp"
 
 static thread_local std::string g_err;
@@ -135,6 +137,10 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e)) c->useGraphs = false;
     e = getenv("LDU_FUSE_ROWS");
     if (e) c->fuseRows = atoi(e);
+    e = getenv("LDU_SMALL");
+    if (e) c->smallKernels = atoi(e);
+    e = getenv("LDU_SMALL_MAX");
+    if (e) c->smallMaxCells = std::min(atoi(e), 8192);
     e = getenv("LDU_P2P_PROXY");
     if (e) k_set_p2p_proxy(atoi(e));
     e = getenv("LDU_P2P_SLABS");

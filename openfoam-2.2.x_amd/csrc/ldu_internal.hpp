@@ -66,6 +66,8 @@ struct ldu_ctx {
     int gsPipeline = 1;
     int gsPipelineMaxSkew = 4;       // pipeline sweeps only if upper neighbours are <= this many levels ahead              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
+    int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
+    int smallMaxCells = 256;         // LDU_SMALL_MAX (<= 8192); measured: wins up to ~200 cells, loses above
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
     int p2pMaxBlocksPerCU = 5;       // register-limited residency of the sweep kernels
@@ -115,6 +117,7 @@ struct ldu_addr {
     std::vector<int> levelSliceStart;      // size nLevels+1
     int nSlices = 0;
     long nEntries = 0;                     // padded entry count
+    int maxRowWidth = 0;                   // max over rows of nL + nU
     std::vector<Segment> segs;
     std::vector<double> faceWeights;
     bool finalized = false;
@@ -249,6 +252,7 @@ struct SweepArgs {
 int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
 int k_xcd_census(ldu_ctx* ctx);
+int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_set_p2p_proxy(int n);
 int k_set_p2p_backoff(unsigned n);
 int k_read_p2p_dbg(int* out);

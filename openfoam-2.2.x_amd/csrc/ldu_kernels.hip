@@ -1332,6 +1332,144 @@ sweep_p2p_gs_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int n
     }
 }
 
+// ---------------------------------------------------------------- small matrices: one wavefront, x in LDS
+// The coarse half of a GAMG hierarchy is a chain of small matrices (36 ... 5 k cells) with 15-90
+// dependency levels of mostly ONE slice each: a cross-CU hand-off per level (1-1.5 us) is most of
+// their smoothing time.  Here ONE wavefront keeps the solution vector in LDS and walks the slices
+// of k GaussSeidel sweeps in level order - slices of one level are independent, consecutive levels
+// are ordered by the wave's own program order, so there is no barrier and no hand-off at all.
+// The coefficients of the next two slices are in flight while a slice is computed (they do not
+// depend on the sweep).  Arithmetic per row = GaussSeidelSmoother.C:151-176, identical to the
+// other engines (bit-exact).
+// Measured (216^3 GAMG hierarchy, 4 sweeps): 36 cells 0.067 ms (slab engine 0.095), 150 cells 0.121
+// (0.140), 608 cells 0.182 (0.185), 4908 cells 0.467 (0.259): ~0.8-1.1 us per slice - one exposed
+// global-load round trip, the 4+2W loads of two slices do not fit the 63-deep vmcnt window - so it
+// is only used up to ctx->smallMaxCells (256) cells.
+// (A 512/1024-thread version with a workgroup barrier per level measured 1.2-2.3 us per level: idle
+//  waves either issue the same loads - the CU's address pipeline becomes the bound - or skip them
+//  behind a branch, after which the compiler must drain all prefetches at the join.)
+#define SMALL_MAX_CELLS 8192
+#define SMALL_MAX_LDS (144 * 1024)
+
+template <int W> struct SmallRow { int r; unsigned char nl, nu; int c[W]; double v[W]; double b, d; };
+
+// Branch-free on purpose: the wave always issues the same 4 + 2W loads (clamped to row 0 past the end),
+// so the compiler knows exactly how many loads are in flight and never drains them at a join.
+template <int W>
+__device__ __forceinline__ void small_load(const int* __restrict__ sRow, const int* __restrict__ sEnt,
+                                           const SliceTab& T, bool on, int s0, int lane,
+                                           const double* __restrict__ rhs, const double* __restrict__ diag,
+                                           const double* __restrict__ val, SmallRow<W>& R)
+{
+    const int s = on ? s0 : 0;
+    const int r0 = sRow[s];
+    const bool have = on && lane < sRow[s + 1] - r0;
+    const int r = have ? r0 + lane : 0;
+    const long ent = have ? (long)sEnt[s] + lane : 0;
+    R.nl = T.nL[r];   // (no arithmetic on loaded values here: it would wait for them)
+    R.nu = T.nU[r];
+    R.b = rhs[r];
+    R.d = diag[r];
+#pragma unroll
+    for (int q = 0; q < W; q++)
+    {
+        const long e = ent + (long)q * LDU_WAVE;   // the entry arrays are padded: always readable
+        R.c[q] = T.col[e];
+        R.v[q] = val[e];
+    }
+    R.r = have ? r : -1;
+}
+
+template <int W>
+__global__ void __launch_bounds__(LDU_WAVE)
+gs_small_kernel(SliceTab T, int nSlices, int nCells, int k, double* __restrict__ psi,
+                const double* __restrict__ rhs, const double* __restrict__ diag, const double* __restrict__ val)
+{
+    extern __shared__ double smem[];
+    double* x = smem;
+    int* sRow = (int*)(x + nCells);
+    int* sEnt = sRow + nSlices + 1;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < nCells; i += LDU_WAVE) x[i] = psi[i];
+    for (int i = lane; i <= nSlices; i += LDU_WAVE) sRow[i] = T.sliceRow[i];
+    for (int i = lane; i < nSlices; i += LDU_WAVE) sEnt[i] = T.sliceEnt[i];
+    __syncthreads();
+    // three register sets rotate statically (item i lives in set i % 3), nothing moves them
+    SmallRow<W> R0, R1, R2;
+    int sNext = 0, sweepNext = 0;             // cursor of the next slice to load
+    int left = nSlices * k;
+#define SMALL_FILL(R)                                                                     \
+    do {                                                                                  \
+        small_load<W>(sRow, sEnt, T, sweepNext < k, sNext, lane, rhs, diag, val, (R));    \
+        if (++sNext == nSlices) { sNext = 0; sweepNext++; }                               \
+    } while (0)
+#define SMALL_STEP(CUR, FILL)                                                             \
+    do {                                                                                  \
+        SMALL_FILL(FILL);                                                                 \
+        {                                                                                 \
+            double acc = (CUR).b;                                                         \
+            const int nn = (int)(CUR).nl + (int)(CUR).nu;                                 \
+            _Pragma("unroll") for (int q = 0; q < W; q++)                                 \
+            {                                                                             \
+                const double xq = x[(CUR).c[q] & (SMALL_MAX_CELLS - 1)];                  \
+                if (q < nn) acc -= (CUR).v[q] * xq;                                       \
+            }                                                                             \
+            if ((CUR).r >= 0) x[(CUR).r] = acc / (CUR).d;                                 \
+        }                                                                                 \
+        /* the next slice may read what this one wrote: LDS is in order within a wave */  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+        --left;                                                                           \
+    } while (0)
+    SMALL_FILL(R0);
+    SMALL_FILL(R1);
+    while (left > 0)
+    {
+        SMALL_STEP(R0, R2);
+        if (left == 0) break;
+        SMALL_STEP(R1, R0);
+        if (left == 0) break;
+        SMALL_STEP(R2, R1);
+    }
+#undef SMALL_STEP
+#undef SMALL_FILL
+    for (int i = lane; i < nCells; i += LDU_WAVE) psi[i] = x[i];
+}
+
+template <int W>
+static int launch_gs_small(ldu_addr* a, const SliceTab& T, size_t lds, int k, double* psi, const double* rhs,
+                           const double* diag, const double* val)
+{
+    static bool attrSet = false;
+    if (!attrSet)
+    {
+        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_small_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          SMALL_MAX_LDS));
+        attrSet = true;
+    }
+    gs_small_kernel<W><<<1, LDU_WAVE, lds, a->ctx->stream>>>(T, a->nSlices, a->nCells, k, psi, rhs, diag, val);
+    return 0;
+}
+
+// returns 1 when the addressing does not qualify
+int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->smallKernels || a->nCells > ctx->smallMaxCells || a->nCells == 0 || k <= 0 || a->maxRowWidth > 16)
+        return 1;
+    const size_t lds = sizeof(double) * (size_t)a->nCells + sizeof(int) * (2 * ((size_t)a->nSlices + 1));
+    if (lds > SMALL_MAX_LDS) return 1;
+    SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    ctx->profStart(a, 4);
+    int rc;
+    if (a->maxRowWidth <= 8) rc = launch_gs_small<8>(a, T, lds, k, psi, rhs, diag, val);
+    else if (a->maxRowWidth <= 12) rc = launch_gs_small<12>(a, T, lds, k, psi, rhs, diag, val);
+    else rc = launch_gs_small<16>(a, T, lds, k, psi, rhs, diag, val);
+    ctx->profStop(a, 4);
+    if (rc) return -1;
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // Host side: topological task order for k pipelined sweeps (cached per k in the addressing).
 int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
                      const double* val)

@@ -214,6 +214,7 @@ int plan_build(ldu_addr* a)
             sliceCnt.push_back(cnt);
             sliceEnt.push_back((int)ent);
             sliceW.push_back(W);
+            a->maxRowWidth = std::max(a->maxRowWidth, W);
             ent += (long)W * LDU_WAVE;
             if (ent > 2000000000L)
             {
@@ -225,7 +226,7 @@ int plan_build(ldu_addr* a)
     a->levelSliceStart[nLevels] = (int)sliceRow.size();
     a->nSlices = (int)sliceRow.size();
     // 512 padding entries: the fast GaussSeidel path reads 8 entries per row unconditionally
-    const long entPad = ent + 512;
+    const long entPad = ent + 1024;   // (the small-matrix kernel reads 16)
     a->nEntries = entPad;
     sliceRow.push_back(nC);
 

@@ -184,6 +184,12 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     hipStream_t s = a->ctx->stream;
     double* bPrime = nullptr;
     if (a->nPatchFaces || sym) bPrime = m->workVec(12);
+    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P)
+    {
+        // small matrix: every sweep inside one workgroup, solution vector in LDS
+        const int rc = k_sweep_gs_small(a, nSweeps, psi, source, m->d_diag, m->d_valA);
+        if (rc <= 0) return rc;
+    }
     if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && a->ctx->gsPipeline && nSweeps >= 2)
     {
         // consecutive sweeps pipelined inside one launch (bit-identical to separate sweeps)

@@ -1,5 +1,6 @@
 """GPU (-m gpu): every sweep engine variant must reproduce the oracle's sequential sweeps bit for bit:
-the chip-wide point-to-point engine (LDU_P2P_SLABS=0), the XCD-slab engine with 1, 3 and 8 slabs
+the single-workgroup LDS kernels of small matrices, the chip-wide point-to-point engine
+(LDU_P2P_SLABS=0), the XCD-slab engine with 1, 3 and 8 slabs
 (cross-slab dependencies through the write-through copies), pipelined GaussSeidel on both, and the
 level-kernel engine.  Cases: hex box (regular DAG), asymmetric box, irregular graph with wide rows."""
 import os
@@ -19,8 +20,10 @@ ENGINES = {
     "slab8_bpc3": {"LDU_P2P_SLABS": "8", "LDU_P2P_BPC": "3"},
     "auto": {},
     "levels": {"LDU_SWEEP": "levels"},
+    "nosmall": {"LDU_SMALL": "0"},
+    "small8192": {"LDU_SMALL_MAX": "8192"},
 }
-KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP")
+KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX")
 
 
 def _problems():
@@ -35,6 +38,16 @@ def _problems():
     p = cases.random_graph(30000, 9, 400)
     p["psi"] = rng.randn(p["nCells"])
     out["graph"] = p
+    # <= 8192 cells: the single-wavefront LDS kernel (engine "small8192"; default limit 256 cells: "chain")
+    p = cases.box3d(19, 20, 21)
+    p["psi"] = rng.randn(p["nCells"])
+    out["box_small"] = p
+    p = cases.random_graph(5000, 11, 300, asym=True)   # rows wider than the 8-entry fast path
+    p["psi"] = rng.randn(p["nCells"])
+    out["graph_small"] = p
+    p = cases.laplacian2d(1, 37)   # a chain: one row per level
+    p["psi"] = rng.randn(p["nCells"])
+    out["chain"] = p
     return out
 
 
