@@ -1,0 +1,68 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE - tier 2 of the reference oracle: the reference's own
+# libfiniteVolume units compiled from the sources where they lie under /root/reference (same
+# recipe as build_ref.sh), archived STATICALLY so that the linker pulls only the units the driver
+# reaches (fvMesh, geometry, interpolation / gradient / laplacian / convection schemes, basic patch
+# fields) - the units that need libmeshTools / libtriSurface (mapped and AMI patches, wall distance;
+# triSurface needs flex, absent here) are never pulled and nothing stands in for them.
+# Used once to pin oracle/fv_oracle.py: tests/golden/make_fv_golden.py runs oracle/_ref/fv_driver and
+# commits the vectors.  Not part of __graft_entry__.build() (10 min); outputs only into oracle/_ref/.
+set -e
+REF=${REF:-/root/reference}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/_ref"
+W="$OUT/build"
+JOBS=${JOBS:-8}
+if [ ! -d "$REF/src/finiteVolume" ]; then
+    echo "build_ref_fv.sh: $REF not present - nothing to do" >&2
+    exit 0
+fi
+[ -f "$OUT/libOpenFOAM.so" ] || bash "$HERE/build_ref.sh"
+mkdir -p "$W/fvobj"
+for lib in finiteVolume meshTools triSurface fileFormats; do
+    d="$W/inc_$lib"
+    if [ ! -f "$d/.done" ]; then
+        mkdir -p "$d"
+        find "$REF/src/$lib" \( -name '*.[CH]' -o -name '*.h' \) -exec ln -sf {} "$d/" \;
+        touch "$d/.done"
+    fi
+done
+cpp -P -traditional-cpp -DWM_DP -Dlinux64 "$REF/src/finiteVolume/Make/files" 2>/dev/null | python3 -c '
+import sys,re
+vars={}
+for line in sys.stdin:
+    line=line.strip()
+    if not line: continue
+    m=re.match(r"^(\w+)\s*=\s*(.*)$", line)
+    if m:
+        v=m.group(2)
+        for k,val in vars.items(): v=v.replace("$(%s)"%k,val)
+        vars[m.group(1)]=v; continue
+    for k,val in vars.items(): line=line.replace("$(%s)"%k,val)
+    if line.startswith("LIB") or line.startswith("EXE") or line.endswith(".H"): continue
+    print(line)' | sed "s!^!$REF/src/finiteVolume/!" > "$W/fvsources.txt"
+
+CXXFLAGS="-m64 -std=gnu++98 -Dlinux64 -DWM_DP -DNoRepository -ftemplate-depth-100 -O2 -fPIC -w -fpermissive -fno-access-control -I$W/inc_finiteVolume -I$W/inc_meshTools -I$W/inc_triSurface -I$W/inc_fileFormats -I$W/inc"
+{
+    echo "CXXFLAGS=$CXXFLAGS"
+    echo "OBJS="
+    i=0
+    while read -r src; do
+        i=$((i+1))
+        o="$W/fvobj/f$i.o"
+        echo "OBJS+=$o"
+        echo "$o: $src"
+        printf '\t@g++ $(CXXFLAGS) -c %s -o %s || echo "FAILED %s" >> %s/fvfailed.txt\n' "$src" "$o" "$src" "$W"
+    done < "$W/fvsources.txt"
+    echo "all: \$(OBJS)"
+} > "$W/Makefile.fv"
+rm -f "$W/fvfailed.txt"
+make -s -k -C "$W" -f "$W/Makefile.fv" -j"$JOBS" all || true
+rm -f "$OUT/libfiniteVolume.a"
+ar rcs "$OUT/libfiniteVolume.a" "$W"/fvobj/*.o
+echo "build_ref_fv.sh: $(ls "$W"/fvobj/*.o | wc -l) units archived; failed: $(cat "$W/fvfailed.txt" 2>/dev/null | wc -l)"
+if [ -f "$HERE/fv_driver.C" ]; then
+    g++ $CXXFLAGS -o "$OUT/fv_driver" "$HERE/fv_driver.C" "$OUT/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm \
+        -Wl,-rpath,'$ORIGIN'
+    echo "build_ref_fv.sh: OK -> $OUT/fv_driver"
+fi

@@ -1,0 +1,160 @@
+"""TEST INFRASTRUCTURE - writes a hex-box polyMesh case (OpenFOAM-2.2.x on-disk format: points, faces,
+owner, neighbour, boundary + the system dictionaries fvMesh insists on) and runs oracle/_ref/fv_driver
+(the reference's own libfiniteVolume units) on it.  Internal faces come out in the upper-triangular
+order of openfoam-2.2.x_amd/cases.py::box_addressing, so the driver's arrays line up with ours."""
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(HERE, "_ref")
+
+HEADER = """FoamFile
+{
+    version     2.0;
+    format      ascii;
+    class       %s;
+    location    "%s";
+    object      %s;
+}
+"""
+
+
+def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5)):
+    """points (perturbed, graded), faces (vertex lists, owner->neighbour right-handed), owner, neighbour,
+    boundary patches.  Returns dict."""
+    rng = np.random.RandomState(seed)
+
+    def axis(n, g):
+        t = np.linspace(0.0, 1.0, n + 1)
+        return (np.exp(np.log(g) * t) - 1.0) / (g - 1.0) if g != 1.0 else t
+
+    X, Y, Z = axis(nx, grading[0]) * 1.0, axis(ny, grading[1]) * 0.7, axis(nz, grading[2]) * 1.3
+    pts = np.zeros(((nx + 1) * (ny + 1) * (nz + 1), 3))
+
+    def pid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    for k in range(nz + 1):
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                p = np.array([X[i], Y[j], Z[k]])
+                if 0 < i < nx and 0 < j < ny and 0 < k < nz:   # interior vertices only: flat boundary
+                    h = np.array([X[i + 1] - X[i], Y[j + 1] - Y[j], Z[k + 1] - Z[k]])
+                    p = p + jitter * h * (rng.rand(3) - 0.5)
+                pts[pid(i, j, k)] = p
+
+    def cid(i, j, k):
+        return i + nx * (j + ny * k)
+
+    def face_x(i, j, k):   # face at x-index i (between cells i-1 and i), normal +x
+        return [pid(i, j, k), pid(i, j + 1, k), pid(i, j + 1, k + 1), pid(i, j, k + 1)]
+
+    def face_y(i, j, k):   # normal +y
+        return [pid(i, j, k), pid(i, j, k + 1), pid(i + 1, j, k + 1), pid(i + 1, j, k)]
+
+    def face_z(i, j, k):   # normal +z
+        return [pid(i, j, k), pid(i + 1, j, k), pid(i + 1, j + 1, k), pid(i, j + 1, k)]
+
+    faces, owner, nei = [], [], []
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                c = cid(i, j, k)
+                if i + 1 < nx:
+                    faces.append(face_x(i + 1, j, k)); owner.append(c); nei.append(cid(i + 1, j, k))
+                if j + 1 < ny:
+                    faces.append(face_y(i, j + 1, k)); owner.append(c); nei.append(cid(i, j + 1, k))
+                if k + 1 < nz:
+                    faces.append(face_z(i, j, k + 1)); owner.append(c); nei.append(cid(i, j, k + 1))
+    nInt = len(faces)
+    patches = []
+
+    def add_patch(name, flist):
+        start = len(faces)
+        for fv, c in flist:
+            faces.append(fv); owner.append(c)
+        patches.append((name, len(flist), start))
+
+    add_patch("xmin", [(face_x(0, j, k)[::-1], cid(0, j, k)) for k in range(nz) for j in range(ny)])
+    add_patch("xmax", [(face_x(nx, j, k), cid(nx - 1, j, k)) for k in range(nz) for j in range(ny)])
+    add_patch("ymin", [(face_y(i, 0, k)[::-1], cid(i, 0, k)) for k in range(nz) for i in range(nx)])
+    add_patch("ymax", [(face_y(i, ny, k), cid(i, ny - 1, k)) for k in range(nz) for i in range(nx)])
+    add_patch("zmin", [(face_z(i, j, 0)[::-1], cid(i, j, 0)) for j in range(ny) for i in range(nx)])
+    add_patch("zmax", [(face_z(i, j, nz), cid(i, j, nz - 1)) for j in range(ny) for i in range(nx)])
+    return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32),
+                neighbour=np.array(nei, dtype=np.int32), nInternalFaces=nInt, patches=patches,
+                nCells=nx * ny * nz)
+
+
+def write_case(case, mesh):
+    pm = os.path.join(case, "constant", "polyMesh")
+    os.makedirs(pm, exist_ok=True)
+    os.makedirs(os.path.join(case, "system"), exist_ok=True)
+    with open(os.path.join(pm, "points"), "w") as f:
+        f.write(HEADER % ("vectorField", "constant/polyMesh", "points"))
+        f.write("%d\n(\n" % len(mesh["points"]))
+        for p in mesh["points"]:
+            f.write("(%.17g %.17g %.17g)\n" % tuple(p))
+        f.write(")\n")
+    with open(os.path.join(pm, "faces"), "w") as f:
+        f.write(HEADER % ("faceList", "constant/polyMesh", "faces"))
+        f.write("%d\n(\n" % len(mesh["faces"]))
+        for fv in mesh["faces"]:
+            f.write("4(%d %d %d %d)\n" % tuple(fv))
+        f.write(")\n")
+    for name, arr in (("owner", mesh["owner"]), ("neighbour", mesh["neighbour"])):
+        with open(os.path.join(pm, name), "w") as f:
+            f.write(HEADER % ("labelList", "constant/polyMesh", name))
+            f.write("%d\n(\n" % len(arr))
+            f.write("\n".join(str(int(v)) for v in arr))
+            f.write("\n)\n")
+    with open(os.path.join(pm, "boundary"), "w") as f:
+        f.write(HEADER % ("polyBoundaryMesh", "constant/polyMesh", "boundary"))
+        f.write("%d\n(\n" % len(mesh["patches"]))
+        for name, n, start in mesh["patches"]:
+            f.write("%s\n{\n    type patch;\n    nFaces %d;\n    startFace %d;\n}\n" % (name, n, start))
+        f.write(")\n")
+    with open(os.path.join(case, "system", "controlDict"), "w") as f:
+        f.write(HEADER % ("dictionary", "system", "controlDict"))
+        f.write("application fv_driver;\nstartFrom startTime;\nstartTime 0;\nstopAt endTime;\nendTime 1;\n"
+                "deltaT 1;\nwriteControl timeStep;\nwriteInterval 1;\nwriteFormat ascii;\nwritePrecision 17;\n"
+                "timeFormat general;\ntimePrecision 6;\nrunTimeModifiable false;\n")
+    with open(os.path.join(case, "system", "fvSchemes"), "w") as f:
+        f.write(HEADER % ("dictionary", "system", "fvSchemes"))
+        f.write("ddtSchemes { default steadyState; }\ngradSchemes { default Gauss linear; }\n"
+                "divSchemes { default Gauss linear; }\nlaplacianSchemes { default Gauss linear uncorrected; }\n"
+                "interpolationSchemes { default linear; }\nsnGradSchemes { default uncorrected; }\n"
+                "fluxRequired { default no; }\n")
+    with open(os.path.join(case, "system", "fvSolution"), "w") as f:
+        f.write(HEADER % ("dictionary", "system", "fvSolution"))
+        f.write("solvers { }\n")
+
+
+def driver_available():
+    return os.path.exists(os.path.join(REF, "fv_driver"))
+
+
+def run_driver(case, mesh, vf, U, phi, gamma):
+    """-> dict name -> array (vectors reshaped to [n,3])"""
+    inp = os.path.join(case, "in.bin")
+    outp = os.path.join(case, "out.bin")
+    np.concatenate([vf, U.reshape(-1), phi, gamma]).astype(np.float64).tofile(inp)
+    env = dict(os.environ, WM_PROJECT="OpenFOAM", WM_PROJECT_VERSION="2.2.x", WM_PROJECT_DIR=REF,
+               LD_LIBRARY_PATH=REF + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FOAM_SIGFPE="false")
+    r = subprocess.run([os.path.join(REF, "fv_driver"), case, inp, outp], env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("fv_driver failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+    res = {}
+    with open(outp, "rb") as f:
+        while True:
+            hdr = f.read(64)
+            if len(hdr) < 64:
+                break
+            name, n = hdr.split(b"\0", 1)[0].decode().split()
+            a = np.fromfile(f, dtype=np.float64, count=int(n))
+            res[name] = a
+    for k in ("Sf", "interpolate_v", "surfaceIntegrate_v", "gaussGrad", "phiU"):
+        res[k] = res[k].reshape(-1, 3)
+    return res

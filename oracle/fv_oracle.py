@@ -3,9 +3,10 @@ lduMatrix, internal faces only.  Each function follo
 /root/reference/src/finiteVolume/... literally: np.add.at / np.subtract.at apply the updates one
 face at a time in ascending face order, i.e. in the reference's accumulation order.
 
-PARITY UNPINNED: libfiniteVolume is not built in this container (needs ~1000 units, SURVEY.md 8c
-Tier 2), so these restatements have not been executed against the reference.  negSumDiag is the
-exception: it lives in libOpenFOAM and is pinned through lduMatrix (test_oracle_vs_ref.py).
+PINNED against the reference's own libfiniteVolume: oracle/build_ref_fv.sh compiles its units from
+/root/reference, oracle/fv_driver.C runs them on a perturbed graded hex box, the vectors are committed
+as tests/golden/fv_*.npz (tests/golden/make_fv_golden.py) and tests/test_fv_oracle_golden.py requires
+every function below to reproduce them bit for bit.
 """
 import numpy as np
 
@@ -61,3 +62,16 @@ def fvm_div(nC, l, u, w, phi):
     lower = -w * phi
     upper = lower + phi
     return neg_sum_diag(nC, l, u, lower, upper), upper, lower
+
+
+def upwind_weights(phi):
+    """upwind::limiter / weights, finiteVolume/interpolation/surfaceInterpolation/limitedSchemes/upwind/
+    upwind.H: weights = pos(faceFlux)  (pos(0) = 1)"""
+    return (phi >= 0).astype(np.float64)
+
+
+def face_area_pair_weights(Sf, magSf):
+    """faceAreaPairGAMGAgglomeration.C:48-73: mag(cmptMultiply(Sf/sqrt(magSf), vector(1, 1.01, 1.02)))"""
+    t = Sf / np.sqrt(magSf)[:, None]
+    t = t * np.array([1.0, 1.01, 1.02])
+    return np.sqrt(t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1] + t[:, 2] * t[:, 2])

@@ -1,0 +1,46 @@
+"""Generates tests/golden/fv_*.npz: inputs + outputs of the REFERENCE's own finite-volume stencils
+(oracle/_ref/fv_driver = libfiniteVolume units compiled from /root/reference by oracle/build_ref_fv.sh)
+on perturbed, graded hex boxes.  Run here (the reference does not travel); the .npz files are data:
+addressing, geometry, input fields, reference outputs.   python tests/golden/make_fv_golden.py"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fv_case  # noqa: E402
+
+CASES = {"fv_box_7x6x5": (7, 6, 5, 3), "fv_box_12x3x9": (12, 3, 9, 8)}
+
+
+def generate(name):
+    nx, ny, nz, seed = CASES[name]
+    mesh = fv_case.box_mesh(nx, ny, nz, seed=seed)
+    rng = np.random.RandomState(100 + seed)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf = rng.randn(nC)
+    U = rng.randn(nC, 3)
+    phi = rng.randn(nF)
+    phi[::7] = 0.0            # pos(0) = 1 in the upwind weights
+    gamma = 0.5 + rng.rand(nF)
+    with tempfile.TemporaryDirectory() as d:
+        case = os.path.join(d, "case")
+        fv_case.write_case(case, mesh)
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma)
+    l = mesh["owner"][:nF].astype(np.int32)
+    u = mesh["neighbour"].astype(np.int32)
+    assert np.array_equal(res.pop("owner"), l) and np.array_equal(res.pop("neighbour"), u)
+    out = dict(nCells=nC, lowerAddr=l, upperAddr=u, vf=vf, U=U, phi=phi, gamma=gamma)
+    out.update({"ref_" + k: v for k, v in res.items()})
+    return out
+
+
+if __name__ == "__main__":
+    if not fv_case.driver_available():
+        raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
+    for name in CASES:
+        data = generate(name)
+        np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+        print(name, "cells", data["nCells"], "faces", data["lowerAddr"].size, sorted(k for k in data if k.startswith("ref_")))

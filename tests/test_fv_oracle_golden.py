@@ -1,0 +1,56 @@
+"""CPU: oracle/fv_oracle.py (numpy restatement of the fv face stencils)
+against vectors produced by the REFERENCE's own libfiniteVolume (tests/golden/make_fv_golden.py ->
+oracle/_ref/fv_driver).  Bit-exact: same operations in the same order."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fv_oracle  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NAMES = ["fv_box_7x6x5", "fv_box_12x3x9"]
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fv_oracle_matches_reference(name):
+    g = load(name)
+    l, u, nC = g["lowerAddr"], g["upperAddr"], int(g["nCells"])
+    w, d, V, Sf = g["ref_weights"], g["ref_deltaCoeffs"], g["ref_V"], g["ref_Sf"]
+    eq = np.array_equal
+    assert eq(fv_oracle.interpolate(l, u, w, g["vf"]), g["ref_interpolate_s"])
+    assert eq(fv_oracle.interpolate(l, u, w, g["U"]), g["ref_interpolate_v"])
+    assert eq(fv_oracle.interpolate(l, u, g["ref_upwindWeights"], g["vf"]), g["ref_interpolate_upwind"])
+    assert eq(fv_oracle.upwind_weights(g["phi"]), g["ref_upwindWeights"])
+    assert eq(fv_oracle.surface_integrate(l, u, g["phi"], V), g["ref_surfaceIntegrate_s"])
+    assert eq(fv_oracle.surface_integrate(l, u, g["ref_phiU"], V), g["ref_surfaceIntegrate_v"])
+    assert eq(fv_oracle.gauss_grad(l, u, Sf, g["ref_interpolate_s"], V), g["ref_gaussGrad"])
+    assert eq(fv_oracle.sn_grad(l, u, d, g["vf"]), g["ref_snGrad"])
+    diag, upper = fv_oracle.fvm_laplacian(nC, l, u, d, g["ref_gammaMagSf"])
+    assert eq(upper, g["ref_laplacian_upper"]) and eq(diag, g["ref_laplacian_diag"])
+    for kind, wk in (("linear", w), ("upwind", g["ref_upwindWeights"])):
+        diag, upper, lower = fv_oracle.fvm_div(nC, l, u, wk, g["phi"])
+        assert eq(lower, g["ref_div_%s_lower" % kind]), kind
+        assert eq(upper, g["ref_div_%s_upper" % kind]), kind
+        assert eq(diag, g["ref_div_%s_diag" % kind]), kind
+    assert eq(fv_oracle.face_area_pair_weights(Sf, g["ref_magSf"]), g["ref_faceAreaPairWeights"])
+
+
+def test_fixture_is_live_when_the_reference_build_exists(tmp_path):
+    """With oracle/_ref/fv_driver present (this container), regenerate one fixture and require identity."""
+    import fv_case
+    if not fv_case.driver_available():
+        pytest.skip("oracle/_ref/fv_driver not built (oracle/build_ref_fv.sh)")
+    sys.path.insert(0, GOLDEN)
+    import make_fv_golden
+    fresh = make_fv_golden.generate("fv_box_7x6x5")
+    old = load("fv_box_7x6x5")
+    for k in old:
+        assert np.array_equal(np.asarray(fresh[k]), old[k]), k

@@ -1,6 +1,8 @@
 """GPU (-m gpu): finite-volume face stencils through the C ABI vs the numpy
-restatement oracle/fv_oracle.py.  Bit-exact: the kernels gather per cell in the reference's face
-order.  (fv oracle: parity unpinned, see its header.)"""
+restatement oracle/fv_oracle.py AND directly vs the vectors of the reference's own libfiniteVolume
+(tests/golden/fv_*.npz, produced by oracle/_ref/fv_driver).  Bit-exact: the kernels gather per cell
+in the reference's face order."""
+import os
 import numpy as np
 import pytest
 
@@ -45,6 +47,29 @@ def test_fv_stencils_bitexact(ctx, gen):
     d, up, lo = a.fvmDiv(lam, phi)
     d0, up0, lo0 = fo.fvm_div(nC, l, u, lam, phi)
     assert np.array_equal(up, up0) and np.array_equal(lo, lo0) and np.array_equal(d, d0)
+    a.close()
+
+
+@pytest.mark.parametrize("name", ["fv_box_7x6x5", "fv_box_12x3x9"])
+def test_fv_kernels_against_reference_vectors(ctx, name):
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")))
+    l, u, nC = g["lowerAddr"], g["upperAddr"], int(g["nCells"])
+    w, d, V, Sf = g["ref_weights"], g["ref_deltaCoeffs"], g["ref_V"], g["ref_Sf"]
+    a = capi.Addressing(ctx, nC, l, u)
+    eq = np.array_equal
+    assert eq(a.interpolate(w, g["vf"]), g["ref_interpolate_s"])
+    assert eq(a.interpolate(w, g["U"]), g["ref_interpolate_v"])
+    assert eq(a.interpolate(g["ref_upwindWeights"], g["vf"]), g["ref_interpolate_upwind"])
+    assert eq(a.surfaceIntegrate(g["phi"], V), g["ref_surfaceIntegrate_s"])
+    assert eq(a.surfaceIntegrate(g["ref_phiU"], V), g["ref_surfaceIntegrate_v"])
+    assert eq(a.gaussGrad(Sf, g["ref_interpolate_s"], V), g["ref_gaussGrad"])
+    assert eq(a.snGrad(d, g["vf"]), g["ref_snGrad"])
+    diag, upper = a.fvmLaplacian(d, g["ref_gammaMagSf"])
+    assert eq(upper, g["ref_laplacian_upper"]) and eq(diag, g["ref_laplacian_diag"])
+    for kind, wk in (("linear", w), ("upwind", g["ref_upwindWeights"])):
+        diag, upper, lower = a.fvmDiv(wk, g["phi"])
+        assert eq(lower, g["ref_div_%s_lower" % kind]) and eq(upper, g["ref_div_%s_upper" % kind])
+        assert eq(diag, g["ref_div_%s_diag" % kind])
     a.close()
 
 
