@@ -189,6 +189,43 @@ int ldu_fvm_laplacian(ldu_addr* a, const double* deltaCoeffs, const double* gamm
 int ldu_fvm_div(ldu_addr* a, const double* weights, const double* faceFlux, double* diag,
                 double* upper, double* lower);
 
+/* ---- fvMatrix glue executed around every solve, scalar matrices ------------
+ * Replaces the O(nCells + nBoundaryFaces) host loops of
+ *   src/finiteVolume/fvMatrices/fvMatrix/fvMatrix.C: addBoundaryDiag :116-131, addBoundarySource
+ *   :150-178, setReference :509-521, relax :525-655, A :722-746, flux :865-943; H = the scalar
+ *   specialisation fvScalarMatrix.C:209-237
+ * so that diag/source/psi stay in HBM between assembly and ldu_solve.  Cells and faces in the caller's
+ * (original) numbering; pointers host or device.
+ * A boundary = the patches of the fvMesh in order: patchSizes[nPatches], faceCells of all patches
+ * concatenated (lduAddr().patchAddr(patchI)), coupled[patchI] = fvPatchField::coupled().  Per-patch
+ * coefficient arrays (internalCoeffs_, boundaryCoeffs_, patchNeighbourField) are passed concatenated in
+ * the same order. */
+typedef struct ldu_fv_boundary ldu_fv_boundary;
+int ldu_fv_boundary_create(ldu_addr* a, int32_t nPatches, const int32_t* patchSizes, const int32_t* faceCells,
+                           const int32_t* coupled /* may be NULL: none */, ldu_fv_boundary** out);
+int ldu_fv_boundary_destroy(ldu_fv_boundary* b);
+/* diag[faceCells] += internalCoeffs  (fvMatrix.C:116-131) */
+int ldu_fvm_addBoundaryDiag(ldu_fv_boundary* b, const double* internalCoeffs, double* diag);
+/* source[faceCells] += boundaryCoeffs (non-coupled) | boundaryCoeffs*patchNeighbourField (coupled, if couples) */
+int ldu_fvm_addBoundarySource(ldu_fv_boundary* b, const double* boundaryCoeffs, const double* patchNeighbourField,
+                              int32_t couples, double* source);
+/* fvMatrix<scalar>::relax(alpha): diag and source updated in place; lower NULL = symmetric */
+int ldu_fvm_relax(ldu_fv_boundary* b, double alpha, const double* internalCoeffs, const double* boundaryCoeffs,
+                  const double* upper, const double* lower, const double* psi, double* diag, double* source);
+/* source[celli] += diag[celli]*value; diag[celli] += diag[celli]   (celli < 0: no-op) */
+int ldu_fvm_setReference(ldu_addr* a, int32_t celli, double value, double* diag, double* source);
+/* A = (diag + boundary diag)/V */
+int ldu_fvm_A(ldu_fv_boundary* b, const double* internalCoeffs, const double* diag, const double* V, double* A);
+/* H = (lduMatrix::H(psi) + source + boundary source)/V */
+int ldu_fvm_H(ldu_fv_boundary* b, const double* internalCoeffs, const double* boundaryCoeffs,
+              const double* patchNeighbourField, const double* upper, const double* lower, const double* psi,
+              const double* source, const double* V, double* H);
+/* flux: internal faces = lduMatrix::faceH(psi); boundary faces (concatenated) =
+ * internalCoeffs*psi[faceCells] - boundaryCoeffs[*patchNeighbourField on coupled patches] */
+int ldu_fvm_flux(ldu_fv_boundary* b, const double* internalCoeffs, const double* boundaryCoeffs,
+                 const double* patchNeighbourField, const double* upper, const double* lower, const double* psi,
+                 double* fluxInternal, double* fluxBoundary);
+
 #ifdef __cplusplus
 }
 #endif

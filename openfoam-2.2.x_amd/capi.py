@@ -27,6 +27,8 @@ EXPORTS = [
     "ldu_gSumProd", "ldu_gSumMag", "ldu_precondition", "ldu_smooth", "ldu_solve", "ldu_gamg_levels",
     "ldu_gamg_level_data", "ldu_fv_interpolate", "ldu_fvc_surfaceIntegrate", "ldu_fvc_gaussGrad",
     "ldu_fvc_snGrad", "ldu_fvm_laplacian", "ldu_fvm_div", "ldu_profile_begin", "ldu_profile_end",
+    "ldu_fv_boundary_create", "ldu_fv_boundary_destroy", "ldu_fvm_addBoundaryDiag", "ldu_fvm_addBoundarySource",
+    "ldu_fvm_relax", "ldu_fvm_setReference", "ldu_fvm_A", "ldu_fvm_H", "ldu_fvm_flux",
 ]
 
 
@@ -345,3 +347,70 @@ def from_problem(ctx, p):
     m = Matrix(a)
     m.set_coeffs(p["diag"], p["upper"], p.get("lower"))
     return a, m
+
+
+class FvBoundary:
+    """ldu_fv_boundary: the patches of an fvMesh (sizes, faceCells, coupled flags) for the fvMatrix glue
+    (fvMatrix.C addBoundaryDiag/addBoundarySource/relax/A/H/flux).  Coefficient arrays are concatenated
+    over the patches in patch order."""
+
+    def __init__(self, addr, face_cells, coupled=None):
+        self.addr = addr
+        self.sizes = np.array([len(fc) for fc in face_cells], dtype=np.int32)
+        fc = (np.concatenate([np.asarray(x, dtype=np.int32) for x in face_cells]) if len(face_cells)
+              else np.zeros(0, dtype=np.int32))
+        self.fc = np.ascontiguousarray(fc, dtype=np.int32)
+        self.n = int(self.fc.size)
+        cp = np.zeros(len(face_cells), dtype=np.int32) if coupled is None else np.asarray(coupled, dtype=np.int32)
+        self.h = C.c_void_p()
+        _chk(lib().ldu_fv_boundary_create(addr.h, len(face_cells), _ptr(self.sizes), _ptr(self.fc), _ptr(cp),
+                                          C.byref(self.h)))
+
+    def addBoundaryDiag(self, iC, diag):
+        d = np.array(diag, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_addBoundaryDiag(self.h, _ptr(_f64(iC)), _ptr(d)))
+        return d
+
+    def addBoundarySource(self, bC, pnf, source, couples=True):
+        s = np.array(source, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_addBoundarySource(self.h, _ptr(_f64(bC)), _ptr(_f64(pnf)) if pnf is not None else None,
+                                             int(couples), _ptr(s)))
+        return s
+
+    def relax(self, alpha, iC, bC, upper, lower, psi, diag, source):
+        d = np.array(diag, dtype=np.float64, copy=True)
+        s = np.array(source, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_relax(self.h, C.c_double(alpha), _ptr(_f64(iC)), _ptr(_f64(bC)), _ptr(_f64(upper)),
+                                 _ptr(_f64(lower)) if lower is not None else None, _ptr(_f64(psi)), _ptr(d), _ptr(s)))
+        return d, s
+
+    def setReference(self, celli, value, diag, source):
+        d = np.array(diag, dtype=np.float64, copy=True)
+        s = np.array(source, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_setReference(self.addr.h, int(celli), C.c_double(value), _ptr(d), _ptr(s)))
+        return d, s
+
+    def A(self, iC, diag, V):
+        out = np.zeros(self.addr.nCells)
+        _chk(lib().ldu_fvm_A(self.h, _ptr(_f64(iC)), _ptr(_f64(diag)), _ptr(_f64(V)), _ptr(out)))
+        return out
+
+    def H(self, iC, bC, pnf, upper, lower, psi, source, V):
+        out = np.zeros(self.addr.nCells)
+        _chk(lib().ldu_fvm_H(self.h, _ptr(_f64(iC)), _ptr(_f64(bC)), _ptr(_f64(pnf)) if pnf is not None else None,
+                             _ptr(_f64(upper)), _ptr(_f64(lower)) if lower is not None else None, _ptr(_f64(psi)),
+                             _ptr(_f64(source)), _ptr(_f64(V)), _ptr(out)))
+        return out
+
+    def flux(self, iC, bC, pnf, upper, lower, psi):
+        fi = np.zeros(self.addr.nFaces)
+        fb = np.zeros(self.n)
+        _chk(lib().ldu_fvm_flux(self.h, _ptr(_f64(iC)), _ptr(_f64(bC)), _ptr(_f64(pnf)) if pnf is not None else None,
+                                _ptr(_f64(upper)), _ptr(_f64(lower)) if lower is not None else None, _ptr(_f64(psi)),
+                                _ptr(fi), _ptr(fb)))
+        return fi, fb
+
+    def close(self):
+        if self.h:
+            lib().ldu_fv_boundary_destroy(self.h)
+            self.h = C.c_void_p()

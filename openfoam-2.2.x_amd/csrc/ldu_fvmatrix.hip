@@ -1,0 +1,407 @@
+// fvMatrix glue executed around every solve, scalar matrices:
+// addBoundaryDiag / addBoundarySource (fvMatrix.C:116-178), setReference (:509-521), relax (:525-655),
+// A (:722-746), H (fvScalarMatrix.C:209-237), flux (:865-943).  Everything stays in HBM between assembly and solve.
+//
+// Layout: ORIGINAL cell / face numbering (these run before the matrix is handed to the solver).
+// One thread per cell; a cell walks its boundary faces in (patch, face) order - the order in which
+// the reference's patch loops touch it - and its internal faces in the reference's face order
+// (faces whose upper cell it is, ascending, then the faces it owns, ascending), so every result is
+// bit-identical to the sequential loops (-ffp-contract=off).
+#include <algorithm>
+#include <vector>
+
+#include "ldu_internal.hpp"
+
+struct ldu_fv_boundary {
+    ldu_addr* a = nullptr;
+    int nPatches = 0;
+    int nFacesTotal = 0;
+    std::vector<int> sizes, offsets, coupled;
+    int* d_cellStart = nullptr;        // [nCells+1] CSR over cells
+    int* d_cellFace = nullptr;         // [nFacesTotal] index into the concatenated patch-face arrays
+    int* d_faceCells = nullptr;        // [nFacesTotal]
+    unsigned char* d_coupled = nullptr;  // [nFacesTotal] per patch face: its patch is coupled
+};
+
+static bool dev_ptr(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice;
+}
+
+// host/device staging (same contract as the other fv entry points: any pointer may be host or device)
+struct GlueBuf {
+    hipStream_t s;
+    std::vector<void*> owned;
+    explicit GlueBuf(hipStream_t ss) : s(ss) {}
+    ~GlueBuf() { for (void* p : owned) (void)hipFree(p); }
+    const double* in(const double* user, size_t n)
+    {
+        if (!user || dev_ptr(user)) return user;
+        double* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(double) * (n ? n : 1)) != hipSuccess) return nullptr;
+        owned.push_back(d);
+        (void)hipMemcpyAsync(d, user, sizeof(double) * n, hipMemcpyHostToDevice, s);
+        return d;
+    }
+    double* inout(double* user, size_t n, bool copyIn)
+    {
+        if (dev_ptr(user)) return user;
+        double* d = nullptr;
+        if (hipMalloc((void**)&d, sizeof(double) * (n ? n : 1)) != hipSuccess) return nullptr;
+        owned.push_back(d);
+        if (copyIn) (void)hipMemcpyAsync(d, user, sizeof(double) * n, hipMemcpyHostToDevice, s);
+        return d;
+    }
+    int finish(double* user, double* dev, size_t n)
+    {
+        if (user != dev) LDU_CHECK_HIP(hipMemcpyAsync(user, dev, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+};
+
+#define GLUE_BLK 256
+static inline int glue_grid(int n) { return (n + GLUE_BLK - 1) / GLUE_BLK; }
+
+// ---------------------------------------------------------------- kernels
+
+// fvMatrix.C:116-131 (and addCmptAvBoundaryDiag for a scalar): diag[faceCells] += internalCoeffs
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_addBoundaryDiag_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                            const double* __restrict__ iC, double* __restrict__ diag)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const int b = cs[c], e = cs[c + 1];
+    if (b == e) return;
+    double d = diag[c];
+    for (int j = b; j < e; j++) d += iC[cf[j]];
+    diag[c] = d;
+}
+
+// fvMatrix.C:150-178
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_addBoundarySource_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                              const unsigned char* __restrict__ coupled, const double* __restrict__ bC,
+                              const double* __restrict__ pnf, int couples, double* __restrict__ source)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const int b = cs[c], e = cs[c + 1];
+    if (b == e) return;
+    double s = source[c];
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        if (!coupled[f]) s += bC[f];
+        else if (couples) s += bC[f] * pnf[f];
+    }
+    source[c] = s;
+}
+
+// fvMatrix.C:525-655, Type = scalar
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_relax_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                  const unsigned char* __restrict__ coupled, const double* __restrict__ iC,
+                  const double* __restrict__ bC, const int* __restrict__ losortStart,
+                  const int* __restrict__ losort, const int* __restrict__ ownerStart,
+                  const double* __restrict__ upper, const double* __restrict__ lower, double alpha,
+                  const double* __restrict__ psi, double* __restrict__ diag, double* __restrict__ source)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const double D0 = diag[c];
+    double D = D0;
+    // sumMagOffDiag (lduMatrixOperations.C:67-83), this cell's updates in face order
+    double sumOff = 0.0;
+    for (int j = losortStart[c]; j < losortStart[c + 1]; j++) sumOff += fabs(lower[losort[j]]);
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++) sumOff += fabs(upper[f]);
+    const int b = cs[c], e = cs[c + 1];
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        if (coupled[f])
+        {
+            D += iC[f];
+            sumOff += fabs(bC[f]);
+        }
+        else
+            D += fabs(iC[f]);             // cmptMax(cmptMag(.)) of a scalar
+    }
+    D = fmax(fabs(D), sumOff);            // max(mag(D), sumOff)
+    D /= alpha;
+    for (int j = b; j < e; j++) D -= iC[cf[j]];   // component 0 / cmptMin of a scalar
+    diag[c] = D;
+    source[c] += (D - D0) * psi[c];
+}
+
+// fvMatrix.C:722-746: A = D()/V, D() = diag + cmptAv(internalCoeffs)
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_A_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf, const double* __restrict__ iC,
+              const double* __restrict__ diag, const double* __restrict__ V, double* __restrict__ A)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    double d = diag[c];
+    for (int j = cs[c]; j < cs[c + 1]; j++) d += iC[cf[j]];
+    A[c] = d / V[c];
+}
+
+// fvMatrix<scalar>::H = the scalar specialisation fvScalarMatrix.C:209-237 (no boundary-diagonal term);
+// lduMatrix::H = lduMatrixTemplates.C:32-69
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_H_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+              const unsigned char* __restrict__ coupled, const double* __restrict__ iC,
+              const double* __restrict__ bC, const double* __restrict__ pnf,
+              const int* __restrict__ losortStart, const int* __restrict__ losort,
+              const int* __restrict__ ownerStart, const int* __restrict__ l, const int* __restrict__ u,
+              const double* __restrict__ upper, const double* __restrict__ lower,
+              const double* __restrict__ psi, const double* __restrict__ source, const double* __restrict__ V,
+              double* __restrict__ H)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const int b = cs[c], e = cs[c + 1];
+    // lduMatrix::H(psi)
+    double hl = 0.0;
+    for (int j = losortStart[c]; j < losortStart[c + 1]; j++)
+    {
+        const int f = losort[j];
+        hl -= lower[f] * psi[l[f]];
+    }
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++) hl -= upper[f] * psi[u[f]];
+    double h = hl + source[c];
+    // addBoundarySource (couples = true)
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        h += coupled[f] ? bC[f] * pnf[f] : bC[f];
+    }
+    H[c] = h / V[c];
+}
+
+// fvMatrix.C:865-943: internal faces = lduMatrix::faceH (lduMatrixTemplates.C:104-135)
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_flux_internal_kernel(int nFaces, const int* __restrict__ l, const int* __restrict__ u,
+                          const double* __restrict__ upper, const double* __restrict__ lower,
+                          const double* __restrict__ psi, double* __restrict__ flux)
+{
+    const int f = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (f >= nFaces) return;
+    flux[f] = upper[f] * psi[u[f]] - lower[f] * psi[l[f]];
+}
+
+// boundary faces: internalCoeffs*patchInternalField - (coupled ? boundaryCoeffs*patchNeighbourField : boundaryCoeffs)
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_flux_boundary_kernel(int n, const int* __restrict__ faceCells, const unsigned char* __restrict__ coupled,
+                          const double* __restrict__ iC, const double* __restrict__ bC,
+                          const double* __restrict__ pnf, const double* __restrict__ psi,
+                          double* __restrict__ flux)
+{
+    const int f = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (f >= n) return;
+    const double ic = iC[f] * psi[faceCells[f]];
+    const double nc = coupled[f] ? bC[f] * pnf[f] : bC[f];
+    flux[f] = ic - nc;
+}
+
+__global__ void glue_setReference_kernel(int celli, double value, double* diag, double* source)
+{
+    source[celli] += diag[celli] * value;
+    diag[celli] += diag[celli];
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" {
+
+int ldu_fv_boundary_create(ldu_addr* a, int32_t nPatches, const int32_t* patchSizes, const int32_t* faceCells,
+                           const int32_t* coupled, ldu_fv_boundary** out)
+{
+    if (!a || !out || nPatches < 0) { ldu_set_error("ldu_fv_boundary_create: bad arguments"); return -2; }
+    ldu_fv_boundary* b = new ldu_fv_boundary();
+    b->a = a;
+    b->nPatches = nPatches;
+    int off = 0;
+    for (int p = 0; p < nPatches; p++)
+    {
+        b->sizes.push_back(patchSizes[p]);
+        b->offsets.push_back(off);
+        b->coupled.push_back(coupled ? coupled[p] : 0);
+        off += patchSizes[p];
+    }
+    b->nFacesTotal = off;
+    const int nC = a->nCells;
+    std::vector<int> cs(nC + 1, 0), cf(off), fc(off);
+    std::vector<unsigned char> cp(off, 0);
+    for (int i = 0; i < off; i++)
+    {
+        if (faceCells[i] < 0 || faceCells[i] >= nC)
+        {
+            delete b;
+            ldu_set_error("ldu_fv_boundary_create: faceCells out of range");
+            return -2;
+        }
+        fc[i] = faceCells[i];
+        cs[faceCells[i] + 1]++;
+    }
+    for (int c = 0; c < nC; c++) cs[c + 1] += cs[c];
+    {
+        std::vector<int> pos(cs.begin(), cs.end() - 1);
+        for (int p = 0; p < nPatches; p++)
+            for (int i = 0; i < b->sizes[p]; i++)
+            {
+                const int g = b->offsets[p] + i;           // ascending (patch, face): the reference's order
+                cf[pos[fc[g]]++] = g;
+                cp[g] = (unsigned char)(b->coupled[p] ? 1 : 0);
+            }
+    }
+    auto up = [&](void** d, const void* h, size_t bytes) -> int {
+        LDU_CHECK_HIP(hipMalloc(d, bytes ? bytes : 4));
+        if (bytes) LDU_CHECK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (up((void**)&b->d_cellStart, cs.data(), sizeof(int) * cs.size())
+        || up((void**)&b->d_cellFace, cf.data(), sizeof(int) * cf.size())
+        || up((void**)&b->d_faceCells, fc.data(), sizeof(int) * fc.size())
+        || up((void**)&b->d_coupled, cp.data(), cp.size()))
+    {
+        delete b;
+        return -1;
+    }
+    *out = b;
+    return 0;
+}
+
+int ldu_fv_boundary_destroy(ldu_fv_boundary* b)
+{
+    if (!b) return 0;
+    (void)hipFree(b->d_cellStart); (void)hipFree(b->d_cellFace);
+    (void)hipFree(b->d_faceCells); (void)hipFree(b->d_coupled);
+    delete b;
+    return 0;
+}
+
+int ldu_fvm_addBoundaryDiag(ldu_fv_boundary* b, const double* internalCoeffs, double* diag)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs, b->nFacesTotal);
+    double* d = B.inout(diag, a->nCells, true);
+    glue_addBoundaryDiag_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace,
+                                                                         iC, d);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(diag, d, a->nCells);
+}
+
+int ldu_fvm_addBoundarySource(ldu_fv_boundary* b, const double* boundaryCoeffs, const double* patchNeighbourField,
+                              int32_t couples, double* source)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* bC = B.in(boundaryCoeffs, b->nFacesTotal);
+    const double* pnf = B.in(patchNeighbourField, b->nFacesTotal);
+    if (couples && !pnf)
+        for (int c : b->coupled)
+            if (c) { ldu_set_error("ldu_fvm_addBoundarySource: coupled patches need patchNeighbourField"); return -2; }
+    double* s = B.inout(source, a->nCells, true);
+    glue_addBoundarySource_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart,
+        b->d_cellFace, b->d_coupled, bC, pnf, couples, s);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(source, s, a->nCells);
+}
+
+int ldu_fvm_relax(ldu_fv_boundary* b, double alpha, const double* internalCoeffs, const double* boundaryCoeffs,
+                  const double* upper, const double* lower, const double* psi, double* diag, double* source)
+{
+    if (alpha <= 0) return 0;   // fvMatrix.C:527-530
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs, b->nFacesTotal);
+    const double* bC = B.in(boundaryCoeffs, b->nFacesTotal);
+    const double* up = B.in(upper, a->nFaces);
+    const double* lo = lower ? B.in(lower, a->nFaces) : up;
+    const double* x = B.in(psi, a->nCells);
+    double* d = B.inout(diag, a->nCells, true);
+    double* s = B.inout(source, a->nCells, true);
+    glue_relax_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace,
+        b->d_coupled, iC, bC, a->d_losortStart, a->d_losort, a->d_ownerStart, up, lo, alpha, x, d, s);
+    LDU_CHECK_HIP(hipGetLastError());
+    if (B.finish(diag, d, a->nCells)) return -1;
+    return B.finish(source, s, a->nCells);
+}
+
+int ldu_fvm_setReference(ldu_addr* a, int32_t celli, double value, double* diag, double* source)
+{
+    if (celli < 0) return 0;    // fvMatrix.C:516
+    if (celli >= a->nCells) { ldu_set_error("ldu_fvm_setReference: cell out of range"); return -2; }
+    GlueBuf B(a->ctx->stream);
+    double* d = B.inout(diag, a->nCells, true);
+    double* s = B.inout(source, a->nCells, true);
+    glue_setReference_kernel<<<1, 1, 0, B.s>>>(celli, value, d, s);
+    LDU_CHECK_HIP(hipGetLastError());
+    if (B.finish(diag, d, a->nCells)) return -1;
+    return B.finish(source, s, a->nCells);
+}
+
+int ldu_fvm_A(ldu_fv_boundary* b, const double* internalCoeffs, const double* diag, const double* V, double* A)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs, b->nFacesTotal);
+    const double* d = B.in(diag, a->nCells);
+    const double* v = B.in(V, a->nCells);
+    double* o = B.inout(A, a->nCells, false);
+    glue_A_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace, iC, d, v, o);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(A, o, a->nCells);
+}
+
+int ldu_fvm_H(ldu_fv_boundary* b, const double* internalCoeffs, const double* boundaryCoeffs,
+              const double* patchNeighbourField, const double* upper, const double* lower, const double* psi,
+              const double* source, const double* V, double* H)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs, b->nFacesTotal);
+    const double* bC = B.in(boundaryCoeffs, b->nFacesTotal);
+    const double* pnf = B.in(patchNeighbourField, b->nFacesTotal);
+    const double* up = B.in(upper, a->nFaces);
+    const double* lo = lower ? B.in(lower, a->nFaces) : up;
+    const double* x = B.in(psi, a->nCells);
+    const double* s = B.in(source, a->nCells);
+    const double* v = B.in(V, a->nCells);
+    double* o = B.inout(H, a->nCells, false);
+    if (!pnf) pnf = bC;   // never dereferenced without coupled patches
+    glue_H_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace, b->d_coupled,
+        iC, bC, pnf, a->d_losortStart, a->d_losort, a->d_ownerStart, a->d_l, a->d_u, up, lo, x, s, v, o);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(H, o, a->nCells);
+}
+
+int ldu_fvm_flux(ldu_fv_boundary* b, const double* internalCoeffs, const double* boundaryCoeffs,
+                 const double* patchNeighbourField, const double* upper, const double* lower, const double* psi,
+                 double* fluxInternal, double* fluxBoundary)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs, b->nFacesTotal);
+    const double* bC = B.in(boundaryCoeffs, b->nFacesTotal);
+    const double* pnf = B.in(patchNeighbourField, b->nFacesTotal);
+    const double* up = B.in(upper, a->nFaces);
+    const double* lo = lower ? B.in(lower, a->nFaces) : up;
+    const double* x = B.in(psi, a->nCells);
+    double* fi = B.inout(fluxInternal, a->nFaces, false);
+    double* fb = B.inout(fluxBoundary, b->nFacesTotal, false);
+    if (!pnf) pnf = bC;
+    glue_flux_internal_kernel<<<glue_grid(a->nFaces), GLUE_BLK, 0, B.s>>>(a->nFaces, a->d_l, a->d_u, up, lo, x, fi);
+    if (b->nFacesTotal)
+        glue_flux_boundary_kernel<<<glue_grid(b->nFacesTotal), GLUE_BLK, 0, B.s>>>(b->nFacesTotal, b->d_faceCells,
+            b->d_coupled, iC, bC, pnf, x, fb);
+    LDU_CHECK_HIP(hipGetLastError());
+    if (B.finish(fluxInternal, fi, a->nFaces)) return -1;
+    return B.finish(fluxBoundary, fb, b->nFacesTotal);
+}
+
+}  // extern "C"

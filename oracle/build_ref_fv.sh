@@ -58,11 +58,21 @@ CXXFLAGS="-m64 -std=gnu++98 -Dlinux64 -DWM_DP -DNoRepository -ftemplate-depth-10
 } > "$W/Makefile.fv"
 rm -f "$W/fvfailed.txt"
 make -s -k -C "$W" -f "$W/Makefile.fv" -j"$JOBS" all || true
-rm -f "$OUT/libfiniteVolume.a"
-ar rcs "$OUT/libfiniteVolume.a" "$W"/fvobj/*.o
+rm -f "$W/libfiniteVolume.a"
+ar rcs "$W/libfiniteVolume.a" "$W"/fvobj/*.o
 echo "build_ref_fv.sh: $(ls "$W"/fvobj/*.o | wc -l) units archived; failed: $(cat "$W/fvfailed.txt" 2>/dev/null | wc -l)"
+# units whose only entry point is a static registration object (run-time selection of the cyclic patch
+# and its patch fields) are not reachable through symbols: name them explicitly
+FORCE=""
+for u in fvMesh/fvPatches/constraint/cyclic/cyclicFvPatch.C \
+         fields/fvPatchFields/constraint/cyclic/cyclicFvPatchFields.C \
+         fields/fvPatchFields/basic/fixedValue/fixedValueFvPatchFields.C \
+         fields/fvsPatchFields/constraint/cyclic/cyclicFvsPatchFields.C; do
+    i=$(grep -n "/$u\$" "$W/fvsources.txt" | head -1 | cut -d: -f1)
+    [ -n "$i" ] && FORCE="$FORCE $W/fvobj/f$i.o"
+done
 if [ -f "$HERE/fv_driver.C" ]; then
-    g++ $CXXFLAGS -o "$OUT/fv_driver" "$HERE/fv_driver.C" "$OUT/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm \
+    g++ $CXXFLAGS -o "$OUT/fv_driver" "$HERE/fv_driver.C" $FORCE "$W/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm \
         -Wl,-rpath,'$ORIGIN'
     echo "build_ref_fv.sh: OK -> $OUT/fv_driver"
 fi

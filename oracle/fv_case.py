@@ -21,7 +21,7 @@ HEADER = """FoamFile
 """
 
 
-def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5)):
+def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5), cyclic_x=False):
     """points (perturbed, graded), faces (vertex lists, owner->neighbour right-handed), owner, neighbour,
     boundary patches.  Returns dict."""
     rng = np.random.RandomState(seed)
@@ -75,7 +75,10 @@ def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5)):
         start = len(faces)
         for fv, c in flist:
             faces.append(fv); owner.append(c)
-        patches.append((name, len(flist), start))
+        extra = ""
+        if cyclic_x and name in ("xmin", "xmax"):
+            extra = "cyclic " + ("xmax" if name == "xmin" else "xmin")
+        patches.append((name, len(flist), start, extra))
 
     add_patch("xmin", [(face_x(0, j, k)[::-1], cid(0, j, k)) for k in range(nz) for j in range(ny)])
     add_patch("xmax", [(face_x(nx, j, k), cid(nx - 1, j, k)) for k in range(nz) for j in range(ny)])
@@ -113,8 +116,12 @@ def write_case(case, mesh):
     with open(os.path.join(pm, "boundary"), "w") as f:
         f.write(HEADER % ("polyBoundaryMesh", "constant/polyMesh", "boundary"))
         f.write("%d\n(\n" % len(mesh["patches"]))
-        for name, n, start in mesh["patches"]:
-            f.write("%s\n{\n    type patch;\n    nFaces %d;\n    startFace %d;\n}\n" % (name, n, start))
+        for name, n, start, extra in mesh["patches"]:
+            if extra.startswith("cyclic"):
+                f.write("%s\n{\n    type cyclic;\n    neighbourPatch %s;\n    nFaces %d;\n    startFace %d;\n}\n"
+                        % (name, extra.split()[1], n, start))
+            else:
+                f.write("%s\n{\n    type patch;\n    nFaces %d;\n    startFace %d;\n}\n" % (name, n, start))
         f.write(")\n")
     with open(os.path.join(case, "system", "controlDict"), "w") as f:
         f.write(HEADER % ("dictionary", "system", "controlDict"))
@@ -126,7 +133,7 @@ def write_case(case, mesh):
         f.write("ddtSchemes { default steadyState; }\ngradSchemes { default Gauss linear; }\n"
                 "divSchemes { default Gauss linear; }\nlaplacianSchemes { default Gauss linear uncorrected; }\n"
                 "interpolationSchemes { default linear; }\nsnGradSchemes { default uncorrected; }\n"
-                "fluxRequired { default no; }\n")
+                "fluxRequired { default no; T; }\n")
     with open(os.path.join(case, "system", "fvSolution"), "w") as f:
         f.write(HEADER % ("dictionary", "system", "fvSolution"))
         f.write("solvers { }\n")
@@ -136,14 +143,15 @@ def driver_available():
     return os.path.exists(os.path.join(REF, "fv_driver"))
 
 
-def run_driver(case, mesh, vf, U, phi, gamma):
+def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils"):
     """-> dict name -> array (vectors reshaped to [n,3])"""
     inp = os.path.join(case, "in.bin")
     outp = os.path.join(case, "out.bin")
     np.concatenate([vf, U.reshape(-1), phi, gamma]).astype(np.float64).tofile(inp)
     env = dict(os.environ, WM_PROJECT="OpenFOAM", WM_PROJECT_VERSION="2.2.x", WM_PROJECT_DIR=REF,
                LD_LIBRARY_PATH=REF + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FOAM_SIGFPE="false")
-    r = subprocess.run([os.path.join(REF, "fv_driver"), case, inp, outp], env=env, capture_output=True, text=True)
+    r = subprocess.run([os.path.join(REF, "fv_driver"), case, inp, outp, mode], env=env, capture_output=True,
+                       text=True)
     if r.returncode != 0:
         raise RuntimeError("fv_driver failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
     res = {}
@@ -156,5 +164,6 @@ def run_driver(case, mesh, vf, U, phi, gamma):
             a = np.fromfile(f, dtype=np.float64, count=int(n))
             res[name] = a
     for k in ("Sf", "interpolate_v", "surfaceIntegrate_v", "gaussGrad", "phiU"):
-        res[k] = res[k].reshape(-1, 3)
+        if k in res:
+            res[k] = res[k].reshape(-1, 3)
     return res

@@ -4,7 +4,7 @@
 // kernels ldu_fv_* / ldu_fvc_* / ldu_fvm_* (SURVEY.md 8a rows a30, a33-a39).
 // Our code; only reference HEADERS are included.  Never shipped, never linked into the product.
 //
-// usage: fv_driver <caseDir> <in.bin> <out.bin>
+// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue]
 //   in.bin : vf[nC] U[3 nC] phi[nF] gamma[nF]            (nF = internal faces)
 //   out.bin: sections "name count" + doubles, see put()
 #include "argList.H"
@@ -24,7 +24,12 @@
 #include "calculatedFvPatchFields.H"
 #include "calculatedFvsPatchFields.H"
 #include "zeroGradientFvPatchFields.H"
+#include "cyclicFvPatch.H"
+#include "cyclicFvPatchFields.H"
+#include "cyclicFvsPatchFields.H"
+#include "fixedValueFvPatchFields.H"
 #include <cstdio>
+#include <string>
 #include <vector>
 
 using namespace Foam;
@@ -45,9 +50,117 @@ static void put(const char* name, const vectorField& f)
     put(name, reinterpret_cast<const double*>(f.begin()), 3L * f.size());
 }
 
+// fvMatrix glue: a scalar transport matrix with fixedValue / zeroGradient / cyclic
+// patches; dumps the matrix, the patch coefficient sets and what the reference's own fvMatrix methods
+// make of them (fvMatrix.C: addBoundaryDiag, addBoundarySource, A, H, flux, relax, setReference).
+static int glue(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
+{
+    const label nC = mesh.nCells();
+    const label nF = mesh.nInternalFaces();
+    dimensionSet::debug = 0;   // synthetic dimensionless fields: no dimension checking of the matrix sum
+    wordList types(mesh.boundary().size());
+    forAll(types, p)
+    {
+        types[p] = mesh.boundary()[p].coupled() ? word("cyclic") : (p % 2 ? word("zeroGradient") : word("fixedValue"));
+    }
+    volScalarField T(IOobject("T", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0), types);
+    for (label c = 0; c < nC; c++) T.internalField()[c] = in[c];
+    forAll(types, p)
+    {
+        if (types[p] == "fixedValue") T.boundaryField()[p] == scalar(0.7 + 0.1 * p);
+    }
+    T.correctBoundaryConditions();
+    surfaceScalarField phi(IOobject("phi", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
+    surfaceScalarField gamma(IOobject("gamma", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
+    for (label f = 0; f < nF; f++)
+    {
+        phi.internalField()[f] = in[(size_t)4 * nC + f];
+        gamma.internalField()[f] = in[(size_t)4 * nC + nF + f];
+    }
+    forAll(phi.boundaryField(), p)
+    {
+        forAll(phi.boundaryField()[p], i)
+        {
+            phi.boundaryField()[p][i] = 0.05 * ((i % 5) - 2) * (mesh.boundary()[p].coupled() ? 0.0 : 1.0);
+            gamma.boundaryField()[p][i] = 0.8 + 0.01 * (i % 7);
+        }
+    }
+    surfaceScalarField gammaMagSf("gammaMagSf", gamma * mesh.magSf());
+    tmp<fvScalarMatrix> tLap =
+        fv::gaussLaplacianScheme<scalar, scalar>::fvmLaplacianUncorrected(gammaMagSf, mesh.deltaCoeffs(), T);
+    fv::gaussConvectionScheme<scalar> cs(mesh, phi, tmp<surfaceInterpolationScheme<scalar> >(new upwind<scalar>(mesh, phi)));
+    tmp<fvScalarMatrix> tDiv = cs.fvmDiv(phi, T);
+    fvScalarMatrix M(tDiv() - tLap());
+    for (label c = 0; c < nC; c++) M.source()[c] = 0.3 * in[nC + 3 * c];
+
+    put("diag", M.diag());
+    put("upper", M.upper());
+    put("lower", M.lower());
+    put("source", M.source());
+    put("psi", T.internalField());
+    put("V", mesh.V().field());
+    {
+        scalarField np(1, scalar(mesh.boundary().size()));
+        put("nPatches", np);
+    }
+    forAll(mesh.boundary(), p)
+    {
+        const labelUList& fc = mesh.lduAddr().patchAddr(p);
+        scalarField fcd(fc.size());
+        forAll(fc, i) fcd[i] = fc[i];
+        char nm[64];
+        snprintf(nm, sizeof(nm), "p%d_faceCells", p); put(nm, fcd);
+        scalarField cp(1, T.boundaryField()[p].coupled() ? 1.0 : 0.0);
+        snprintf(nm, sizeof(nm), "p%d_coupled", p); put(nm, cp);
+        snprintf(nm, sizeof(nm), "p%d_internalCoeffs", p); put(nm, M.internalCoeffs()[p]);
+        snprintf(nm, sizeof(nm), "p%d_boundaryCoeffs", p); put(nm, M.boundaryCoeffs()[p]);
+        scalarField pnf(fc.size(), 0.0);
+        if (T.boundaryField()[p].coupled()) pnf = T.boundaryField()[p].patchNeighbourField();
+        snprintf(nm, sizeof(nm), "p%d_pnf", p); put(nm, pnf);
+    }
+    {
+        scalarField d(M.diag());
+        M.addBoundaryDiag(d, 0);
+        put("ref_addBoundaryDiag", d);
+        scalarField s(M.source());
+        M.addBoundarySource(s);
+        put("ref_addBoundarySource", s);
+        scalarField s2(M.source());
+        M.addBoundarySource(s2, false);
+        put("ref_addBoundarySource_nocouples", s2);
+    }
+    put("ref_A", M.A()().internalField());
+    put("ref_H", M.H()().internalField());
+    {
+        tmp<surfaceScalarField> fl = M.flux();
+        put("ref_flux_internal", fl().internalField());
+        forAll(fl().boundaryField(), p)
+        {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "p%d_ref_flux", p);
+            scalarField b(fl().boundaryField()[p]);
+            put(nm, b);
+        }
+    }
+    {
+        fvScalarMatrix R(M);
+        R.relax(0.7);
+        put("ref_relax_diag", R.diag());
+        put("ref_relax_source", R.source());
+    }
+    {
+        fvScalarMatrix R(M);
+        R.setReference(5, 1.3, true);
+        put("ref_setReference_diag", R.diag());
+        put("ref_setReference_source", R.source());
+    }
+    fclose(out);
+    return 0;
+}
+
 int main(int argc, char* argv[])
 {
-    if (argc != 4) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin\n"); return 2; }
+    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue]\n"); return 2; }
     fileName caseDir(argv[1]);
     Time runTime(Time::controlDictName, fileName(caseDir.path()), fileName(caseDir.name()));
     fvMesh mesh(IOobject(fvMesh::defaultRegion, runTime.timeName(), runTime, IOobject::MUST_READ));
@@ -65,6 +178,7 @@ int main(int argc, char* argv[])
         fclose(f);
     }
     out = fopen(argv[3], "wb");
+    if (argc == 5 && std::string(argv[4]) == "glue") return glue(mesh, runTime, in);
 
     // fields: internal values from the input, boundary values zero ("calculated")
     volScalarField vf(IOobject("vf", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0),

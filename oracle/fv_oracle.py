@@ -75,3 +75,103 @@ def face_area_pair_weights(Sf, magSf):
     t = Sf / np.sqrt(magSf)[:, None]
     t = t * np.array([1.0, 1.01, 1.02])
     return np.sqrt(t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1] + t[:, 2] * t[:, 2])
+
+
+# ---------------------------------------------------------------- fvMatrix glue
+# scalar matrices; patches = list of dicts {faceCells, internalCoeffs, boundaryCoeffs, coupled, pnf}
+
+def add_boundary_diag(diag, patches):
+    """fvMatrix::addBoundaryDiag, fvMatrices/fvMatrix/fvMatrix.C:116-131 (cmpt 0 of a scalar)"""
+    d = diag.copy()
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            d[c] += p["internalCoeffs"][i]
+    return d
+
+
+def add_boundary_source(source, patches, couples=True):
+    """fvMatrix::addBoundarySource, fvMatrix.C:150-178"""
+    s = source.copy()
+    for p in patches:
+        if not p["coupled"]:
+            for i, c in enumerate(p["faceCells"]):
+                s[c] += p["boundaryCoeffs"][i]
+        elif couples:
+            for i, c in enumerate(p["faceCells"]):
+                s[c] += p["boundaryCoeffs"][i] * p["pnf"][i]
+    return s
+
+
+def sum_mag_off_diag(nC, l, u, lower, upper):
+    """lduMatrix::sumMagOffDiag, OpenFOAM/matrices/lduMatrix/lduMatrix/lduMatrixOperations.C:67-83"""
+    s = np.zeros(nC)
+    for f in range(l.size):
+        s[u[f]] += abs(lower[f])
+        s[l[f]] += abs(upper[f])
+    return s
+
+
+def relax(alpha, diag, source, l, u, upper, lower, psi, patches):
+    """fvMatrix<scalar>::relax, fvMatrix.C:525-655"""
+    if alpha <= 0:
+        return diag.copy(), source.copy()
+    D = diag.copy()
+    D0 = diag.copy()
+    sumOff = sum_mag_off_diag(D.size, l, u, lower, upper)
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            if p["coupled"]:
+                D[c] += p["internalCoeffs"][i]
+                sumOff[c] += abs(p["boundaryCoeffs"][i])
+            else:
+                D[c] += abs(p["internalCoeffs"][i])      # cmptMax(cmptMag(.))
+    D = np.maximum(np.abs(D), sumOff)
+    D = D / alpha
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            D[c] -= p["internalCoeffs"][i]               # component 0 (coupled) / cmptMin (non-coupled)
+    return D, source + (D - D0) * psi
+
+
+def set_reference(celli, value, diag, source):
+    """fvMatrix::setReference, fvMatrix.C:509-521"""
+    d, s = diag.copy(), source.copy()
+    if celli >= 0:
+        s[celli] += d[celli] * value
+        d[celli] += d[celli]
+    return d, s
+
+
+def fvm_A(diag, patches, V):
+    """fvMatrix::A, fvMatrix.C:722-746: D()/V with D() = diag + cmptAv(internalCoeffs) (:689-694)"""
+    return add_boundary_diag(diag, patches) / V
+
+
+def ldu_H(nC, l, u, lower, upper, psi):
+    """lduMatrix::H, lduMatrixTemplates.C:32-69"""
+    h = np.zeros(nC)
+    for f in range(l.size):
+        h[u[f]] -= lower[f] * psi[l[f]]
+        h[l[f]] -= upper[f] * psi[u[f]]
+    return h
+
+
+def fvm_H(diag, source, l, u, upper, lower, psi, patches, V):
+    """fvMatrix<scalar>::H - the scalar SPECIALISATION, fvMatrices/fvScalarMatrix/fvScalarMatrix.C:209-237:
+    (lduMatrix::H(psi) + source), addBoundarySource, /V.  (The generic fvMatrix<Type>::H, fvMatrix.C:751-813,
+    also adds (cmptAv(internalCoeffs) - internalCoeffs.component(cmpt))*psi, which is not exactly zero in
+    floating point when a cell has several boundary faces.)"""
+    h = ldu_H(diag.size, l, u, lower, upper, psi) + source
+    h = add_boundary_source(h, patches, couples=True)
+    return h / V
+
+
+def fvm_flux(l, u, upper, lower, psi, patches):
+    """fvMatrix::flux, fvMatrix.C:865-943; internal part = lduMatrix::faceH (lduMatrixTemplates.C:92-97)"""
+    fi = upper * psi[u] - lower * psi[l]
+    fb = []
+    for p in patches:
+        ic = p["internalCoeffs"] * psi[p["faceCells"]]
+        nc = p["boundaryCoeffs"] * p["pnf"] if p["coupled"] else p["boundaryCoeffs"]
+        fb.append(ic - nc)
+    return fi, fb

@@ -37,6 +37,27 @@ def generate(name):
     return out
 
 
+GLUE_CASES = {"fvglue_box_6x5x4_cyclic": (6, 5, 4, 5, True), "fvglue_box_3x9x2": (3, 9, 2, 6, False)}
+
+
+def generate_glue(name):
+    nx, ny, nz, seed, cyc = GLUE_CASES[name]
+    mesh = fv_case.box_mesh(nx, ny, nz, seed=seed, cyclic_x=cyc)
+    rng = np.random.RandomState(200 + seed)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
+    with tempfile.TemporaryDirectory() as d:
+        case = os.path.join(d, "case")
+        fv_case.write_case(case, mesh)
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="glue")
+    out = dict(nCells=nC, lowerAddr=mesh["owner"][:nF].astype(np.int32), upperAddr=mesh["neighbour"].astype(np.int32))
+    for k, v in res.items():
+        if k.endswith("_faceCells"):
+            v = v.astype(np.int32)
+        out[k] = v
+    return out
+
+
 if __name__ == "__main__":
     if not fv_case.driver_available():
         raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
@@ -44,3 +65,8 @@ if __name__ == "__main__":
         data = generate(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "faces", data["lowerAddr"].size, sorted(k for k in data if k.startswith("ref_")))
+    for name in GLUE_CASES:
+        data = generate_glue(name)
+        np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+        print(name, "cells", data["nCells"], "patches", int(data["nPatches"][0]),
+              "coupled", [int(data["p%d_coupled" % p][0]) for p in range(int(data["nPatches"][0]))])

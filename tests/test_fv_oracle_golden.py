@@ -54,3 +54,36 @@ def test_fixture_is_live_when_the_reference_build_exists(tmp_path):
     old = load("fv_box_7x6x5")
     for k in old:
         assert np.array_equal(np.asarray(fresh[k]), old[k]), k
+
+
+GLUE = ["fvglue_box_6x5x4_cyclic", "fvglue_box_3x9x2"]
+
+
+def glue_patches(g):
+    return [dict(faceCells=g["p%d_faceCells" % p], internalCoeffs=g["p%d_internalCoeffs" % p],
+                 boundaryCoeffs=g["p%d_boundaryCoeffs" % p], coupled=bool(g["p%d_coupled" % p][0]),
+                 pnf=g["p%d_pnf" % p]) for p in range(int(g["nPatches"][0]))]
+
+
+@pytest.mark.parametrize("name", GLUE)
+def test_fvmatrix_glue_oracle_matches_reference(name):
+    """fvMatrix::addBoundaryDiag/addBoundarySource/A/H/flux/relax/setReference as executed by the
+    reference's own fvMatrix (fixedValue, zeroGradient and cyclic patches) - bit-exact."""
+    g = load(name)
+    P = glue_patches(g)
+    l, u = g["lowerAddr"], g["upperAddr"]
+    eq = np.array_equal
+    assert any(p["coupled"] for p in P) == ("cyclic" in name)
+    assert eq(fv_oracle.add_boundary_diag(g["diag"], P), g["ref_addBoundaryDiag"])
+    assert eq(fv_oracle.add_boundary_source(g["source"], P), g["ref_addBoundarySource"])
+    assert eq(fv_oracle.add_boundary_source(g["source"], P, couples=False), g["ref_addBoundarySource_nocouples"])
+    assert eq(fv_oracle.fvm_A(g["diag"], P, g["V"]), g["ref_A"])
+    assert eq(fv_oracle.fvm_H(g["diag"], g["source"], l, u, g["upper"], g["lower"], g["psi"], P, g["V"]), g["ref_H"])
+    fi, fb = fv_oracle.fvm_flux(l, u, g["upper"], g["lower"], g["psi"], P)
+    assert eq(fi, g["ref_flux_internal"])
+    for p in range(len(P)):
+        assert eq(fb[p], g["p%d_ref_flux" % p]), p
+    d, s = fv_oracle.relax(0.7, g["diag"], g["source"], l, u, g["upper"], g["lower"], g["psi"], P)
+    assert eq(d, g["ref_relax_diag"]) and eq(s, g["ref_relax_source"])
+    d, s = fv_oracle.set_reference(5, 1.3, g["diag"], g["source"])
+    assert eq(d, g["ref_setReference_diag"]) and eq(s, g["ref_setReference_source"])
