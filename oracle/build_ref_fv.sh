@@ -67,6 +67,7 @@ FORCE=""
 for u in fvMesh/fvPatches/constraint/cyclic/cyclicFvPatch.C \
          fields/fvPatchFields/constraint/cyclic/cyclicFvPatchFields.C \
          fields/fvPatchFields/basic/fixedValue/fixedValueFvPatchFields.C \
+         fvMatrices/solvers/GAMGSymSolver/GAMGAgglomerations/faceAreaPairGAMGAgglomeration/faceAreaPairGAMGAgglomeration.C \
          fields/fvsPatchFields/constraint/cyclic/cyclicFvsPatchFields.C; do
     i=$(grep -n "/$u\$" "$W/fvsources.txt" | head -1 | cut -d: -f1)
     [ -n "$i" ] && FORCE="$FORCE $W/fvobj/f$i.o"

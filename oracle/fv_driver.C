@@ -4,7 +4,7 @@
 // kernels ldu_fv_* / ldu_fvc_* / ldu_fvm_* (SURVEY.md 8a rows a30, a33-a39).
 // Our code; only reference HEADERS are included.  Never shipped, never linked into the product.
 //
-// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue]
+// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue|solve]
 //   in.bin : vf[nC] U[3 nC] phi[nF] gamma[nF]            (nF = internal faces)
 //   out.bin: sections "name count" + doubles, see put()
 #include "argList.H"
@@ -158,9 +158,74 @@ static int glue(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
     return 0;
 }
 
+// End to end through the reference's own application-level call: fvScalarMatrix::solve(dict) ->
+// solveSegregated (fvScalarMatrix.C:136-183: addBoundaryDiag, addBoundarySource(couples=false),
+// lduMatrix::solver::New(...)->solve) with GAMG + the REAL faceAreaPairGAMGAgglomeration of
+// libfiniteVolume (weights from mesh.Sf()), and with PCG/DIC.
+static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
+{
+    const label nC = mesh.nCells();
+    const label nF = mesh.nInternalFaces();
+    dimensionSet::debug = 0;
+    wordList types(mesh.boundary().size());
+    forAll(types, p) types[p] = (p % 2 ? word("zeroGradient") : word("fixedValue"));
+    surfaceScalarField gamma(IOobject("gamma", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
+    for (label f = 0; f < nF; f++) gamma.internalField()[f] = in[(size_t)4 * nC + nF + f];
+    forAll(gamma.boundaryField(), p)
+        forAll(gamma.boundaryField()[p], i) gamma.boundaryField()[p][i] = 0.8 + 0.01 * (i % 7);
+    surfaceScalarField gammaMagSf("gammaMagSf", gamma * mesh.magSf());
+    {
+        scalarField w(mag(cmptMultiply(mesh.Sf().internalField() / sqrt(mesh.magSf().internalField()),
+                                       vector(1, 1.01, 1.02))));
+        put("faceAreaPairWeights", w);
+    }
+    const char* dicts[2] = {
+        "solver GAMG; smoother GaussSeidel; agglomerator faceAreaPair; nCellsInCoarsestLevel 10; mergeLevels 1; "
+        "cacheAgglomeration off; tolerance 1e-10; relTol 0; nPreSweeps 0; nPostSweeps 2; nFinestSweeps 2;",
+        "solver PCG; preconditioner DIC; tolerance 1e-10; relTol 0;"};
+    for (int k = 0; k < 2; k++)
+    {
+        volScalarField T(IOobject(k ? "Tp" : "Tg", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0),
+                         types);
+        for (label c = 0; c < nC; c++) T.internalField()[c] = 0.0;
+        forAll(types, p)
+            if (types[p] == "fixedValue") T.boundaryField()[p] == scalar(0.7 + 0.1 * p);
+        tmp<fvScalarMatrix> tLap =
+            fv::gaussLaplacianScheme<scalar, scalar>::fvmLaplacianUncorrected(gammaMagSf, mesh.deltaCoeffs(), T);
+        fvScalarMatrix M(-tLap());
+        for (label c = 0; c < nC; c++) M.source()[c] = 0.01 * in[c];
+        if (k == 0)
+        {
+            put("diag", M.diag());
+            put("upper", M.upper());
+            put("source", M.source());
+            scalarField np(1, scalar(mesh.boundary().size()));
+            put("nPatches", np);
+            forAll(mesh.boundary(), p)
+            {
+                const labelUList& fc = mesh.lduAddr().patchAddr(p);
+                scalarField fcd(fc.size());
+                forAll(fc, i) fcd[i] = fc[i];
+                char nm[64];
+                snprintf(nm, sizeof(nm), "p%d_faceCells", p); put(nm, fcd);
+                snprintf(nm, sizeof(nm), "p%d_internalCoeffs", p); put(nm, M.internalCoeffs()[p]);
+                snprintf(nm, sizeof(nm), "p%d_boundaryCoeffs", p); put(nm, M.boundaryCoeffs()[p]);
+            }
+        }
+        dictionary d(IStringStream(dicts[k])());
+        solverPerformance perf = M.solve(d);
+        scalarField pf(4);
+        pf[0] = perf.initialResidual(); pf[1] = perf.finalResidual(); pf[2] = perf.nIterations(); pf[3] = perf.converged();
+        put(k ? "ref_pcg_perf" : "ref_gamg_perf", pf);
+        put(k ? "ref_pcg_psi" : "ref_gamg_psi", T.internalField());
+    }
+    fclose(out);
+    return 0;
+}
+
 int main(int argc, char* argv[])
 {
-    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue]\n"); return 2; }
+    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|solve]\n"); return 2; }
     fileName caseDir(argv[1]);
     Time runTime(Time::controlDictName, fileName(caseDir.path()), fileName(caseDir.name()));
     fvMesh mesh(IOobject(fvMesh::defaultRegion, runTime.timeName(), runTime, IOobject::MUST_READ));
@@ -179,6 +244,7 @@ int main(int argc, char* argv[])
     }
     out = fopen(argv[3], "wb");
     if (argc == 5 && std::string(argv[4]) == "glue") return glue(mesh, runTime, in);
+    if (argc == 5 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in);
 
     // fields: internal values from the input, boundary values zero ("calculated")
     volScalarField vf(IOobject("vf", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0),

@@ -58,6 +58,25 @@ def generate_glue(name):
     return out
 
 
+SOLVE_CASES = {"fvsolve_box_14x12x10": (14, 12, 10, 9)}
+
+
+def generate_solve(name):
+    nx, ny, nz, seed = SOLVE_CASES[name]
+    mesh = fv_case.box_mesh(nx, ny, nz, seed=seed)
+    rng = np.random.RandomState(300 + seed)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
+    with tempfile.TemporaryDirectory() as d:
+        case = os.path.join(d, "case")
+        fv_case.write_case(case, mesh)
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve")
+    out = dict(nCells=nC, lowerAddr=mesh["owner"][:nF].astype(np.int32), upperAddr=mesh["neighbour"].astype(np.int32))
+    for k, v in res.items():
+        out[k] = v.astype(np.int32) if k.endswith("_faceCells") else v
+    return out
+
+
 if __name__ == "__main__":
     if not fv_case.driver_available():
         raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
@@ -65,6 +84,10 @@ if __name__ == "__main__":
         data = generate(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "faces", data["lowerAddr"].size, sorted(k for k in data if k.startswith("ref_")))
+    for name in SOLVE_CASES:
+        data = generate_solve(name)
+        np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+        print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
     for name in GLUE_CASES:
         data = generate_glue(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)

@@ -87,3 +87,35 @@ def test_fvmatrix_glue_oracle_matches_reference(name):
     assert eq(d, g["ref_relax_diag"]) and eq(s, g["ref_relax_source"])
     d, s = fv_oracle.set_reference(5, 1.3, g["diag"], g["source"])
     assert eq(d, g["ref_setReference_diag"]) and eq(s, g["ref_setReference_source"])
+
+
+def solve_problem(g):
+    """what fvScalarMatrix::solveSegregated hands to lduMatrix::solver (fvScalarMatrix.C:152-167)"""
+    nP = int(g["nPatches"][0])
+    P = [dict(faceCells=g["p%d_faceCells" % p], internalCoeffs=g["p%d_internalCoeffs" % p],
+              boundaryCoeffs=g["p%d_boundaryCoeffs" % p], coupled=False, pnf=None) for p in range(nP)]
+    diag = fv_oracle.add_boundary_diag(g["diag"], P)
+    source = fv_oracle.add_boundary_source(g["source"], P, couples=False)
+    return dict(nCells=int(g["nCells"]), lowerAddr=g["lowerAddr"], upperAddr=g["upperAddr"], diag=diag,
+                upper=g["upper"], source=source, psi=np.zeros(int(g["nCells"])),
+                faceWeights=g["ref_faceAreaPairWeights"] if "ref_faceAreaPairWeights" in g else g["faceAreaPairWeights"])
+
+
+def test_end_to_end_fvmatrix_solve_oracle(oracle):
+    """The reference's own fvScalarMatrix::solve (real faceAreaPairGAMGAgglomeration from libfiniteVolume,
+    weights from mesh.Sf()) against glue restatement + C solver restatement: same V-cycle / iteration
+    counts, residuals to 1e-6, solution to 1e-9."""
+    g = load("fvsolve_box_14x12x10")
+    p = solve_problem(g)
+    S = oracle.System(p)
+    x, perf = S.solve(p["psi"], p["source"], solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                      nCellsInCoarsestLevel=10, mergeLevels=1, tolerance=1e-10, relTol=0)
+    r = g["ref_gamg_perf"]
+    assert perf["nIterations"] == int(r[2]) and perf["converged"]
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-9 * np.max(np.abs(g["ref_gamg_psi"]))
+    x, perf = S.solve(p["psi"], p["source"], solver="PCG", precond="DIC", tolerance=1e-10, relTol=0)
+    r = g["ref_pcg_perf"]
+    assert perf["nIterations"] == int(r[2])
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
+    assert np.max(np.abs(x - g["ref_pcg_psi"])) <= 1e-9 * np.max(np.abs(g["ref_pcg_psi"]))
