@@ -201,15 +201,31 @@ def main():
         import oracle_py
         cn = args.cpu_n or n
         cp = p if cn == n else cases.box3d(cn)
-        S = oracle_py.System(cp)
-        okw = dict(smoother="GaussSeidel", nCellsInCoarsestLevel=10, mergeLevels=1,
-                   agglomerator="faceAreaPair", tolerance=1e-7, relTol=0.01)
-        secs, setup = S.time_gamg_vcycles(cp["source"], nVcycles=2, **okw)
         scale = (cn ** 3) / float(n ** 3)
-        cpu = dict(value=round(2.0 / secs * scale, 4), unit="V-cycles/s", cores=1, kind="port",
-                   sample="oracle (C restatement, gcc -O2, 1 thread): 2 GAMG V-cycles on the %d^3 box "
-                          "(%.1f s; agglomeration %.1f s excluded, cached like cacheAgglomeration)"
-                          % (cn, secs, setup) + ("" if cn == n else "; scaled by cell count to %d^3" % n))
+        note = "" if cn == n else "; scaled by cell count to %d^3" % n
+        if oracle_py.ref_available():
+            # the reference's own libOpenFOAM (oracle/_ref, built from /root/reference by oracle/build_ref.sh)
+            # on this host: the same GAMG p-solve, second of two solves (agglomeration cached like the
+            # GPU run's cacheAgglomeration), 1 thread (the reference has no threading, no MPI here)
+            d = oracle_py.dict_string(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                                      nCellsInCoarsestLevel=10, mergeLevels=1, cacheAgglomeration="on",
+                                      tolerance=1e-7, relTol=0.01)
+            res, _ = oracle_py.run_ref("time", dict(cp, psi=np.zeros(cp["nCells"])), d)
+            t_first, t_second, it_first, it_second = [float(v) for v in res["time"]]
+            cpu = dict(value=round(it_second / t_second * scale, 4), unit="V-cycles/s", cores=1, kind="reference",
+                       sample="oracle/_ref/ref_driver = the reference's own lduMatrix::solver (GAMG, GaussSeidel, "
+                              "faceAreaPair weights supplied) on the %d^3 box: second solve %d V-cycles in %.2f s "
+                              "(first solve incl. agglomeration %.2f s)%s"
+                              % (cn, int(it_second), t_second, t_first, note))
+        else:
+            S = oracle_py.System(cp)
+            okw = dict(smoother="GaussSeidel", nCellsInCoarsestLevel=10, mergeLevels=1,
+                       agglomerator="faceAreaPair", tolerance=1e-7, relTol=0.01)
+            secs, setup = S.time_gamg_vcycles(cp["source"], nVcycles=2, **okw)
+            cpu = dict(value=round(2.0 / secs * scale, 4), unit="V-cycles/s", cores=1, kind="port",
+                       sample="oracle (C restatement, gcc -O2, 1 thread): 2 GAMG V-cycles on the %d^3 box "
+                              "(%.1f s; agglomeration %.1f s excluded, cached like cacheAgglomeration)"
+                              % (cn, secs, setup) + note)
 
     if rank == 0:
         out = {

@@ -11,6 +11,7 @@
  *
  * usage:  ref_driver <mode> <problem.ldub> <out.ldub> <caseDir> ["dict string"]
  *   mode = solve   : lduMatrix::solver::New(...)->solve(psi, source)
+ *   mode = time    : the same, twice, timed, silent (bench.py cpu_baseline kind "reference")
  *          ops     : Amul/Tmul/sumA/residual/preconditioners/smoothers on psi, source
  *          agglom  : GAMG agglomeration + level matrices dump
  *
@@ -32,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <time.h>
 #include <cstring>
 #include <map>
 #include <string>
@@ -244,6 +246,30 @@ int main(int argc, char* argv[])
             double(perf.converged()), double(perf.singular())
         };
         putD("perf", pv, 5);
+    }
+    else if (mode == "time")
+    {
+        // CPU baseline of bench.py: the reference's own solver timed on this host, no debug output.
+        // Two solves from the same initial guess: the first builds (and, with cacheAgglomeration on,
+        // caches) the agglomeration, the second is the steady-state cost bench.py compares against.
+        dictionary dict(mkDict(dictStr));
+        const scalarField psi0(psi);
+        double secs[2] = {0, 0};
+        double its[2] = {0, 0};
+        for (int rep = 0; rep < 2; rep++)
+        {
+            psi = psi0;
+            timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            solverPerformance perf =
+                lduMatrix::solver::New("p", A, bc, ic, ifs, dict)->solve(psi, source);
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            secs[rep] = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+            its[rep] = perf.nIterations();
+        }
+        double tv[4] = {secs[0], secs[1], its[0], its[1]};
+        putD("time", tv, 4);
+        putS("psi", psi);
     }
     else if (mode == "ops")
     {
