@@ -167,3 +167,81 @@ def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils"):
         if k in res:
             res[k] = res[k].reshape(-1, 3)
     return res
+
+
+def split_box_mesh(nxh, ny, nz, seed=4, jitter=0.15):
+    """Two geometrically IDENTICAL half boxes A and B (B = A translated by Lx), coupled only through a
+    cyclic patch pair half0 (A's x-max faces) / half1 (B's x-min faces) whose faces coincide: inside ONE
+    reference process this is exactly the arithmetic of a 2-rank run with one processor patch per rank
+    (coupled-interface update, frozen neighbour values per sweep, sub-domain-local DIC/agglomeration).
+    Cells: A = 0..nA-1, B = nA..2nA-1, each in natural order; identical halves => identical
+    agglomeration in both, so the combined nCellsInCoarsestLevel criterion equals the and-reduced one."""
+    rng = np.random.RandomState(seed)
+    nx = nxh
+    X = np.linspace(0.0, 1.0, nx + 1)
+    Y = (np.exp(np.log(1.8) * np.linspace(0, 1, ny + 1)) - 1.0) / 0.8 * 0.7
+    Z = np.linspace(0.0, 1.1, nz + 1)
+    nP = (nx + 1) * (ny + 1) * (nz + 1)
+
+    def pid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    ptsA = np.zeros((nP, 3))
+    for k in range(nz + 1):
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                p = np.array([X[i], Y[j], Z[k]])
+                if 0 < i < nx and 0 < j < ny and 0 < k < nz:
+                    h = np.array([X[1] - X[0], Y[j + 1] - Y[j], Z[1] - Z[0]])
+                    p = p + jitter * h * (rng.rand(3) - 0.5)
+                ptsA[pid(i, j, k)] = p
+    ptsB = ptsA + np.array([1.0, 0.0, 0.0])
+    pts = np.vstack([ptsA, ptsB])
+    nA = nx * ny * nz
+
+    def cid(i, j, k):
+        return i + nx * (j + ny * k)
+
+    def fx(i, j, k, o):
+        return [o + pid(i, j, k), o + pid(i, j + 1, k), o + pid(i, j + 1, k + 1), o + pid(i, j, k + 1)]
+
+    def fy(i, j, k, o):
+        return [o + pid(i, j, k), o + pid(i, j, k + 1), o + pid(i + 1, j, k + 1), o + pid(i + 1, j, k)]
+
+    def fz(i, j, k, o):
+        return [o + pid(i, j, k), o + pid(i + 1, j, k), o + pid(i + 1, j + 1, k), o + pid(i, j + 1, k)]
+
+    faces, owner, nei = [], [], []
+    for half, (po, co) in enumerate(((0, 0), (nP, nA))):
+        for k in range(nz):
+            for j in range(ny):
+                for i in range(nx):
+                    c = co + cid(i, j, k)
+                    if i + 1 < nx:
+                        faces.append(fx(i + 1, j, k, po)); owner.append(c); nei.append(co + cid(i + 1, j, k))
+                    if j + 1 < ny:
+                        faces.append(fy(i, j + 1, k, po)); owner.append(c); nei.append(co + cid(i, j + 1, k))
+                    if k + 1 < nz:
+                        faces.append(fz(i, j, k + 1, po)); owner.append(c); nei.append(co + cid(i, j, k + 1))
+    nInt = len(faces)
+    patches = []
+
+    def add_patch(name, flist, extra=""):
+        start = len(faces)
+        for fv, c in flist:
+            faces.append(fv); owner.append(c)
+        patches.append((name, len(flist), start, extra))
+
+    jk = [(j, k) for k in range(nz) for j in range(ny)]
+    add_patch("half0", [(fx(nx, j, k, 0), cid(nx - 1, j, k)) for j, k in jk], "cyclic half1")
+    add_patch("half1", [(fx(0, j, k, nP)[::-1], nA + cid(0, j, k)) for j, k in jk], "cyclic half0")
+    add_patch("xmin", [(fx(0, j, k, 0)[::-1], cid(0, j, k)) for j, k in jk])
+    add_patch("xmax", [(fx(nx, j, k, nP), nA + cid(nx - 1, j, k)) for j, k in jk])
+    both = ((0, 0), (nP, nA))
+    add_patch("ymin", [(fy(i, 0, k, po)[::-1], co + cid(i, 0, k)) for po, co in both for k in range(nz) for i in range(nx)])
+    add_patch("ymax", [(fy(i, ny, k, po), co + cid(i, ny - 1, k)) for po, co in both for k in range(nz) for i in range(nx)])
+    add_patch("zmin", [(fz(i, j, 0, po)[::-1], co + cid(i, j, 0)) for po, co in both for j in range(ny) for i in range(nx)])
+    add_patch("zmax", [(fz(i, j, nz, po), co + cid(i, j, nz - 1)) for po, co in both for j in range(ny) for i in range(nx)])
+    return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32),
+                neighbour=np.array(nei, dtype=np.int32), nInternalFaces=nInt, patches=patches,
+                nCells=2 * nA, nHalf=nA)

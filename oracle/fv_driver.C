@@ -4,7 +4,7 @@
 // kernels ldu_fv_* / ldu_fvc_* / ldu_fvm_* (SURVEY.md 8a rows a30, a33-a39).
 // Our code; only reference HEADERS are included.  Never shipped, never linked into the product.
 //
-// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue|solve]
+// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue|solve|solve2]
 //   in.bin : vf[nC] U[3 nC] phi[nF] gamma[nF]            (nF = internal faces)
 //   out.bin: sections "name count" + doubles, see put()
 #include "argList.H"
@@ -162,13 +162,16 @@ static int glue(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
 // solveSegregated (fvScalarMatrix.C:136-183: addBoundaryDiag, addBoundarySource(couples=false),
 // lduMatrix::solver::New(...)->solve) with GAMG + the REAL faceAreaPairGAMGAgglomeration of
 // libfiniteVolume (weights from mesh.Sf()), and with PCG/DIC.
-static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
+static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in, const char* extraControls)
 {
     const label nC = mesh.nCells();
     const label nF = mesh.nInternalFaces();
     dimensionSet::debug = 0;
     wordList types(mesh.boundary().size());
-    forAll(types, p) types[p] = (p % 2 ? word("zeroGradient") : word("fixedValue"));
+    forAll(types, p)
+    {
+        types[p] = mesh.boundary()[p].coupled() ? word("cyclic") : (p % 2 ? word("zeroGradient") : word("fixedValue"));
+    }
     surfaceScalarField gamma(IOobject("gamma", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
     for (label f = 0; f < nF; f++) gamma.internalField()[f] = in[(size_t)4 * nC + nF + f];
     forAll(gamma.boundaryField(), p)
@@ -179,10 +182,10 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
                                        vector(1, 1.01, 1.02))));
         put("faceAreaPairWeights", w);
     }
-    const char* dicts[2] = {
-        "solver GAMG; smoother GaussSeidel; agglomerator faceAreaPair; nCellsInCoarsestLevel 10; mergeLevels 1; "
-        "cacheAgglomeration off; tolerance 1e-10; relTol 0; nPreSweeps 0; nPostSweeps 2; nFinestSweeps 2;",
-        "solver PCG; preconditioner DIC; tolerance 1e-10; relTol 0;"};
+    std::string d0 = std::string("solver GAMG; smoother GaussSeidel; agglomerator faceAreaPair; mergeLevels 1; "
+        "cacheAgglomeration off; tolerance 1e-10; relTol 0; nPreSweeps 0; nPostSweeps 2; nFinestSweeps 2; ")
+        + extraControls;
+    const char* dicts[2] = {d0.c_str(), "solver PCG; preconditioner DIC; tolerance 1e-10; relTol 0;"};
     for (int k = 0; k < 2; k++)
     {
         volScalarField T(IOobject(k ? "Tp" : "Tg", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0),
@@ -210,6 +213,8 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
                 snprintf(nm, sizeof(nm), "p%d_faceCells", p); put(nm, fcd);
                 snprintf(nm, sizeof(nm), "p%d_internalCoeffs", p); put(nm, M.internalCoeffs()[p]);
                 snprintf(nm, sizeof(nm), "p%d_boundaryCoeffs", p); put(nm, M.boundaryCoeffs()[p]);
+                scalarField cp(1, T.boundaryField()[p].coupled() ? 1.0 : 0.0);
+                snprintf(nm, sizeof(nm), "p%d_coupled", p); put(nm, cp);
             }
         }
         dictionary d(IStringStream(dicts[k])());
@@ -225,7 +230,7 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
 
 int main(int argc, char* argv[])
 {
-    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|solve]\n"); return 2; }
+    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|solve|solve2]\n"); return 2; }
     fileName caseDir(argv[1]);
     Time runTime(Time::controlDictName, fileName(caseDir.path()), fileName(caseDir.name()));
     fvMesh mesh(IOobject(fvMesh::defaultRegion, runTime.timeName(), runTime, IOobject::MUST_READ));
@@ -244,7 +249,10 @@ int main(int argc, char* argv[])
     }
     out = fopen(argv[3], "wb");
     if (argc == 5 && std::string(argv[4]) == "glue") return glue(mesh, runTime, in);
-    if (argc == 5 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in);
+    if (argc == 5 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in, "nCellsInCoarsestLevel 10;");
+    // two identical halves coupled by a cyclic pair = serial emulation of a 2-rank run: the combined
+    // coarsest-level criterion 2n equals the and-reduced per-rank criterion n
+    if (argc == 5 && std::string(argv[4]) == "solve2") return solveMode(mesh, runTime, in, "nCellsInCoarsestLevel 20;");
 
     // fields: internal values from the input, boundary values zero ("calculated")
     volScalarField vf(IOobject("vf", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0),

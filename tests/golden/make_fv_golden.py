@@ -77,6 +77,23 @@ def generate_solve(name):
     return out
 
 
+def generate_solve2(name="fvsolve2_halves_6x8x7"):
+    """serial emulation of a 2-rank run by the reference itself (see fv_case.split_box_mesh)"""
+    mesh = fv_case.split_box_mesh(6, 8, 7)
+    rng = np.random.RandomState(77)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
+    with tempfile.TemporaryDirectory() as d:
+        case = os.path.join(d, "case")
+        fv_case.write_case(case, mesh)
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve2")
+    out = dict(nCells=nC, nHalf=mesh["nHalf"], lowerAddr=mesh["owner"][:nF].astype(np.int32),
+               upperAddr=mesh["neighbour"].astype(np.int32))
+    for k, v in res.items():
+        out[k] = v.astype(np.int32) if k.endswith("_faceCells") else v
+    return out
+
+
 if __name__ == "__main__":
     if not fv_case.driver_available():
         raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
@@ -88,6 +105,9 @@ if __name__ == "__main__":
         data = generate_solve(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
+    data = generate_solve2()
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fvsolve2_halves_6x8x7.npz"), **data)
+    print("fvsolve2_halves_6x8x7 cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
     for name in GLUE_CASES:
         data = generate_glue(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)

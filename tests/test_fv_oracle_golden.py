@@ -119,3 +119,55 @@ def test_end_to_end_fvmatrix_solve_oracle(oracle):
     assert perf["nIterations"] == int(r[2])
     np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
     assert np.max(np.abs(x - g["ref_pcg_psi"])) <= 1e-9 * np.max(np.abs(g["ref_pcg_psi"]))
+
+
+def two_rank_problem(g):
+    """fvsolve2 fixture -> the two rank-local problems of the equivalent 2-rank run: rank A = cells
+    [0, nHalf), rank B = the rest; the cyclic pair half0/half1 becomes one processor patch per rank."""
+    nP, nC, nH = int(g["nPatches"][0]), int(g["nCells"]), int(g["nHalf"])
+    P = [dict(faceCells=g["p%d_faceCells" % p], internalCoeffs=g["p%d_internalCoeffs" % p],
+              boundaryCoeffs=g["p%d_boundaryCoeffs" % p], coupled=bool(g["p%d_coupled" % p][0]), pnf=None)
+         for p in range(nP)]
+    assert [p["coupled"] for p in P[:2]] == [True, True] and not any(p["coupled"] for p in P[2:])
+    diag = fv_oracle.add_boundary_diag(g["diag"], P)                      # fvScalarMatrix.C:152-153
+    source = fv_oracle.add_boundary_source(g["source"], P, couples=False)  # :155-156
+    l, u = g["lowerAddr"], g["upperAddr"]
+    w = g["faceAreaPairWeights"]
+    subs = []
+    for r in range(2):
+        lo, hi = (0, nH) if r == 0 else (nH, nC)
+        fsel = (l >= lo) & (l < hi)
+        assert np.all((u[fsel] >= lo) & (u[fsel] < hi))
+        q = P[r]
+        patch = dict(faceCells=(q["faceCells"] - lo).astype(np.int32), bouCoeffs=q["boundaryCoeffs"],
+                     intCoeffs=q["internalCoeffs"], nbrDom=1 - r, nbrRank=1 - r, nbrPatch=0)
+        subs.append(dict(nCells=hi - lo, lowerAddr=(l[fsel] - lo).astype(np.int32),
+                         upperAddr=(u[fsel] - lo).astype(np.int32), diag=diag[lo:hi].copy(),
+                         upper=g["upper"][fsel].copy(), source=source[lo:hi].copy(), psi=np.zeros(hi - lo),
+                         faceWeights=w[fsel].copy(), patches=[patch],
+                         patches_dev=[dict(faceCells=patch["faceCells"], nbrRank=1 - r)]))
+    return subs
+
+
+def test_two_rank_algorithm_against_reference_cyclic_emulation(oracle):
+    """8(e) pin: the reference itself, in ONE process, solves two identical half boxes coupled only by a
+    cyclic patch pair (real cyclicFvPatchField / cyclicGAMGInterface) - arithmetically a 2-rank run with
+    one processor patch per rank.  The multi-domain oracle (rank-local DIC / GaussSeidel / agglomeration,
+    interface updates, rank-ordered sums) must reproduce it: same V-cycle / iteration counts, residuals to
+    1e-6, solution to 1e-8.  (Not bit-exact: the reference sums over all cells in one sequence, ranks sum
+    locally and then add.)"""
+    g = load("fvsolve2_halves_6x8x7")
+    subs = two_rank_problem(g)
+    S = oracle.System(subs)
+    b = np.concatenate([s["source"] for s in subs])
+    x, perf = S.solve(np.zeros(b.size), b, solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                      nCellsInCoarsestLevel=10, mergeLevels=1, tolerance=1e-10, relTol=0)
+    r = g["ref_gamg_perf"]
+    assert perf["nIterations"] == int(r[2]) and perf["converged"]
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-8 * np.max(np.abs(g["ref_gamg_psi"]))
+    x, perf = S.solve(np.zeros(b.size), b, solver="PCG", precond="DIC", tolerance=1e-10, relTol=0)
+    r = g["ref_pcg_perf"]
+    assert perf["nIterations"] == int(r[2])
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
+    assert np.max(np.abs(x - g["ref_pcg_psi"])) <= 1e-8 * np.max(np.abs(g["ref_pcg_psi"]))

@@ -125,3 +125,29 @@ def test_rccl_backend_single_rank(oracle, monkeypatch):
     assert perf["nIterations"] == po["nIterations"]
     np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
     m.close(); a.close(); ctx.close()
+
+
+def test_two_ranks_against_reference_cyclic_emulation():
+    """8(e) pin on the device: 2 ranks (threads, local communicator) with one processor patch each against
+    the reference's own single-process solve of the same system coupled by a cyclic pair
+    (tests/golden/fvsolve2_halves_6x8x7.npz; see test_fv_oracle_golden.py for the construction)."""
+    from test_fv_oracle_golden import load, two_rank_problem
+    g = load("fvsolve2_halves_6x8x7")
+    subs = two_rank_problem(g)
+    kw_g = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
+                mergeLevels=1, tolerance=1e-10, relTol=0)
+    kw_p = dict(solver="PCG", preconditioner="DIC", tolerance=1e-10, relTol=0)
+
+    def fn(r, ctx, a, m):
+        xg, pg = m.solve(subs[r]["psi"], subs[r]["source"], **kw_g)
+        xp, pp = m.solve(subs[r]["psi"], subs[r]["source"], **kw_p)
+        return xg, pg, xp, pp
+    res = run_ranks(subs, fn)
+    for (ix, ip, key) in ((0, 1, "gamg"), (2, 3, "pcg")):
+        x = np.concatenate([r[ix] for r in res])
+        perf = res[0][ip]
+        ref = g["ref_%s_perf" % key]
+        assert perf["nIterations"] == int(ref[2]), key
+        np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], ref[:2], rtol=1e-6)
+        xr = g["ref_%s_psi" % key]
+        assert np.max(np.abs(x - xr)) <= 1e-8 * np.max(np.abs(xr)), key
