@@ -143,15 +143,15 @@ def driver_available():
     return os.path.exists(os.path.join(REF, "fv_driver"))
 
 
-def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils"):
+def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils", controls=None):
     """-> dict name -> array (vectors reshaped to [n,3])"""
     inp = os.path.join(case, "in.bin")
     outp = os.path.join(case, "out.bin")
     np.concatenate([vf, U.reshape(-1), phi, gamma]).astype(np.float64).tofile(inp)
     env = dict(os.environ, WM_PROJECT="OpenFOAM", WM_PROJECT_VERSION="2.2.x", WM_PROJECT_DIR=REF,
                LD_LIBRARY_PATH=REF + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FOAM_SIGFPE="false")
-    r = subprocess.run([os.path.join(REF, "fv_driver"), case, inp, outp, mode], env=env, capture_output=True,
-                       text=True)
+    cmd = [os.path.join(REF, "fv_driver"), case, inp, outp, mode] + ([controls] if controls else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("fv_driver failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
     res = {}
@@ -170,12 +170,16 @@ def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils"):
 
 
 def split_box_mesh(nxh, ny, nz, seed=4, jitter=0.15):
-    """Two geometrically IDENTICAL half boxes A and B (B = A translated by Lx), coupled only through a
-    cyclic patch pair half0 (A's x-max faces) / half1 (B's x-min faces) whose faces coincide: inside ONE
-    reference process this is exactly the arithmetic of a 2-rank run with one processor patch per rank
-    (coupled-interface update, frozen neighbour values per sweep, sub-domain-local DIC/agglomeration).
-    Cells: A = 0..nA-1, B = nA..2nA-1, each in natural order; identical halves => identical
-    agglomeration in both, so the combined nCellsInCoarsestLevel criterion equals the and-reduced one."""
+    return chain_box_mesh(2, nxh, ny, nz, seed=seed, jitter=jitter)
+
+
+def chain_box_mesh(nBoxes, nxh, ny, nz, seed=4, jitter=0.15):
+    """nBoxes geometrically IDENTICAL boxes in a row (box b = box 0 translated by b*Lx), neighbours coupled
+    only through cyclic patch pairs j<b>a (box b's x-max faces) / j<b>b (box b+1's x-min faces) whose
+    faces coincide: inside ONE reference process this is exactly the arithmetic of an nBoxes-rank run
+    with processor patches (coupled-interface update, frozen neighbour values per sweep, sub-domain-local
+    DIC/agglomeration).  Cells of box b = [b*nA, (b+1)*nA) in natural order; identical boxes => identical
+    agglomeration in all, so the combined nCellsInCoarsestLevel criterion equals the and-reduced one."""
     rng = np.random.RandomState(seed)
     nx = nxh
     X = np.linspace(0.0, 1.0, nx + 1)
@@ -195,8 +199,7 @@ def split_box_mesh(nxh, ny, nz, seed=4, jitter=0.15):
                     h = np.array([X[1] - X[0], Y[j + 1] - Y[j], Z[1] - Z[0]])
                     p = p + jitter * h * (rng.rand(3) - 0.5)
                 ptsA[pid(i, j, k)] = p
-    ptsB = ptsA + np.array([1.0, 0.0, 0.0])
-    pts = np.vstack([ptsA, ptsB])
+    pts = np.vstack([ptsA + np.array([float(b), 0.0, 0.0]) for b in range(nBoxes)])
     nA = nx * ny * nz
 
     def cid(i, j, k):
@@ -211,8 +214,9 @@ def split_box_mesh(nxh, ny, nz, seed=4, jitter=0.15):
     def fz(i, j, k, o):
         return [o + pid(i, j, k), o + pid(i + 1, j, k), o + pid(i + 1, j + 1, k), o + pid(i, j + 1, k)]
 
+    boxes = [(b * nP, b * nA) for b in range(nBoxes)]
     faces, owner, nei = [], [], []
-    for half, (po, co) in enumerate(((0, 0), (nP, nA))):
+    for po, co in boxes:
         for k in range(nz):
             for j in range(ny):
                 for i in range(nx):
@@ -233,15 +237,17 @@ def split_box_mesh(nxh, ny, nz, seed=4, jitter=0.15):
         patches.append((name, len(flist), start, extra))
 
     jk = [(j, k) for k in range(nz) for j in range(ny)]
-    add_patch("half0", [(fx(nx, j, k, 0), cid(nx - 1, j, k)) for j, k in jk], "cyclic half1")
-    add_patch("half1", [(fx(0, j, k, nP)[::-1], nA + cid(0, j, k)) for j, k in jk], "cyclic half0")
+    for b in range(nBoxes - 1):
+        (pa, ca), (pb, cb) = boxes[b], boxes[b + 1]
+        add_patch("j%da" % b, [(fx(nx, j, k, pa), ca + cid(nx - 1, j, k)) for j, k in jk], "cyclic j%db" % b)
+        add_patch("j%db" % b, [(fx(0, j, k, pb)[::-1], cb + cid(0, j, k)) for j, k in jk], "cyclic j%da" % b)
     add_patch("xmin", [(fx(0, j, k, 0)[::-1], cid(0, j, k)) for j, k in jk])
-    add_patch("xmax", [(fx(nx, j, k, nP), nA + cid(nx - 1, j, k)) for j, k in jk])
-    both = ((0, 0), (nP, nA))
-    add_patch("ymin", [(fy(i, 0, k, po)[::-1], co + cid(i, 0, k)) for po, co in both for k in range(nz) for i in range(nx)])
-    add_patch("ymax", [(fy(i, ny, k, po), co + cid(i, ny - 1, k)) for po, co in both for k in range(nz) for i in range(nx)])
-    add_patch("zmin", [(fz(i, j, 0, po)[::-1], co + cid(i, j, 0)) for po, co in both for j in range(ny) for i in range(nx)])
-    add_patch("zmax", [(fz(i, j, nz, po), co + cid(i, j, nz - 1)) for po, co in both for j in range(ny) for i in range(nx)])
+    pl, cl = boxes[-1]
+    add_patch("xmax", [(fx(nx, j, k, pl), cl + cid(nx - 1, j, k)) for j, k in jk])
+    add_patch("ymin", [(fy(i, 0, k, po)[::-1], co + cid(i, 0, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
+    add_patch("ymax", [(fy(i, ny, k, po), co + cid(i, ny - 1, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
+    add_patch("zmin", [(fz(i, j, 0, po)[::-1], co + cid(i, j, 0)) for po, co in boxes for j in range(ny) for i in range(nx)])
+    add_patch("zmax", [(fz(i, j, nz, po), co + cid(i, j, nz - 1)) for po, co in boxes for j in range(ny) for i in range(nx)])
     return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32),
                 neighbour=np.array(nei, dtype=np.int32), nInternalFaces=nInt, patches=patches,
-                nCells=2 * nA, nHalf=nA)
+                nCells=nBoxes * nA, nHalf=nA, nBoxes=nBoxes)

@@ -4,7 +4,7 @@
 // kernels ldu_fv_* / ldu_fvc_* / ldu_fvm_* (SURVEY.md 8a rows a30, a33-a39).
 // Our code; only reference HEADERS are included.  Never shipped, never linked into the product.
 //
-// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue|solve|solve2]
+// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue|solve|solve2] [extra GAMG controls for solve]
 //   in.bin : vf[nC] U[3 nC] phi[nF] gamma[nF]            (nF = internal faces)
 //   out.bin: sections "name count" + doubles, see put()
 #include "argList.H"
@@ -230,7 +230,7 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
 
 int main(int argc, char* argv[])
 {
-    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|solve|solve2]\n"); return 2; }
+    if (argc < 4 || argc > 6) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|solve|solve2] [extra GAMG controls for solve]\n"); return 2; }
     fileName caseDir(argv[1]);
     Time runTime(Time::controlDictName, fileName(caseDir.path()), fileName(caseDir.name()));
     fvMesh mesh(IOobject(fvMesh::defaultRegion, runTime.timeName(), runTime, IOobject::MUST_READ));
@@ -248,8 +248,9 @@ int main(int argc, char* argv[])
         fclose(f);
     }
     out = fopen(argv[3], "wb");
-    if (argc == 5 && std::string(argv[4]) == "glue") return glue(mesh, runTime, in);
+    if (argc >= 5 && std::string(argv[4]) == "glue") return glue(mesh, runTime, in);
     if (argc == 5 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in, "nCellsInCoarsestLevel 10;");
+    if (argc == 6 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in, argv[5]);
     // two identical halves coupled by a cyclic pair = serial emulation of a 2-rank run: the combined
     // coarsest-level criterion 2n equals the and-reduced per-rank criterion n
     if (argc == 5 && std::string(argv[4]) == "solve2") return solveMode(mesh, runTime, in, "nCellsInCoarsestLevel 20;");

@@ -77,17 +77,22 @@ def generate_solve(name):
     return out
 
 
-def generate_solve2(name="fvsolve2_halves_6x8x7"):
-    """serial emulation of a 2-rank run by the reference itself (see fv_case.split_box_mesh)"""
-    mesh = fv_case.split_box_mesh(6, 8, 7)
-    rng = np.random.RandomState(77)
+CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6": (4, 5, 6, 6, 78)}
+
+
+def generate_chain(name):
+    """serial emulation of an N-rank run by the reference itself (see fv_case.chain_box_mesh)"""
+    nB, nxh, ny, nz, seed = CHAIN_CASES[name]
+    mesh = fv_case.chain_box_mesh(nB, nxh, ny, nz)
+    rng = np.random.RandomState(seed)
     nC, nF = mesh["nCells"], mesh["nInternalFaces"]
     vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
     with tempfile.TemporaryDirectory() as d:
         case = os.path.join(d, "case")
         fv_case.write_case(case, mesh)
-        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve2")
-    out = dict(nCells=nC, nHalf=mesh["nHalf"], lowerAddr=mesh["owner"][:nF].astype(np.int32),
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve",
+                                 controls="nCellsInCoarsestLevel %d;" % (10 * nB))
+    out = dict(nCells=nC, nHalf=mesh["nHalf"], nBoxes=nB, lowerAddr=mesh["owner"][:nF].astype(np.int32),
                upperAddr=mesh["neighbour"].astype(np.int32))
     for k, v in res.items():
         out[k] = v.astype(np.int32) if k.endswith("_faceCells") else v
@@ -105,9 +110,10 @@ if __name__ == "__main__":
         data = generate_solve(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
-    data = generate_solve2()
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fvsolve2_halves_6x8x7.npz"), **data)
-    print("fvsolve2_halves_6x8x7 cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
+    for name in CHAIN_CASES:
+        data = generate_chain(name)
+        np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+        print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
     for name in GLUE_CASES:
         data = generate_glue(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)

@@ -122,42 +122,64 @@ def test_end_to_end_fvmatrix_solve_oracle(oracle):
 
 
 def two_rank_problem(g):
-    """fvsolve2 fixture -> the two rank-local problems of the equivalent 2-rank run: rank A = cells
-    [0, nHalf), rank B = the rest; the cyclic pair half0/half1 becomes one processor patch per rank."""
+    return n_rank_problem(g)
+
+
+def n_rank_problem(g):
+    """chain fixture -> the rank-local problems of the equivalent N-rank run: rank r = cells
+    [r*nHalf, (r+1)*nHalf); the cyclic pair j<b>a / j<b>b (patches 2b, 2b+1) becomes one processor patch
+    on rank b (towards b+1) and one on rank b+1 (towards b); per rank the patches are listed in ascending
+    neighbour rank, as decomposePar writes them."""
     nP, nC, nH = int(g["nPatches"][0]), int(g["nCells"]), int(g["nHalf"])
+    nB = int(g["nBoxes"]) if "nBoxes" in g else 2
     P = [dict(faceCells=g["p%d_faceCells" % p], internalCoeffs=g["p%d_internalCoeffs" % p],
               boundaryCoeffs=g["p%d_boundaryCoeffs" % p], coupled=bool(g["p%d_coupled" % p][0]), pnf=None)
          for p in range(nP)]
-    assert [p["coupled"] for p in P[:2]] == [True, True] and not any(p["coupled"] for p in P[2:])
+    nJ = 2 * (nB - 1)
+    assert all(p["coupled"] for p in P[:nJ]) and not any(p["coupled"] for p in P[nJ:])
     diag = fv_oracle.add_boundary_diag(g["diag"], P)                      # fvScalarMatrix.C:152-153
     source = fv_oracle.add_boundary_source(g["source"], P, couples=False)  # :155-156
     l, u = g["lowerAddr"], g["upperAddr"]
     w = g["faceAreaPairWeights"]
     subs = []
-    for r in range(2):
-        lo, hi = (0, nH) if r == 0 else (nH, nC)
+    for r in range(nB):
+        lo, hi = r * nH, (r + 1) * nH
         fsel = (l >= lo) & (l < hi)
         assert np.all((u[fsel] >= lo) & (u[fsel] < hi))
-        q = P[r]
-        patch = dict(faceCells=(q["faceCells"] - lo).astype(np.int32), bouCoeffs=q["boundaryCoeffs"],
-                     intCoeffs=q["internalCoeffs"], nbrDom=1 - r, nbrRank=1 - r, nbrPatch=0)
+        patches = []
+        if r > 0:          # towards r-1: the 'b' side of junction r-1
+            q = P[2 * (r - 1) + 1]
+            patches.append(dict(faceCells=(q["faceCells"] - lo).astype(np.int32), bouCoeffs=q["boundaryCoeffs"],
+                                intCoeffs=q["internalCoeffs"], nbrDom=r - 1, nbrRank=r - 1))
+        if r < nB - 1:     # towards r+1: the 'a' side of junction r
+            q = P[2 * r]
+            patches.append(dict(faceCells=(q["faceCells"] - lo).astype(np.int32), bouCoeffs=q["boundaryCoeffs"],
+                                intCoeffs=q["internalCoeffs"], nbrDom=r + 1, nbrRank=r + 1))
         subs.append(dict(nCells=hi - lo, lowerAddr=(l[fsel] - lo).astype(np.int32),
                          upperAddr=(u[fsel] - lo).astype(np.int32), diag=diag[lo:hi].copy(),
                          upper=g["upper"][fsel].copy(), source=source[lo:hi].copy(), psi=np.zeros(hi - lo),
-                         faceWeights=w[fsel].copy(), patches=[patch],
-                         patches_dev=[dict(faceCells=patch["faceCells"], nbrRank=1 - r)]))
+                         faceWeights=w[fsel].copy(), patches=patches,
+                         patches_dev=[dict(faceCells=q["faceCells"], nbrRank=q["nbrRank"]) for q in patches]))
+    for r in range(nB):    # pairing for the oracle: my patch towards nb <-> nb's patch towards me
+        for q in subs[r]["patches"]:
+            nb = q["nbrDom"]
+            q["nbrPatch"] = [j for j, q2 in enumerate(subs[nb]["patches"]) if q2["nbrDom"] == r][0]
     return subs
 
 
-def test_two_rank_algorithm_against_reference_cyclic_emulation(oracle):
-    """8(e) pin: the reference itself, in ONE process, solves two identical half boxes coupled only by a
-    cyclic patch pair (real cyclicFvPatchField / cyclicGAMGInterface) - arithmetically a 2-rank run with
-    one processor patch per rank.  The multi-domain oracle (rank-local DIC / GaussSeidel / agglomeration,
+CHAINS = ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6"]
+
+
+@pytest.mark.parametrize("name", CHAINS)
+def test_two_rank_algorithm_against_reference_cyclic_emulation(oracle, name):
+    """8(e) pin: the reference itself, in ONE process, solves N identical boxes in a row coupled only by
+    cyclic patch pairs (real cyclicFvPatchField / cyclicGAMGInterface) - arithmetically an N-rank run with
+    processor patches (2 ranks: one patch each; 4 ranks: the middle ranks have two).  The multi-domain oracle (rank-local DIC / GaussSeidel / agglomeration,
     interface updates, rank-ordered sums) must reproduce it: same V-cycle / iteration counts, residuals to
     1e-6, solution to 1e-8.  (Not bit-exact: the reference sums over all cells in one sequence, ranks sum
     locally and then add.)"""
-    g = load("fvsolve2_halves_6x8x7")
-    subs = two_rank_problem(g)
+    g = load(name)
+    subs = n_rank_problem(g)
     S = oracle.System(subs)
     b = np.concatenate([s["source"] for s in subs])
     x, perf = S.solve(np.zeros(b.size), b, solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",

@@ -127,13 +127,14 @@ def test_rccl_backend_single_rank(oracle, monkeypatch):
     m.close(); a.close(); ctx.close()
 
 
-def test_two_ranks_against_reference_cyclic_emulation():
-    """8(e) pin on the device: 2 ranks (threads, local communicator) with one processor patch each against
-    the reference's own single-process solve of the same system coupled by a cyclic pair
-    (tests/golden/fvsolve2_halves_6x8x7.npz; see test_fv_oracle_golden.py for the construction)."""
-    from test_fv_oracle_golden import load, two_rank_problem
-    g = load("fvsolve2_halves_6x8x7")
-    subs = two_rank_problem(g)
+@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6"])
+def test_two_ranks_against_reference_cyclic_emulation(name):
+    """8(e) pin on the device: 2 / 4 ranks (threads, local communicator) with processor patches against the
+    reference's own single-process solve of the same system coupled by cyclic pairs
+    (tests/golden/fvsolve*_*.npz; see test_fv_oracle_golden.py for the construction)."""
+    from test_fv_oracle_golden import load, n_rank_problem
+    g = load(name)
+    subs = n_rank_problem(g)
     kw_g = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
                 mergeLevels=1, tolerance=1e-10, relTol=0)
     kw_p = dict(solver="PCG", preconditioner="DIC", tolerance=1e-10, relTol=0)
