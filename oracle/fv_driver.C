@@ -185,7 +185,24 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
     std::string d0 = std::string("solver GAMG; smoother GaussSeidel; agglomerator faceAreaPair; mergeLevels 1; "
         "cacheAgglomeration off; tolerance 1e-10; relTol 0; nPreSweeps 0; nPostSweeps 2; nFinestSweeps 2; ")
         + extraControls;
-    const char* dicts[2] = {d0.c_str(), "solver PCG; preconditioner DIC; tolerance 1e-10; relTol 0;"};
+    // "asym" in the controls: add an upwind convection term (asymmetric matrix, interface coefficients
+    // that differ between the two sides) and use PBiCG/DILU as the Krylov solver
+    const bool asym = std::string(extraControls).find("asymmetric") != std::string::npos;
+    if (asym) d0 = d0.substr(0, d0.find("asymmetric"));
+    const char* dicts[2] = {d0.c_str(), asym ? "solver PBiCG; preconditioner DILU; tolerance 1e-10; relTol 0;"
+                                             : "solver PCG; preconditioner DIC; tolerance 1e-10; relTol 0;"};
+    surfaceScalarField phi(IOobject("phi", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
+    if (asym)
+    {
+        for (label f = 0; f < nF; f++) phi.internalField()[f] = 0.004 * in[(size_t)4 * nC + f];
+        forAll(phi.boundaryField(), p)
+        {
+            if (!mesh.boundary()[p].coupled()) continue;
+            // the flux through a cyclic face leaves one side and enters the other
+            const scalar sgn = (p % 2) ? -1.0 : 1.0;
+            forAll(phi.boundaryField()[p], i) phi.boundaryField()[p][i] = sgn * 0.003 * (1 + (i % 4));
+        }
+    }
     for (int k = 0; k < 2; k++)
     {
         volScalarField T(IOobject(k ? "Tp" : "Tg", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0),
@@ -196,11 +213,18 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
         tmp<fvScalarMatrix> tLap =
             fv::gaussLaplacianScheme<scalar, scalar>::fvmLaplacianUncorrected(gammaMagSf, mesh.deltaCoeffs(), T);
         fvScalarMatrix M(-tLap());
+        if (asym)
+        {
+            fv::gaussConvectionScheme<scalar> cs(mesh, phi,
+                tmp<surfaceInterpolationScheme<scalar> >(new upwind<scalar>(mesh, phi)));
+            M += cs.fvmDiv(phi, T);
+        }
         for (label c = 0; c < nC; c++) M.source()[c] = 0.01 * in[c];
         if (k == 0)
         {
             put("diag", M.diag());
             put("upper", M.upper());
+            if (asym) put("lower", M.lower());
             put("source", M.source());
             scalarField np(1, scalar(mesh.boundary().size()));
             put("nPatches", np);

@@ -77,7 +77,8 @@ def generate_solve(name):
     return out
 
 
-CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6": (4, 5, 6, 6, 78)}
+CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6": (4, 5, 6, 6, 78),
+               "fvsolve3_chain_asym_5x7x6": (3, 5, 7, 6, 79)}
 
 
 def generate_chain(name):
@@ -91,7 +92,7 @@ def generate_chain(name):
         case = os.path.join(d, "case")
         fv_case.write_case(case, mesh)
         res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve",
-                                 controls="nCellsInCoarsestLevel %d;" % (10 * nB))
+                                 controls="nCellsInCoarsestLevel %d;%s" % (10 * nB, " asymmetric" if "asym" in name else ""))
     out = dict(nCells=nC, nHalf=mesh["nHalf"], nBoxes=nB, lowerAddr=mesh["owner"][:nF].astype(np.int32),
                upperAddr=mesh["neighbour"].astype(np.int32))
     for k, v in res.items():

@@ -127,7 +127,7 @@ def test_rccl_backend_single_rank(oracle, monkeypatch):
     m.close(); a.close(); ctx.close()
 
 
-@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6"])
+@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6"])
 def test_two_ranks_against_reference_cyclic_emulation(name):
     """8(e) pin on the device: 2 / 4 ranks (threads, local communicator) with processor patches against the
     reference's own single-process solve of the same system coupled by cyclic pairs
@@ -138,6 +138,8 @@ def test_two_ranks_against_reference_cyclic_emulation(name):
     kw_g = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
                 mergeLevels=1, tolerance=1e-10, relTol=0)
     kw_p = dict(solver="PCG", preconditioner="DIC", tolerance=1e-10, relTol=0)
+    if "asym" in name:
+        kw_p = dict(solver="PBiCG", preconditioner="DILU", tolerance=1e-10, relTol=0)
 
     def fn(r, ctx, a, m):
         xg, pg = m.solve(subs[r]["psi"], subs[r]["source"], **kw_g)
