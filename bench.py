@@ -155,7 +155,8 @@ def main():
         ms = prof[key]["ms"] / prof[key]["count"]
         ach = per_launch * gs_bytes / (ms * 1e-3) / 1e9
         kname = ("sweep_p2p_gs_multi_kernel: %d pipelined GaussSeidel sweeps of the finest level per launch"
-                 % per_launch) if key == "gs_multi" else "sweep_p2p_kernel<SW_GS_FWD>: one GaussSeidel sweep"
+                 % per_launch) if key == "gs_multi" else \
+            "sweep_slab_kernel / sweep_p2p_kernel <SW_GS_FWD>: one GaussSeidel sweep of the rank's finest level"
         traffic = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -196,7 +197,7 @@ def main():
         extra["pcg_error"] = str(e)
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:   # the CPU leg is timed at N=1 only
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py
         cn = args.cpu_n or n
