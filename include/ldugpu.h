@@ -91,6 +91,12 @@ int ldu_addr_create(ldu_ctx* ctx, ldu_addr** a, int32_t nCells, int32_t nFaces,
 /* Coupled (processor) patch: lduAddr().patchAddr(patchI) = faceCells; neighbour rank
  * (processorLduInterface::neighbProcNo).  Patches must be added in patch order. */
 int ldu_addr_add_patch(ldu_addr* a, int32_t nPatchFaces, const int32_t* faceCells, int32_t nbrRank);
+/* cyclic coupled patch (cyclicLduInterface, src/OpenFOAM/matrices/lduMatrix/lduAddressing/lduInterface/
+ * cyclicLduInterface.H): the neighbour is patch `nbrPatch` (index in order of addition, may be added
+ * later) of the SAME addressing; face i pairs with face i of the neighbour patch.  Untransformed
+ * coupling only (scalars / translational cyclics: cyclicFvPatchField::updateInterfaceMatrix with
+ * doTransform() false). */
+int ldu_addr_add_cyclic_patch(ldu_addr* a, int32_t nFaces, const int32_t* faceCells, int32_t nbrPatch);
 /* Call after the last add_patch (builds the device-side schedule). */
 int ldu_addr_finalize(ldu_addr* a);
 int ldu_addr_destroy(ldu_addr* a);

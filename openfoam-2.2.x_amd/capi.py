@@ -21,7 +21,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_addr_create", "ldu_addr_add_patch",
-    "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
+    "ldu_addr_add_cyclic_patch", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
     "ldu_gSumProd", "ldu_gSumMag", "ldu_precondition", "ldu_smooth", "ldu_solve", "ldu_gamg_levels",
@@ -156,7 +156,10 @@ class Addressing:
         _chk(lib().ldu_addr_create(ctx.h, C.byref(self.h), self.nCells, self.nFaces, _ptr(l), _ptr(u)))
         for p in patches:
             fc = np.ascontiguousarray(p["faceCells"], dtype=np.int32)
-            _chk(lib().ldu_addr_add_patch(self.h, int(fc.size), _ptr(fc), int(p["nbrRank"])))
+            if p.get("nbrPatch") is not None and p.get("cyclic"):
+                _chk(lib().ldu_addr_add_cyclic_patch(self.h, int(fc.size), _ptr(fc), int(p["nbrPatch"])))
+            else:
+                _chk(lib().ldu_addr_add_patch(self.h, int(fc.size), _ptr(fc), int(p["nbrRank"])))
         if patches:
             _chk(lib().ldu_addr_finalize(self.h))
         if faceWeights is not None:

@@ -223,7 +223,30 @@ int ldu_addr_add_patch(ldu_addr* a, int32_t n, const int32_t* faceCells, int32_t
     return 0;
 }
 
-int ldu_addr_finalize(ldu_addr* a) { return plan_finalize_patches(a); }
+int ldu_addr_add_cyclic_patch(ldu_addr* a, int32_t n, const int32_t* faceCells, int32_t nbrPatch)
+{
+    if (nbrPatch < 0) { ldu_set_error("ldu_addr_add_cyclic_patch: nbrPatch must be >= 0"); return -12; }
+    const int rc = ldu_addr_add_patch(a, n, faceCells, -1);
+    if (rc) return rc;
+    a->patches.back().nbrPatch = nbrPatch;
+    return 0;
+}
+
+int ldu_addr_finalize(ldu_addr* a)
+{
+    for (size_t p = 0; p < a->patches.size(); p++)
+    {
+        const int q = a->patches[p].nbrPatch;
+        if (q < 0) continue;
+        if (q >= (int)a->patches.size() || q == (int)p || a->patches[q].nbrPatch != (int)p
+            || a->patches[q].n != a->patches[p].n)
+        {
+            ldu_set_error("ldu_addr_finalize: cyclic patch " + std::to_string(p) + " has no matching neighbour patch");
+            return -12;
+        }
+    }
+    return plan_finalize_patches(a);
+}
 
 int ldu_addr_destroy(ldu_addr* a)
 {

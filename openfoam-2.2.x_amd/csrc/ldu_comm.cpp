@@ -155,9 +155,20 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
     if (a->patches.empty()) return 0;
+    // cyclic patches: the neighbour values are this rank's own send buffer of the paired patch
+    // (cyclicGAMGInterface::internalFieldTransfer / cyclicFvPatchField::patchNeighbourField)
+    bool remote = false;
+    for (auto& P : a->patches)
+    {
+        if (P.nbrPatch < 0) { remote = true; continue; }
+        if (P.n)
+            LDU_CHECK_HIP(hipMemcpyAsync(P.d_recv, a->patches[P.nbrPatch].d_send, sizeof(double) * P.n,
+                                         hipMemcpyDeviceToDevice, s));
+    }
+    if (!remote) return 0;
     if (!ctx->comm)
     {
-        ldu_set_error("coupled patches present but no communicator (ldu_ctx_comm_init)");
+        ldu_set_error("processor patches present but no communicator (ldu_ctx_comm_init)");
         return -4;
     }
     if (ctx->comm->local)
@@ -169,7 +180,7 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
         for (int p = 0; p < (int)a->patches.size(); p++)
         {
             Patch& P = a->patches[p];
-            if (!P.n) continue;
+            if (!P.n || P.nbrPatch >= 0) continue;
             const ldu_addr* na = G->addr[P.nbrRank];
             const int q = paired_patch(a->patches, p, na->patches, ctx->rank);
             if (q < 0 || na->patches[q].n != P.n) { ldu_set_error("local exchange: unpaired patch"); return -4; }
@@ -182,7 +193,7 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
     LDU_CHECK_NCCL(ncclGroupStart());
     for (auto& p : a->patches)
     {
-        if (p.n == 0) continue;
+        if (p.n == 0 || p.nbrPatch >= 0) continue;
         LDU_CHECK_NCCL(ncclSend(p.d_send, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, s));
         LDU_CHECK_NCCL(ncclRecv(p.d_recv, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, s));
     }
@@ -223,7 +234,14 @@ int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
 {
     recv.assign(patches.size(), std::vector<int>());
     if (patches.empty()) return 0;
-    if (!ctx->comm) { ldu_set_error("coupled patches present but no communicator"); return -4; }
+    bool remote = false;
+    for (size_t p = 0; p < patches.size(); p++)
+    {
+        if (patches[p].nbrPatch >= 0) recv[p] = send[patches[p].nbrPatch];   // cyclic: local
+        else remote = true;
+    }
+    if (!remote) return 0;
+    if (!ctx->comm) { ldu_set_error("processor patches present but no communicator"); return -4; }
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;
@@ -239,6 +257,7 @@ int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
         G->barrier();
         for (int p = 0; p < (int)patches.size(); p++)
         {
+            if (patches[p].nbrPatch >= 0) continue;
             Pub nb;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -273,7 +292,7 @@ int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
     for (size_t p = 0; p < patches.size(); p++)
     {
         const size_t n = send[p].size();
-        if (n)
+        if (n && patches[p].nbrPatch < 0)
         {
             LDU_CHECK_NCCL(ncclSend(ds + off, n, ncclInt, patches[p].nbrRank, ctx->comm->comm, s));
             LDU_CHECK_NCCL(ncclRecv(dr + off, n, ncclInt, patches[p].nbrRank, ctx->comm->comm, s));
@@ -284,8 +303,8 @@ int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
     off = 0;
     for (size_t p = 0; p < patches.size(); p++)
     {
-        recv[p].resize(send[p].size());
-        if (send[p].size())
+        if (patches[p].nbrPatch < 0) recv[p].resize(send[p].size());
+        if (send[p].size() && patches[p].nbrPatch < 0)
             LDU_CHECK_HIP(hipMemcpyAsync(recv[p].data(), dr + off, sizeof(int) * send[p].size(), hipMemcpyDeviceToHost, s));
         off += send[p].size();
     }

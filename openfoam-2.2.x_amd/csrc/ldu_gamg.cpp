@@ -184,6 +184,7 @@ static void coarse_addressing(int nFineFaces, const int* lower, const int* upper
 // coarse image of one processor patch (processorGAMGInterface.C:47-126)
 struct HostPatch {
     int nbrRank = -1;
+    int nbrPatch = -1;            // cyclic
     std::vector<int> faceCells;   // coarse cell per coarse patch face
     std::vector<int> fra;         // faceRestrictAddressing: fine patch face -> coarse patch face
 };
@@ -244,7 +245,10 @@ static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fine
             {
                 HostPatch& HP = L.patches[p];
                 HP.nbrRank = fine->patches[p].nbrRank;
-                const bool master = ctx->rank < HP.nbrRank;
+                HP.nbrPatch = fine->patches[p].nbrPatch;
+                // processorGAMGInterface.C:84 myProcNo() < neighbProcNo(); cyclicGAMGInterface.C:86 owner()
+                // (= index < neighbour index, cyclicPolyPatch)
+                const bool master = HP.nbrPatch >= 0 ? (int)p < HP.nbrPatch : ctx->rank < HP.nbrRank;
                 std::map<std::pair<int, int>, int> seen;
                 HP.fra.resize(send[p].size());
                 for (size_t ffi = 0; ffi < send[p].size(); ffi++)
@@ -428,6 +432,7 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                     Patch P;
                     P.n = (int)hp.faceCells.size();
                     P.nbrRank = hp.nbrRank;
+                    P.nbrPatch = hp.nbrPatch;
                     P.faceCells = hp.faceCells;
                     L.addr->patches.push_back(P);
                 }

@@ -98,6 +98,7 @@ struct Segment {
 struct Patch {
     int n = 0;
     int nbrRank = -1;
+    int nbrPatch = -1;            // >= 0: cyclic - the neighbour is patch nbrPatch of the SAME addressing
     std::vector<int> faceCells;   // original numbering
     int* d_faceCells = nullptr;   // new numbering
     double* d_send = nullptr;

@@ -17,6 +17,7 @@
 
 #include "lduMatrix.H"
 #include "processorLduInterface.H"
+#include "cyclicLduInterface.H"
 #include "addToRunTimeSelectionTable.H"
 #include "Pstream.H"
 #include "Switch.H"
@@ -119,21 +120,46 @@ static hipLduEntry& hipLookup
             "hipLookup"
         );
         bool any = false;
+        // position of every coupled patch in the library's patch list (= order of addition)
+        labelList libIndex(interfaces.size(), -1);
+        {
+            label k = 0;
+            forAll(interfaces, patchi) if (interfaces.set(patchi)) libIndex[patchi] = k++;
+        }
         forAll(interfaces, patchi)
         {
             if (interfaces.set(patchi))
             {
-                const processorLduInterface* pp =
-                    dynamic_cast<const processorLduInterface*>(&interfaces[patchi].interface());
-                if (!pp)
+                const lduInterface& li = interfaces[patchi].interface();
+                const processorLduInterface* pp = dynamic_cast<const processorLduInterface*>(&li);
+                const cyclicLduInterface* cp = dynamic_cast<const cyclicLduInterface*>(&li);
+                const labelUList& fc = la.patchAddr(patchi);
+                if (pp)
+                {
+                    hipCheck(ldu_addr_add_patch(e.addr, fc.size(), fc.begin(), pp->neighbProcNo()), "hipLookup");
+                }
+                else if (cp)
+                {
+                    if (cp->forwardT().size())
+                    {
+                        FatalErrorIn("hipLookup")
+                            << "cyclic patch " << patchi << " carries a rotation: only untransformed "
+                            << "(translational) cyclics are supported on the GPU path" << exit(FatalError);
+                    }
+                    const label nb = cp->neighbPatchID();
+                    if (nb < 0 || nb >= libIndex.size() || libIndex[nb] < 0)
+                    {
+                        FatalErrorIn("hipLookup") << "cyclic patch " << patchi << ": neighbour patch " << nb
+                            << " is not a coupled interface of this matrix" << exit(FatalError);
+                    }
+                    hipCheck(ldu_addr_add_cyclic_patch(e.addr, fc.size(), fc.begin(), libIndex[nb]), "hipLookup");
+                }
+                else
                 {
                     FatalErrorIn("hipLookup")
-                        << "only processor coupled patches are supported on the GPU path, patch "
-                        << patchi << " is " << interfaces[patchi].interface().type()
-                        << exit(FatalError);
+                        << "only processor and cyclic coupled patches are supported on the GPU path, patch "
+                        << patchi << " is " << li.type() << exit(FatalError);
                 }
-                const labelUList& fc = la.patchAddr(patchi);
-                hipCheck(ldu_addr_add_patch(e.addr, fc.size(), fc.begin(), pp->neighbProcNo()), "hipLookup");
                 any = true;
             }
         }

@@ -91,7 +91,7 @@ def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5), cyclic_x=
                 nCells=nx * ny * nz)
 
 
-def write_case(case, mesh):
+def write_case(case, mesh, libs=None):
     pm = os.path.join(case, "constant", "polyMesh")
     os.makedirs(pm, exist_ok=True)
     os.makedirs(os.path.join(case, "system"), exist_ok=True)
@@ -128,6 +128,8 @@ def write_case(case, mesh):
         f.write("application fv_driver;\nstartFrom startTime;\nstartTime 0;\nstopAt endTime;\nendTime 1;\n"
                 "deltaT 1;\nwriteControl timeStep;\nwriteInterval 1;\nwriteFormat ascii;\nwritePrecision 17;\n"
                 "timeFormat general;\ntimePrecision 6;\nrunTimeModifiable false;\n")
+        if libs:
+            f.write("libs (%s);\n" % " ".join('"%s"' % x for x in libs))
     with open(os.path.join(case, "system", "fvSchemes"), "w") as f:
         f.write(HEADER % ("dictionary", "system", "fvSchemes"))
         f.write("ddtSchemes { default steadyState; }\ngradSchemes { default Gauss linear; }\n"
@@ -152,6 +154,7 @@ def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils", controls=None):
                LD_LIBRARY_PATH=REF + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FOAM_SIGFPE="false")
     cmd = [os.path.join(REF, "fv_driver"), case, inp, outp, mode] + ([controls] if controls else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    run_driver.last_stdout = r.stdout
     if r.returncode != 0:
         raise RuntimeError("fv_driver failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
     res = {}

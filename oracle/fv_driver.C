@@ -29,6 +29,7 @@
 #include "cyclicFvsPatchFields.H"
 #include "fixedValueFvPatchFields.H"
 #include <cstdio>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -181,6 +182,11 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
         scalarField w(mag(cmptMultiply(mesh.Sf().internalField() / sqrt(mesh.magSf().internalField()),
                                        vector(1, 1.01, 1.02))));
         put("faceAreaPairWeights", w);
+        // when the product's plugin is loaded (libs (...) in controlDict): hand it the geometric
+        // agglomeration weights
+        typedef void (*setw_t)(const double*, int);
+        setw_t fn = (setw_t)dlsym(RTLD_DEFAULT, "hipLduSetFaceWeights");
+        if (fn) fn(w.begin(), w.size());
     }
     std::string d0 = std::string("solver GAMG; smoother GaussSeidel; agglomerator faceAreaPair; mergeLevels 1; "
         "cacheAgglomeration off; tolerance 1e-10; relTol 0; nPreSweeps 0; nPostSweeps 2; nFinestSweeps 2; ")

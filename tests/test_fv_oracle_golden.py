@@ -170,6 +170,29 @@ def n_rank_problem(g):
     return subs
 
 
+def cyclic_problem(g):
+    """chain fixture as ONE domain whose coupled patches are the cyclic pairs themselves
+    (cyclicLduInterface: patch 2b pairs with patch 2b+1)"""
+    nP, nC = int(g["nPatches"][0]), int(g["nCells"])
+    nB = int(g["nBoxes"]) if "nBoxes" in g else 2
+    P = [dict(faceCells=g["p%d_faceCells" % p], internalCoeffs=g["p%d_internalCoeffs" % p],
+              boundaryCoeffs=g["p%d_boundaryCoeffs" % p], coupled=bool(g["p%d_coupled" % p][0]), pnf=None)
+         for p in range(nP)]
+    nJ = 2 * (nB - 1)
+    diag = fv_oracle.add_boundary_diag(g["diag"], P)
+    source = fv_oracle.add_boundary_source(g["source"], P, couples=False)
+    patches = [dict(faceCells=P[p]["faceCells"].astype(np.int32), bouCoeffs=P[p]["boundaryCoeffs"],
+                    intCoeffs=P[p]["internalCoeffs"], nbrDom=0, nbrRank=-1, nbrPatch=p ^ 1, cyclic=True)
+               for p in range(nJ)]
+    sp = dict(nCells=nC, lowerAddr=g["lowerAddr"], upperAddr=g["upperAddr"], diag=diag, upper=g["upper"],
+              source=source, psi=np.zeros(nC), faceWeights=g["faceAreaPairWeights"], patches=patches,
+              patches_dev=[dict(faceCells=q["faceCells"], nbrRank=-1, nbrPatch=q["nbrPatch"], cyclic=True)
+                           for q in patches])
+    if "lower" in g:
+        sp["lower"] = g["lower"]
+    return sp
+
+
 CHAINS = ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6"]
 
 
@@ -197,3 +220,25 @@ def test_two_rank_algorithm_against_reference_cyclic_emulation(oracle, name):
     assert perf["nIterations"] == int(r[2])
     np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
     assert np.max(np.abs(x - g["ref_pcg_psi"])) <= 1e-8 * np.max(np.abs(g["ref_pcg_psi"]))
+
+
+@pytest.mark.parametrize("name", CHAINS)
+def test_cyclic_patches_single_domain_oracle(oracle, name):
+    """cyclic coupled patches inside ONE domain (cyclicLduInterface / cyclicGAMGInterface): the same
+    fixtures, solved as the reference solved them - one process, cyclic pairs.  nCellsInCoarsestLevel is
+    the combined 10 x nBoxes the reference used."""
+    g = load(name)
+    sp = cyclic_problem(g)
+    nB = int(g["nBoxes"]) if "nBoxes" in g else 2
+    S = oracle.System([sp])
+    x, perf = S.solve(sp["psi"], sp["source"], solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                      nCellsInCoarsestLevel=10 * nB, mergeLevels=1, tolerance=1e-10, relTol=0)
+    r = g["ref_gamg_perf"]
+    assert perf["nIterations"] == int(r[2]) and perf["converged"]
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-11 * np.max(np.abs(g["ref_gamg_psi"]))
+    kry = dict(solver="PBiCG", precond="DILU") if "asym" in name else dict(solver="PCG", precond="DIC")
+    x, perf = S.solve(sp["psi"], sp["source"], tolerance=1e-10, relTol=0, **kry)
+    r = g["ref_pcg_perf"]
+    assert perf["nIterations"] == int(r[2])
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
