@@ -151,6 +151,10 @@ struct ldu_addr {
     int* d_bStart = nullptr;               // [nBRows+1]
     int* d_bFace = nullptr;                // [nPatchFaces] index into concatenated patch-face arrays
     int* d_pfCell = nullptr;               // [nPatchFaces] faceCells (new numbering), concatenated
+    // nonBlockingGaussSeidel: per row, index into bRow (-1: no coupled face) and the number of its
+    // lower-part entries whose ORIGINAL cell index is below blockStart (= smallest coupled faceCell)
+    int* d_nbRowB = nullptr;               // [nCells]
+    unsigned char* d_nbK0 = nullptr;       // [nCells]
     double* d_sendAll = nullptr;           // [nPatchFaces]
     double* d_recvAll = nullptr;           // [nPatchFaces]
 
@@ -253,6 +257,8 @@ struct SweepArgs {
 int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
 int k_xcd_census(ldu_ctx* ctx);
+int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
+                           const double* bou);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_set_p2p_proxy(int n);
 int k_set_p2p_backoff(unsigned n);

@@ -377,6 +377,73 @@ static int launch_sweep(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     return -1;
 }
 
+// nonBlockingGaussSeidelSmoother.C:147-237 as a row gather, one launch per dependency level.  Same
+// values as GaussSeidel; a row with coupled faces adds their contributions AFTER its lower neighbours
+// below blockStart and BEFORE the others (the reference sweeps the cells below blockStart before the
+// halo arrives).  Rarely selected, so it runs on the simple level kernels, not on the sweep engines.
+__global__ void __launch_bounds__(BLK)
+gs_nonblocking_level_kernel(SliceTab T, int sliceBegin, int sliceEnd, const int* __restrict__ rowB,
+                            const unsigned char* __restrict__ k0s, const int* __restrict__ bStart,
+                            const int* __restrict__ bFace, const double* __restrict__ bou,
+                            const double* __restrict__ recv, double* __restrict__ psi,
+                            const double* __restrict__ source, const double* __restrict__ diag,
+                            const double* __restrict__ val)
+{
+    const int s = sliceBegin + blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (s >= sliceEnd) return;
+    const int lane = threadIdx.x & 63;
+    if (lane >= T.sliceCnt[s]) return;
+    const int r = T.sliceRow[s] + lane;
+    const int nl = T.nL[r], nu = T.nU[r];
+    const long ent = (long)T.sliceEnt[s] + lane;
+    const int bi = rowB[r];
+    const int k0 = bi >= 0 ? (int)k0s[r] : nl;
+    double acc = source[r];
+    for (int k = 0; k < k0; k++)
+    {
+        const long e = ent + (long)k * LDU_WAVE;
+        acc -= val[e] * psi[T.col[e]];
+    }
+    if (bi >= 0)
+    {
+        // updateMatrixInterfaces with the negated coefficients (:120-128, :198-205):
+        // bPrime[faceCells] -= (-bouCoeffs)*pnf, patch by patch, face by face
+        for (int j = bStart[bi]; j < bStart[bi + 1]; j++)
+        {
+            const int f = bFace[j];
+            acc -= (-bou[f]) * recv[f];
+        }
+        for (int k = k0; k < nl; k++)
+        {
+            const long e = ent + (long)k * LDU_WAVE;
+            acc -= val[e] * psi[T.col[e]];
+        }
+    }
+    for (int k = nl; k < nl + nu; k++)
+    {
+        const long e = ent + (long)k * LDU_WAVE;
+        acc -= val[e] * psi[T.col[e]];
+    }
+    psi[r] = acc / diag[r];
+}
+
+// one sweep; the halo (recv buffers) must have been exchanged by the caller
+int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
+                           const double* bou)
+{
+    SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    hipStream_t s = a->ctx->stream;
+    for (int L = 0; L < a->nLevels; L++)
+    {
+        const int s0 = a->levelSliceStart[L], s1 = a->levelSliceStart[L + 1];
+        if (s1 == s0) continue;
+        gs_nonblocking_level_kernel<<<cdiv(s1 - s0, WPB), BLK, 0, s>>>(T, s0, s1, a->d_nbRowB, a->d_nbK0,
+            a->d_bStart, a->d_bFace, bou, a->d_recvAll, psi, source, diag, val);
+    }
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------- persistent point-to-point sweep
 //
 // One launch per sweep.  Slices are taken in dependency-level order through a chunk ticket

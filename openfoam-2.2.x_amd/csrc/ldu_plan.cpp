@@ -427,6 +427,27 @@ int plan_finalize_patches(ldu_addr* a)
         bFace.insert(bFace.end(), perRow[i].begin(), perRow[i].end());
     }
     a->nBRows = (int)bRow.size();
+    {
+        // nonBlockingGaussSeidelSmoother.C:66-79: blockStart_ = smallest cell touched by a coupled patch
+        int blockStart = a->nCells;
+        for (auto& p : a->patches)
+            for (int c : p.faceCells) blockStart = std::min(blockStart, c);
+        std::vector<int> rowB(a->nCells, -1);
+        std::vector<unsigned char> k0(a->nCells, 0);
+        for (size_t i = 0; i < bRow.size(); i++) rowB[bRow[i]] = (int)i;
+        for (int r = 0; r < a->nCells; r++)
+        {
+            const int c = a->perm[r];
+            int k = 0;   // lower-part entries are in ascending face order = ascending owner
+            for (int j = a->losortStart[c]; j < a->losortStart[c + 1]; j++)
+                if (a->l[a->losort[j]] < blockStart) k++;
+            k0[r] = (unsigned char)k;
+        }
+        if (a->d_nbRowB) { (void)hipFree(a->d_nbRowB); a->d_nbRowB = nullptr; }
+        if (a->d_nbK0) { (void)hipFree(a->d_nbK0); a->d_nbK0 = nullptr; }
+        if (upload(&a->d_nbRowB, rowB)) return -1;
+        if (upload(&a->d_nbK0, k0)) return -1;
+    }
     if (upload(&a->d_bRow, bRow)) return -1;
     if (upload(&a->d_bStart, bStart)) return -1;
     if (upload(&a->d_bFace, bFace)) return -1;
@@ -459,7 +480,7 @@ void plan_free(ldu_addr* a)
                     a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,
                     a->d_pfCell, a->d_sendAll, a->d_recvAll, a->p2p[0].d_granule, a->p2p[0].d_ticket,
                     a->p2p[1].d_granule, a->p2p[1].d_ticket, a->d_gateF, a->d_gateB,
-                    a->d_sliceDone, a->d_slabList, a->d_colX, a->d_xflag, a->p2p[0].d_X, a->p2p[0].d_ctl,
+                    a->d_sliceDone, a->d_nbRowB, a->d_nbK0, a->d_slabList, a->d_colX, a->d_xflag, a->p2p[0].d_X, a->p2p[0].d_ctl,
                     a->p2p[1].d_X, a->p2p[1].d_ctl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : a->scratch) if (p) (void)hipFree(p);

@@ -264,11 +264,15 @@ int dev_smooth(ldu_matrix* m, int smoother, double* psi, const double* source, i
         // nonBlockingGaussSeidelSmoother.C:46-240 sweeps the cells below blockStart_ before the halo
         // arrives and the rest after it.  Without coupled patches there is nothing to wait for and the
         // cell loop is the GaussSeidel loop, operation for operation.  With coupled patches the halo
-        // term enters bPrime between the two blocks (a different rounding order): not implemented.
+        // term enters bPrime between the two blocks (a different rounding order): level kernels.
         if (m->a->nPatchFaces)
         {
-            ldu_set_error("nonBlockingGaussSeidel with coupled patches is not implemented; use GaussSeidel");
-            return -3;
+            for (int sweep = 0; sweep < nSweeps; sweep++)
+            {
+                if (halo_start(m, psi)) return -1;
+                if (k_sweep_gs_nonblocking(m->a, psi, source, m->d_diag, m->d_valA, m->d_bou)) return -1;
+            }
+            return 0;
         }
         return smooth_gs(m, psi, source, nSweeps, false);
     case LDU_SM_SYMGAUSSSEIDEL: return smooth_gs(m, psi, source, nSweeps, true);

@@ -176,7 +176,7 @@ def split_box_mesh(nxh, ny, nz, seed=4, jitter=0.15):
     return chain_box_mesh(2, nxh, ny, nz, seed=seed, jitter=jitter)
 
 
-def chain_box_mesh(nBoxes, nxh, ny, nz, seed=4, jitter=0.15):
+def chain_box_mesh(nBoxes, nxh, ny, nz, seed=4, jitter=0.15, axis="x"):
     """nBoxes geometrically IDENTICAL boxes in a row (box b = box 0 translated by b*Lx), neighbours coupled
     only through cyclic patch pairs j<b>a (box b's x-max faces) / j<b>b (box b+1's x-min faces) whose
     faces coincide: inside ONE reference process this is exactly the arithmetic of an nBoxes-rank run
@@ -202,7 +202,10 @@ def chain_box_mesh(nBoxes, nxh, ny, nz, seed=4, jitter=0.15):
                     h = np.array([X[1] - X[0], Y[j + 1] - Y[j], Z[1] - Z[0]])
                     p = p + jitter * h * (rng.rand(3) - 0.5)
                 ptsA[pid(i, j, k)] = p
-    pts = np.vstack([ptsA + np.array([float(b), 0.0, 0.0]) for b in range(nBoxes)])
+    # axis "z": the boxes are stacked in z and coupled through z-max / z-min, so that the coupled cells of
+    # box 0 are its LAST cells and have lower neighbours below blockStart (nonBlockingGaussSeidel)
+    shift = np.array([1.0, 0.0, 0.0]) if axis == "x" else np.array([0.0, 0.0, 1.1])
+    pts = np.vstack([ptsA + b * shift for b in range(nBoxes)])
     nA = nx * ny * nz
 
     def cid(i, j, k):
@@ -240,17 +243,30 @@ def chain_box_mesh(nBoxes, nxh, ny, nz, seed=4, jitter=0.15):
         patches.append((name, len(flist), start, extra))
 
     jk = [(j, k) for k in range(nz) for j in range(ny)]
-    for b in range(nBoxes - 1):
-        (pa, ca), (pb, cb) = boxes[b], boxes[b + 1]
-        add_patch("j%da" % b, [(fx(nx, j, k, pa), ca + cid(nx - 1, j, k)) for j, k in jk], "cyclic j%db" % b)
-        add_patch("j%db" % b, [(fx(0, j, k, pb)[::-1], cb + cid(0, j, k)) for j, k in jk], "cyclic j%da" % b)
-    add_patch("xmin", [(fx(0, j, k, 0)[::-1], cid(0, j, k)) for j, k in jk])
+    ij = [(i, j) for j in range(ny) for i in range(nx)]
     pl, cl = boxes[-1]
-    add_patch("xmax", [(fx(nx, j, k, pl), cl + cid(nx - 1, j, k)) for j, k in jk])
-    add_patch("ymin", [(fy(i, 0, k, po)[::-1], co + cid(i, 0, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
-    add_patch("ymax", [(fy(i, ny, k, po), co + cid(i, ny - 1, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
-    add_patch("zmin", [(fz(i, j, 0, po)[::-1], co + cid(i, j, 0)) for po, co in boxes for j in range(ny) for i in range(nx)])
-    add_patch("zmax", [(fz(i, j, nz, po), co + cid(i, j, nz - 1)) for po, co in boxes for j in range(ny) for i in range(nx)])
+    if axis == "x":
+        for b in range(nBoxes - 1):
+            (pa, ca), (pb, cb) = boxes[b], boxes[b + 1]
+            add_patch("j%da" % b, [(fx(nx, j, k, pa), ca + cid(nx - 1, j, k)) for j, k in jk], "cyclic j%db" % b)
+            add_patch("j%db" % b, [(fx(0, j, k, pb)[::-1], cb + cid(0, j, k)) for j, k in jk], "cyclic j%da" % b)
+        add_patch("xmin", [(fx(0, j, k, 0)[::-1], cid(0, j, k)) for j, k in jk])
+        add_patch("xmax", [(fx(nx, j, k, pl), cl + cid(nx - 1, j, k)) for j, k in jk])
+        add_patch("ymin", [(fy(i, 0, k, po)[::-1], co + cid(i, 0, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
+        add_patch("ymax", [(fy(i, ny, k, po), co + cid(i, ny - 1, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
+        add_patch("zmin", [(fz(i, j, 0, po)[::-1], co + cid(i, j, 0)) for po, co in boxes for j in range(ny) for i in range(nx)])
+        add_patch("zmax", [(fz(i, j, nz, po), co + cid(i, j, nz - 1)) for po, co in boxes for j in range(ny) for i in range(nx)])
+    else:
+        for b in range(nBoxes - 1):
+            (pa, ca), (pb, cb) = boxes[b], boxes[b + 1]
+            add_patch("j%da" % b, [(fz(i, j, nz, pa), ca + cid(i, j, nz - 1)) for i, j in ij], "cyclic j%db" % b)
+            add_patch("j%db" % b, [(fz(i, j, 0, pb)[::-1], cb + cid(i, j, 0)) for i, j in ij], "cyclic j%da" % b)
+        add_patch("zmin", [(fz(i, j, 0, 0)[::-1], cid(i, j, 0)) for i, j in ij])
+        add_patch("zmax", [(fz(i, j, nz, pl), cl + cid(i, j, nz - 1)) for i, j in ij])
+        add_patch("xmin", [(fx(0, j, k, po)[::-1], co + cid(0, j, k)) for po, co in boxes for j, k in jk])
+        add_patch("xmax", [(fx(nx, j, k, po), co + cid(nx - 1, j, k)) for po, co in boxes for j, k in jk])
+        add_patch("ymin", [(fy(i, 0, k, po)[::-1], co + cid(i, 0, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
+        add_patch("ymax", [(fy(i, ny, k, po), co + cid(i, ny - 1, k)) for po, co in boxes for k in range(nz) for i in range(nx)])
     return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32),
                 neighbour=np.array(nei, dtype=np.int32), nInternalFaces=nInt, patches=patches,
                 nCells=nBoxes * nA, nHalf=nA, nBoxes=nBoxes)

@@ -188,7 +188,9 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
         setw_t fn = (setw_t)dlsym(RTLD_DEFAULT, "hipLduSetFaceWeights");
         if (fn) fn(w.begin(), w.size());
     }
-    std::string d0 = std::string("solver GAMG; smoother GaussSeidel; agglomerator faceAreaPair; mergeLevels 1; "
+    const bool ownSmoother = std::string(extraControls).find("smoother ") != std::string::npos;
+    std::string d0 = std::string("solver GAMG; ") + (ownSmoother ? "" : "smoother GaussSeidel; ")
+        + std::string("agglomerator faceAreaPair; mergeLevels 1; "
         "cacheAgglomeration off; tolerance 1e-10; relTol 0; nPreSweeps 0; nPostSweeps 2; nFinestSweeps 2; ")
         + extraControls;
     // "asym" in the controls: add an upwind convection term (asymmetric matrix, interface coefficients
@@ -246,6 +248,27 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
                 scalarField cp(1, T.boundaryField()[p].coupled() ? 1.0 : 0.0);
                 snprintf(nm, sizeof(nm), "p%d_coupled", p); put(nm, cp);
             }
+            // the smoothers themselves on this system (what solveSegregated hands over), 3 sweeps from a
+            // non-trivial start: bit-level reference for GaussSeidel and nonBlockingGaussSeidel with
+            // coupled (cyclic) interfaces
+            scalarField saveDiag(M.diag());
+            M.addBoundaryDiag(M.diag(), 0);
+            scalarField totalSource(M.source());
+            M.addBoundarySource(totalSource, false);
+            const char* smNames[2] = {"GaussSeidel", "nonBlockingGaussSeidel"};
+            scalarField x0(nC);
+            for (label c = 0; c < nC; c++) x0[c] = 0.1 * in[nC + 3 * c + 1];
+            put("smooth_x0", x0);
+            for (int si = 0; si < 2; si++)
+            {
+                dictionary sd;
+                sd.add("smoother", word(smNames[si]));
+                scalarField x(x0);
+                lduMatrix::smoother::New(T.name(), M, M.boundaryCoeffs(), M.internalCoeffs(),
+                                         T.boundaryField().scalarInterfaces(), sd)->smooth(x, totalSource, 0, 3);
+                put((std::string("ref_smooth_") + smNames[si]).c_str(), x);
+            }
+            M.diag() = saveDiag;
         }
         dictionary d(IStringStream(dicts[k])());
         solverPerformance perf = M.solve(d);

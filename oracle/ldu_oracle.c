@@ -502,6 +502,59 @@ static void gs_forward(const orc_dom* D, double* psi, double* bPrime)
     }
 }
 
+/* cells [c0, c1) of the same loop (nonBlockingGaussSeidelSmoother.C:167-196 and :207-235) */
+static void gs_forward_range(const orc_dom* D, double* psi, double* bPrime, int c0, int c1)
+{
+    for (int celli = c0; celli < c1; celli++)
+    {
+        const int fStart = D->ownerStart[celli], fEnd = D->ownerStart[celli + 1];
+        double psii = bPrime[celli];
+        for (int facei = fStart; facei < fEnd; facei++)
+            psii -= D->upper[facei] * psi[D->u[facei]];
+        psii /= D->diag[celli];
+        for (int facei = fStart; facei < fEnd; facei++)
+            bPrime[D->u[facei]] -= D->lower[facei] * psii;
+        psi[celli] = psii;
+    }
+}
+
+/* smoothers/nonBlockingGaussSeidel/nonBlockingGaussSeidelSmoother.C:46-245: the cells below
+ * blockStart_ (= smallest cell index touched by a coupled patch, :66-79) are swept BEFORE the coupled
+ * contributions are added to bPrime (:198-205), the rest after: same values as GaussSeidel, but a
+ * boundary cell accumulates source, lower neighbours < blockStart, interfaces, lower neighbours >= blockStart */
+static void smooth_gs_nonblocking(const orc_sys* s, double* psiAll, const double* sourceAll, int nSweeps)
+{
+    double* bPrimeAll = (double*)malloc(sizeof(double) * (size_t)(s->nCellsTotal + 1));
+    int* blockStart = (int*)malloc(sizeof(int) * (size_t)(s->nDom + 1));
+    for (int d = 0; d < s->nDom; d++)
+    {
+        const orc_dom* D = &s->dom[d];
+        blockStart[d] = D->nCells;
+        for (int p = 0; p < D->nPatches; p++)
+            for (int i = 0; i < D->patches[p].n; i++)
+                if (D->patches[p].faceCells[i] < blockStart[d]) blockStart[d] = D->patches[p].faceCells[i];
+    }
+    for (int sweep = 0; sweep < nSweeps; sweep++)
+    {
+        for (int d = 0; d < s->nDom; d++)
+        {
+            const orc_dom* D = &s->dom[d];
+            double* bPrime = bPrimeAll + D->cellOffset;
+            for (int c = 0; c < D->nCells; c++) bPrime[c] = sourceAll[D->cellOffset + c];
+            gs_forward_range(D, psiAll + D->cellOffset, bPrime, 0, blockStart[d]);
+        }
+        for (int d = 0; d < s->nDom; d++)
+            update_interfaces(s, d, bPrimeAll + s->dom[d].cellOffset, psiAll, 0, -1.0);
+        for (int d = 0; d < s->nDom; d++)
+        {
+            const orc_dom* D = &s->dom[d];
+            gs_forward_range(D, psiAll + D->cellOffset, bPrimeAll + D->cellOffset, blockStart[d], D->nCells);
+        }
+    }
+    free(blockStart);
+    free(bPrimeAll);
+}
+
 /* smoothers/symGaussSeidel/symGaussSeidelSmoother.C:178-205 (bPrime NOT reset) */
 static void gs_reverse(const orc_dom* D, double* psi, double* bPrime)
 {
@@ -598,6 +651,7 @@ void orc_smooth(const orc_sys* s, int smoother, double* psi, const double* sourc
     {
     case ORC_SM_GS:    smooth_gs(s, psi, source, nSweeps, 0); break;
     case ORC_SM_SYMGS: smooth_gs(s, psi, source, nSweeps, 1); break;
+    case ORC_SM_NONBLOCKINGGS: smooth_gs_nonblocking(s, psi, source, nSweeps); break;
     case ORC_SM_DIC:
     case ORC_SM_DILU:
     case ORC_SM_FDIC:  smooth_dic(s, smoother, psi, source, nSweeps); break;

@@ -62,7 +62,7 @@ enum { ORC_PCG = 0, ORC_PBICG = 1, ORC_SMOOTH = 2, ORC_GAMG = 3, ORC_DIAGONAL = 
 enum { ORC_PRE_NONE = 0, ORC_PRE_DIAGONAL = 1, ORC_PRE_DIC = 2, ORC_PRE_FDIC = 3,
        ORC_PRE_DILU = 4, ORC_PRE_GAMG = 5 };
 enum { ORC_SM_GS = 0, ORC_SM_SYMGS = 1, ORC_SM_DIC = 2, ORC_SM_DILU = 3,
-       ORC_SM_DICGS = 4, ORC_SM_DILUGS = 5, ORC_SM_FDIC = 6 };
+       ORC_SM_DICGS = 4, ORC_SM_DILUGS = 5, ORC_SM_FDIC = 6, ORC_SM_NONBLOCKINGGS = 7 };
 enum { ORC_AGG_FACEAREAPAIR = 0, ORC_AGG_ALGEBRAICPAIR = 1 };
 
 typedef struct orc_opts {

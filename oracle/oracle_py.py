@@ -17,7 +17,7 @@ _LIB = None
 SOLVERS = {"PCG": 0, "PBiCG": 1, "smoothSolver": 2, "GAMG": 3, "diagonal": 4}
 PRECONDS = {"none": 0, "diagonal": 1, "DIC": 2, "FDIC": 3, "DILU": 4, "GAMG": 5}
 SMOOTHERS = {"GaussSeidel": 0, "symGaussSeidel": 1, "DIC": 2, "DILU": 3,
-             "DICGaussSeidel": 4, "DILUGaussSeidel": 5, "FDIC": 6}
+             "DICGaussSeidel": 4, "DILUGaussSeidel": 5, "FDIC": 6, "nonBlockingGaussSeidel": 7}
 AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 
 

@@ -78,13 +78,14 @@ def generate_solve(name):
 
 
 CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6": (4, 5, 6, 6, 78),
-               "fvsolve3_chain_asym_5x7x6": (3, 5, 7, 6, 79)}
+               "fvsolve3_chain_asym_5x7x6": (3, 5, 7, 6, 79),
+               "fvsolve3_chain_nonblocking_4x7x6": (3, 4, 7, 6, 80)}
 
 
 def generate_chain(name):
     """serial emulation of an N-rank run by the reference itself (see fv_case.chain_box_mesh)"""
     nB, nxh, ny, nz, seed = CHAIN_CASES[name]
-    mesh = fv_case.chain_box_mesh(nB, nxh, ny, nz)
+    mesh = fv_case.chain_box_mesh(nB, nxh, ny, nz, axis="z" if "nonblocking" in name else "x")
     rng = np.random.RandomState(seed)
     nC, nF = mesh["nCells"], mesh["nInternalFaces"]
     vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
@@ -92,7 +93,9 @@ def generate_chain(name):
         case = os.path.join(d, "case")
         fv_case.write_case(case, mesh)
         res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve",
-                                 controls="nCellsInCoarsestLevel %d;%s" % (10 * nB, " asymmetric" if "asym" in name else ""))
+                                 controls="nCellsInCoarsestLevel %d;%s%s" % (
+                                     10 * nB, " smoother nonBlockingGaussSeidel;" if "nonblocking" in name else "",
+                                     " asymmetric" if "asym" in name else ""))
     out = dict(nCells=nC, nHalf=mesh["nHalf"], nBoxes=nB, lowerAddr=mesh["owner"][:nF].astype(np.int32),
                upperAddr=mesh["neighbour"].astype(np.int32))
     for k, v in res.items():

@@ -193,7 +193,12 @@ def cyclic_problem(g):
     return sp
 
 
-CHAINS = ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6"]
+CHAINS = ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6",
+          "fvsolve3_chain_nonblocking_4x7x6"]
+
+
+def SMOOTHER(name):
+    return "nonBlockingGaussSeidel" if "nonblocking" in name else "GaussSeidel"
 
 
 @pytest.mark.parametrize("name", CHAINS)
@@ -208,7 +213,7 @@ def test_two_rank_algorithm_against_reference_cyclic_emulation(oracle, name):
     subs = n_rank_problem(g)
     S = oracle.System(subs)
     b = np.concatenate([s["source"] for s in subs])
-    x, perf = S.solve(np.zeros(b.size), b, solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+    x, perf = S.solve(np.zeros(b.size), b, solver="GAMG", smoother=SMOOTHER(name), agglomerator="faceAreaPair",
                       nCellsInCoarsestLevel=10, mergeLevels=1, tolerance=1e-10, relTol=0)
     r = g["ref_gamg_perf"]
     assert perf["nIterations"] == int(r[2]) and perf["converged"]
@@ -231,7 +236,7 @@ def test_cyclic_patches_single_domain_oracle(oracle, name):
     sp = cyclic_problem(g)
     nB = int(g["nBoxes"]) if "nBoxes" in g else 2
     S = oracle.System([sp])
-    x, perf = S.solve(sp["psi"], sp["source"], solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+    x, perf = S.solve(sp["psi"], sp["source"], solver="GAMG", smoother=SMOOTHER(name), agglomerator="faceAreaPair",
                       nCellsInCoarsestLevel=10 * nB, mergeLevels=1, tolerance=1e-10, relTol=0)
     r = g["ref_gamg_perf"]
     assert perf["nIterations"] == int(r[2]) and perf["converged"]
@@ -242,3 +247,22 @@ def test_cyclic_patches_single_domain_oracle(oracle, name):
     r = g["ref_pcg_perf"]
     assert perf["nIterations"] == int(r[2])
     np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", CHAINS)
+def test_smoothers_with_coupled_interfaces_bitexact(oracle, name):
+    """GaussSeidel and nonBlockingGaussSeidel (3 sweeps) on the coupled systems, as run by the reference's
+    own smoother classes with real cyclic interfaces: BIT-exact, both as one domain with cyclic patches and
+    as N ranks with processor patches (every cell accumulates source / lower neighbours / interface terms
+    in the same order in both settings)."""
+    g = load(name)
+    x0 = g["smooth_x0"]
+    assert not np.array_equal(g["ref_smooth_GaussSeidel"], g["ref_smooth_nonBlockingGaussSeidel"]) \
+        or "nonblocking" not in name
+    for make in (cyclic_problem, n_rank_problem):
+        sub = make(g)
+        subs = [sub] if isinstance(sub, dict) else sub
+        S = oracle.System(subs)
+        b = np.concatenate([s["source"] for s in subs])
+        for sm in ("GaussSeidel", "nonBlockingGaussSeidel"):
+            assert np.array_equal(S.smooth(sm, x0, b, 3), g["ref_smooth_" + sm]), (make.__name__, sm)

@@ -127,15 +127,16 @@ def test_rccl_backend_single_rank(oracle, monkeypatch):
     m.close(); a.close(); ctx.close()
 
 
-@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6"])
+@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6",
+                                  "fvsolve3_chain_nonblocking_4x7x6"])
 def test_two_ranks_against_reference_cyclic_emulation(name):
     """8(e) pin on the device: 2 / 4 ranks (threads, local communicator) with processor patches against the
     reference's own single-process solve of the same system coupled by cyclic pairs
     (tests/golden/fvsolve*_*.npz; see test_fv_oracle_golden.py for the construction)."""
-    from test_fv_oracle_golden import load, n_rank_problem
+    from test_fv_oracle_golden import load, n_rank_problem, SMOOTHER
     g = load(name)
     subs = n_rank_problem(g)
-    kw_g = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
+    kw_g = dict(solver="GAMG", smoother=SMOOTHER(name), agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
                 mergeLevels=1, tolerance=1e-10, relTol=0)
     kw_p = dict(solver="PCG", preconditioner="DIC", tolerance=1e-10, relTol=0)
     if "asym" in name:
@@ -154,3 +155,21 @@ def test_two_ranks_against_reference_cyclic_emulation(name):
         np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], ref[:2], rtol=1e-6)
         xr = g["ref_%s_psi" % key]
         assert np.max(np.abs(x - xr)) <= 1e-8 * np.max(np.abs(xr)), key
+
+
+@pytest.mark.parametrize("name", ["fvsolve4_chain_5x6x6", "fvsolve3_chain_nonblocking_4x7x6"])
+def test_smoothers_n_ranks_bitexact_against_reference(name):
+    """GaussSeidel / nonBlockingGaussSeidel across ranks (processor patches): bit-exact against the
+    reference's own smoothers on the cyclic-coupled emulation."""
+    from test_fv_oracle_golden import load, n_rank_problem
+    g = load(name)
+    subs = n_rank_problem(g)
+    nH = int(g["nHalf"])
+    x0 = g["smooth_x0"]
+
+    def fn(r, ctx, a, m):
+        return {sm: m.smooth(sm, x0[r * nH:(r + 1) * nH], subs[r]["source"], 3)
+                for sm in ("GaussSeidel", "nonBlockingGaussSeidel")}
+    res = run_ranks(subs, fn)
+    for sm in ("GaussSeidel", "nonBlockingGaussSeidel"):
+        assert np.array_equal(np.concatenate([r[sm] for r in res]), g["ref_smooth_" + sm]), sm

@@ -243,11 +243,12 @@ def test_level_schedule_large_levels(ctx, oracle):
         c2.close()
 
 
-@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6"])
+@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6",
+                                  "fvsolve3_chain_nonblocking_4x7x6"])
 def test_cyclic_patches_against_reference(ctx, name):
     """cyclic coupled patches on ONE rank (ldu_addr_add_cyclic_patch): the reference's own single-process
     solves with real cyclic patches (tests/golden/fvsolve*.npz), GAMG + Krylov."""
-    from test_fv_oracle_golden import load, cyclic_problem
+    from test_fv_oracle_golden import load, cyclic_problem, SMOOTHER
     g = load(name)
     sp = cyclic_problem(g)
     nB = int(g["nBoxes"]) if "nBoxes" in g else 2
@@ -257,7 +258,7 @@ def test_cyclic_patches_against_reference(ctx, name):
     m.set_coeffs(sp["diag"], sp["upper"], sp.get("lower"))
     for i, q in enumerate(sp["patches"]):
         m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
-    x, perf = m.solve(sp["psi"], sp["source"], solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+    x, perf = m.solve(sp["psi"], sp["source"], solver="GAMG", smoother=SMOOTHER(name), agglomerator="faceAreaPair",
                       nCellsInCoarsestLevel=10 * nB, mergeLevels=1, tolerance=1e-10, relTol=0)
     r = g["ref_gamg_perf"]
     assert perf["nIterations"] == int(r[2]) and perf["converged"]
@@ -269,4 +270,22 @@ def test_cyclic_patches_against_reference(ctx, name):
     assert perf["nIterations"] == int(r[2])
     np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
     assert np.max(np.abs(x - g["ref_pcg_psi"])) <= 1e-8 * np.max(np.abs(g["ref_pcg_psi"]))
+    m.close(); a.close()
+
+
+@pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve3_chain_asym_5x7x6", "fvsolve3_chain_nonblocking_4x7x6"])
+def test_smoothers_with_cyclic_patches_bitexact(ctx, name):
+    """GaussSeidel / nonBlockingGaussSeidel with coupled (cyclic) patches: bit-exact against the reference's
+    own smoother classes (3 sweeps; the nonblocking fixture is the one where the two differ)."""
+    from test_fv_oracle_golden import load, cyclic_problem
+    g = load(name)
+    sp = cyclic_problem(g)
+    a = capi.Addressing(ctx, sp["nCells"], sp["lowerAddr"], sp["upperAddr"], sp["faceWeights"],
+                        patches=sp["patches_dev"])
+    m = capi.Matrix(a)
+    m.set_coeffs(sp["diag"], sp["upper"], sp.get("lower"))
+    for i, q in enumerate(sp["patches"]):
+        m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+    for sm in ("GaussSeidel", "nonBlockingGaussSeidel"):
+        assert np.array_equal(m.smooth(sm, g["smooth_x0"], sp["source"], 3), g["ref_smooth_" + sm]), sm
     m.close(); a.close()
