@@ -232,6 +232,20 @@ int ldu_fvm_flux(ldu_fv_boundary* b, const double* internalCoeffs, const double*
                  const double* patchNeighbourField, const double* upper, const double* lower, const double* psi,
                  double* fluxInternal, double* fluxBoundary);
 
+/* vector (3-component) matrices, fvMatrix<vector>: scalar diag/upper/lower, vector psi / source ([nCells][3])
+ * and per-patch vector coefficients ([nPatchFaces][3], concatenated as above).  Same reference loops with
+ * Type = vector: component(.,cmpt), cmptMultiply, cmptAv, cmptMax(cmptMag(.)), cmptMin. */
+int ldu_fvm_addBoundaryDiagCmpt(ldu_fv_boundary* b, const double* internalCoeffs3, int32_t cmpt, double* diag);
+int ldu_fvm_addBoundarySourceV(ldu_fv_boundary* b, const double* boundaryCoeffs3, const double* patchNeighbourField3,
+                               int32_t couples, double* source3);
+int ldu_fvm_relaxV(ldu_fv_boundary* b, double alpha, const double* internalCoeffs3, const double* boundaryCoeffs3,
+                   const double* upper, const double* lower, const double* psi3, double* diag, double* source3);
+int ldu_fvm_AV(ldu_fv_boundary* b, const double* internalCoeffs3, const double* diag, const double* V, double* A);
+/* the generic fvMatrix<Type>::H (fvMatrix.C:751-813), not the scalar specialisation */
+int ldu_fvm_HV(ldu_fv_boundary* b, const double* internalCoeffs3, const double* boundaryCoeffs3,
+               const double* patchNeighbourField3, const double* upper, const double* lower, const double* psi3,
+               const double* source3, const double* V, double* H3);
+
 #ifdef __cplusplus
 }
 #endif

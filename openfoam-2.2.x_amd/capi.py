@@ -29,6 +29,7 @@ EXPORTS = [
     "ldu_fvc_snGrad", "ldu_fvm_laplacian", "ldu_fvm_div", "ldu_profile_begin", "ldu_profile_end",
     "ldu_fv_boundary_create", "ldu_fv_boundary_destroy", "ldu_fvm_addBoundaryDiag", "ldu_fvm_addBoundarySource",
     "ldu_fvm_relax", "ldu_fvm_setReference", "ldu_fvm_A", "ldu_fvm_H", "ldu_fvm_flux",
+    "ldu_fvm_addBoundaryDiagCmpt", "ldu_fvm_addBoundarySourceV", "ldu_fvm_relaxV", "ldu_fvm_AV", "ldu_fvm_HV",
 ]
 
 
@@ -412,6 +413,37 @@ class FvBoundary:
                                 _ptr(_f64(upper)), _ptr(_f64(lower)) if lower is not None else None, _ptr(_f64(psi)),
                                 _ptr(fi), _ptr(fb)))
         return fi, fb
+
+    # ---- vector matrices: coefficient arrays [n][3]
+    def addBoundaryDiagCmpt(self, iC3, cmpt, diag):
+        d = np.array(diag, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_addBoundaryDiagCmpt(self.h, _ptr(_f64(iC3)), int(cmpt), _ptr(d)))
+        return d
+
+    def addBoundarySourceV(self, bC3, pnf3, source3, couples=True):
+        s = np.array(source3, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_addBoundarySourceV(self.h, _ptr(_f64(bC3)), _ptr(_f64(pnf3)) if pnf3 is not None else None,
+                                              int(couples), _ptr(s)))
+        return s
+
+    def relaxV(self, alpha, iC3, bC3, upper, lower, psi3, diag, source3):
+        d = np.array(diag, dtype=np.float64, copy=True)
+        s = np.array(source3, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_relaxV(self.h, C.c_double(alpha), _ptr(_f64(iC3)), _ptr(_f64(bC3)), _ptr(_f64(upper)),
+                                  _ptr(_f64(lower)) if lower is not None else None, _ptr(_f64(psi3)), _ptr(d), _ptr(s)))
+        return d, s
+
+    def AV(self, iC3, diag, V):
+        out = np.zeros(self.addr.nCells)
+        _chk(lib().ldu_fvm_AV(self.h, _ptr(_f64(iC3)), _ptr(_f64(diag)), _ptr(_f64(V)), _ptr(out)))
+        return out
+
+    def HV(self, iC3, bC3, pnf3, upper, lower, psi3, source3, V):
+        out = np.zeros((self.addr.nCells, 3))
+        _chk(lib().ldu_fvm_HV(self.h, _ptr(_f64(iC3)), _ptr(_f64(bC3)), _ptr(_f64(pnf3)) if pnf3 is not None else None,
+                              _ptr(_f64(upper)), _ptr(_f64(lower)) if lower is not None else None, _ptr(_f64(psi3)),
+                              _ptr(_f64(source3)), _ptr(_f64(V)), _ptr(out)))
+        return out
 
     def close(self):
         if self.h:

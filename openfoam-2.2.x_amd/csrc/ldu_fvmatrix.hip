@@ -213,6 +213,144 @@ __global__ void glue_setReference_kernel(int celli, double value, double* diag, 
     diag[celli] += diag[celli];
 }
 
+// ---------------------------------------------------------------- vector (3-component) matrices
+// fvMatrix<vector>: one scalar lduMatrix (diag/upper/lower) + vector source, psi and per-patch vector
+// coefficients (AoS [n][3], as Field<vector>).  VectorSpaceI.H:376-418: cmptMax / cmptMin over the
+// components, cmptAv = ((v0 + v1) + v2)/3.
+__device__ __forceinline__ double cmpt_av3(const double* v) { return ((v[0] + v[1]) + v[2]) / 3; }
+
+// fvMatrix.C:116-131, addBoundaryDiag(diag, cmpt)
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_addBoundaryDiagCmpt_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                                const double* __restrict__ iC3, int cmpt, double* __restrict__ diag)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const int b = cs[c], e = cs[c + 1];
+    if (b == e) return;
+    double d = diag[c];
+    for (int j = b; j < e; j++) d += iC3[3 * cf[j] + cmpt];
+    diag[c] = d;
+}
+
+// fvMatrix.C:150-178 for Type = vector (coupled: cmptMultiply(pbc, pnf))
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_addBoundarySourceV_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                               const unsigned char* __restrict__ coupled, const double* __restrict__ bC3,
+                               const double* __restrict__ pnf3, int couples, double* __restrict__ source3)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const int b = cs[c], e = cs[c + 1];
+    if (b == e) return;
+    double s[3] = {source3[3 * c], source3[3 * c + 1], source3[3 * c + 2]};
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        if (!coupled[f])
+            for (int k = 0; k < 3; k++) s[k] += bC3[3 * f + k];
+        else if (couples)
+            for (int k = 0; k < 3; k++) s[k] += bC3[3 * f + k] * pnf3[3 * f + k];
+    }
+    for (int k = 0; k < 3; k++) source3[3 * c + k] = s[k];
+}
+
+// fvMatrix.C:525-655, Type = vector
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_relaxV_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                   const unsigned char* __restrict__ coupled, const double* __restrict__ iC3,
+                   const double* __restrict__ bC3, const int* __restrict__ losortStart,
+                   const int* __restrict__ losort, const int* __restrict__ ownerStart,
+                   const double* __restrict__ upper, const double* __restrict__ lower, double alpha,
+                   const double* __restrict__ psi3, double* __restrict__ diag, double* __restrict__ source3)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const double D0 = diag[c];
+    double D = D0;
+    double sumOff = 0.0;
+    for (int j = losortStart[c]; j < losortStart[c + 1]; j++) sumOff += fabs(lower[losort[j]]);
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++) sumOff += fabs(upper[f]);
+    const int b = cs[c], e = cs[c + 1];
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        const double* ic = iC3 + 3 * f;
+        if (coupled[f])
+        {
+            D += ic[0];                                   // component(iCoeffs[face], 0)
+            sumOff += fabs(bC3[3 * f]);                   // mag(component(pCoeffs[face], 0))
+        }
+        else
+            D += fmax(fmax(fabs(ic[0]), fabs(ic[1])), fabs(ic[2]));   // cmptMax(cmptMag(.))
+    }
+    D = fmax(fabs(D), sumOff);
+    D /= alpha;
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        const double* ic = iC3 + 3 * f;
+        D -= coupled[f] ? ic[0] : fmin(fmin(ic[0], ic[1]), ic[2]);     // component 0 | cmptMin
+    }
+    diag[c] = D;
+    const double dd = D - D0;
+    for (int k = 0; k < 3; k++) source3[3 * c + k] += dd * psi3[3 * c + k];
+}
+
+// fvMatrix.C:722-746 with D() = diag + cmptAv(internalCoeffs) (:689-694)
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_AV_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf, const double* __restrict__ iC3,
+               const double* __restrict__ diag, const double* __restrict__ V, double* __restrict__ A)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    double d = diag[c];
+    for (int j = cs[c]; j < cs[c + 1]; j++) d += cmpt_av3(iC3 + 3 * cf[j]);
+    A[c] = d / V[c];
+}
+
+// fvMatrix<Type>::H, the generic template fvMatrix.C:751-813 (vector): per component
+// (cmptAv(iC) - iC.component(cmpt)) summed over the cell's boundary faces, times psi; + lduMatrix::H(psi)
+// + source; + boundary source; / V
+__global__ void __launch_bounds__(GLUE_BLK)
+glue_HV_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+               const unsigned char* __restrict__ coupled, const double* __restrict__ iC3,
+               const double* __restrict__ bC3, const double* __restrict__ pnf3,
+               const int* __restrict__ losortStart, const int* __restrict__ losort,
+               const int* __restrict__ ownerStart, const int* __restrict__ l, const int* __restrict__ u,
+               const double* __restrict__ upper, const double* __restrict__ lower,
+               const double* __restrict__ psi3, const double* __restrict__ source3, const double* __restrict__ V,
+               double* __restrict__ H3)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const int b = cs[c], e = cs[c + 1];
+    double h[3];
+    for (int k = 0; k < 3; k++)
+    {
+        double bd = 0.0;                                  // addBoundaryDiag(bdc, cmpt)
+        for (int j = b; j < e; j++) bd += iC3[3 * cf[j] + k];
+        bd = -bd;                                         // negate
+        for (int j = b; j < e; j++) bd += cmpt_av3(iC3 + 3 * cf[j]);   // addCmptAvBoundaryDiag
+        h[k] = bd * psi3[3 * c + k];
+    }
+    double hl[3] = {0.0, 0.0, 0.0};                       // lduMatrix::H(psi), lduMatrixTemplates.C:32-69
+    for (int j = losortStart[c]; j < losortStart[c + 1]; j++)
+    {
+        const int f = losort[j];
+        for (int k = 0; k < 3; k++) hl[k] -= lower[f] * psi3[3 * l[f] + k];
+    }
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+        for (int k = 0; k < 3; k++) hl[k] -= upper[f] * psi3[3 * u[f] + k];
+    for (int k = 0; k < 3; k++) h[k] += hl[k] + source3[3 * c + k];
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        for (int k = 0; k < 3; k++) h[k] += coupled[f] ? bC3[3 * f + k] * pnf3[3 * f + k] : bC3[3 * f + k];
+    }
+    for (int k = 0; k < 3; k++) H3[3 * c + k] = h[k] / V[c];
+}
+
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -402,6 +540,89 @@ int ldu_fvm_flux(ldu_fv_boundary* b, const double* internalCoeffs, const double*
     LDU_CHECK_HIP(hipGetLastError());
     if (B.finish(fluxInternal, fi, a->nFaces)) return -1;
     return B.finish(fluxBoundary, fb, b->nFacesTotal);
+}
+
+int ldu_fvm_addBoundaryDiagCmpt(ldu_fv_boundary* b, const double* internalCoeffs3, int32_t cmpt, double* diag)
+{
+    if (cmpt < 0 || cmpt > 2) { ldu_set_error("ldu_fvm_addBoundaryDiagCmpt: cmpt must be 0..2"); return -2; }
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs3, 3 * (size_t)b->nFacesTotal);
+    double* d = B.inout(diag, a->nCells, true);
+    glue_addBoundaryDiagCmpt_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart,
+        b->d_cellFace, iC, cmpt, d);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(diag, d, a->nCells);
+}
+
+int ldu_fvm_addBoundarySourceV(ldu_fv_boundary* b, const double* boundaryCoeffs3, const double* patchNeighbourField3,
+                               int32_t couples, double* source3)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* bC = B.in(boundaryCoeffs3, 3 * (size_t)b->nFacesTotal);
+    const double* pnf = B.in(patchNeighbourField3, 3 * (size_t)b->nFacesTotal);
+    if (!pnf) pnf = bC;
+    double* s = B.inout(source3, 3 * (size_t)a->nCells, true);
+    glue_addBoundarySourceV_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart,
+        b->d_cellFace, b->d_coupled, bC, pnf, couples, s);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(source3, s, 3 * (size_t)a->nCells);
+}
+
+int ldu_fvm_relaxV(ldu_fv_boundary* b, double alpha, const double* internalCoeffs3, const double* boundaryCoeffs3,
+                   const double* upper, const double* lower, const double* psi3, double* diag, double* source3)
+{
+    if (alpha <= 0) return 0;
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs3, 3 * (size_t)b->nFacesTotal);
+    const double* bC = B.in(boundaryCoeffs3, 3 * (size_t)b->nFacesTotal);
+    const double* up = B.in(upper, a->nFaces);
+    const double* lo = lower ? B.in(lower, a->nFaces) : up;
+    const double* x = B.in(psi3, 3 * (size_t)a->nCells);
+    double* d = B.inout(diag, a->nCells, true);
+    double* s = B.inout(source3, 3 * (size_t)a->nCells, true);
+    glue_relaxV_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace,
+        b->d_coupled, iC, bC, a->d_losortStart, a->d_losort, a->d_ownerStart, up, lo, alpha, x, d, s);
+    LDU_CHECK_HIP(hipGetLastError());
+    if (B.finish(diag, d, a->nCells)) return -1;
+    return B.finish(source3, s, 3 * (size_t)a->nCells);
+}
+
+int ldu_fvm_AV(ldu_fv_boundary* b, const double* internalCoeffs3, const double* diag, const double* V, double* A)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs3, 3 * (size_t)b->nFacesTotal);
+    const double* d = B.in(diag, a->nCells);
+    const double* v = B.in(V, a->nCells);
+    double* o = B.inout(A, a->nCells, false);
+    glue_AV_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace, iC, d, v, o);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(A, o, a->nCells);
+}
+
+int ldu_fvm_HV(ldu_fv_boundary* b, const double* internalCoeffs3, const double* boundaryCoeffs3,
+               const double* patchNeighbourField3, const double* upper, const double* lower, const double* psi3,
+               const double* source3, const double* V, double* H3)
+{
+    ldu_addr* a = b->a;
+    GlueBuf B(a->ctx->stream);
+    const double* iC = B.in(internalCoeffs3, 3 * (size_t)b->nFacesTotal);
+    const double* bC = B.in(boundaryCoeffs3, 3 * (size_t)b->nFacesTotal);
+    const double* pnf = B.in(patchNeighbourField3, 3 * (size_t)b->nFacesTotal);
+    const double* up = B.in(upper, a->nFaces);
+    const double* lo = lower ? B.in(lower, a->nFaces) : up;
+    const double* x = B.in(psi3, 3 * (size_t)a->nCells);
+    const double* s = B.in(source3, 3 * (size_t)a->nCells);
+    const double* v = B.in(V, a->nCells);
+    double* o = B.inout(H3, 3 * (size_t)a->nCells, false);
+    if (!pnf) pnf = bC;
+    glue_HV_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace, b->d_coupled,
+        iC, bC, pnf, a->d_losortStart, a->d_losort, a->d_ownerStart, a->d_l, a->d_u, up, lo, x, s, v, o);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(H3, o, 3 * (size_t)a->nCells);
 }
 
 }  // extern "C"

@@ -169,6 +169,11 @@ def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils", controls=None):
     for k in ("Sf", "interpolate_v", "surfaceIntegrate_v", "gaussGrad", "phiU"):
         if k in res:
             res[k] = res[k].reshape(-1, 3)
+    if mode == "glueV":
+        for k in list(res):
+            if k in ("source", "psi", "ref_addBoundarySource", "ref_addBoundarySource_nocouples", "ref_H",
+                     "ref_relax_source") or k.endswith(("_internalCoeffs", "_boundaryCoeffs", "_pnf")):
+                res[k] = res[k].reshape(-1, 3)
     return res
 
 

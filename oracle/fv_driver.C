@@ -4,7 +4,7 @@
 // kernels ldu_fv_* / ldu_fvc_* / ldu_fvm_* (SURVEY.md 8a rows a30, a33-a39).
 // Our code; only reference HEADERS are included.  Never shipped, never linked into the product.
 //
-// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue|solve|solve2] [extra GAMG controls for solve]
+// usage: fv_driver <caseDir> <in.bin> <out.bin> [stencils|glue|glueV|solve|solve2] [extra GAMG controls for solve]
 //   in.bin : vf[nC] U[3 nC] phi[nF] gamma[nF]            (nF = internal faces)
 //   out.bin: sections "name count" + doubles, see put()
 #include "argList.H"
@@ -159,6 +159,96 @@ static int glue(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
     return 0;
 }
 
+// the same glue for a VECTOR matrix (U-equation like): fvm::div(phi, U) - fvm::laplacian(gamma, U) with
+// fixedValue / zeroGradient / cyclic patches
+static int glueV(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
+{
+    const label nC = mesh.nCells();
+    const label nF = mesh.nInternalFaces();
+    dimensionSet::debug = 0;
+    wordList types(mesh.boundary().size());
+    forAll(types, p)
+    {
+        types[p] = mesh.boundary()[p].coupled() ? word("cyclic") : (p % 2 ? word("zeroGradient") : word("fixedValue"));
+    }
+    volVectorField U(IOobject("U", runTime.timeName(), mesh), mesh, dimensionedVector("0", dimless, vector::zero), types);
+    for (label c = 0; c < nC; c++) U.internalField()[c] = vector(in[nC + 3 * c], in[nC + 3 * c + 1], in[nC + 3 * c + 2]);
+    forAll(types, p)
+        if (types[p] == "fixedValue") U.boundaryField()[p] == vector(0.3 + 0.1 * p, -0.2, 0.05 * p);
+    U.correctBoundaryConditions();
+    surfaceScalarField phi(IOobject("phi", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
+    surfaceScalarField gamma(IOobject("gamma", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
+    for (label f = 0; f < nF; f++)
+    {
+        phi.internalField()[f] = in[(size_t)4 * nC + f];
+        gamma.internalField()[f] = in[(size_t)4 * nC + nF + f];
+    }
+    forAll(phi.boundaryField(), p)
+        forAll(phi.boundaryField()[p], i)
+        {
+            phi.boundaryField()[p][i] = 0.05 * ((i % 5) - 2) * (mesh.boundary()[p].coupled() ? 0.0 : 1.0);
+            gamma.boundaryField()[p][i] = 0.8 + 0.01 * (i % 7);
+        }
+    surfaceScalarField gammaMagSf("gammaMagSf", gamma * mesh.magSf());
+    tmp<fvVectorMatrix> tLap =
+        fv::gaussLaplacianScheme<vector, scalar>::fvmLaplacianUncorrected(gammaMagSf, mesh.deltaCoeffs(), U);
+    fv::gaussConvectionScheme<vector> cs(mesh, phi, tmp<surfaceInterpolationScheme<vector> >(new upwind<vector>(mesh, phi)));
+    tmp<fvVectorMatrix> tDiv = cs.fvmDiv(phi, U);
+    fvVectorMatrix M(tDiv() - tLap());
+    for (label c = 0; c < nC; c++) M.source()[c] = 0.3 * vector(in[c], in[nC + 3 * c], -in[c]);
+
+    put("diag", M.diag());
+    put("upper", M.upper());
+    put("lower", M.lower());
+    put("source", M.source());
+    put("psi", U.internalField());
+    put("V", mesh.V().field());
+    {
+        scalarField np(1, scalar(mesh.boundary().size()));
+        put("nPatches", np);
+    }
+    forAll(mesh.boundary(), p)
+    {
+        const labelUList& fc = mesh.lduAddr().patchAddr(p);
+        scalarField fcd(fc.size());
+        forAll(fc, i) fcd[i] = fc[i];
+        char nm[64];
+        snprintf(nm, sizeof(nm), "p%d_faceCells", p); put(nm, fcd);
+        scalarField cp(1, U.boundaryField()[p].coupled() ? 1.0 : 0.0);
+        snprintf(nm, sizeof(nm), "p%d_coupled", p); put(nm, cp);
+        snprintf(nm, sizeof(nm), "p%d_internalCoeffs", p); put(nm, M.internalCoeffs()[p]);
+        snprintf(nm, sizeof(nm), "p%d_boundaryCoeffs", p); put(nm, M.boundaryCoeffs()[p]);
+        vectorField pnf(fc.size(), vector::zero);
+        if (U.boundaryField()[p].coupled()) pnf = U.boundaryField()[p].patchNeighbourField();
+        snprintf(nm, sizeof(nm), "p%d_pnf", p); put(nm, pnf);
+    }
+    for (direction cmpt = 0; cmpt < 3; cmpt++)
+    {
+        scalarField d(M.diag());
+        M.addBoundaryDiag(d, cmpt);
+        char nm[64];
+        snprintf(nm, sizeof(nm), "ref_addBoundaryDiag%d", cmpt); put(nm, d);
+    }
+    {
+        vectorField s(M.source());
+        M.addBoundarySource(s);
+        put("ref_addBoundarySource", s);
+        vectorField s2(M.source());
+        M.addBoundarySource(s2, false);
+        put("ref_addBoundarySource_nocouples", s2);
+    }
+    put("ref_A", M.A()().internalField());
+    put("ref_H", M.H()().internalField());
+    {
+        fvVectorMatrix R(M);
+        R.relax(0.7);
+        put("ref_relax_diag", R.diag());
+        put("ref_relax_source", R.source());
+    }
+    fclose(out);
+    return 0;
+}
+
 // End to end through the reference's own application-level call: fvScalarMatrix::solve(dict) ->
 // solveSegregated (fvScalarMatrix.C:136-183: addBoundaryDiag, addBoundarySource(couples=false),
 // lduMatrix::solver::New(...)->solve) with GAMG + the REAL faceAreaPairGAMGAgglomeration of
@@ -283,7 +373,7 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
 
 int main(int argc, char* argv[])
 {
-    if (argc < 4 || argc > 6) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|solve|solve2] [extra GAMG controls for solve]\n"); return 2; }
+    if (argc < 4 || argc > 6) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|glueV|solve|solve2] [extra GAMG controls for solve]\n"); return 2; }
     fileName caseDir(argv[1]);
     Time runTime(Time::controlDictName, fileName(caseDir.path()), fileName(caseDir.name()));
     fvMesh mesh(IOobject(fvMesh::defaultRegion, runTime.timeName(), runTime, IOobject::MUST_READ));
@@ -302,6 +392,7 @@ int main(int argc, char* argv[])
     }
     out = fopen(argv[3], "wb");
     if (argc >= 5 && std::string(argv[4]) == "glue") return glue(mesh, runTime, in);
+    if (argc >= 5 && std::string(argv[4]) == "glueV") return glueV(mesh, runTime, in);
     if (argc == 5 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in, "nCellsInCoarsestLevel 10;");
     if (argc == 6 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in, argv[5]);
     // two identical halves coupled by a cyclic pair = serial emulation of a 2-rank run: the combined

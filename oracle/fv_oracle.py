@@ -175,3 +175,84 @@ def fvm_flux(l, u, upper, lower, psi, patches):
         nc = p["boundaryCoeffs"] * p["pnf"] if p["coupled"] else p["boundaryCoeffs"]
         fb.append(ic - nc)
     return fi, fb
+
+
+# ---- vector (3-component) matrices: coefficient arrays [n][3]
+def cmpt_av(v):
+    """VectorSpaceI.H:400-418: ((v0 + v1) + v2)/3"""
+    return ((v[..., 0] + v[..., 1]) + v[..., 2]) / 3
+
+
+def add_boundary_diag_cmpt(diag, patches, cmpt):
+    """fvMatrix::addBoundaryDiag(diag, cmpt), fvMatrix.C:116-131"""
+    d = diag.copy()
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            d[c] += p["internalCoeffs"][i, cmpt]
+    return d
+
+
+def add_boundary_source_v(source, patches, couples=True):
+    """fvMatrix<vector>::addBoundarySource, fvMatrix.C:150-178 (cmptMultiply on coupled patches)"""
+    s = source.copy()
+    for p in patches:
+        if not p["coupled"]:
+            for i, c in enumerate(p["faceCells"]):
+                s[c] += p["boundaryCoeffs"][i]
+        elif couples:
+            for i, c in enumerate(p["faceCells"]):
+                s[c] += p["boundaryCoeffs"][i] * p["pnf"][i]
+    return s
+
+
+def relax_v(alpha, diag, source, l, u, upper, lower, psi, patches):
+    """fvMatrix<vector>::relax, fvMatrix.C:525-655"""
+    D = diag.copy()
+    D0 = diag.copy()
+    sumOff = sum_mag_off_diag(D.size, l, u, lower, upper)
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            ic = p["internalCoeffs"][i]
+            if p["coupled"]:
+                D[c] += ic[0]
+                sumOff[c] += abs(p["boundaryCoeffs"][i][0])
+            else:
+                D[c] += max(max(abs(ic[0]), abs(ic[1])), abs(ic[2]))
+    D = np.maximum(np.abs(D), sumOff)
+    D = D / alpha
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            ic = p["internalCoeffs"][i]
+            D[c] -= ic[0] if p["coupled"] else min(min(ic[0], ic[1]), ic[2])
+    return D, source + ((D - D0)[:, None] * psi)
+
+
+def fvm_A_v(diag, patches, V):
+    """fvMatrix::A with D() = diag + cmptAv(internalCoeffs), fvMatrix.C:689-694, 722-746"""
+    d = diag.copy()
+    for p in patches:
+        av = cmpt_av(p["internalCoeffs"])
+        for i, c in enumerate(p["faceCells"]):
+            d[c] += av[i]
+    return d / V
+
+
+def fvm_H_v(diag, source, l, u, upper, lower, psi, patches, V):
+    """fvMatrix<vector>::H, the generic template fvMatrix.C:751-813"""
+    nC = diag.size
+    h = np.zeros((nC, 3))
+    for k in range(3):
+        bd = add_boundary_diag_cmpt(np.zeros(nC), patches, k)
+        bd = -bd
+        for p in patches:
+            av = cmpt_av(p["internalCoeffs"])
+            for i, c in enumerate(p["faceCells"]):
+                bd[c] += av[i]
+        h[:, k] = bd * psi[:, k]
+    hl = np.zeros((nC, 3))
+    for f in range(l.size):
+        hl[u[f]] -= lower[f] * psi[l[f]]
+        hl[l[f]] -= upper[f] * psi[u[f]]
+    h = h + (hl + source)
+    h = add_boundary_source_v(h, patches, couples=True)
+    return h / V[:, None]

@@ -40,8 +40,11 @@ def generate(name):
 GLUE_CASES = {"fvglue_box_6x5x4_cyclic": (6, 5, 4, 5, True), "fvglue_box_3x9x2": (3, 9, 2, 6, False)}
 
 
-def generate_glue(name):
-    nx, ny, nz, seed, cyc = GLUE_CASES[name]
+GLUEV_CASES = {"fvglueV_box_5x6x4_cyclic": (5, 6, 4, 11, True)}
+
+
+def generate_glue(name, mode="glue"):
+    nx, ny, nz, seed, cyc = (GLUE_CASES if mode == "glue" else GLUEV_CASES)[name]
     mesh = fv_case.box_mesh(nx, ny, nz, seed=seed, cyclic_x=cyc)
     rng = np.random.RandomState(200 + seed)
     nC, nF = mesh["nCells"], mesh["nInternalFaces"]
@@ -49,7 +52,7 @@ def generate_glue(name):
     with tempfile.TemporaryDirectory() as d:
         case = os.path.join(d, "case")
         fv_case.write_case(case, mesh)
-        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="glue")
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode=mode)
     out = dict(nCells=nC, lowerAddr=mesh["owner"][:nF].astype(np.int32), upperAddr=mesh["neighbour"].astype(np.int32))
     for k, v in res.items():
         if k.endswith("_faceCells"):
@@ -118,6 +121,10 @@ if __name__ == "__main__":
         data = generate_chain(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
+    for name in GLUEV_CASES:
+        data = generate_glue(name, mode="glueV")
+        np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+        print(name, "cells", data["nCells"], "vector matrix, patches", int(data["nPatches"][0]))
     for name in GLUE_CASES:
         data = generate_glue(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)

@@ -266,3 +266,21 @@ def test_smoothers_with_coupled_interfaces_bitexact(oracle, name):
         b = np.concatenate([s["source"] for s in subs])
         for sm in ("GaussSeidel", "nonBlockingGaussSeidel"):
             assert np.array_equal(S.smooth(sm, x0, b, 3), g["ref_smooth_" + sm]), (make.__name__, sm)
+
+
+def test_vector_fvmatrix_glue_oracle_matches_reference():
+    """fvMatrix<vector> (U-equation like, fixedValue / zeroGradient / cyclic patches): addBoundaryDiag per
+    component, addBoundarySource, A (cmptAv), the generic H, relax - bit-exact against the reference."""
+    g = load("fvglueV_box_5x6x4_cyclic")
+    P = glue_patches(g)
+    l, u = g["lowerAddr"], g["upperAddr"]
+    eq = np.array_equal
+    assert any(p["coupled"] for p in P)
+    for k in range(3):
+        assert eq(fv_oracle.add_boundary_diag_cmpt(g["diag"], P, k), g["ref_addBoundaryDiag%d" % k])
+    assert eq(fv_oracle.add_boundary_source_v(g["source"], P), g["ref_addBoundarySource"])
+    assert eq(fv_oracle.add_boundary_source_v(g["source"], P, couples=False), g["ref_addBoundarySource_nocouples"])
+    assert eq(fv_oracle.fvm_A_v(g["diag"], P, g["V"]), g["ref_A"])
+    assert eq(fv_oracle.fvm_H_v(g["diag"], g["source"], l, u, g["upper"], g["lower"], g["psi"], P, g["V"]), g["ref_H"])
+    d, s = fv_oracle.relax_v(0.7, g["diag"], g["source"], l, u, g["upper"], g["lower"], g["psi"], P)
+    assert eq(d, g["ref_relax_diag"]) and eq(s, g["ref_relax_source"])

@@ -184,3 +184,24 @@ def test_end_to_end_assembly_to_solve_against_reference(ctx):
     np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
     assert np.max(np.abs(x - g["ref_pcg_psi"])) <= 1e-9 * np.max(np.abs(g["ref_pcg_psi"]))
     m.close(); B.close(); a.close()
+
+
+def test_vector_fvmatrix_glue_against_reference_vectors(ctx):
+    """ldu_fvm_*V (fvMatrix<vector>) vs the reference's own fvVectorMatrix: bit-exact."""
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fvglueV_box_5x6x4_cyclic.npz")))
+    nP = int(g["nPatches"][0])
+    l, u, nC = g["lowerAddr"], g["upperAddr"], int(g["nCells"])
+    a = capi.Addressing(ctx, nC, l, u)
+    cat = lambda key: np.concatenate([g["p%d_%s" % (p, key)] for p in range(nP)])
+    iC, bC, pnf = cat("internalCoeffs"), cat("boundaryCoeffs"), cat("pnf")
+    B = capi.FvBoundary(a, [g["p%d_faceCells" % p] for p in range(nP)], [int(g["p%d_coupled" % p][0]) for p in range(nP)])
+    eq = np.array_equal
+    for k in range(3):
+        assert eq(B.addBoundaryDiagCmpt(iC, k, g["diag"]), g["ref_addBoundaryDiag%d" % k])
+    assert eq(B.addBoundarySourceV(bC, pnf, g["source"]), g["ref_addBoundarySource"])
+    assert eq(B.addBoundarySourceV(bC, pnf, g["source"], couples=False), g["ref_addBoundarySource_nocouples"])
+    assert eq(B.AV(iC, g["diag"], g["V"]), g["ref_A"])
+    assert eq(B.HV(iC, bC, pnf, g["upper"], g["lower"], g["psi"], g["source"], g["V"]), g["ref_H"])
+    d, s = B.relaxV(0.7, iC, bC, g["upper"], g["lower"], g["psi"], g["diag"], g["source"])
+    assert eq(d, g["ref_relax_diag"]) and eq(s, g["ref_relax_source"])
+    B.close(); a.close()
