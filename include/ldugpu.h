@@ -246,6 +246,19 @@ int ldu_fvm_HV(ldu_fv_boundary* b, const double* internalCoeffs3, const double* 
                const double* patchNeighbourField3, const double* upper, const double* lower, const double* psi3,
                const double* source3, const double* V, double* H3);
 
+/* ---- higher-order schemes of the motorBike set-up, internal field ----------
+ * linearUpwind<scalar>::correction (linearUpwind.C:87-91): corr[f] = (Cf[f] - C[c]) & gradVf[c],
+ * c = faceFlux[f] > 0 ? owner : neighbour.  C3 [nCells][3], Cf3 [nFaces][3], gradVf3 [nCells][3]. */
+int ldu_fv_linearUpwindCorrection(ldu_addr* a, const double* faceFlux, const double* C3, const double* Cf3,
+                                  const double* gradVf3, double* corr);
+/* cellLimitedGrad<scalar>::calcGrad (cellLimitedGrads.C:46-196): limits grad3 (in/out, the basic scheme's
+ * gradient) so that the face extrapolates stay within the min/max of the neighbouring values; k as in
+ * `cellLimited Gauss linear k`.  boundaryValues / boundaryCf3: per patch face (concatenated, order of
+ * ldu_fv_boundary_create) the patch value - patchNeighbourField on coupled patches - and the face centre;
+ * b may be NULL (no boundary faces). */
+int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf, const double* boundaryValues,
+                            const double* C3, const double* Cf3, const double* boundaryCf3, double* grad3);
+
 #ifdef __cplusplus
 }
 #endif

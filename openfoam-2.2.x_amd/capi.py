@@ -30,6 +30,7 @@ EXPORTS = [
     "ldu_fv_boundary_create", "ldu_fv_boundary_destroy", "ldu_fvm_addBoundaryDiag", "ldu_fvm_addBoundarySource",
     "ldu_fvm_relax", "ldu_fvm_setReference", "ldu_fvm_A", "ldu_fvm_H", "ldu_fvm_flux",
     "ldu_fvm_addBoundaryDiagCmpt", "ldu_fvm_addBoundarySourceV", "ldu_fvm_relaxV", "ldu_fvm_AV", "ldu_fvm_HV",
+    "ldu_fv_linearUpwindCorrection", "ldu_fvc_cellLimitedGrad",
 ]
 
 
@@ -166,6 +167,12 @@ class Addressing:
         if faceWeights is not None:
             w = np.ascontiguousarray(faceWeights, dtype=np.float64)
             _chk(lib().ldu_addr_set_face_weights(self.h, _ptr(w)))
+
+    def linearUpwindCorrection(self, phi, C3, Cf3, grad3):
+        out = np.zeros(self.nFaces)
+        _chk(lib().ldu_fv_linearUpwindCorrection(self.h, _ptr(_f64(phi)), _ptr(_f64(C3)), _ptr(_f64(Cf3)),
+                                                 _ptr(_f64(grad3)), _ptr(out)))
+        return out
 
     def info(self):
         nl, ns, ne = C.c_int32(), C.c_int32(), C.c_int64()
@@ -413,6 +420,12 @@ class FvBoundary:
                                 _ptr(_f64(upper)), _ptr(_f64(lower)) if lower is not None else None, _ptr(_f64(psi)),
                                 _ptr(fi), _ptr(fb)))
         return fi, fb
+
+    def cellLimitedGrad(self, k, vsf, bVal, C3, Cf3, bCf3, grad3):
+        g = np.array(grad3, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvc_cellLimitedGrad(self.addr.h, self.h, C.c_double(k), _ptr(_f64(vsf)), _ptr(_f64(bVal)),
+                                           _ptr(_f64(C3)), _ptr(_f64(Cf3)), _ptr(_f64(bCf3)), _ptr(g)))
+        return g
 
     # ---- vector matrices: coefficient arrays [n][3]
     def addBoundaryDiagCmpt(self, iC3, cmpt, diag):

@@ -351,6 +351,84 @@ glue_HV_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ c
     for (int k = 0; k < 3; k++) H3[3 * c + k] = h[k] / V[c];
 }
 
+// ---------------------------------------------------------------- higher-order schemes
+// linearUpwind<scalar>::correction, interpolation/surfaceInterpolation/schemes/linearUpwind/linearUpwind.C:87-91
+// (internal faces): corr[f] = (Cf[f] - C[c]) & gradVf[c], c = faceFlux[f] > 0 ? owner : neighbour
+__global__ void __launch_bounds__(GLUE_BLK)
+fv_linearUpwind_kernel(int nFaces, const int* __restrict__ l, const int* __restrict__ u,
+                       const double* __restrict__ phi, const double* __restrict__ C3,
+                       const double* __restrict__ Cf3, const double* __restrict__ grad3, double* __restrict__ corr)
+{
+    const int f = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (f >= nFaces) return;
+    const int c = phi[f] > 0 ? l[f] : u[f];
+    const double dx = Cf3[3 * f] - C3[3 * c], dy = Cf3[3 * f + 1] - C3[3 * c + 1], dz = Cf3[3 * f + 2] - C3[3 * c + 2];
+    corr[f] = dx * grad3[3 * c] + dy * grad3[3 * c + 1] + dz * grad3[3 * c + 2];
+}
+
+// cellLimitedGrad<scalar>::limitFace, cellLimitedGrad.H:136-152 (VSMALL = 1e-300, doubleScalar.H)
+__device__ __forceinline__ void limit_face(double& limiter, double maxDelta, double minDelta, double extrapolate)
+{
+    if (extrapolate > maxDelta + 1.0e-300) limiter = fmin(limiter, maxDelta / extrapolate);
+    else if (extrapolate < minDelta - 1.0e-300) limiter = fmin(limiter, minDelta / extrapolate);
+}
+
+// cellLimitedGrad<scalar>::calcGrad, gradSchemes/limitedGradSchemes/cellLimitedGrad/cellLimitedGrads.C:46-196:
+// min / max of the neighbour values (internal faces, then patch faces: patchNeighbourField on coupled patches,
+// the patch value otherwise), k-relaxation of the bounds, limiter = min over the cell's faces, g *= limiter.
+// max / min are order-independent, so a per-cell gather reproduces the face loops exactly.
+__global__ void __launch_bounds__(GLUE_BLK)
+fv_cellLimitedGrad_kernel(int nCells, double k, const int* __restrict__ cs, const int* __restrict__ cf,
+                          const int* __restrict__ losortStart, const int* __restrict__ losort,
+                          const int* __restrict__ ownerStart, const int* __restrict__ l, const int* __restrict__ u,
+                          const double* __restrict__ vsf, const double* __restrict__ bVal,
+                          const double* __restrict__ C3, const double* __restrict__ Cf3,
+                          const double* __restrict__ bCf3, double* __restrict__ g3)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    const double v = vsf[c];
+    double mx = v, mn = v;
+    for (int j = losortStart[c]; j < losortStart[c + 1]; j++)
+    {
+        const double o = vsf[l[losort[j]]];
+        mx = fmax(mx, o); mn = fmin(mn, o);
+    }
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+    {
+        const double o = vsf[u[f]];
+        mx = fmax(mx, o); mn = fmin(mn, o);
+    }
+    const int b = cs ? cs[c] : 0, e = cs ? cs[c + 1] : 0;
+    for (int j = b; j < e; j++)
+    {
+        const double o = bVal[cf[j]];
+        mx = fmax(mx, o); mn = fmin(mn, o);
+    }
+    mx -= v; mn -= v;
+    if (k < 1.0)
+    {
+        const double mm = (1.0 / k - 1.0) * (mx - mn);
+        mx += mm; mn -= mm;
+    }
+    const double gx = g3[3 * c], gy = g3[3 * c + 1], gz = g3[3 * c + 2];
+    const double cx = C3[3 * c], cy = C3[3 * c + 1], cz = C3[3 * c + 2];
+    double lim = 1.0;
+    for (int j = losortStart[c]; j < losortStart[c + 1]; j++)
+    {
+        const int f = losort[j];
+        limit_face(lim, mx, mn, (Cf3[3 * f] - cx) * gx + (Cf3[3 * f + 1] - cy) * gy + (Cf3[3 * f + 2] - cz) * gz);
+    }
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+        limit_face(lim, mx, mn, (Cf3[3 * f] - cx) * gx + (Cf3[3 * f + 1] - cy) * gy + (Cf3[3 * f + 2] - cz) * gz);
+    for (int j = b; j < e; j++)
+    {
+        const int f = cf[j];
+        limit_face(lim, mx, mn, (bCf3[3 * f] - cx) * gx + (bCf3[3 * f + 1] - cy) * gy + (bCf3[3 * f + 2] - cz) * gz);
+    }
+    g3[3 * c] = gx * lim; g3[3 * c + 1] = gy * lim; g3[3 * c + 2] = gz * lim;
+}
+
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -623,6 +701,40 @@ int ldu_fvm_HV(ldu_fv_boundary* b, const double* internalCoeffs3, const double* 
         iC, bC, pnf, a->d_losortStart, a->d_losort, a->d_ownerStart, a->d_l, a->d_u, up, lo, x, s, v, o);
     LDU_CHECK_HIP(hipGetLastError());
     return B.finish(H3, o, 3 * (size_t)a->nCells);
+}
+
+int ldu_fv_linearUpwindCorrection(ldu_addr* a, const double* faceFlux, const double* C3, const double* Cf3,
+                                  const double* gradVf3, double* corr)
+{
+    GlueBuf B(a->ctx->stream);
+    const double* phi = B.in(faceFlux, a->nFaces);
+    const double* c = B.in(C3, 3 * (size_t)a->nCells);
+    const double* cf = B.in(Cf3, 3 * (size_t)a->nFaces);
+    const double* g = B.in(gradVf3, 3 * (size_t)a->nCells);
+    double* o = B.inout(corr, a->nFaces, false);
+    fv_linearUpwind_kernel<<<glue_grid(a->nFaces), GLUE_BLK, 0, B.s>>>(a->nFaces, a->d_l, a->d_u, phi, c, cf, g, o);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(corr, o, a->nFaces);
+}
+
+int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf, const double* boundaryValues,
+                            const double* C3, const double* Cf3, const double* boundaryCf3, double* grad3)
+{
+    if (k < 1.0e-15) return 0;   // cellLimitedGrads.C:58-61 (k_ < SMALL: unlimited)
+    if (b && b->a != a) { ldu_set_error("ldu_fvc_cellLimitedGrad: boundary belongs to another addressing"); return -2; }
+    GlueBuf B(a->ctx->stream);
+    const size_t nB = b ? (size_t)b->nFacesTotal : 0;
+    const double* v = B.in(vsf, a->nCells);
+    const double* bv = B.in(boundaryValues, nB);
+    const double* c = B.in(C3, 3 * (size_t)a->nCells);
+    const double* cf = B.in(Cf3, 3 * (size_t)a->nFaces);
+    const double* bcf = B.in(boundaryCf3, 3 * nB);
+    double* g = B.inout(grad3, 3 * (size_t)a->nCells, true);
+    fv_cellLimitedGrad_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, k, b ? b->d_cellStart : nullptr,
+        b ? b->d_cellFace : nullptr, a->d_losortStart, a->d_losort, a->d_ownerStart, a->d_l, a->d_u, v, bv, c, cf,
+        bcf, g);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(grad3, g, 3 * (size_t)a->nCells);
 }
 
 }  // extern "C"

@@ -67,6 +67,8 @@ FORCE=""
 for u in fvMesh/fvPatches/constraint/cyclic/cyclicFvPatch.C \
          fields/fvPatchFields/constraint/cyclic/cyclicFvPatchFields.C \
          fields/fvPatchFields/basic/fixedValue/fixedValueFvPatchFields.C \
+         finiteVolume/gradSchemes/gaussGrad/gaussGrads.C \
+         interpolation/surfaceInterpolation/schemes/linear/linear.C \
          fvMatrices/solvers/GAMGSymSolver/GAMGAgglomerations/faceAreaPairGAMGAgglomeration/faceAreaPairGAMGAgglomeration.C \
          fields/fvsPatchFields/constraint/cyclic/cyclicFvsPatchFields.C; do
     i=$(grep -n "/$u\$" "$W/fvsources.txt" | head -1 | cut -d: -f1)

@@ -19,6 +19,8 @@
 #include "uncorrectedSnGrad.H"
 #include "gaussLaplacianScheme.H"
 #include "gaussConvectionScheme.H"
+#include "linearUpwind.H"
+#include "cellLimitedGrad.H"
 #include "fvcSurfaceIntegrate.H"
 #include "fvMatrices.H"
 #include "calculatedFvPatchFields.H"
@@ -496,6 +498,40 @@ int main(int argc, char* argv[])
         put("div_upwind_lower", Mu().lower());
         put("div_upwind_upper", Mu().upper());
         put("div_upwind_diag", Mu().diag());
+    }
+    // ---- 8f rank 2: linearUpwind correction and cellLimited Gauss linear gradient (scalar)
+    {
+        put("C", mesh.C().internalField());
+        put("Cf", mesh.Cf().internalField());
+        scalarField nb(1, scalar(mesh.boundary().size()));
+        put("nPatches", nb);
+        forAll(mesh.boundary(), p)
+        {
+            const labelUList& fc = mesh.boundary()[p].faceCells();
+            scalarField fcd(fc.size());
+            forAll(fc, i) fcd[i] = fc[i];
+            char nm[64];
+            snprintf(nm, sizeof(nm), "p%d_faceCells", p); put(nm, fcd);
+            snprintf(nm, sizeof(nm), "p%d_Cf", p); put(nm, mesh.Cf().boundaryField()[p]);
+            snprintf(nm, sizeof(nm), "p%d_value", p); put(nm, vf.boundaryField()[p]);
+        }
+        IStringStream lu("grad(vf)");
+        linearUpwind<scalar> sch(mesh, phi, lu);
+        tmp<surfaceScalarField> corr = sch.correction(vf);
+        put("linearUpwind_correction", corr().internalField());
+        {
+            IStringStream gs("Gauss linear");
+            tmp<volVectorField> g0 = fv::gradScheme<scalar>::New(mesh, gs)().calcGrad(vf, "g0");
+            put("gaussLinearGrad", g0().internalField());
+        }
+        const char* ks[2] = {"1", "0.5"};
+        for (int i = 0; i < 2; i++)
+        {
+            IStringStream cl((std::string("Gauss linear ") + ks[i]).c_str());
+            fv::cellLimitedGrad<scalar> clg(mesh, cl);
+            tmp<volVectorField> g = clg.calcGrad(vf, "g");
+            put(i ? "cellLimitedGrad_k05" : "cellLimitedGrad_k1", g().internalField());
+        }
     }
     // addressing as the reference sees it (must equal the generator's)
     {

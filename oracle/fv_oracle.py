@@ -256,3 +256,53 @@ def fvm_H_v(diag, source, l, u, upper, lower, psi, patches, V):
     h = h + (hl + source)
     h = add_boundary_source_v(h, patches, couples=True)
     return h / V[:, None]
+
+
+# ---------------------------------------------------------------- higher-order schemes
+def linear_upwind_correction(l, u, phi, C, Cf, grad):
+    """linearUpwind<scalar>::correction, interpolation/surfaceInterpolation/schemes/linearUpwind/
+    linearUpwind.C:87-91 (internal faces)"""
+    c = np.where(phi > 0, l, u)
+    d = Cf - C[c]
+    g = grad[c]
+    return d[:, 0] * g[:, 0] + d[:, 1] * g[:, 1] + d[:, 2] * g[:, 2]
+
+
+def cell_limited_grad(k, l, u, vsf, C, Cf, grad, patches):
+    """cellLimitedGrad<scalar>::calcGrad, gradSchemes/limitedGradSchemes/cellLimitedGrad/
+    cellLimitedGrads.C:46-196 + limitFace cellLimitedGrad.H:136-152.  patches: dicts faceCells, value, Cf"""
+    VSMALL = 1.0e-300
+    g = grad.copy()
+    mx, mn = vsf.copy(), vsf.copy()
+    for f in range(l.size):
+        o, n = l[f], u[f]
+        mx[o] = max(mx[o], vsf[n]); mn[o] = min(mn[o], vsf[n])
+        mx[n] = max(mx[n], vsf[o]); mn[n] = min(mn[n], vsf[o])
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            mx[c] = max(mx[c], p["value"][i]); mn[c] = min(mn[c], p["value"][i])
+    mx = mx - vsf
+    mn = mn - vsf
+    if k < 1.0:
+        mm = (1.0 / k - 1.0) * (mx - mn)
+        mx = mx + mm
+        mn = mn - mm
+    lim = np.ones(vsf.size)
+
+    def limit(c, ex):
+        if ex > mx[c] + VSMALL:
+            lim[c] = min(lim[c], mx[c] / ex)
+        elif ex < mn[c] - VSMALL:
+            lim[c] = min(lim[c], mn[c] / ex)
+
+    def dot(a, b):
+        return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+    for f in range(l.size):
+        o, n = l[f], u[f]
+        limit(o, dot(Cf[f] - C[o], g[o]))
+        limit(n, dot(Cf[f] - C[n], g[n]))
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            limit(c, dot(p["Cf"][i] - C[c], g[c]))
+    return g * lim[:, None]

@@ -33,7 +33,7 @@ def generate(name):
     u = mesh["neighbour"].astype(np.int32)
     assert np.array_equal(res.pop("owner"), l) and np.array_equal(res.pop("neighbour"), u)
     out = dict(nCells=nC, lowerAddr=l, upperAddr=u, vf=vf, U=U, phi=phi, gamma=gamma)
-    out.update({"ref_" + k: v for k, v in res.items()})
+    out.update({"ref_" + k: (v.astype(np.int32) if k.endswith("_faceCells") else v) for k, v in res.items()})
     return out
 
 

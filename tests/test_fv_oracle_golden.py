@@ -284,3 +284,24 @@ def test_vector_fvmatrix_glue_oracle_matches_reference():
     assert eq(fv_oracle.fvm_H_v(g["diag"], g["source"], l, u, g["upper"], g["lower"], g["psi"], P, g["V"]), g["ref_H"])
     d, s = fv_oracle.relax_v(0.7, g["diag"], g["source"], l, u, g["upper"], g["lower"], g["psi"], P)
     assert eq(d, g["ref_relax_diag"]) and eq(s, g["ref_relax_source"])
+
+
+def stencil_patches(g):
+    return [dict(faceCells=g["ref_p%d_faceCells" % p], value=g["ref_p%d_value" % p], Cf=g["ref_p%d_Cf" % p])
+            for p in range(int(g["ref_nPatches"][0]))]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_higher_order_schemes_oracle_matches_reference(name):
+    """8f rank 2: linearUpwind<scalar>::correction and cellLimited Gauss linear (k = 1, 0.5) gradients
+    against the reference's own scheme classes - bit-exact."""
+    g = load(name)
+    l, u = g["lowerAddr"], g["upperAddr"]
+    C, Cf, g0 = g["ref_C"], g["ref_Cf"], g["ref_gaussLinearGrad"]
+    assert np.array_equal(g0, g["ref_gaussGrad"])     # zero boundary values: the basic gradient of the fixture
+    assert np.array_equal(fv_oracle.linear_upwind_correction(l, u, g["phi"], C, Cf, g0), g["ref_linearUpwind_correction"])
+    P = stencil_patches(g)
+    lim1 = fv_oracle.cell_limited_grad(1.0, l, u, g["vf"], C, Cf, g0, P)
+    assert np.array_equal(lim1, g["ref_cellLimitedGrad_k1"])
+    assert not np.array_equal(lim1, g0)               # the limiter is active somewhere
+    assert np.array_equal(fv_oracle.cell_limited_grad(0.5, l, u, g["vf"], C, Cf, g0, P), g["ref_cellLimitedGrad_k05"])

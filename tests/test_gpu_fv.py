@@ -205,3 +205,21 @@ def test_vector_fvmatrix_glue_against_reference_vectors(ctx):
     d, s = B.relaxV(0.7, iC, bC, g["upper"], g["lower"], g["psi"], g["diag"], g["source"])
     assert eq(d, g["ref_relax_diag"]) and eq(s, g["ref_relax_source"])
     B.close(); a.close()
+
+
+@pytest.mark.parametrize("name", ["fv_box_7x6x5", "fv_box_12x3x9"])
+def test_higher_order_schemes_against_reference_vectors(ctx, name):
+    """ldu_fv_linearUpwindCorrection / ldu_fvc_cellLimitedGrad vs the reference's own linearUpwind<scalar>
+    and cellLimitedGrad<scalar> (k = 1 and 0.5): bit-exact."""
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")))
+    l, u, nC = g["lowerAddr"], g["upperAddr"], int(g["nCells"])
+    nP = int(g["ref_nPatches"][0])
+    a = capi.Addressing(ctx, nC, l, u)
+    C, Cf, g0 = g["ref_C"], g["ref_Cf"], g["ref_gaussLinearGrad"]
+    assert np.array_equal(a.linearUpwindCorrection(g["phi"], C, Cf, g0), g["ref_linearUpwind_correction"])
+    B = capi.FvBoundary(a, [g["ref_p%d_faceCells" % p] for p in range(nP)], [0] * nP)
+    bVal = np.concatenate([g["ref_p%d_value" % p] for p in range(nP)])
+    bCf = np.concatenate([g["ref_p%d_Cf" % p] for p in range(nP)])
+    assert np.array_equal(B.cellLimitedGrad(1.0, g["vf"], bVal, C, Cf, bCf, g0), g["ref_cellLimitedGrad_k1"])
+    assert np.array_equal(B.cellLimitedGrad(0.5, g["vf"], bVal, C, Cf, bCf, g0), g["ref_cellLimitedGrad_k05"])
+    B.close(); a.close()
