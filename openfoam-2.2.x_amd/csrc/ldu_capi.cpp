@@ -137,6 +137,14 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e)) c->useGraphs = false;
     e = getenv("LDU_FUSE_ROWS");
     if (e) c->fuseRows = atoi(e);
+    e = getenv("LDU_CLUSTER");
+    if (e) c->clusterEngine = atoi(e);
+    e = getenv("LDU_CLUSTER_MULTI");
+    if (e) c->clusterMulti = atoi(e);
+    e = getenv("LDU_CLUSTER_MIN");
+    if (e) c->clusterMinCells = atoi(e);
+    e = getenv("LDU_CLUSTER_BPC");
+    if (e && atoi(e) > 0) c->clusterBlocksPerCU = atoi(e);
     e = getenv("LDU_SMALL");
     if (e) c->smallKernels = atoi(e);
     e = getenv("LDU_SMALL_MAX");

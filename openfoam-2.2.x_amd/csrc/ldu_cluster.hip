@@ -1,0 +1,807 @@
+// Cluster sweep engine ("row blocking"): fewer, fatter hand-offs.
+//
+// The level-scheduled engines pay one cross-CU hand-off (1.0-1.4 us) per dependency LEVEL: 646 of them on
+// the 216^3 box.  Here the cells are grouped into compact clusters of <= 64 cells (one wavefront); the
+// dependencies INSIDE a cluster are resolved by the wave itself, step by step through LDS (~0.15 us per
+// step, no other wave involved), and only dependencies BETWEEN clusters go through the granule hand-off.
+// For 4x4x4 blocks of a hex mesh: 10 internal steps per cluster, 163 cluster levels instead of 646.
+//
+// Clusters must form an acyclic quotient graph.  Any topological order of the cell DAG cut into
+// consecutive chunks has that property (edges only run forward in the order), so the clusters are grown
+// greedily IN a topological order: a cluster only ever absorbs "ready" cells (all lower neighbours already
+// placed), preferring the ready cell with most neighbours inside the cluster (compact blobs; first come
+// first served on ties, which yields cubes on structured numberings).
+//
+// The arithmetic per row is untouched (same accumulation order, -ffp-contract=off): bit-identical results.
+// The engine is a secondary structure of an addressing: its own row order, entry table and granules;
+// vectors stay in the level-ordered numbering and are reached through a row map.
+#include <algorithm>
+#include <map>
+#include <queue>
+#include <vector>
+
+#include "ldu_internal.hpp"
+
+#define CL_BLK 256
+#define CL_WPB (CL_BLK / LDU_WAVE)
+#define CL_MAXD 6      // dependencies (lower resp. upper neighbours) per row held in registers
+#define CL_SPIN_LIMIT (1u << 22)
+
+typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
+
+struct ClusterPlan {
+    int nSlices = 0;
+    long nEntries = 0;
+    int nClusterLevels = 0;
+    double avgDepth = 0;
+    bool eligible = false;
+    int maxDep = CL_MAXD;             // max over rows of max(nL, nU): picks the kernel instantiation
+    int* d_sliceRow = nullptr;        // [nSlices+1] first cluster-row of a cluster
+    int* d_sliceEnt = nullptr;        // [nSlices]
+    unsigned char* d_sliceDepth = nullptr;   // [nSlices] internal steps
+    int* d_map = nullptr;             // [nCells] cluster-row -> level-ordered row
+    unsigned char* d_nL = nullptr;    // [nCells] per cluster-row
+    unsigned char* d_nU = nullptr;
+    unsigned char* d_intra = nullptr; // [nCells] internal level of the row inside its cluster
+    int* d_colF = nullptr;            // [nEntries] lower part: cluster-row of the column; upper part: level row
+    int* d_colB = nullptr;            // [nEntries] lower part: level row; upper part: cluster-row
+    int* d_src = nullptr;             // [nEntries] index of the entry in the level-ordered SELL arrays
+    uint4* d_granule = nullptr;       // [nCells+1]
+    unsigned* d_ticket = nullptr;
+    unsigned ticketBase = 0;
+    unsigned epoch = 0;
+    int gen = 0;
+    std::vector<int> levelStart;      // [nClusterLevels+1] clusters of one cluster level are contiguous
+    std::vector<int> upLevel;         // [nClusterLevels] running max of the cluster level holding an upper neighbour
+    struct Tasks { int* d = nullptr; int n = 0; };
+    std::map<int, Tasks> tasks;       // k -> topological (sweep, cluster) list of k pipelined GaussSeidel sweeps
+    struct Conv { double* d = nullptr; unsigned long long stamp = 0; };
+    std::map<const double*, Conv> conv;   // level-layout value array -> cluster-layout copy
+};
+
+template <class T>
+static int cl_upload(T** dst, const std::vector<T>& src)
+{
+    const size_t n = src.size() ? src.size() : 1;
+    LDU_CHECK_HIP(hipMalloc((void**)dst, n * sizeof(T)));
+    if (src.size()) LDU_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void cluster_free(ldu_addr* a)
+{
+    ClusterPlan* P = a->cluster;
+    if (!P) return;
+    void* ptrs[] = {P->d_sliceRow, P->d_sliceEnt, P->d_sliceDepth, P->d_map, P->d_nL, P->d_nU, P->d_intra,
+                    P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& kv : P->conv) if (kv.second.d) (void)hipFree(kv.second.d);
+    for (auto& kv : P->tasks) if (kv.second.d) (void)hipFree(kv.second.d);
+    delete P;
+    a->cluster = nullptr;
+}
+
+// Builds the plan on first use.  Returns 0 and sets P->eligible.
+static int cluster_build(ldu_addr* a)
+{
+    if (a->cluster) return 0;
+    ClusterPlan* P = new ClusterPlan();
+    a->cluster = P;
+    const int nC = a->nCells, nF = a->nFaces;
+    const std::vector<int>& l = a->l;
+    const std::vector<int>& u = a->u;
+    // eligibility: register-resident dependencies
+    int maxDep = 0;
+    for (int c = 0; c < nC; c++)
+    {
+        maxDep = std::max(maxDep, a->losortStart[c + 1] - a->losortStart[c]);
+        maxDep = std::max(maxDep, a->ownerStart[c + 1] - a->ownerStart[c]);
+    }
+    if (maxDep > CL_MAXD) return 0;
+    P->maxDep = maxDep;
+    if (nC < 64) return 0;
+
+    // ---- greedy clustering in a topological order
+    std::vector<int> indeg(nC, 0), cluster(nC, -1), intra(nC, 0);
+    for (int f = 0; f < nF; f++) indeg[u[f]]++;
+    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+    for (int c = 0; c < nC; c++) if (!indeg[c]) ready.push(c);
+    std::vector<std::vector<int>> members;
+    std::vector<int> cLevel, cDepth;
+    std::vector<int> cand;
+    while (!ready.empty())
+    {
+        const int seed = ready.top(); ready.pop();
+        if (cluster[seed] >= 0) continue;
+        const int id = (int)members.size();
+        members.emplace_back();
+        cand.clear(); cand.push_back(seed);
+        int lev = 0, depth = 0;
+        while (!cand.empty() && (int)members[id].size() < LDU_WAVE)
+        {
+            // most neighbours already inside; the earliest candidate wins ties
+            int bi = 0, bscore = -1;
+            for (size_t t = 0; t < cand.size(); t++)
+            {
+                const int c = cand[t];
+                int sc = 0;
+                for (int j = a->losortStart[c]; j < a->losortStart[c + 1]; j++)
+                    if (cluster[l[a->losort[j]]] == id) sc++;
+                if (sc > bscore) { bscore = sc; bi = (int)t; }
+            }
+            const int c = cand[bi];
+            cand.erase(cand.begin() + bi);
+            cluster[c] = id;
+            members[id].push_back(c);
+            int il = 0;
+            for (int j = a->losortStart[c]; j < a->losortStart[c + 1]; j++)
+            {
+                const int p = l[a->losort[j]];
+                if (cluster[p] == id) il = std::max(il, intra[p] + 1);
+                else lev = std::max(lev, cLevel[cluster[p]] + 1);
+            }
+            intra[c] = il;
+            depth = std::max(depth, il + 1);
+            for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++)
+                if (--indeg[u[f]] == 0) cand.push_back(u[f]);
+        }
+        for (int c : cand) ready.push(c);
+        cLevel.push_back(lev);
+        cDepth.push_back(depth);
+    }
+    const int nCl = (int)members.size();
+    // ---- schedule order: by cluster level (ties: creation order) = a topological order of the quotient
+    std::vector<int> order(nCl);
+    for (int i = 0; i < nCl; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cLevel[x] < cLevel[y]; });
+    P->nSlices = nCl;
+    int maxLev = 0; double sumDepth = 0;
+    for (int i = 0; i < nCl; i++) { maxLev = std::max(maxLev, cLevel[i]); sumDepth += cDepth[i]; }
+    P->nClusterLevels = maxLev + 1;
+    P->avgDepth = sumDepth / std::max(1, nCl);
+
+    std::vector<int> sliceRow(nCl + 1, 0), sliceEnt(nCl, 0), map(nC), crowOf(nC);
+    std::vector<unsigned char> sliceDepth(nCl), nL(nC), nU(nC), intraR(nC);
+    long ent = 0;
+    int row = 0;
+    std::vector<int> sliceW(nCl);
+    for (int s = 0; s < nCl; s++)
+    {
+        const int id = order[s];
+        sliceRow[s] = row;
+        sliceDepth[s] = (unsigned char)cDepth[id];
+        int W = 0;
+        for (int c : members[id])
+        {
+            crowOf[c] = row;
+            map[row] = a->iperm[c];
+            const int cl_ = a->losortStart[c + 1] - a->losortStart[c], cu = a->ownerStart[c + 1] - a->ownerStart[c];
+            nL[row] = (unsigned char)cl_; nU[row] = (unsigned char)cu;
+            intraR[row] = (unsigned char)intra[c];
+            W = std::max(W, cl_ + cu);
+            row++;
+        }
+        sliceW[s] = W;
+        sliceEnt[s] = (int)ent;
+        ent += (long)W * LDU_WAVE;
+        if (ent > 2000000000L) return 0;
+    }
+    sliceRow[nCl] = row;
+    P->nEntries = ent + 1024;
+    {
+        // cluster-level ranges and, per level, the highest cluster level that holds an upper neighbour
+        P->levelStart.assign(P->nClusterLevels + 1, 0);
+        for (int s = 0; s < nCl; s++) P->levelStart[cLevel[order[s]] + 1]++;
+        for (int L = 0; L < P->nClusterLevels; L++) P->levelStart[L + 1] += P->levelStart[L];
+        P->upLevel.assign(P->nClusterLevels, 0);
+        for (int f = 0; f < nF; f++)
+        {
+            const int La = cLevel[cluster[l[f]]], Lb = cLevel[cluster[u[f]]];
+            if (Lb > P->upLevel[La]) P->upLevel[La] = Lb;
+        }
+        for (int L = 0; L < P->nClusterLevels; L++)
+        {
+            if (P->upLevel[L] < L) P->upLevel[L] = L;
+            if (L && P->upLevel[L] < P->upLevel[L - 1]) P->upLevel[L] = P->upLevel[L - 1];
+        }
+    }
+    // position of every (level-row, entry k) in the level-ordered SELL arrays
+    std::vector<int> lvlSliceOfRow(nC), lvlSliceRow, lvlSliceEnt;
+    {
+        lvlSliceRow.resize(a->nSlices + 1); lvlSliceEnt.resize(a->nSlices);
+        LDU_CHECK_HIP(hipMemcpy(lvlSliceRow.data(), a->d_sliceRow, sizeof(int) * (a->nSlices + 1), hipMemcpyDeviceToHost));
+        LDU_CHECK_HIP(hipMemcpy(lvlSliceEnt.data(), a->d_sliceEnt, sizeof(int) * a->nSlices, hipMemcpyDeviceToHost));
+        for (int s = 0; s < a->nSlices; s++)
+            for (int r = lvlSliceRow[s]; r < lvlSliceRow[s + 1]; r++) lvlSliceOfRow[r] = s;
+    }
+    std::vector<int> colF((size_t)P->nEntries, 0), colB((size_t)P->nEntries, 0), src((size_t)P->nEntries, 0);
+    for (int s = 0; s < nCl; s++)
+    {
+        const int id = order[s];
+        for (size_t i = 0; i < members[id].size(); i++)
+        {
+            const int c = members[id][i];
+            const int r = sliceRow[s] + (int)i;
+            const int lr = a->iperm[c];
+            const int ls = lvlSliceOfRow[lr];
+            const long lbase = (long)lvlSliceEnt[ls] + (lr - lvlSliceRow[ls]);
+            const long base = (long)sliceEnt[s] + (long)i;
+            int k = 0;
+            for (int j = a->losortStart[c]; j < a->losortStart[c + 1]; j++, k++)
+            {
+                const int nb = l[a->losort[j]];
+                colF[base + (long)k * LDU_WAVE] = crowOf[nb];
+                colB[base + (long)k * LDU_WAVE] = a->iperm[nb];
+                src[base + (long)k * LDU_WAVE] = (int)(lbase + (long)k * LDU_WAVE);
+            }
+            for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++, k++)
+            {
+                const int nb = u[f];
+                colF[base + (long)k * LDU_WAVE] = a->iperm[nb];
+                colB[base + (long)k * LDU_WAVE] = crowOf[nb];
+                src[base + (long)k * LDU_WAVE] = (int)(lbase + (long)k * LDU_WAVE);
+            }
+            for (; k < sliceW[s]; k++)
+            {
+                colF[base + (long)k * LDU_WAVE] = r; colB[base + (long)k * LDU_WAVE] = r;
+                src[base + (long)k * LDU_WAVE] = (int)lbase;
+            }
+            (void)r;
+        }
+    }
+    if (cl_upload(&P->d_sliceRow, sliceRow) || cl_upload(&P->d_sliceEnt, sliceEnt) || cl_upload(&P->d_sliceDepth, sliceDepth)
+        || cl_upload(&P->d_map, map) || cl_upload(&P->d_nL, nL) || cl_upload(&P->d_nU, nU) || cl_upload(&P->d_intra, intraR)
+        || cl_upload(&P->d_colF, colF) || cl_upload(&P->d_colB, colB) || cl_upload(&P->d_src, src))
+        return -1;
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
+    LDU_CHECK_HIP(hipMemset(P->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned)));
+    LDU_CHECK_HIP(hipMemset(P->d_ticket, 0, sizeof(unsigned)));
+    P->gen = a->ctx->p2pGen;
+    P->eligible = true;
+    if (getenv("LDU_VERBOSE"))
+        fprintf(stderr, "[ldugpu] cluster plan: %d cells -> %d clusters (avg %.1f cells, avg %.1f internal steps), "
+                        "%d cluster levels (dependency levels: %d)\n",
+                nC, nCl, (double)nC / std::max(1, nCl), P->avgDepth, P->nClusterLevels, a->nLevels);
+    return 0;
+}
+
+// ---------------------------------------------------------------- kernels
+
+__global__ void __launch_bounds__(CL_BLK)
+cl_convert_kernel(long n, const int* __restrict__ src, const double* __restrict__ in, double* __restrict__ out)
+{
+    for (long i = (long)blockIdx.x * CL_BLK + threadIdx.x; i < n; i += (long)gridDim.x * CL_BLK) out[i] = in[src[i]];
+}
+
+__device__ __forceinline__ void cl_store(uint4* G, int row, double v, unsigned tag)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    cl_u32x4 d;
+    d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
+    uint4* p = G + row;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+}
+
+__device__ __forceinline__ void cl_load3(const uint4* p0, const uint4* p1, const uint4* p2, cl_u32x4& g0,
+                                         cl_u32x4& g1, cl_u32x4& g2)
+{
+    asm volatile(
+        "global_load_dwordx4 %0, %3, off sc1\n\t"
+        "global_load_dwordx4 %1, %4, off sc1\n\t"
+        "global_load_dwordx4 %2, %5, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(g0), "=&v"(g1), "=&v"(g2)
+        : "v"(p0), "v"(p1), "v"(p2)
+        : "memory");
+}
+
+__device__ __forceinline__ double cl_value(const cl_u32x4& g)
+{
+    return __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
+}
+
+struct ClTab {
+    const int* sliceRow; const int* sliceEnt; const unsigned char* sliceDepth; const int* map;
+    const unsigned char* nL; const unsigned char* nU; const unsigned char* intra;
+    const int* colDep;      // dependency part in cluster rows, the other part in level rows
+};
+
+// MODE as SweepMode.  FWD modes: dependencies = lower part (entries 0..nl-1, ascending); BWD modes:
+// dependencies = upper part, DEscending (TRI_BWD) resp. ascending (GS_BWD, symGaussSeidelSmoother.C:178-205).
+template <int MODE, int ND>
+__device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, double* __restrict__ lds,
+                                           uint4* __restrict__ G, unsigned tag, volatile int* abortFlag,
+                                           double* __restrict__ w, const double* __restrict__ rhs,
+                                           const double* __restrict__ scale, const double* __restrict__ val,
+                                           const double* __restrict__ val2, double* __restrict__ aux)
+{
+    constexpr bool FWD = (MODE == SW_TRI_FWD || MODE == SW_RD || MODE == SW_GS_FWD);
+    const int row0 = T.sliceRow[s];
+    const int cnt = T.sliceRow[s + 1] - row0;
+    const int depth = T.sliceDepth[s];
+    const bool on = lane < cnt;
+    const int r = row0 + (on ? lane : 0);
+    const int lr = T.map[r];
+    const int nl = on ? T.nL[r] : 0, nu = on ? T.nU[r] : 0;
+    const int myLv = on ? (int)T.intra[r] : 255;
+    const long ent = (long)T.sliceEnt[s] + (on ? lane : 0);
+    const int nd = FWD ? nl : nu;            // dependencies
+    const int d0 = FWD ? 0 : nl;             // first dependency entry
+    // everything that does not depend on this sweep
+    int c[ND];
+    double v[ND], v2[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+    {
+        const bool need = k < nd;
+        const long e = ent + (long)(d0 + k) * LDU_WAVE;
+        c[k] = need ? T.colDep[e] : r;
+        v[k] = need ? val[e] : 0.0;
+        v2[k] = (MODE == SW_RD && need) ? val2[e] : 0.0;
+    }
+    double acc, dd = 1.0;
+    if (MODE == SW_TRI_FWD) acc = scale[lr] * rhs[lr];
+    else if (MODE == SW_TRI_BWD) acc = w[lr];
+    else if (MODE == SW_RD) acc = scale[lr];
+    else { acc = rhs[lr]; dd = scale[lr]; }
+    double xu[ND], vu[ND];
+    if (MODE == SW_GS_FWD)
+    {
+        // old values of the upper neighbours (level rows), loaded before anything of this sweep is written
+#pragma unroll
+        for (int k = 0; k < ND; k++)
+        {
+            const bool need = k < nu;
+            const long e = ent + (long)(nl + k) * LDU_WAVE;
+            vu[k] = need ? val[e] : 0.0;
+            xu[k] = need ? w[T.colDep[e]] : 0.0;
+        }
+    }
+    // external dependencies (other clusters): wait for all of them up front
+    double xe[ND];
+    bool internal[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) internal[k] = (k < nd) && (c[k] >= row0 && c[k] < row0 + cnt);
+#pragma unroll
+    for (int k0 = 0; k0 < ND; k0 += 3)
+    {
+        const bool e0 = (k0 < nd) && !internal[k0], e1 = (k0 + 1 < nd) && !internal[k0 + 1],
+                   e2 = (k0 + 2 < nd) && !internal[k0 + 2];
+        xe[k0] = 1.0; xe[k0 + 1] = 1.0; xe[k0 + 2] = 1.0;   // unused slots: finite, non-zero (coefficient 0)
+        if (__any(e0 | e1 | e2))
+        {
+            cl_u32x4 g0, g1, g2;
+            unsigned spins = 0;
+            for (;;)
+            {
+                cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], g0, g1, g2);
+                bool ok = true;
+                if (e0) ok &= (g0.y == tag) & (g0.w == tag);
+                if (e1) ok &= (g1.y == tag) & (g1.w == tag);
+                if (e2) ok &= (g2.y == tag) & (g2.w == tag);
+                if (ok) break;
+                if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (e0) xe[k0] = cl_value(g0);
+            if (e1) xe[k0 + 1] = cl_value(g1);
+            if (e2) xe[k0 + 2] = cl_value(g2);
+        }
+    }
+    // LDS image of what a row reads: slot i < 64 = value of cluster row i (written when it is computed),
+    // slot 64 + k*64 + lane = this lane's k-th dependency when it comes from outside (or is unused).
+    // Every lane then runs the same branch-free code in every step; only the rows of the step's internal
+    // level commit.  Unused dependencies have coefficient 0 and read the finite 1.0: acc - 0*1 == acc.
+    int slot[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+    {
+        slot[k] = internal[k] ? c[k] - row0 : LDU_WAVE + k * LDU_WAVE + lane;
+        lds[LDU_WAVE + k * LDU_WAVE + lane] = xe[k];
+    }
+    double pu[ND];
+    if (MODE == SW_GS_FWD)
+    {
+#pragma unroll
+        for (int k = 0; k < ND; k++) pu[k] = vu[k] * xu[k];   // 0*0 for unused entries
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int st = 0; st < depth; st++)
+    {
+        const int lv = FWD ? st : depth - 1 - st;
+        double t = acc;
+        if (MODE == SW_TRI_BWD)
+        {
+            // DICPreconditioner.C:119-122: owned faces in DEscending order
+#pragma unroll
+            for (int k = ND - 1; k >= 0; k--) t -= v[k] * lds[slot[k]];
+        }
+        else if (MODE == SW_RD)
+        {
+#pragma unroll
+            for (int k = 0; k < ND; k++) t -= (v2[k] * v[k]) / lds[slot[k]];
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < ND; k++) t -= v[k] * lds[slot[k]];
+        }
+        if (myLv == lv)
+        {
+            double out = t;
+            if (MODE == SW_GS_FWD)
+            {
+                if (aux) aux[lr] = t;
+#pragma unroll
+                for (int k = 0; k < ND; k++)
+                    if (k < nu) t -= pu[k];
+                out = t / dd;
+            }
+            else if (MODE == SW_GS_BWD) out = t / dd;
+            lds[lane] = out;
+            w[lr] = out;
+            cl_store(G, r, out, tag);
+        }
+        // LDS is in order within a wave: make this step's values visible to the next step
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int MODE, bool DESC, int ND>
+__global__ void __launch_bounds__(CL_BLK)
+sweep_cluster_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, uint4* G, unsigned tag,
+                     int* abortFlag, double* w, const double* rhs, const double* scale, const double* val,
+                     const double* val2, double* aux)
+{
+    __shared__ int s_chunk[2];
+    __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + CL_MAXD)];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    int nextT = 0;
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    for (int it = 0;; it++)
+    {
+        if (threadIdx.x == 0)
+        {
+            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            s_chunk[it & 1] = t;
+            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+        }
+        __syncthreads();
+        const int chunk = s_chunk[it & 1];
+        if (chunk >= nChunks) return;
+        const int si = chunk * CL_WPB + wave;
+        if (si < nSlices)
+            cl_cluster<MODE, ND>(T, DESC ? nSlices - 1 - si : si, lane, s_x[wave], G, tag, abortFlag, w, rhs, scale, val,
+                             val2, aux);
+    }
+}
+
+// level-layout value array -> cluster layout (cached until any coefficient array is rewritten)
+static const double* cluster_values(ldu_addr* a, const double* levelVal, hipStream_t s)
+{
+    if (!levelVal) return nullptr;
+    ClusterPlan* P = a->cluster;
+    ClusterPlan::Conv& C = P->conv[levelVal];
+    if (!C.d)
+        if (hipMalloc((void**)&C.d, sizeof(double) * (size_t)P->nEntries) != hipSuccess) return nullptr;
+    if (C.stamp != a->ctx->valStamp)
+    {
+        int grid = (int)std::min<long>((P->nEntries + CL_BLK - 1) / CL_BLK, 8192);
+        cl_convert_kernel<<<grid, CL_BLK, 0, s>>>(P->nEntries - 1024, P->d_src, levelVal, C.d);
+        C.stamp = a->ctx->valStamp;
+    }
+    return C.d;
+}
+
+template <int MODE, bool DESC>
+static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
+{
+    ldu_ctx* ctx = a->ctx;
+    ClusterPlan& P = *a->cluster;
+    const double* val = cluster_values(a, g.val, s);
+    const double* val2 = cluster_values(a, g.val2, s);
+    if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
+    constexpr bool FWD = (MODE == SW_TRI_FWD || MODE == SW_RD || MODE == SW_GS_FWD);
+    ClTab T{P.d_sliceRow, P.d_sliceEnt, P.d_sliceDepth, P.d_map, P.d_nL, P.d_nU, P.d_intra, FWD ? P.d_colF : P.d_colB};
+    const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
+    int grid = ctx->numCUs * ctx->clusterBlocksPerCU;
+    if (grid > nChunks) grid = nChunks;
+    if (grid < 1) grid = 1;
+    if (P.gen != ctx->p2pGen)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
+        P.ticketBase = 0;
+        P.gen = ctx->p2pGen;
+    }
+    P.epoch++;
+    if (P.epoch == 0) P.epoch = 1;
+    if (P.maxDep <= 3)
+        sweep_cluster_kernel<MODE, DESC, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticket, P.ticketBase,
+            P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
+    else
+        sweep_cluster_kernel<MODE, DESC, CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticket, P.ticketBase,
+            P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
+    P.ticketBase += (unsigned)(nChunks + grid);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static bool cluster_pays(const ldu_addr* a, int kind);
+
+// returns 1 when the cluster engine does not take this sweep
+int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->clusterEngine || a->nCells < ctx->clusterMinCells || g.lane != 0) return 1;
+    if (cluster_build(a) < 0) return -1;
+    if (!a->cluster->eligible) return 1;
+    if (!cluster_pays(a, (g.mode == SW_GS_FWD || g.mode == SW_GS_BWD) ? 1 : 0)) return 1;
+    switch (g.mode)
+    {
+    case SW_TRI_FWD: return launch_cluster<SW_TRI_FWD, false>(a, g, s);
+    case SW_TRI_BWD: return launch_cluster<SW_TRI_BWD, true>(a, g, s);
+    case SW_RD:      return launch_cluster<SW_RD, false>(a, g, s);
+    case SW_GS_FWD:  return launch_cluster<SW_GS_FWD, false>(a, g, s);
+    case SW_GS_BWD:  return launch_cluster<SW_GS_BWD, true>(a, g, s);
+    }
+    return 1;
+}
+
+// Does the cluster engine pay for this addressing?  Hand-offs: clusterLevels x (1.4 us + internal steps x S)
+// against levels x (1.4 us chip-wide | 1.0 us on narrow levels, where the slab engine runs).  S measured:
+// ~0.1 us per step for the triangular sweeps, ~0.2 (3 dependencies) / 0.25 (6) for GaussSeidel (division).
+// kind: 0 = triangular sweeps, 1 = GaussSeidel (single or pipelined)
+static bool cluster_pays(const ldu_addr* a, int kind)
+{
+    const ClusterPlan& P = *a->cluster;
+    if (a->ctx->clusterEngine > 1) return true;   // LDU_CLUSTER=2: forced
+    const double S = kind == 0 ? 0.1 : (P.maxDep <= 3 ? 0.2 : 0.25);
+    const double perLevel = (a->nSlabs > 0 && a->slabWidth <= (kind == 0 ? 24.0 : 16.0)) ? 1.0 : 1.4;
+    return P.nClusterLevels * (1.4 + P.avgDepth * S) < 0.85 * a->nLevels * perLevel;
+}
+
+bool k_cluster_active(ldu_addr* a)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->clusterEngine || !ctx->sweepP2P || a->nCells < ctx->clusterMinCells) return false;
+    if (cluster_build(a) < 0) return false;
+    return a->cluster->eligible && cluster_pays(a, 1);
+}
+
+// ---------------------------------------------------------------- k pipelined GaussSeidel sweeps on clusters
+// Same idea as sweep_p2p_gs_multi_kernel: sweep j+1 of a row needs sweep j+1's values of its lower
+// neighbours and sweep j's values of its upper neighbours, so sweep j+1 trails sweep j by the cluster-level
+// distance to the upper neighbours.  Tag tag0+j marks "value of sweep j"; only the last sweep writes psi.
+// A row's sweep-j value is still in its granule when its lower neighbours read it in sweep j+1: the row
+// itself cannot run sweep j+1 before those lower neighbours have published theirs.
+template <int ND>
+__device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict__ colUp, int s, int j, int k,
+                                           int lane, double* __restrict__ lds, uint4* __restrict__ G, unsigned tag0,
+                                           volatile int* abortFlag, double* __restrict__ psi,
+                                           const double* __restrict__ rhs, const double* __restrict__ diag,
+                                           const double* __restrict__ val)
+{
+    const int row0 = T.sliceRow[s];
+    const int cnt = T.sliceRow[s + 1] - row0;
+    const int depth = T.sliceDepth[s];
+    const bool on = lane < cnt;
+    const int r = row0 + (on ? lane : 0);
+    const int lr = T.map[r];
+    const int nl = on ? T.nL[r] : 0, nu = on ? T.nU[r] : 0;
+    const int myLv = on ? (int)T.intra[r] : 255;
+    const long ent = (long)T.sliceEnt[s] + (on ? lane : 0);
+    const unsigned tagNew = tag0 + (unsigned)j;
+    int c[ND], cu[ND];
+    double v[ND], vu[ND];
+#pragma unroll
+    for (int q = 0; q < ND; q++)
+    {
+        const long e = ent + (long)q * LDU_WAVE;
+        const long eu = ent + (long)(nl + q) * LDU_WAVE;
+        c[q] = q < nl ? T.colDep[e] : r;
+        v[q] = q < nl ? val[e] : 0.0;
+        // upper neighbours: level rows (old psi, sweep 0) or cluster rows (granules of the previous sweep)
+        cu[q] = q < nu ? (j == 0 ? T.colDep[eu] : colUp[eu]) : (j == 0 ? lr : r);
+        vu[q] = q < nu ? val[eu] : 0.0;
+    }
+    const double acc0 = rhs[lr];
+    const double dd = diag[lr];
+    double xu[ND];
+    if (j == 0)
+    {
+#pragma unroll
+        for (int q = 0; q < ND; q++) xu[q] = psi[cu[q]];
+    }
+    else
+    {
+        const unsigned t = tagNew - 1u;
+#pragma unroll
+        for (int k0 = 0; k0 < ND; k0 += 3)
+        {
+            xu[k0] = 0.0; xu[k0 + 1] = 0.0; xu[k0 + 2] = 0.0;
+            const bool e0 = k0 < nu, e1 = k0 + 1 < nu, e2 = k0 + 2 < nu;
+            if (__any(e0 | e1 | e2))
+            {
+                cl_u32x4 g0, g1, g2;
+                unsigned spins = 0;
+                for (;;)
+                {
+                    cl_load3(G + cu[k0], G + cu[k0 + 1], G + cu[k0 + 2], g0, g1, g2);
+                    bool ok = true;
+                    if (e0) ok &= (g0.y == t) & (g0.w == t);
+                    if (e1) ok &= (g1.y == t) & (g1.w == t);
+                    if (e2) ok &= (g2.y == t) & (g2.w == t);
+                    if (ok) break;
+                    if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (e0) xu[k0] = cl_value(g0);
+                if (e1) xu[k0 + 1] = cl_value(g1);
+                if (e2) xu[k0 + 2] = cl_value(g2);
+            }
+        }
+    }
+    double xe[ND];
+    bool internal[ND];
+#pragma unroll
+    for (int q = 0; q < ND; q++) internal[q] = (q < nl) && (c[q] >= row0 && c[q] < row0 + cnt);
+#pragma unroll
+    for (int k0 = 0; k0 < ND; k0 += 3)
+    {
+        const bool e0 = (k0 < nl) && !internal[k0], e1 = (k0 + 1 < nl) && !internal[k0 + 1],
+                   e2 = (k0 + 2 < nl) && !internal[k0 + 2];
+        xe[k0] = 1.0; xe[k0 + 1] = 1.0; xe[k0 + 2] = 1.0;
+        if (__any(e0 | e1 | e2))
+        {
+            cl_u32x4 g0, g1, g2;
+            unsigned spins = 0;
+            for (;;)
+            {
+                cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], g0, g1, g2);
+                bool ok = true;
+                if (e0) ok &= (g0.y == tagNew) & (g0.w == tagNew);
+                if (e1) ok &= (g1.y == tagNew) & (g1.w == tagNew);
+                if (e2) ok &= (g2.y == tagNew) & (g2.w == tagNew);
+                if (ok) break;
+                if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (e0) xe[k0] = cl_value(g0);
+            if (e1) xe[k0 + 1] = cl_value(g1);
+            if (e2) xe[k0 + 2] = cl_value(g2);
+        }
+    }
+    int slot[ND];
+    double pu[ND];
+#pragma unroll
+    for (int q = 0; q < ND; q++)
+    {
+        slot[q] = internal[q] ? c[q] - row0 : LDU_WAVE + q * LDU_WAVE + lane;
+        lds[LDU_WAVE + q * LDU_WAVE + lane] = xe[q];
+        pu[q] = vu[q] * xu[q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int st = 0; st < depth; st++)
+    {
+        double t = acc0;
+#pragma unroll
+        for (int q = 0; q < ND; q++) t -= v[q] * lds[slot[q]];
+        if (myLv == st)
+        {
+#pragma unroll
+            for (int q = 0; q < ND; q++)
+                if (q < nu) t -= pu[q];
+            const double out = t / dd;
+            lds[lane] = out;
+            if (j == k - 1) psi[lr] = out;
+            cl_store(G, r, out, tagNew);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int ND>
+__global__ void __launch_bounds__(CL_BLK)
+sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int* __restrict__ tasks, int nTasks,
+                              int nChunks, int k, unsigned* ticket, unsigned ticketBase, uint4* G, unsigned tag0,
+                              int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
+{
+    __shared__ int s_chunk[2];
+    __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + CL_MAXD)];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    int nextT = 0;
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    for (int it = 0;; it++)
+    {
+        if (threadIdx.x == 0)
+        {
+            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            s_chunk[it & 1] = t;
+            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+        }
+        __syncthreads();
+        const int chunk = s_chunk[it & 1];
+        if (chunk >= nChunks) return;
+        const int ti = chunk * CL_WPB + wave;
+        if (ti < nTasks)
+        {
+            const int task = tasks[ti];
+            cl_gs_task<ND>(T, colUp, task & 0x0fffffff, task >> 28, k, lane, s_x[wave], G, tag0, abortFlag, psi, rhs, diag,
+                       val);
+        }
+    }
+}
+
+// k pipelined GaussSeidel sweeps; returns 1 when the cluster engine does not take them
+int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* valA)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!k_cluster_active(a) || k < 1 || k > 7) return 1;
+    ClusterPlan& P = *a->cluster;
+    hipStream_t s = ctx->stream;
+    auto it = P.tasks.find(k);
+    if (it == P.tasks.end())
+    {
+        const int nLev = P.nClusterLevels;
+        std::vector<int> tasks;
+        tasks.reserve((size_t)k * P.nSlices);
+        std::vector<int> next(k, 0);
+        bool progress = true;
+        while (progress)
+        {
+            progress = false;
+            for (int j = 0; j < k; j++)
+            {
+                const int L = next[j];
+                if (L >= nLev) continue;
+                // sweep j may take cluster level L once sweep j-1 has emitted every level <= upLevel[L]
+                if (j > 0 && next[j - 1] <= P.upLevel[L]) continue;
+                for (int sl = P.levelStart[L]; sl < P.levelStart[L + 1]; sl++) tasks.push_back((j << 28) | sl);
+                next[j]++;
+                progress = true;
+            }
+        }
+        ClusterPlan::Tasks T;
+        T.n = (int)tasks.size();
+        LDU_CHECK_HIP(hipMalloc((void**)&T.d, sizeof(int) * (tasks.size() + 1)));
+        LDU_CHECK_HIP(hipMemcpy(T.d, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice));
+        it = P.tasks.emplace(k, T).first;
+    }
+    const double* val = cluster_values(a, valA, s);
+    if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
+    ClTab T{P.d_sliceRow, P.d_sliceEnt, P.d_sliceDepth, P.d_map, P.d_nL, P.d_nU, P.d_intra, P.d_colF};
+    const int nTasks = it->second.n;
+    const int nChunks = (nTasks + CL_WPB - 1) / CL_WPB;
+    int bpc = ctx->clusterBlocksPerCU * (k > 1 ? 2 : 1);
+    if (bpc > 4) bpc = 4;
+    int grid = ctx->numCUs * bpc;
+    if (grid > nChunks) grid = nChunks;
+    if (grid < 1) grid = 1;
+    if (P.gen != ctx->p2pGen)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
+        P.ticketBase = 0;
+        P.gen = ctx->p2pGen;
+    }
+    if (P.epoch > 0xffffff00u)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
+        P.epoch = 0;
+    }
+    const unsigned tag0 = P.epoch + 1;
+    P.epoch += (unsigned)k;
+    ctx->profStart(a, 4);
+    if (P.maxDep <= 3)
+        sweep_cluster_gs_multi_kernel<3><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
+            P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+    else
+        sweep_cluster_gs_multi_kernel<CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
+            P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+    ctx->profStop(a, 4);
+    P.ticketBase += (unsigned)(nChunks + grid);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}

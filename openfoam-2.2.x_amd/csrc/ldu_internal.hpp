@@ -36,6 +36,7 @@ void ldu_set_error(const std::string& msg);
     } while (0)
 
 struct ldu_comm_impl;  // RCCL wrapper (ldu_comm.cpp)
+struct ClusterPlan;    // ldu_cluster.hip
 #define LDU_PROF_NCAT 8
 
 // scalar slots on the device
@@ -66,6 +67,12 @@ struct ldu_ctx {
     int gsPipeline = 1;
     int gsPipelineMaxSkew = 4;       // pipeline sweeps only if upper neighbours are <= this many levels ahead              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
+    // cluster (row-blocking) sweep engine, ldu_cluster.hip
+    int clusterEngine = 1;           // LDU_CLUSTER=0: off
+    int clusterMinCells = 50000;     // LDU_CLUSTER_MIN
+    int clusterBlocksPerCU = 2;      // LDU_CLUSTER_BPC
+    int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
+    unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
     int smallMaxCells = 256;         // LDU_SMALL_MAX (<= 8192); measured: wins up to ~200 cells, loses above
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
@@ -188,6 +195,8 @@ struct ldu_addr {
     int* d_colX = nullptr;                 // [nEntries]
     unsigned char* d_xflag = nullptr;      // [nCells] 1 = has a neighbour in another slab
 
+    ClusterPlan* cluster = nullptr;        // secondary structure of the cluster sweep engine (lazy)
+
     // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
     struct GsTasks { int* d_tasks = nullptr; int n = 0; int* d_slabTasks = nullptr; int slabStart[9] = {0}; };
     std::map<int, GsTasks> gsTasks;
@@ -257,6 +266,10 @@ struct SweepArgs {
 int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
 int k_xcd_census(ldu_ctx* ctx);
+int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s);   // 1 = not taken
+bool k_cluster_active(ldu_addr* a);
+int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* valA);
+void cluster_free(ldu_addr* a);
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);

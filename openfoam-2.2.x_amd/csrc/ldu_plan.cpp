@@ -467,6 +467,7 @@ int plan_finalize_patches(ldu_addr* a)
 
 void plan_free(ldu_addr* a)
 {
+    cluster_free(a);
     for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
     a->graphs.clear();
     for (auto& kv : a->gsTasks)

@@ -199,7 +199,8 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         {
             const int k = left > 4 ? 4 : left;
             if (k == 1) break;   // a single remaining sweep: the plain engine below
-            const int rc = k_sweep_gs_multi(a, k, psi, source, m->d_diag, m->d_valA);
+            int rc = a->ctx->clusterMulti ? k_sweep_cluster_gs_multi(a, k, psi, source, m->d_diag, m->d_valA) : 1;
+            if (rc > 0) rc = k_sweep_gs_multi(a, k, psi, source, m->d_diag, m->d_valA);
             if (rc < 0) return -1;
             if (rc > 0) { pipelined = false; break; }   // DAG too skewed: sweep by sweep
             left -= k;

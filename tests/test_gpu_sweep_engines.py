@@ -1,5 +1,5 @@
 """GPU (-m gpu): every sweep engine variant must reproduce the oracle's sequential sweeps bit for bit:
-the single-workgroup LDS kernels of small matrices, the chip-wide point-to-point engine
+the cluster (row-blocking) engine, the single-wavefront LDS kernel of small matrices, the chip-wide point-to-point engine
 (LDU_P2P_SLABS=0), the XCD-slab engine with 1, 3 and 8 slabs
 (cross-slab dependencies through the write-through copies), pipelined GaussSeidel on both, and the
 level-kernel engine.  Cases: hex box (regular DAG), asymmetric box, irregular graph with wide rows."""
@@ -21,9 +21,13 @@ ENGINES = {
     "auto": {},
     "levels": {"LDU_SWEEP": "levels"},
     "nosmall": {"LDU_SMALL": "0"},
+    "cluster": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1"},
+    "cluster_bpc1": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1", "LDU_CLUSTER_BPC": "1"},
+    "nocluster": {"LDU_CLUSTER": "0"},
     "small8192": {"LDU_SMALL_MAX": "8192"},
 }
-KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX")
+KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
+        "LDU_CLUSTER_BPC")
 
 
 def _problems():
@@ -45,6 +49,9 @@ def _problems():
     p = cases.random_graph(5000, 11, 300, asym=True)   # rows wider than the 8-entry fast path
     p["psi"] = rng.randn(p["nCells"])
     out["graph_small"] = p
+    p = cases.random_graph(20000, 2, 60)   # irregular, <= 6 lower / upper neighbours: cluster-eligible
+    p["psi"] = rng.randn(p["nCells"])
+    out["graph_sparse"] = p
     p = cases.laplacian2d(1, 37)   # a chain: one row per level
     p["psi"] = rng.randn(p["nCells"])
     out["chain"] = p
