@@ -154,13 +154,19 @@ def main():
     if key in prof and prof[key]["count"]:
         ms = prof[key]["ms"] / prof[key]["count"]
         ach = per_launch * gs_bytes / (ms * 1e-3) / 1e9
-        kname = ("sweep_p2p_gs_multi_kernel: %d pipelined GaussSeidel sweeps of the finest level per launch"
-                 % per_launch) if key == "gs_multi" else \
-            "sweep_slab_kernel / sweep_p2p_kernel <SW_GS_FWD>: one GaussSeidel sweep of the rank's finest level"
+        eng = addr.sweep_engine(2 if key == "gs_multi" else 1)
+        kernels = {"chip-wide point-to-point": ("sweep_p2p_gs_multi_kernel", "sweep_p2p_kernel<SW_GS_FWD>"),
+                   "XCD slabs": ("sweep_slab_gs_multi_kernel", "sweep_slab_kernel<SW_GS_FWD>"),
+                   "clusters": ("sweep_cluster_gs_multi_kernel", "sweep_cluster_kernel<SW_GS_FWD>"),
+                   "single wavefront": ("gs_small_kernel", "gs_small_kernel"),
+                   "level kernels": ("sweep_level_kernel", "sweep_level_kernel")}[eng]
+        kname = ("%s (%s engine): %d pipelined GaussSeidel sweeps of the finest level per launch"
+                 % (kernels[0], eng, per_launch)) if key == "gs_multi" else \
+            "%s (%s engine): one GaussSeidel sweep of the rank's finest level" % (kernels[1], eng)
         traffic = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if key == "gs_multi" and n == 216 and world == 1:
+            if key == "gs_multi" and n == 216 and world == 1 and pj.get("kernel", "") == kernels[0]:
                 traffic = pj["bytes_per_launch"]   # separate rocprofv3 --pmc passes, see profiles/r01_pmc_traffic.md
         except Exception:
             pass

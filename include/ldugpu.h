@@ -102,6 +102,10 @@ int ldu_addr_finalize(ldu_addr* a);
 int ldu_addr_destroy(ldu_addr* a);
 /* Diagnostics: dependency levels of the triangular sweeps etc. */
 int ldu_addr_info(const ldu_addr* a, int32_t* nLevels, int32_t* nSlices, int64_t* nEntriesPadded);
+/* which sweep engine serves kind (0 triangular DIC/DILU sweeps, 1 one GaussSeidel sweep, 2 two pipelined
+ * GaussSeidel sweeps) on this addressing: 0 chip-wide point-to-point, 1 XCD slabs, 2 clusters, 3 single
+ * wavefront, 4 level kernels.  Measurement / test introspection. */
+int ldu_addr_sweep_engine(ldu_addr* a, int32_t kind);
 /* Face weights for the geometric agglomerator (faceAreaPairGAMGAgglomeration.C:48-73
  * computes them from Sf; the shim passes mag(cmptMultiply(Sf/sqrt(magSf),(1,1.01,1.02)))). */
 int ldu_addr_set_face_weights(ldu_addr* a, const double* faceWeights);

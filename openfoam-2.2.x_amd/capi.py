@@ -21,7 +21,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_addr_create", "ldu_addr_add_patch",
-    "ldu_addr_add_cyclic_patch", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
+    "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
     "ldu_gSumProd", "ldu_gSumMag", "ldu_precondition", "ldu_smooth", "ldu_solve", "ldu_gamg_levels",
@@ -173,6 +173,14 @@ class Addressing:
         _chk(lib().ldu_fv_linearUpwindCorrection(self.h, _ptr(_f64(phi)), _ptr(_f64(C3)), _ptr(_f64(Cf3)),
                                                  _ptr(_f64(grad3)), _ptr(out)))
         return out
+
+    ENGINES = ("chip-wide point-to-point", "XCD slabs", "clusters", "single wavefront", "level kernels")
+
+    def sweep_engine(self, kind):
+        rc = lib().ldu_addr_sweep_engine(self.h, int(kind))
+        if rc < 0:
+            _chk(rc)
+        return self.ENGINES[rc]
 
     def info(self):
         nl, ns, ne = C.c_int32(), C.c_int32(), C.c_int64()

@@ -139,12 +139,14 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->fuseRows = atoi(e);
     e = getenv("LDU_CLUSTER");
     if (e) c->clusterEngine = atoi(e);
+    e = getenv("LDU_CLUSTER_BPC_MULTI");
+    if (e && atoi(e) > 0) c->clusterBlocksPerCUMulti = atoi(e);
     e = getenv("LDU_CLUSTER_MULTI");
     if (e) c->clusterMulti = atoi(e);
     e = getenv("LDU_CLUSTER_MIN");
     if (e) c->clusterMinCells = atoi(e);
     e = getenv("LDU_CLUSTER_BPC");
-    if (e && atoi(e) > 0) c->clusterBlocksPerCU = atoi(e);
+    if (e && atoi(e) > 0) { c->clusterBlocksPerCU = atoi(e); c->clusterBpcForced = 1; }
     e = getenv("LDU_SMALL");
     if (e) c->smallKernels = atoi(e);
     e = getenv("LDU_SMALL_MAX");
@@ -229,6 +231,12 @@ int ldu_addr_add_patch(ldu_addr* a, int32_t n, const int32_t* faceCells, int32_t
     a->patches.push_back(p);
     a->finalized = false;
     return 0;
+}
+
+int ldu_addr_sweep_engine(ldu_addr* a, int32_t kind)
+{
+    if (kind < 0 || kind > 2) { ldu_set_error("ldu_addr_sweep_engine: kind must be 0..2"); return -2; }
+    return k_engine_of(a, kind);
 }
 
 int ldu_addr_add_cyclic_patch(ldu_addr* a, int32_t n, const int32_t* faceCells, int32_t nbrPatch)

@@ -104,14 +104,19 @@ static int cluster_build(ldu_addr* a)
     // ---- greedy clustering in a topological order
     std::vector<int> indeg(nC, 0), cluster(nC, -1), intra(nC, 0);
     for (int f = 0; f < nF; f++) indeg[u[f]]++;
-    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
-    for (int c = 0; c < nC; c++) if (!indeg[c]) ready.push(c);
+    // seeds in (dependency level, index) order: the clusters are created along the wavefront, so the
+    // fragments left over where blobs do not tile (mesh dimensions that are no multiple of the blob size)
+    // depend on their neighbours in parallel instead of forming one serial chain (54^3 box: 51 cluster
+    // levels instead of 95 with index-ordered seeds; 40 would be ideal)
+    typedef std::pair<int, int> Seed;
+    std::priority_queue<Seed, std::vector<Seed>, std::greater<Seed>> ready;
+    for (int c = 0; c < nC; c++) if (!indeg[c]) ready.push(Seed(a->level[c], c));
     std::vector<std::vector<int>> members;
     std::vector<int> cLevel, cDepth;
     std::vector<int> cand;
     while (!ready.empty())
     {
-        const int seed = ready.top(); ready.pop();
+        const int seed = ready.top().second; ready.pop();
         if (cluster[seed] >= 0) continue;
         const int id = (int)members.size();
         members.emplace_back();
@@ -145,7 +150,7 @@ static int cluster_build(ldu_addr* a)
             for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++)
                 if (--indeg[u[f]] == 0) cand.push_back(u[f]);
         }
-        for (int c : cand) ready.push(c);
+        for (int c : cand) ready.push(Seed(a->level[c], c));
         cLevel.push_back(lev);
         cDepth.push_back(depth);
     }
@@ -407,6 +412,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
         for (int k = 0; k < ND; k++) pu[k] = vu[k] * xu[k];   // 0*0 for unused entries
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double res = 0.0, auxv = 0.0;
     for (int st = 0; st < depth; st++)
     {
         const int lv = FWD ? st : depth - 1 - st;
@@ -432,7 +438,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
             double out = t;
             if (MODE == SW_GS_FWD)
             {
-                if (aux) aux[lr] = t;
+                auxv = t;
 #pragma unroll
                 for (int k = 0; k < ND; k++)
                     if (k < nu) t -= pu[k];
@@ -440,11 +446,19 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
             }
             else if (MODE == SW_GS_BWD) out = t / dd;
             lds[lane] = out;
-            w[lr] = out;
-            cl_store(G, r, out, tag);
+            res = out;
         }
         // LDS is in order within a wave: make this step's values visible to the next step
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // publish the whole cluster at once: one coalesced granule store instead of a partial-line store per
+    // step (PMC: 1.9x write amplification before).  Nothing is lost on the critical path: a consumer
+    // cluster waits for ALL its external rows, and the last of them finishes in the last step anyway.
+    if (on)
+    {
+        if (MODE == SW_GS_FWD && aux) aux[lr] = auxv;
+        w[lr] = res;
+        cl_store(G, r, res, tag);
     }
 }
 
@@ -506,7 +520,11 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     constexpr bool FWD = (MODE == SW_TRI_FWD || MODE == SW_RD || MODE == SW_GS_FWD);
     ClTab T{P.d_sliceRow, P.d_sliceEnt, P.d_sliceDepth, P.d_map, P.d_nL, P.d_nU, P.d_intra, FWD ? P.d_colF : P.d_colB};
     const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
-    int grid = ctx->numCUs * ctx->clusterBlocksPerCU;
+    // one workgroup per CU while a cluster level holds few clusters (fewer waiting waves: faster hand-offs),
+    // two when it is wide (tools/det_probe.py: 64^3 .104 / .114 ms, 216^3 .763 / .603 ms at 1 / 2 per CU)
+    int bpc = ctx->clusterBlocksPerCU;
+    if (!ctx->clusterBpcForced && P.nSlices < 150 * P.nClusterLevels) bpc = 1;
+    int grid = ctx->numCUs * bpc;
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
     if (P.gen != ctx->p2pGen)
@@ -683,6 +701,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
         pu[q] = vu[q] * xu[q];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double res = 0.0;
     for (int st = 0; st < depth; st++)
     {
         double t = acc0;
@@ -695,10 +714,14 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                 if (q < nu) t -= pu[q];
             const double out = t / dd;
             lds[lane] = out;
-            if (j == k - 1) psi[lr] = out;
-            cl_store(G, r, out, tagNew);
+            res = out;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (on)
+    {
+        if (j == k - 1) psi[lr] = res;
+        cl_store(G, r, res, tagNew);
     }
 }
 
@@ -775,8 +798,7 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     ClTab T{P.d_sliceRow, P.d_sliceEnt, P.d_sliceDepth, P.d_map, P.d_nL, P.d_nU, P.d_intra, P.d_colF};
     const int nTasks = it->second.n;
     const int nChunks = (nTasks + CL_WPB - 1) / CL_WPB;
-    int bpc = ctx->clusterBlocksPerCU * (k > 1 ? 2 : 1);
-    if (bpc > 4) bpc = 4;
+    int bpc = ctx->clusterBlocksPerCUMulti;
     int grid = ctx->numCUs * bpc;
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
@@ -804,4 +826,12 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     P.ticketBase += (unsigned)(nChunks + grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+bool k_cluster_kind_active(ldu_addr* a, int kind)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->clusterEngine || !ctx->sweepP2P || a->nCells < ctx->clusterMinCells) return false;
+    if (cluster_build(a) < 0) return false;
+    return a->cluster->eligible && cluster_pays(a, kind == 0 ? 0 : 1);
 }

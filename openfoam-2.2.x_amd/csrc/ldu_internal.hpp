@@ -71,6 +71,8 @@ struct ldu_ctx {
     int clusterEngine = 1;           // LDU_CLUSTER=0: off
     int clusterMinCells = 50000;     // LDU_CLUSTER_MIN
     int clusterBlocksPerCU = 2;      // LDU_CLUSTER_BPC
+    int clusterBlocksPerCUMulti = 2; // LDU_CLUSTER_BPC_MULTI (pipelined sweeps)
+    int clusterBpcForced = 0;
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
@@ -268,6 +270,8 @@ int k_set_p2p_sleep(int n);
 int k_xcd_census(ldu_ctx* ctx);
 int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s);   // 1 = not taken
 bool k_cluster_active(ldu_addr* a);
+bool k_cluster_kind_active(ldu_addr* a, int kind);
+int k_engine_of(ldu_addr* a, int kind);
 int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* valA);
 void cluster_free(ldu_addr* a);
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,

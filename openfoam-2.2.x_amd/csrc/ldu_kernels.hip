@@ -945,6 +945,18 @@ static bool use_slab(const ldu_addr* a, int kind, int k = 1)
     return a->nSlabs == 1 && k * a->slabWidth <= 10.0;
 }
 
+// which engine serves a sweep kind on this addressing (introspection for bench.py / tests):
+// 0 chip-wide point-to-point, 1 XCD slabs, 2 clusters, 3 single wavefront (tiny), 4 level kernels
+int k_engine_of(ldu_addr* a, int kind /* 0 triangular, 1 one GaussSeidel sweep, 2 two pipelined sweeps */)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->sweepP2P) return 4;
+    if (kind >= 1 && ctx->smallKernels && a->nCells <= ctx->smallMaxCells && a->maxRowWidth <= 16 && !a->nPatchFaces)
+        return 3;
+    if (kind == 2 ? (ctx->clusterMulti && k_cluster_active(a)) : k_cluster_kind_active(a, kind)) return 2;
+    return use_slab(a, kind, 2) ? 1 : 0;
+}
+
 // per-launch part of SlabCtl: flips the ticket parity (this launch's counters were zeroed by the
 // previous launch on this lane, or by the allocation)
 static void slab_ctl(ldu_addr* a, ldu_addr::P2PLane& P, SlabCtl& C)

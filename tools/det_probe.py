@@ -26,7 +26,7 @@ import json
 CFG = json.loads(os.environ.get("PROBE_CFGS", "{}")) or {"chip": {"LDU_P2P_SLABS": "0"}, "auto": {}}
 for name, env in CFG.items():
     for k in ("LDU_P2P_BPC", "LDU_P2P_SLABS", "LDU_P2P_PROXY", "LDU_P2P_SLEEP", "LDU_P2P_MAXBPC", "LDU_CLUSTER",
-              "LDU_CLUSTER_MIN", "LDU_CLUSTER_BPC"):
+              "LDU_CLUSTER_MIN", "LDU_CLUSTER_BPC", "LDU_CLUSTER_BPC_MULTI"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ctx = capi.Context(0)
