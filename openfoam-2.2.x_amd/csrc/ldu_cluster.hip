@@ -51,6 +51,12 @@ struct ClusterPlan {
     unsigned ticketBase = 0;
     unsigned epoch = 0;
     int gen = 0;
+    // second lane: a concurrent sweep of the same addressing on the second stream (PBiCG's transposed system)
+    uint4* d_granule1 = nullptr;
+    unsigned* d_ticket1 = nullptr;
+    unsigned ticketBase1 = 0;
+    unsigned epoch1 = 0;
+    int gen1 = 0;
     std::vector<int> levelStart;      // [nClusterLevels+1] clusters of one cluster level are contiguous
     std::vector<int> upLevel;         // [nClusterLevels] running max of the cluster level holding an upper neighbour
     struct Tasks { int* d = nullptr; int n = 0; };
@@ -73,7 +79,7 @@ void cluster_free(ldu_addr* a)
     ClusterPlan* P = a->cluster;
     if (!P) return;
     void* ptrs[] = {P->d_sliceRow, P->d_sliceEnt, P->d_sliceDepth, P->d_map, P->d_nL, P->d_nU, P->d_intra,
-                    P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket};
+                    P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket, P->d_granule1, P->d_ticket1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : P->conv) if (kv.second.d) (void)hipFree(kv.second.d);
     for (auto& kv : P->tasks) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -527,21 +533,38 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     int grid = ctx->numCUs * bpc;
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
-    if (P.gen != ctx->p2pGen)
+    uint4* G = P.d_granule;
+    unsigned* ticket = P.d_ticket;
+    unsigned* base = &P.ticketBase;
+    unsigned* epoch = &P.epoch;
+    int* gen = &P.gen;
+    if (g.lane == 1)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
-        P.ticketBase = 0;
-        P.gen = ctx->p2pGen;
+        if (!P.d_granule1)
+        {
+            LDU_CHECK_HIP(hipMalloc((void**)&P.d_granule1, sizeof(uint4) * (size_t)(a->nCells + 1)));
+            LDU_CHECK_HIP(hipMemset(P.d_granule1, 0, sizeof(uint4) * (size_t)(a->nCells + 1)));
+            LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticket1, sizeof(unsigned)));
+            LDU_CHECK_HIP(hipMemset(P.d_ticket1, 0, sizeof(unsigned)));
+            P.gen1 = ctx->p2pGen;
+        }
+        G = P.d_granule1; ticket = P.d_ticket1; base = &P.ticketBase1; epoch = &P.epoch1; gen = &P.gen1;
     }
-    P.epoch++;
-    if (P.epoch == 0) P.epoch = 1;
+    if (*gen != ctx->p2pGen)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), s));
+        *base = 0;
+        *gen = ctx->p2pGen;
+    }
+    (*epoch)++;
+    if (*epoch == 0) *epoch = 1;
     if (P.maxDep <= 3)
-        sweep_cluster_kernel<MODE, DESC, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticket, P.ticketBase,
-            P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
+        sweep_cluster_kernel<MODE, DESC, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, ticket, *base,
+            G, *epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
     else
-        sweep_cluster_kernel<MODE, DESC, CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticket, P.ticketBase,
-            P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
-    P.ticketBase += (unsigned)(nChunks + grid);
+        sweep_cluster_kernel<MODE, DESC, CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, ticket, *base,
+            G, *epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
+    *base += (unsigned)(nChunks + grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -552,7 +575,7 @@ static bool cluster_pays(const ldu_addr* a, int kind);
 int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
-    if (!ctx->clusterEngine || a->nCells < ctx->clusterMinCells || g.lane != 0) return 1;
+    if (!ctx->clusterEngine || a->nCells < ctx->clusterMinCells || g.lane > 1) return 1;
     if (cluster_build(a) < 0) return -1;
     if (!a->cluster->eligible) return 1;
     if (!cluster_pays(a, (g.mode == SW_GS_FWD || g.mode == SW_GS_BWD) ? 1 : 0)) return 1;
