@@ -593,11 +593,14 @@ int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 // Does the cluster engine pay for this addressing?  Hand-offs: clusterLevels x (1.4 us + internal steps x S)
 // against levels x (1.4 us chip-wide | 1.0 us on narrow levels, where the slab engine runs).  S measured:
 // ~0.1 us per step for the triangular sweeps, ~0.2 (3 dependencies) / 0.25 (6) for GaussSeidel (division).
-// kind: 0 = triangular sweeps, 1 = GaussSeidel (single or pipelined)
+// kind: 0 = triangular sweeps, 1 = one GaussSeidel sweep, 2 = pipelined GaussSeidel sweeps.
+// Pipelined sweeps: with k sweeps in flight the level engines cost ~1.8-2.3 us per level, the cluster engine
+// ~4-5 us per cluster level (GAMG hierarchy of the 216^3 box: wins at 2.6x fewer levels, loses at 1.8x).
 static bool cluster_pays(const ldu_addr* a, int kind)
 {
     const ClusterPlan& P = *a->cluster;
     if (a->ctx->clusterEngine > 1) return true;   // LDU_CLUSTER=2: forced
+    if (kind == 2) return 2.4 * P.nClusterLevels <= a->nLevels;
     const double S = kind == 0 ? 0.1 : (P.maxDep <= 3 ? 0.2 : 0.25);
     const double perLevel = (a->nSlabs > 0 && a->slabWidth <= (kind == 0 ? 24.0 : 16.0)) ? 1.0 : 1.4;
     return P.nClusterLevels * (1.4 + P.avgDepth * S) < 0.85 * a->nLevels * perLevel;
@@ -608,7 +611,7 @@ bool k_cluster_active(ldu_addr* a)
     ldu_ctx* ctx = a->ctx;
     if (!ctx->clusterEngine || !ctx->sweepP2P || a->nCells < ctx->clusterMinCells) return false;
     if (cluster_build(a) < 0) return false;
-    return a->cluster->eligible && cluster_pays(a, 1);
+    return a->cluster->eligible && cluster_pays(a, 2);
 }
 
 // ---------------------------------------------------------------- k pipelined GaussSeidel sweeps on clusters
