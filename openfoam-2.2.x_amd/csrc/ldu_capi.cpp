@@ -121,8 +121,6 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->p2pGate = atoi(e);
     e = getenv("LDU_DUAL_STREAM");
     if (e) c->dualStream = atoi(e);
-    e = getenv("LDU_GS_FAST");
-    if (e) c->gsFast = atoi(e);
     e = getenv("LDU_GS_MAXSKEW");
     if (e) c->gsPipelineMaxSkew = atoi(e);
     e = getenv("LDU_GS_PIPELINE");
@@ -151,8 +149,6 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->smallKernels = atoi(e);
     e = getenv("LDU_SMALL_MAX");
     if (e) c->smallMaxCells = std::min(atoi(e), 8192);
-    e = getenv("LDU_P2P_PROXY");
-    if (e) k_set_p2p_proxy(atoi(e));
     e = getenv("LDU_P2P_SLABS");
     if (e) c->p2pSlabs = atoi(e);
     if (c->sweepP2P && c->p2pSlabs != 0 && k_xcd_census(c)) return -1;

@@ -62,7 +62,6 @@ struct ldu_ctx {
     int sweepP2P = 1;
     int p2pGate = 0;                 // slice-completion gate before granule polling (measured slower: off)
     int p2pTrace = 0;                // diagnostic kernels with per-slice tracing
-    int gsFast = 0;                  // software-pipelined GaussSeidel task engine (measured: no gain, off)
     int dualStream = 1;              // PBiCG: A system and transposed system on two streams
     int gsPipeline = 1;
     int gsPipelineMaxSkew = 4;       // pipeline sweeps only if upper neighbours are <= this many levels ahead              // pipeline consecutive GaussSeidel sweeps in one launch
@@ -277,7 +276,6 @@ void cluster_free(ldu_addr* a);
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
-int k_set_p2p_proxy(int n);
 int k_set_p2p_backoff(unsigned n);
 int k_read_p2p_dbg(int* out);
 int k_read_p2p_dbg_records(int* out);

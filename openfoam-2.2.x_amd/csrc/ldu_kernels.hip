@@ -562,35 +562,6 @@ __device__ __forceinline__ double granule_value(const u32x4& g)
     return __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
 }
 
-// Slab engine: same-XCD polls are L2 hits, so hundreds of waiting waves polling 4 KB each per round
-// saturate the XCD's L2 request bandwidth and slow the very hand-offs they wait for.  A waiting
-// wave therefore first watches ONE granule with ONE lane (its rows' dependencies sit in the same
-// level and complete within about one hand-off of each other) and only then polls all of them.
-__device__ int g_p2p_proxy = 0;   // measured: one extra L2 round trip per level, no gain (off)
-int k_set_p2p_proxy(int n)
-{
-    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_proxy), &n, sizeof(int)));
-    return 0;
-}
-__device__ __forceinline__ void proxy_wait(const uint4* p, unsigned tag, bool has, volatile int* abortFlag)
-{
-    const unsigned long long m = __ballot(has);
-    if (!m || !g_p2p_proxy) return;
-    const int leader = __ffsll((long long)m) - 1;
-    if ((int)(threadIdx.x & 63) == leader)
-    {
-        unsigned spins = 0;
-        for (;;)
-        {
-            u32x4 g;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
-            if (g.y == tag && g.w == tag) break;
-            if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) break;   // the full poll reports it
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-}
-
 // acc -= sum_{i=0..n-1} val[e(i)] * (value of row col[e(i)] published in THIS sweep), in order;
 // entry index k(i) = first + i*step.  OP = 0: acc -= v*x ; OP = 1: acc -= (v2*v)/x  (SW_RD)
 template <int OP, bool DIAG = false, bool SLAB = false>
@@ -638,7 +609,6 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             }
             waitEst.gateSlice = -1;
         }
-        if (SLAB && i0 == 0) proxy_wait(gp[0], tag, n > 0, abortFlag);
         u32x4 g0, g1, g2, g3;
         unsigned spins = 0;
         const int sleepN = g_p2p_sleep;
@@ -1043,7 +1013,6 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
     const uint4* gp[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
-    if (SLAB && BASE == 0) proxy_wait(gp[0], t, nu > 0, abortFlag);
     u32x4 g0, g1, g2, g3;
     unsigned spins = 0;
     for (;;)
@@ -1224,192 +1193,6 @@ sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0
             p2p_gs_task<true>(T, task & 0x0fffffff, task >> 28, k, lane, G, C.X, C.xflag, tag0, abortFlag, psi,
                               rhs, diag, val, waitEst);
         }
-    }
-}
-
-// ---- fast path: software-pipelined GaussSeidel task engine ------------------------------------
-// Trace of the generic engine (tools/p2p_trace.py, 216^3): a wave spends 2.9 us per slice in three
-// DEPENDENT load round trips (ticket -> slice meta -> nL/nU -> col/val) before it can even start
-// polling, and the sweep is throughput-bound by waves/(time per slice) on the large levels.  Here
-//   * the next ticket's slice meta is loaded while the current slice is processed,
-//   * the first 8 entries of a row are loaded unconditionally (entry arrays are padded), so
-//     nL/nU, rhs, diag, columns and coefficients are ONE round trip,
-// which leaves ticket->poll = 1 round trip.  Rows with nL > 4 or nL+nU > 8 take the generic path.
-struct SliceMeta { int row, cnt, ent, W; };
-
-__device__ __forceinline__ void gs_load_task(const SliceTab& T, const int* __restrict__ tasks, int nTasks,
-                                             int nChunks, int chunk, int wave, int& task, SliceMeta& M)
-{
-    task = -1;
-    if (chunk >= nChunks) return;
-    const int ti = chunk * P2P_CHUNK + wave;
-    if (ti >= nTasks) return;
-    task = tasks ? tasks[ti] : ti;
-    if (task < 0) return;
-    const int s = task & 0x0fffffff;
-    M.row = T.sliceRow[s];
-    M.cnt = T.sliceCnt[s];
-    M.ent = T.sliceEnt[s];
-    M.W = T.sliceW[s];
-}
-
-__device__ __forceinline__ void gs_task_fast(const SliceTab& T, const SliceMeta& M, int j, int k, int lane,
-                                             uint4* __restrict__ G, unsigned tag0,
-                                             volatile int* abortFlag, double* __restrict__ psi,
-                                             const double* __restrict__ rhs,
-                                             const double* __restrict__ diag,
-                                             const double* __restrict__ val)
-{
-    if (lane >= M.cnt) return;
-    const int r = M.row + lane;
-    const long ent = (long)M.ent + lane;
-    // one round trip: everything that depends only on (row, ent)
-    const int nl = T.nL[r];
-    const int nu = T.nU[r];
-    double acc = rhs[r];
-    const double d = diag[r];
-    int c[8];
-    double v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-    {
-        const long e = ent + (long)q * LDU_WAVE;
-        c[q] = T.col[e];
-        v[q] = val[e];
-    }
-    const int n = nl + nu;
-#pragma unroll
-    for (int q = 0; q < 8; q++) c[q] = q < n ? c[q] : r;   // padding entries: harmless self address
-    const unsigned tagNew = tag0 + (unsigned)j;
-    double xo[8];
-    if (j == 0)
-    {
-        // old values of the upper neighbours: plain loads (values from before this launch)
-#pragma unroll
-        for (int q = 0; q < 8; q++) xo[q] = psi[c[q]];
-    }
-    else
-    {
-        // previous sweep's values (published long ago: that sweep runs ahead of this one)
-        u32x4 g0, g1, g2, g3, g4, g5, g6, g7;
-        unsigned spins = 0;
-        const unsigned t = tagNew - 1u;
-        for (;;)
-        {
-            granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
-            granule_load4(G + c[4], G + c[5], G + c[6], G + c[7], g4, g5, g6, g7);
-            bool ok = true;
-            if (0 >= nl && 0 < n) ok &= (g0.y == t) & (g0.w == t);
-            if (1 >= nl && 1 < n) ok &= (g1.y == t) & (g1.w == t);
-            if (2 >= nl && 2 < n) ok &= (g2.y == t) & (g2.w == t);
-            if (3 >= nl && 3 < n) ok &= (g3.y == t) & (g3.w == t);
-            if (4 >= nl && 4 < n) ok &= (g4.y == t) & (g4.w == t);
-            if (5 >= nl && 5 < n) ok &= (g5.y == t) & (g5.w == t);
-            if (6 >= nl && 6 < n) ok &= (g6.y == t) & (g6.w == t);
-            if (7 >= nl && 7 < n) ok &= (g7.y == t) & (g7.w == t);
-            if (ok) break;
-            if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
-            {
-                *abortFlag = 1;
-                return;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        xo[0] = granule_value(g0); xo[1] = granule_value(g1); xo[2] = granule_value(g2);
-        xo[3] = granule_value(g3); xo[4] = granule_value(g4); xo[5] = granule_value(g5);
-        xo[6] = granule_value(g6); xo[7] = granule_value(g7);
-    }
-    // new values of the lower neighbours (entries 0..nl-1, nl <= 4): the critical path
-    {
-        u32x4 g0, g1, g2, g3;
-        unsigned spins = 0;
-        if (nl > 0)
-        {
-            for (;;)
-            {
-                granule_load4(G + c[0], G + c[1], G + c[2], G + c[3], g0, g1, g2, g3);
-                bool ok = true;
-                if (0 < nl) ok &= (g0.y == tagNew) & (g0.w == tagNew);
-                if (1 < nl) ok &= (g1.y == tagNew) & (g1.w == tagNew);
-                if (2 < nl) ok &= (g2.y == tagNew) & (g2.w == tagNew);
-                if (3 < nl) ok &= (g3.y == tagNew) & (g3.w == tagNew);
-                if (ok) break;
-                if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
-                {
-                    *abortFlag = 1;
-                    return;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (0 < nl) acc -= v[0] * granule_value(g0);
-            if (1 < nl) acc -= v[1] * granule_value(g1);
-            if (2 < nl) acc -= v[2] * granule_value(g2);
-            if (3 < nl) acc -= v[3] * granule_value(g3);
-        }
-    }
-    // upper part in face order (GaussSeidelSmoother.C:160-163)
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-        if (q >= nl && q < n) acc -= v[q] * xo[q];
-    const double out = acc / d;
-    if (j == k - 1) psi[r] = out;
-    granule_store(G, r, out, tagNew);
-}
-
-__global__ void __launch_bounds__(P2P_BLK)
-sweep_p2p_gs_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
-                    unsigned* ticket, unsigned ticketBase, uint4* G, unsigned tag0, int* abortFlag,
-                    double* psi, const double* rhs, const double* diag, const double* val)
-{
-    __shared__ int s_chunk[2];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    P2PStat waitEst = {0, 0, 0, -1, nullptr};
-    int nextT = 0x7fffffff;
-    if (threadIdx.x == 0)
-    {
-        const int a0 = (int)(atomicAdd(ticket, 1u) - ticketBase);
-        s_chunk[0] = (*(volatile int*)abortFlag) ? 0x7fffffff : a0;
-        if (a0 < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
-    }
-    __syncthreads();
-    int cur = s_chunk[0];
-    int task;
-    SliceMeta M;
-    gs_load_task(T, tasks, nTasks, nChunks, cur, wave, task, M);
-    for (int it = 0;; it++)
-    {
-        if (cur >= nChunks) return;
-        if (threadIdx.x == 0)
-        {
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
-            s_chunk[(it + 1) & 1] = t;
-            nextT = 0x7fffffff;
-            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
-        }
-        __syncthreads();
-        const int nxt = s_chunk[(it + 1) & 1];
-        int taskN;
-        SliceMeta MN;
-        gs_load_task(T, tasks, nTasks, nChunks, nxt, wave, taskN, MN);   // in flight during this slice
-        if (task >= 0)
-        {
-            const int s = task & 0x0fffffff, j = task >> 28;
-            // wave-uniform choice: all rows of the slice fit the 8-entry / 4-lower fast path?
-            bool fits = true;
-            if (lane < M.cnt)
-            {
-                const int r = M.row + lane;
-                fits = (T.nL[r] <= 4) && ((int)T.nL[r] + (int)T.nU[r] <= 8);
-            }
-            if (M.W <= 8 && __all(fits))
-                gs_task_fast(T, M, j, k, lane, G, tag0, abortFlag, psi, rhs, diag, val);
-            else
-                p2p_gs_task<false>(T, s, j, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst);
-        }
-        cur = nxt;
-        task = taskN;
-        M = MN;
     }
 }
 
@@ -1685,11 +1468,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         LDU_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    if (ctx->gsFast)
-        sweep_p2p_gs_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
-            P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
-    else
-        sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
+    sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
             P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     ctx->profStop(a, 4);
     P.ticketBase += (unsigned)(nChunks + grid);

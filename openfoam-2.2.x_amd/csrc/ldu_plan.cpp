@@ -66,7 +66,7 @@ static int choose_slabs(const ldu_addr* a, std::vector<int>& slabCell)
     const ldu_ctx* ctx = a->ctx;
     const int nC = a->nCells;
     slabCell.clear();
-    if (!ctx->sweepP2P || ctx->p2pSlabs == 0 || ctx->nXcd <= 0 || ctx->p2pGate || ctx->gsFast || nC == 0)
+    if (!ctx->sweepP2P || ctx->p2pSlabs == 0 || ctx->nXcd <= 0 || ctx->p2pGate || nC == 0)
         return 0;
     const int wavesPerXcd = std::max(1, ctx->numCUs / ctx->nXcd) * ctx->p2pBlocksPerCU * 4;
     int S;
