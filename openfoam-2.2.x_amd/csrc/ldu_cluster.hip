@@ -24,7 +24,7 @@
 
 #define CL_BLK 256
 #define CL_WPB (CL_BLK / LDU_WAVE)
-#define CL_MAXD 6      // dependencies (lower resp. upper neighbours) per row held in registers
+#define CL_MAXD 12     // dependencies (lower resp. upper neighbours) per row held in registers (variants 3 / 6 / 12)
 #define CL_SPIN_LIMIT (1u << 22)
 
 typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
@@ -561,6 +561,9 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     if (P.maxDep <= 3)
         sweep_cluster_kernel<MODE, DESC, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, ticket, *base,
             G, *epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
+    else if (P.maxDep <= 6)
+        sweep_cluster_kernel<MODE, DESC, 6><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, ticket, *base,
+            G, *epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
     else
         sweep_cluster_kernel<MODE, DESC, CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, ticket, *base,
             G, *epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
@@ -601,7 +604,7 @@ static bool cluster_pays(const ldu_addr* a, int kind)
     const ClusterPlan& P = *a->cluster;
     if (a->ctx->clusterEngine > 1) return true;   // LDU_CLUSTER=2: forced
     if (kind == 2) return 2.4 * P.nClusterLevels <= a->nLevels;
-    const double S = kind == 0 ? 0.1 : (P.maxDep <= 3 ? 0.2 : 0.25);
+    const double S = kind == 0 ? 0.1 : (P.maxDep <= 3 ? 0.2 : (P.maxDep <= 6 ? 0.25 : 0.35));
     const double perLevel = (a->nSlabs > 0 && a->slabWidth <= (kind == 0 ? 24.0 : 16.0)) ? 1.0 : 1.4;
     return P.nClusterLevels * (1.4 + P.avgDepth * S) < 0.85 * a->nLevels * perLevel;
 }
@@ -844,6 +847,9 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     ctx->profStart(a, 4);
     if (P.maxDep <= 3)
         sweep_cluster_gs_multi_kernel<3><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
+            P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+    else if (P.maxDep <= 6)
+        sweep_cluster_gs_multi_kernel<6><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     else
         sweep_cluster_gs_multi_kernel<CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
