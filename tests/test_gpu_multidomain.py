@@ -173,3 +173,33 @@ def test_smoothers_n_ranks_bitexact_against_reference(name):
     res = run_ranks(subs, fn)
     for sm in ("GaussSeidel", "nonBlockingGaussSeidel"):
         assert np.array_equal(np.concatenate([r[sm] for r in res]), g["ref_smooth_" + sm]), sm
+
+
+def test_cluster_engine_with_processor_patches(oracle, monkeypatch):
+    """the cluster (row-blocking) sweep engine under processor patches: 2 ranks, GaussSeidel / symGaussSeidel
+    sweeps and DIC across ranks stay bit-exact, GAMG and PCG match the multi-domain oracle"""
+    monkeypatch.setenv("LDU_CLUSTER", "2")
+    monkeypatch.setenv("LDU_CLUSTER_MIN", "1")
+    p, subs, maps = _case(2, False, size=14)
+    rng = np.random.RandomState(9)
+    xs = [rng.randn(s["nCells"]) for s in subs]
+    bs = [rng.randn(s["nCells"]) for s in subs]
+    S = oracle.System(subs)
+    X, B = np.concatenate(xs), np.concatenate(bs)
+    kw = dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4)
+
+    def fn(r, ctx, a, m):
+        assert a.sweep_engine(0) == "clusters" and a.sweep_engine(1) == "clusters"
+        out = dict(gs=m.smooth("GaussSeidel", xs[r], bs[r], 3), sgs=m.smooth("symGaussSeidel", xs[r], bs[r], 2),
+                   dic=m.precondition("DIC", bs[r]))
+        out["solve"] = m.solve(subs[r]["psi"], subs[r]["source"], **kw)
+        return out
+    res = run_ranks(subs, fn)
+    cat = lambda k: np.concatenate([r[k] for r in res])
+    assert np.array_equal(cat("gs"), S.smooth("GaussSeidel", X, B, 3))
+    assert np.array_equal(cat("sgs"), S.smooth("symGaussSeidel", X, B, 2))
+    assert np.array_equal(cat("dic"), np.concatenate([S.precondition("DIC", bs[d], d=d)[0] for d in range(2)]))
+    xo, po = S.solve(np.concatenate([s["psi"] for s in subs]), np.concatenate([s["source"] for s in subs]), **kw)
+    perf = res[0]["solve"][1]
+    assert perf["nIterations"] == po["nIterations"]
+    np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
