@@ -318,6 +318,10 @@ void matrix_free(ldu_matrix* m)
 {
     if (!m) return;
     if (m->gamg) gamg_free(m->gamg);
+    // the cluster engine keeps converted copies of this matrix's value arrays, keyed by their addresses
+    for (const double* v : {(const double*)m->d_valA, (const double*)m->d_valT, (const double*)m->d_valP,
+                            (const double*)m->d_valPT})
+        if (v) cluster_forget(m->a, v);
     if (m->d_lowerO && m->d_lowerO != m->d_upperO) (void)hipFree(m->d_lowerO);
     if (m->d_valT && m->d_valT != m->d_valA) (void)hipFree(m->d_valT);
     void* ptrs[] = {m->d_diagO, m->d_upperO, m->d_diag, m->d_valA, m->d_bou, m->d_int, m->d_rD,

@@ -87,6 +87,16 @@ void cluster_free(ldu_addr* a)
     a->cluster = nullptr;
 }
 
+void cluster_forget(ldu_addr* a, const double* levelVal)
+{
+    if (!a || !a->cluster) return;
+    auto it = a->cluster->conv.find(levelVal);
+    if (it == a->cluster->conv.end()) return;
+    (void)hipStreamSynchronize(a->ctx->stream);
+    if (it->second.d) (void)hipFree(it->second.d);
+    a->cluster->conv.erase(it);
+}
+
 // Builds the plan on first use.  Returns 0 and sets P->eligible.
 static int cluster_build(ldu_addr* a)
 {

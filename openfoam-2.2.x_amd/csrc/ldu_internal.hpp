@@ -273,6 +273,7 @@ bool k_cluster_kind_active(ldu_addr* a, int kind);
 int k_engine_of(ldu_addr* a, int kind);
 int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* valA);
 void cluster_free(ldu_addr* a);
+void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converted copy of a value array
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
