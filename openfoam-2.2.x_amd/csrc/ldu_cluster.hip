@@ -36,13 +36,12 @@ struct ClusterPlan {
     double avgDepth = 0;
     bool eligible = false;
     int maxDep = CL_MAXD;             // max over rows of max(nL, nU): picks the kernel instantiation
-    int* d_sliceRow = nullptr;        // [nSlices+1] first cluster-row of a cluster
+    // cluster s owns the cluster-rows [64 s, 64 s + 64): fixed stride, so a wave finds its rows from the
+    // ticket alone (one dependent load round trip less than with a row table); unused lanes carry intra = 255
     int* d_sliceEnt = nullptr;        // [nSlices]
     unsigned char* d_sliceDepth = nullptr;   // [nSlices] internal steps
-    int* d_map = nullptr;             // [nCells] cluster-row -> level-ordered row
-    unsigned char* d_nL = nullptr;    // [nCells] per cluster-row
-    unsigned char* d_nU = nullptr;
-    unsigned char* d_intra = nullptr; // [nCells] internal level of the row inside its cluster
+    int2* d_rowMeta = nullptr;        // [64 nSlices] {level-ordered row, nL | nU << 8 | internal level << 16}
+    long nRows = 0;                   // 64 nSlices
     int* d_colF = nullptr;            // [nEntries] lower part: cluster-row of the column; upper part: level row
     int* d_colB = nullptr;            // [nEntries] lower part: level row; upper part: cluster-row
     int* d_src = nullptr;             // [nEntries] index of the entry in the level-ordered SELL arrays
@@ -78,7 +77,7 @@ void cluster_free(ldu_addr* a)
 {
     ClusterPlan* P = a->cluster;
     if (!P) return;
-    void* ptrs[] = {P->d_sliceRow, P->d_sliceEnt, P->d_sliceDepth, P->d_map, P->d_nL, P->d_nU, P->d_intra,
+    void* ptrs[] = {P->d_sliceEnt, P->d_sliceDepth, P->d_rowMeta,
                     P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket, P->d_granule1, P->d_ticket1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : P->conv) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -181,24 +180,22 @@ static int cluster_build(ldu_addr* a)
     P->nClusterLevels = maxLev + 1;
     P->avgDepth = sumDepth / std::max(1, nCl);
 
-    std::vector<int> sliceRow(nCl + 1, 0), sliceEnt(nCl, 0), map(nC), crowOf(nC);
-    std::vector<unsigned char> sliceDepth(nCl), nL(nC), nU(nC), intraR(nC);
+    std::vector<int> sliceEnt(nCl, 0), crowOf(nC);
+    std::vector<unsigned char> sliceDepth(nCl);
+    std::vector<int2> rowMeta((size_t)nCl * LDU_WAVE, make_int2(0, 255 << 16));
     long ent = 0;
-    int row = 0;
     std::vector<int> sliceW(nCl);
     for (int s = 0; s < nCl; s++)
     {
         const int id = order[s];
-        sliceRow[s] = row;
         sliceDepth[s] = (unsigned char)cDepth[id];
         int W = 0;
+        int row = s * LDU_WAVE;
         for (int c : members[id])
         {
             crowOf[c] = row;
-            map[row] = a->iperm[c];
             const int cl_ = a->losortStart[c + 1] - a->losortStart[c], cu = a->ownerStart[c + 1] - a->ownerStart[c];
-            nL[row] = (unsigned char)cl_; nU[row] = (unsigned char)cu;
-            intraR[row] = (unsigned char)intra[c];
+            rowMeta[row] = make_int2(a->iperm[c], cl_ | (cu << 8) | (intra[c] << 16));
             W = std::max(W, cl_ + cu);
             row++;
         }
@@ -207,7 +204,7 @@ static int cluster_build(ldu_addr* a)
         ent += (long)W * LDU_WAVE;
         if (ent > 2000000000L) return 0;
     }
-    sliceRow[nCl] = row;
+    P->nRows = (long)nCl * LDU_WAVE;
     P->nEntries = ent + 1024;
     {
         // cluster-level ranges and, per level, the highest cluster level that holds an upper neighbour
@@ -242,7 +239,7 @@ static int cluster_build(ldu_addr* a)
         for (size_t i = 0; i < members[id].size(); i++)
         {
             const int c = members[id][i];
-            const int r = sliceRow[s] + (int)i;
+            const int r = s * LDU_WAVE + (int)i;
             const int lr = a->iperm[c];
             const int ls = lvlSliceOfRow[lr];
             const long lbase = (long)lvlSliceEnt[ls] + (lr - lvlSliceRow[ls]);
@@ -270,12 +267,11 @@ static int cluster_build(ldu_addr* a)
             (void)r;
         }
     }
-    if (cl_upload(&P->d_sliceRow, sliceRow) || cl_upload(&P->d_sliceEnt, sliceEnt) || cl_upload(&P->d_sliceDepth, sliceDepth)
-        || cl_upload(&P->d_map, map) || cl_upload(&P->d_nL, nL) || cl_upload(&P->d_nU, nU) || cl_upload(&P->d_intra, intraR)
+    if (cl_upload(&P->d_sliceEnt, sliceEnt) || cl_upload(&P->d_sliceDepth, sliceDepth) || cl_upload(&P->d_rowMeta, rowMeta)
         || cl_upload(&P->d_colF, colF) || cl_upload(&P->d_colB, colB) || cl_upload(&P->d_src, src))
         return -1;
-    LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
-    LDU_CHECK_HIP(hipMemset(P->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(P->nRows + 1)));
+    LDU_CHECK_HIP(hipMemset(P->d_granule, 0, sizeof(uint4) * (size_t)(P->nRows + 1)));
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned)));
     LDU_CHECK_HIP(hipMemset(P->d_ticket, 0, sizeof(unsigned)));
     P->gen = a->ctx->p2pGen;
@@ -323,8 +319,7 @@ __device__ __forceinline__ double cl_value(const cl_u32x4& g)
 }
 
 struct ClTab {
-    const int* sliceRow; const int* sliceEnt; const unsigned char* sliceDepth; const int* map;
-    const unsigned char* nL; const unsigned char* nU; const unsigned char* intra;
+    const int* sliceEnt; const unsigned char* sliceDepth; const int2* rowMeta;
     const int* colDep;      // dependency part in cluster rows, the other part in level rows
 };
 
@@ -338,15 +333,16 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
                                            const double* __restrict__ val2, double* __restrict__ aux)
 {
     constexpr bool FWD = (MODE == SW_TRI_FWD || MODE == SW_RD || MODE == SW_GS_FWD);
-    const int row0 = T.sliceRow[s];
-    const int cnt = T.sliceRow[s + 1] - row0;
+    const int row0 = s * LDU_WAVE;
+    const int cnt = LDU_WAVE;
     const int depth = T.sliceDepth[s];
-    const bool on = lane < cnt;
-    const int r = row0 + (on ? lane : 0);
-    const int lr = T.map[r];
-    const int nl = on ? T.nL[r] : 0, nu = on ? T.nU[r] : 0;
-    const int myLv = on ? (int)T.intra[r] : 255;
-    const long ent = (long)T.sliceEnt[s] + (on ? lane : 0);
+    const int r = row0 + lane;
+    const int2 rm = T.rowMeta[r];
+    const int myLv = (rm.y >> 16) & 255;
+    const bool on = myLv != 255;
+    const int lr = rm.x;
+    const int nl = on ? (rm.y & 255) : 0, nu = on ? ((rm.y >> 8) & 255) : 0;
+    const long ent = (long)T.sliceEnt[s] + lane;
     const int nd = FWD ? nl : nu;            // dependencies
     const int d0 = FWD ? 0 : nl;             // first dependency entry
     // everything that does not depend on this sweep
@@ -534,7 +530,7 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     const double* val2 = cluster_values(a, g.val2, s);
     if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
     constexpr bool FWD = (MODE == SW_TRI_FWD || MODE == SW_RD || MODE == SW_GS_FWD);
-    ClTab T{P.d_sliceRow, P.d_sliceEnt, P.d_sliceDepth, P.d_map, P.d_nL, P.d_nU, P.d_intra, FWD ? P.d_colF : P.d_colB};
+    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB};
     const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
     // one workgroup per CU while a cluster level holds few clusters (fewer waiting waves: faster hand-offs),
     // two when it is wide (tools/det_probe.py: 64^3 .104 / .114 ms, 216^3 .763 / .603 ms at 1 / 2 per CU)
@@ -552,8 +548,8 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     {
         if (!P.d_granule1)
         {
-            LDU_CHECK_HIP(hipMalloc((void**)&P.d_granule1, sizeof(uint4) * (size_t)(a->nCells + 1)));
-            LDU_CHECK_HIP(hipMemset(P.d_granule1, 0, sizeof(uint4) * (size_t)(a->nCells + 1)));
+            LDU_CHECK_HIP(hipMalloc((void**)&P.d_granule1, sizeof(uint4) * (size_t)(P.nRows + 1)));
+            LDU_CHECK_HIP(hipMemset(P.d_granule1, 0, sizeof(uint4) * (size_t)(P.nRows + 1)));
             LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticket1, sizeof(unsigned)));
             LDU_CHECK_HIP(hipMemset(P.d_ticket1, 0, sizeof(unsigned)));
             P.gen1 = ctx->p2pGen;
@@ -640,15 +636,16 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                                            const double* __restrict__ rhs, const double* __restrict__ diag,
                                            const double* __restrict__ val)
 {
-    const int row0 = T.sliceRow[s];
-    const int cnt = T.sliceRow[s + 1] - row0;
+    const int row0 = s * LDU_WAVE;
+    const int cnt = LDU_WAVE;
     const int depth = T.sliceDepth[s];
-    const bool on = lane < cnt;
-    const int r = row0 + (on ? lane : 0);
-    const int lr = T.map[r];
-    const int nl = on ? T.nL[r] : 0, nu = on ? T.nU[r] : 0;
-    const int myLv = on ? (int)T.intra[r] : 255;
-    const long ent = (long)T.sliceEnt[s] + (on ? lane : 0);
+    const int r = row0 + lane;
+    const int2 rm = T.rowMeta[r];
+    const int myLv = (rm.y >> 16) & 255;
+    const bool on = myLv != 255;
+    const int lr = rm.x;
+    const int nl = on ? (rm.y & 255) : 0, nu = on ? ((rm.y >> 8) & 255) : 0;
+    const long ent = (long)T.sliceEnt[s] + lane;
     const unsigned tagNew = tag0 + (unsigned)j;
     int c[ND], cu[ND];
     double v[ND], vu[ND];
@@ -834,7 +831,7 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     }
     const double* val = cluster_values(a, valA, s);
     if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
-    ClTab T{P.d_sliceRow, P.d_sliceEnt, P.d_sliceDepth, P.d_map, P.d_nL, P.d_nU, P.d_intra, P.d_colF};
+    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, P.d_colF};
     const int nTasks = it->second.n;
     const int nChunks = (nTasks + CL_WPB - 1) / CL_WPB;
     int bpc = ctx->clusterBlocksPerCUMulti;
@@ -849,7 +846,7 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     }
     if (P.epoch > 0xffffff00u)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(P.nRows + 1), s));
         P.epoch = 0;
     }
     const unsigned tag0 = P.epoch + 1;
