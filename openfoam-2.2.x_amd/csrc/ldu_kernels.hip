@@ -150,6 +150,34 @@ row_kernel(int nSlices, const int* __restrict__ sliceRow, const int* __restrict_
     else if (MODE == 1) acc = b[r] - diag[r] * x[r];
     else if (MODE == 2) acc = diag[r];
     else acc = 0.0;
+    const int W = sliceW[s];   // wave-uniform
+    if (W <= 8 && (MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5))
+    {
+        // all of the row's columns, coefficients and x values in flight at once (the loop below issues one
+        // dependent gather per trip); the accumulation order and the k < n guard are unchanged
+        int c[8];
+        double v[8], xv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < W)
+            {
+                const long e = ent + (long)k * LDU_WAVE;
+                c[k] = col[e];       // padding entries point at the row itself
+                v[k] = val[e];
+            }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < W) xv[k] = x[c[k]];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < W && k < n)
+            {
+                if (MODE == 0 || MODE == 5) acc += v[k] * xv[k];
+                else acc -= v[k] * xv[k];
+            }
+        y[r] = acc;
+        return;
+    }
     for (int k = 0; k < n; k++)
     {
         const long e = ent + (long)k * LDU_WAVE;
