@@ -34,13 +34,24 @@ __global__ void fill_sell_kernel(int nSlices, const int* __restrict__ sliceRow,
     const int nl = lane < cnt ? nL[r] : 0;
     const long ent = (long)sliceEnt[s] + lane;
     const int W = sliceW[s];
-    for (int k = 0; k < W; k++)
+    for (int k0 = 0; k0 < W; k0 += 8)
     {
-        const long e = ent + (long)k * LDU_WAVE;
-        const int f = face[e];
-        double v = 0.0;
-        if (f >= 0) v = (k < nl) ? lowerO[f] : upperO[f];
-        val[e] = v;
+        // eight face indices, then eight coefficient gathers in flight
+        int f[8];
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (k0 + j < W) f[j] = face[ent + (long)(k0 + j) * LDU_WAVE];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (k0 + j < W)
+            {
+                v[j] = 0.0;
+                if (f[j] >= 0) v[j] = (k0 + j < nl) ? lowerO[f[j]] : upperO[f[j]];
+            }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (k0 + j < W) val[ent + (long)(k0 + j) * LDU_WAVE] = v[j];
     }
 }
 
