@@ -263,6 +263,56 @@ int ldu_fv_linearUpwindCorrection(ldu_addr* a, const double* faceFlux, const dou
 int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf, const double* boundaryValues,
                             const double* C3, const double* Cf3, const double* boundaryCf3, double* grad3);
 
+/* ---- coupled solvers: LduMatrix<Type, scalar, scalar> (src/OpenFOAM/matrices/LduMatrix) -------------
+ * `type coupled;` in fvSolution (fvMatrixSolve.C:83-85, solveCoupled :222-277) solves every component
+ * of a vector/tensor field at once on the scalar coefficients of the same ldu_matrix.  Fields are
+ * Field<Type> images: nCells x nCmpt doubles, components interleaved, original cell order
+ * (nCmpt = pTraits<Type>::nComponents: 1, 3, 6 or 9).  The matrix source is passed with the call.
+ * Selection follows LduMatrixSolver.C:33-111 / LduMatrixPreconditioner.C:33-103 / LduMatrixSmoother.C:
+ * a matrix without faces is solved by DiagonalSolver whatever the name says; PCICG is registered for
+ * symmetric matrices only, PBiCCCG / PBiCICG for asymmetric ones, SmoothSolver for both
+ * (Solvers/lduSolvers.C:33-50); DILU is an asymmetric-matrix preconditioner only
+ * (Preconditioners/lduPreconditioners.C:41-42) - a name missing from the table is an error (-16), as
+ * the reference's FatalIOError. */
+enum { LDU_CSOLVER_PCICG = 0, LDU_CSOLVER_PBICCCG = 1, LDU_CSOLVER_PBICICG = 2, LDU_CSOLVER_SMOOTHSOLVER = 3,
+       LDU_CSOLVER_DIAGONAL = 4 };
+enum { LDU_CPRE_NONE = 0, LDU_CPRE_DIAGONAL = 1, LDU_CPRE_DILU = 2 };
+enum { LDU_CSM_GAUSSSEIDEL = 0 };
+#define LDU_MAX_CMPT 9
+
+/* LduMatrix::solver controls (LduMatrixSolver.C:120-149): maxIter 1000, tolerance 1e-6*one, relTol zero;
+ * SmoothSolver.C:53-57 nSweeps. */
+typedef struct ldu_coupled_controls {
+    int32_t solver, preconditioner, smoother;
+    int32_t nCmpt;
+    int32_t maxIter, nSweeps;
+    double tolerance[LDU_MAX_CMPT], relTol[LDU_MAX_CMPT];
+} ldu_coupled_controls;
+
+/* SolverPerformance<Type> (LduMatrix/SolverPerformance.H) */
+typedef struct ldu_coupled_perf {
+    double initialResidual[LDU_MAX_CMPT], finalResidual[LDU_MAX_CMPT], normFactor[LDU_MAX_CMPT];
+    int32_t singular[LDU_MAX_CMPT];
+    int32_t nIterations, converged;
+    double solveSeconds;
+} ldu_coupled_perf;
+
+void ldu_coupled_default_controls(ldu_coupled_controls* c, int32_t nCmpt);
+/* LduMatrix::solver::solve(psi) (LduMatrix.H:238): PCICG.C:50-184, PBiCCCG.C:50-192, PBiCICG.C:50-197,
+ * SmoothSolver.C:61-151, DiagonalSolver.C:56-76 */
+int ldu_coupled_solve(ldu_matrix* m, const ldu_coupled_controls* controls, double* psi, const double* source,
+                      ldu_coupled_perf* perf);
+/* LduMatrix::Amul / Tmul / residual (LduMatrixATmul.C:66-114, :117-165, :218-276) */
+int ldu_coupled_amul(ldu_matrix* m, int32_t nCmpt, double* Apsi, const double* psi, int32_t transpose);
+int ldu_coupled_residual(ldu_matrix* m, int32_t nCmpt, double* rA, const double* psi, const double* source);
+/* LduMatrix::preconditioner::precondition / preconditionT (TDILUPreconditioner.C:82-125, :128-176;
+ * DiagonalPreconditioner.C:64-80; NoPreconditioner.C:49-56) */
+int ldu_coupled_precondition(ldu_matrix* m, int32_t preconditioner, int32_t nCmpt, double* wA, const double* rA,
+                             int32_t transpose);
+/* LduMatrix::smoother::smooth (TGaussSeidelSmoother.C:63-153) */
+int ldu_coupled_smooth(ldu_matrix* m, int32_t smoother, int32_t nCmpt, double* psi, const double* source,
+                       int32_t nSweeps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,26 @@ EXPORTS = [
     "ldu_fvm_relax", "ldu_fvm_setReference", "ldu_fvm_A", "ldu_fvm_H", "ldu_fvm_flux",
     "ldu_fvm_addBoundaryDiagCmpt", "ldu_fvm_addBoundarySourceV", "ldu_fvm_relaxV", "ldu_fvm_AV", "ldu_fvm_HV",
     "ldu_fv_linearUpwindCorrection", "ldu_fvc_cellLimitedGrad",
+    "ldu_coupled_default_controls", "ldu_coupled_solve", "ldu_coupled_amul", "ldu_coupled_residual",
+    "ldu_coupled_precondition", "ldu_coupled_smooth",
 ]
+
+# LduMatrix<Type, scalar, scalar> run-time selection names (Solvers/*/*.H TypeName)
+COUPLED_SOLVERS = {"PCICG": 0, "PBiCCCG": 1, "PBiCICG": 2, "SmoothSolver": 3, "diagonal": 4}
+COUPLED_PRECONDITIONERS = {"none": 0, "diagonal": 1, "DILU": 2}
+COUPLED_SMOOTHERS = {"GaussSeidel": 0}
+
+
+class CoupledControls(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("preconditioner", C.c_int32), ("smoother", C.c_int32),
+                ("nCmpt", C.c_int32), ("maxIter", C.c_int32), ("nSweeps", C.c_int32),
+                ("tolerance", C.c_double * 9), ("relTol", C.c_double * 9)]
+
+
+class CoupledPerf(C.Structure):
+    _fields_ = [("initialResidual", C.c_double * 9), ("finalResidual", C.c_double * 9),
+                ("normFactor", C.c_double * 9), ("singular", C.c_int32 * 9),
+                ("nIterations", C.c_int32), ("converged", C.c_int32), ("solveSeconds", C.c_double)]
 
 
 class Controls(C.Structure):
@@ -324,6 +343,61 @@ class Matrix:
                        normFactor=perf.normFactor, nIterations=perf.nIterations,
                        converged=bool(perf.converged), singular=bool(perf.singular),
                        history=hist[:n].copy(), solveSeconds=perf.solveSeconds)
+
+    # ---- coupled family LduMatrix<Type, scalar, scalar>: fields are (nCells, nCmpt) arrays
+    def _fld(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(self.addr.nCells, -1)
+        return x
+
+    def coupled_Amul(self, psi, transpose=False):
+        x = self._fld(psi)
+        y = np.zeros_like(x)
+        _chk(lib().ldu_coupled_amul(self.h, x.shape[1], _ptr(y), _ptr(x), int(transpose)))
+        return y
+
+    def coupled_residual(self, psi, source):
+        x = self._fld(psi)
+        y = np.zeros_like(x)
+        _chk(lib().ldu_coupled_residual(self.h, x.shape[1], _ptr(y), _ptr(x), _ptr(self._fld(source))))
+        return y
+
+    def coupled_precondition(self, kind, rA, transpose=False):
+        r = self._fld(rA)
+        w = np.zeros_like(r)
+        _chk(lib().ldu_coupled_precondition(self.h, COUPLED_PRECONDITIONERS[kind], r.shape[1], _ptr(w), _ptr(r),
+                                            int(transpose)))
+        return w
+
+    def coupled_smooth(self, psi, source, nSweeps, smoother="GaussSeidel"):
+        x = self._fld(psi).copy()
+        _chk(lib().ldu_coupled_smooth(self.h, COUPLED_SMOOTHERS[smoother], x.shape[1], _ptr(x),
+                                      _ptr(self._fld(source)), int(nSweeps)))
+        return x
+
+    def coupled_solve(self, psi, source, solver="PBiCCCG", preconditioner="DILU", smoother="GaussSeidel",
+                      tolerance=1e-6, relTol=0.0, maxIter=1000, nSweeps=1):
+        """LduMatrix<Type,scalar,scalar>::solver::New(...)->solve(psi) ("type coupled;"); tolerance / relTol are
+        Type-valued in the reference's dictionary: scalars are broadcast to every component."""
+        x = self._fld(psi).copy()
+        nc = x.shape[1]
+        c = CoupledControls()
+        lib().ldu_coupled_default_controls(C.byref(c), nc)
+        c.solver, c.preconditioner = COUPLED_SOLVERS[solver], COUPLED_PRECONDITIONERS[preconditioner]
+        c.smoother = COUPLED_SMOOTHERS[smoother]
+        c.maxIter, c.nSweeps = int(maxIter), int(nSweeps)
+        tol = np.broadcast_to(np.asarray(tolerance, dtype=np.float64), (nc,))
+        rel = np.broadcast_to(np.asarray(relTol, dtype=np.float64), (nc,))
+        for i in range(nc):
+            c.tolerance[i], c.relTol[i] = float(tol[i]), float(rel[i])
+        perf = CoupledPerf()
+        _chk(lib().ldu_coupled_solve(self.h, C.byref(c), _ptr(x), _ptr(self._fld(source)), C.byref(perf)))
+        return x, dict(initialResidual=np.array(perf.initialResidual[:nc]),
+                       finalResidual=np.array(perf.finalResidual[:nc]),
+                       normFactor=np.array(perf.normFactor[:nc]), nIterations=perf.nIterations,
+                       converged=bool(perf.converged), singular=[bool(v) for v in perf.singular[:nc]],
+                       solveSeconds=perf.solveSeconds)
 
     def profile_begin(self):
         _chk(lib().ldu_profile_begin(self.h))

@@ -332,7 +332,9 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
                                            const double* __restrict__ scale, const double* __restrict__ val,
                                            const double* __restrict__ val2, double* __restrict__ aux)
 {
-    constexpr bool FWD = (MODE == SW_TRI_FWD || MODE == SW_RD || MODE == SW_GS_FWD);
+    constexpr int B = sw_base(MODE);
+    constexpr bool TF = sw_tform(MODE);
+    constexpr bool FWD = (B == SW_TRI_FWD || B == SW_RD || B == SW_GS_FWD);
     const int row0 = s * LDU_WAVE;
     const int cnt = LDU_WAVE;
     const int depth = T.sliceDepth[s];
@@ -355,15 +357,15 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
         const long e = ent + (long)(d0 + k) * LDU_WAVE;
         c[k] = need ? T.colDep[e] : r;
         v[k] = need ? val[e] : 0.0;
-        v2[k] = (MODE == SW_RD && need) ? val2[e] : 0.0;
+        v2[k] = (B == SW_RD && need) ? val2[e] : 0.0;
     }
     double acc, dd = 1.0;
-    if (MODE == SW_TRI_FWD) acc = scale[lr] * rhs[lr];
-    else if (MODE == SW_TRI_BWD) acc = w[lr];
-    else if (MODE == SW_RD) acc = scale[lr];
+    if (B == SW_TRI_FWD) { dd = scale[lr]; acc = dd * rhs[lr]; }
+    else if (B == SW_TRI_BWD) { acc = w[lr]; if (TF) dd = scale[lr]; }
+    else if (B == SW_RD) acc = scale[lr];
     else { acc = rhs[lr]; dd = scale[lr]; }
     double xu[ND], vu[ND];
-    if (MODE == SW_GS_FWD)
+    if (B == SW_GS_FWD)
     {
         // old values of the upper neighbours (level rows), loaded before anything of this sweep is written
 #pragma unroll
@@ -418,7 +420,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
         lds[LDU_WAVE + k * LDU_WAVE + lane] = xe[k];
     }
     double pu[ND];
-    if (MODE == SW_GS_FWD)
+    if (B == SW_GS_FWD)
     {
 #pragma unroll
         for (int k = 0; k < ND; k++) pu[k] = vu[k] * xu[k];   // 0*0 for unused entries
@@ -429,16 +431,29 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
     {
         const int lv = FWD ? st : depth - 1 - st;
         double t = acc;
-        if (MODE == SW_TRI_BWD)
+        if (B == SW_TRI_BWD)
         {
             // DICPreconditioner.C:119-122: owned faces in DEscending order
 #pragma unroll
-            for (int k = ND - 1; k >= 0; k--) t -= v[k] * lds[slot[k]];
+            for (int k = ND - 1; k >= 0; k--)
+            {
+                if (TF) t -= dd * (v[k] * lds[slot[k]]);
+                else t -= v[k] * lds[slot[k]];
+            }
         }
-        else if (MODE == SW_RD)
+        else if (B == SW_RD)
         {
 #pragma unroll
-            for (int k = 0; k < ND; k++) t -= (v2[k] * v[k]) / lds[slot[k]];
+            for (int k = 0; k < ND; k++)
+            {
+                if (TF) t -= (v2[k] * v[k]) * (1.0 / lds[slot[k]]);
+                else t -= (v2[k] * v[k]) / lds[slot[k]];
+            }
+        }
+        else if (B == SW_TRI_FWD && TF)
+        {
+#pragma unroll
+            for (int k = 0; k < ND; k++) t -= dd * (v[k] * lds[slot[k]]);
         }
         else
         {
@@ -448,15 +463,15 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
         if (myLv == lv)
         {
             double out = t;
-            if (MODE == SW_GS_FWD)
+            if (B == SW_GS_FWD)
             {
                 auxv = t;
 #pragma unroll
                 for (int k = 0; k < ND; k++)
                     if (k < nu) t -= pu[k];
-                out = t / dd;
+                out = TF ? dd * t : t / dd;
             }
-            else if (MODE == SW_GS_BWD) out = t / dd;
+            else if (B == SW_GS_BWD) out = t / dd;
             lds[lane] = out;
             res = out;
         }
@@ -468,7 +483,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
     // cluster waits for ALL its external rows, and the last of them finishes in the last step anyway.
     if (on)
     {
-        if (MODE == SW_GS_FWD && aux) aux[lr] = auxv;
+        if (B == SW_GS_FWD && aux) aux[lr] = auxv;
         w[lr] = res;
         cl_store(G, r, res, tag);
     }
@@ -529,7 +544,7 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     const double* val = cluster_values(a, g.val, s);
     const double* val2 = cluster_values(a, g.val2, s);
     if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
-    constexpr bool FWD = (MODE == SW_TRI_FWD || MODE == SW_RD || MODE == SW_GS_FWD);
+    constexpr bool FWD = (sw_base(MODE) == SW_TRI_FWD || sw_base(MODE) == SW_RD || sw_base(MODE) == SW_GS_FWD);
     ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB};
     const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
     // one workgroup per CU while a cluster level holds few clusters (fewer waiting waves: faster hand-offs),
@@ -587,7 +602,8 @@ int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     if (!ctx->clusterEngine || a->nCells < ctx->clusterMinCells || g.lane > 1) return 1;
     if (cluster_build(a) < 0) return -1;
     if (!a->cluster->eligible) return 1;
-    if (!cluster_pays(a, (g.mode == SW_GS_FWD || g.mode == SW_GS_BWD) ? 1 : 0)) return 1;
+    const int bm = sw_base(g.mode);
+    if (!cluster_pays(a, (bm == SW_GS_FWD || bm == SW_GS_BWD) ? 1 : 0)) return 1;
     switch (g.mode)
     {
     case SW_TRI_FWD: return launch_cluster<SW_TRI_FWD, false>(a, g, s);
@@ -595,6 +611,10 @@ int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     case SW_RD:      return launch_cluster<SW_RD, false>(a, g, s);
     case SW_GS_FWD:  return launch_cluster<SW_GS_FWD, false>(a, g, s);
     case SW_GS_BWD:  return launch_cluster<SW_GS_BWD, true>(a, g, s);
+    case SW_TRI_FWD_T: return launch_cluster<SW_TRI_FWD_T, false>(a, g, s);
+    case SW_TRI_BWD_T: return launch_cluster<SW_TRI_BWD_T, true>(a, g, s);
+    case SW_RD_T:      return launch_cluster<SW_RD_T, false>(a, g, s);
+    case SW_GS_FWD_T:  return launch_cluster<SW_GS_FWD_T, false>(a, g, s);
     }
     return 1;
 }

@@ -241,7 +241,11 @@ struct ldu_matrix {
     std::vector<double*> work;
     double* workVec(int i);
     uint64_t coeffEpoch = 0;
+    // LduMatrix<Type,scalar,scalar> solvers on these coefficients (ldu_coupled.hip)
+    struct CoupledWork* coupled = nullptr;
 };
+void coupled_free(ldu_matrix* m);
+int dev_halo_start(ldu_matrix* m, const double* x);   // initMatrixInterfaces: pack + exchange
 
 // ---------------------------------------------------------------- kernels (ldu_kernels.hip)
 enum SweepMode {
@@ -249,8 +253,18 @@ enum SweepMode {
     SW_TRI_BWD = 1,   // w -= sum_upper(desc) valP*w[col]              (DIC/DILU backward)
     SW_RD = 2,        // rD = diag - sum_lower (valT*valA)/rD[col]     (calcReciprocalD, unreciprocated)
     SW_GS_FWD = 3,    // GaussSeidel forward (optionally stores bPrime)
-    SW_GS_BWD = 4     // symGaussSeidel reverse sweep from the stored bPrime
+    SW_GS_BWD = 4,    // symGaussSeidel reverse sweep from the stored bPrime
+    // The templated LduMatrix<Type,scalar,scalar> family associates differently (TDILUPreconditioner.C:67-70,
+    // :111-120; TGaussSeidelSmoother.C:139): the row factor multiplies the finished product, so the
+    // coefficients cannot be pre-scaled.  val = the unscaled coefficients, scale = rD.
+    SW_TRI_FWD_T = 5, // w = rD*rhs - sum_lower rD*(val*w[col])
+    SW_TRI_BWD_T = 6, // w -= sum_upper(desc) rD*(val*w[col])
+    SW_RD_T = 7,      // rD = diag - sum_lower (valT*valA)*(1/rD[col])
+    SW_GS_FWD_T = 8   // GaussSeidel forward, finished with rD*acc instead of acc/diag
 };
+// mode without the association flavour / is it the templated flavour
+constexpr int sw_base(int m) { return m == 5 ? 0 : m == 6 ? 1 : m == 7 ? 2 : m == 8 ? 3 : m; }
+constexpr bool sw_tform(int m) { return m >= 5; }
 
 struct SweepArgs {
     int mode;

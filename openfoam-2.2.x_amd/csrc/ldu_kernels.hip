@@ -279,40 +279,47 @@ __device__ __forceinline__ void sweep_slice(const SliceTab& T, int s, int lane, 
     const int nl = T.nL[r];
     const int nu = T.nU[r];
     const long ent = (long)T.sliceEnt[s] + lane;
-    if (MODE == SW_TRI_FWD)
+    constexpr int B = sw_base(MODE);
+    constexpr bool TF = sw_tform(MODE);
+    if (B == SW_TRI_FWD)
     {
         // DICPreconditioner.C:109-117 / DILUPreconditioner.C:113-128 with valP = rD[row]*coeff
-        double acc = scale[r] * rhs[r];
+        const double sc = scale[r];
+        double acc = sc * rhs[r];
         for (int k = 0; k < nl; k++)
         {
             const long e = ent + (long)k * LDU_WAVE;
-            acc -= val[e] * w[T.col[e]];
+            if (TF) acc -= sc * (val[e] * w[T.col[e]]);
+            else acc -= val[e] * w[T.col[e]];
         }
         w[r] = acc;
     }
-    else if (MODE == SW_TRI_BWD)
+    else if (B == SW_TRI_BWD)
     {
         // DICPreconditioner.C:119-122: owned faces in DEscending order
         double acc = w[r];
+        const double sc = TF ? scale[r] : 0.0;
         for (int k = nl + nu - 1; k >= nl; k--)
         {
             const long e = ent + (long)k * LDU_WAVE;
-            acc -= val[e] * w[T.col[e]];
+            if (TF) acc -= sc * (val[e] * w[T.col[e]]);
+            else acc -= val[e] * w[T.col[e]];
         }
         w[r] = acc;
     }
-    else if (MODE == SW_RD)
+    else if (B == SW_RD)
     {
         // DICPreconditioner.C:71-74 / DILUPreconditioner.C:72-75 (before the reciprocal)
         double acc = scale[r];
         for (int k = 0; k < nl; k++)
         {
             const long e = ent + (long)k * LDU_WAVE;
-            acc -= (val2[e] * val[e]) / w[T.col[e]];
+            if (TF) acc -= (val2[e] * val[e]) * (1.0 / w[T.col[e]]);
+            else acc -= (val2[e] * val[e]) / w[T.col[e]];
         }
         w[r] = acc;
     }
-    else if (MODE == SW_GS_FWD)
+    else if (B == SW_GS_FWD)
     {
         // GaussSeidelSmoother.C:151-176 as a row gather
         double acc = rhs[r];
@@ -327,7 +334,7 @@ __device__ __forceinline__ void sweep_slice(const SliceTab& T, int s, int lane, 
             const long e = ent + (long)k * LDU_WAVE;
             acc -= val[e] * w[T.col[e]];
         }
-        w[r] = acc / scale[r];
+        w[r] = TF ? scale[r] * acc : acc / scale[r];
     }
     else   // SW_GS_BWD: symGaussSeidelSmoother.C:178-205
     {
@@ -414,6 +421,10 @@ static int launch_sweep(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     case SW_RD:      return launch_sweep_segments<SW_RD, false>(a, g, s);
     case SW_GS_FWD:  return launch_sweep_segments<SW_GS_FWD, false>(a, g, s);
     case SW_GS_BWD:  return launch_sweep_segments<SW_GS_BWD, true>(a, g, s);
+    case SW_TRI_FWD_T: return launch_sweep_segments<SW_TRI_FWD_T, false>(a, g, s);
+    case SW_TRI_BWD_T: return launch_sweep_segments<SW_TRI_BWD_T, true>(a, g, s);
+    case SW_RD_T:      return launch_sweep_segments<SW_RD_T, false>(a, g, s);
+    case SW_GS_FWD_T:  return launch_sweep_segments<SW_GS_FWD_T, false>(a, g, s);
     }
     return -1;
 }
@@ -602,7 +613,8 @@ __device__ __forceinline__ double granule_value(const u32x4& g)
 }
 
 // acc -= sum_{i=0..n-1} val[e(i)] * (value of row col[e(i)] published in THIS sweep), in order;
-// entry index k(i) = first + i*step.  OP = 0: acc -= v*x ; OP = 1: acc -= (v2*v)/x  (SW_RD)
+// entry index k(i) = first + i*step.  OP = 0: acc -= v*x ; OP = 1: acc -= (v2*v)/x  (SW_RD);
+// templated-family association: OP = 2: acc -= sc*(v*x) ; OP = 3: acc -= (v2*v)*(1/x)
 template <int OP, bool DIAG = false, bool SLAB = false>
 __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restrict__ G,
                                                const uint4* __restrict__ X, unsigned tag,
@@ -610,7 +622,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
                                                const double* __restrict__ val,
                                                const double* __restrict__ val2, long ent, int first,
                                                int step, int n, int selfRow, volatile int* abortFlag,
-                                               P2PStat& waitEst)
+                                               P2PStat& waitEst, double sc = 0.0)
 {
     // (An adaptive pre-sleep before the first poll was tried and measured 2-6x SLOWER: the wait
     //  shrinks quickly while the levels grow, so any history-based nap oversleeps at the front.)
@@ -627,7 +639,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             const long e = ent + (long)(first + (i0 + j) * step) * LDU_WAVE;
             c[j] = need ? col[e] : selfRow;
             v[j] = need ? val[e] : 0.0;
-            v2[j] = (OP == 1 && need) ? val2[e] : 0.0;
+            v2[j] = ((OP == 1 || OP == 3) && need) ? val2[e] : 0.0;
             if (SLAB) gp[j] = (c[j] < 0 ? X : G) + (c[j] & 0x7fffffff);
         }
         if (DIAG && i0 == 0 && waitEst.gateSlice >= 0)
@@ -677,12 +689,26 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             if (i0 + 2 < n) acc -= v[2] * x2;
             if (i0 + 3 < n) acc -= v[3] * x3;
         }
-        else
+        else if (OP == 1)
         {
             if (i0 + 0 < n) acc -= (v2[0] * v[0]) / x0;
             if (i0 + 1 < n) acc -= (v2[1] * v[1]) / x1;
             if (i0 + 2 < n) acc -= (v2[2] * v[2]) / x2;
             if (i0 + 3 < n) acc -= (v2[3] * v[3]) / x3;
+        }
+        else if (OP == 2)
+        {
+            if (i0 + 0 < n) acc -= sc * (v[0] * x0);
+            if (i0 + 1 < n) acc -= sc * (v[1] * x1);
+            if (i0 + 2 < n) acc -= sc * (v[2] * x2);
+            if (i0 + 3 < n) acc -= sc * (v[3] * x3);
+        }
+        else
+        {
+            if (i0 + 0 < n) acc -= (v2[0] * v[0]) * (1.0 / x0);
+            if (i0 + 1 < n) acc -= (v2[1] * v[1]) * (1.0 / x1);
+            if (i0 + 2 < n) acc -= (v2[2] * v[2]) * (1.0 / x2);
+            if (i0 + 3 < n) acc -= (v2[3] * v[3]) * (1.0 / x3);
         }
     }
     if (DIAG && g_p2p_trace) waitEst.tReady = wall_clock64();
@@ -707,25 +733,29 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
     const long ent = (long)T.sliceEnt[s] + lane;
     const bool exported = SLAB ? xflag[r] != 0 : false;
     double out;
-    if (MODE == SW_TRI_FWD)
+    constexpr int B = sw_base(MODE);
+    constexpr bool TF = sw_tform(MODE);
+    if (B == SW_TRI_FWD)
     {
-        double acc = scale[r] * rhs[r];
-        if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
+        const double sc = scale[r];
+        double acc = sc * rhs[r];
+        if (!p2p_accumulate<TF ? 2 : 0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst, sc)) return false;
         out = acc;
     }
-    else if (MODE == SW_TRI_BWD)
+    else if (B == SW_TRI_BWD)
     {
         double acc = w[r];
-        if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, nl + nu - 1, -1, nu, r, abortFlag, waitEst)) return false;
+        const double sc = TF ? scale[r] : 0.0;
+        if (!p2p_accumulate<TF ? 2 : 0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, nl + nu - 1, -1, nu, r, abortFlag, waitEst, sc)) return false;
         out = acc;
     }
-    else if (MODE == SW_RD)
+    else if (B == SW_RD)
     {
         double acc = scale[r];
-        if (!p2p_accumulate<1, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
+        if (!p2p_accumulate<TF ? 3 : 1, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         out = acc;
     }
-    else if (MODE == SW_GS_FWD)
+    else if (B == SW_GS_FWD)
     {
         // old values of the upper neighbours: plain loads, issued before the wait
         double acc = rhs[r];
@@ -759,7 +789,7 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
                 acc -= val[e] * w[T.col[e] & 0x7fffffff];
             }
         }
-        out = acc / d;
+        out = TF ? d * acc : acc / d;
     }
     else   // SW_GS_BWD
     {
@@ -985,7 +1015,7 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     ldu_addr::P2PLane* Pp = a->lane(g.lane);
     if (!Pp) { ldu_set_error("p2p lane allocation failed"); return -1; }
     ldu_addr::P2PLane& P = *Pp;
-    if (use_slab(a, (MODE == SW_GS_FWD || MODE == SW_GS_BWD) ? 1 : 0))
+    if (use_slab(a, (sw_base(MODE) == SW_GS_FWD || sw_base(MODE) == SW_GS_BWD) ? 1 : 0))
     {
         SliceTab TS{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_colX};
         SlabCtl C;
@@ -1524,6 +1554,10 @@ static int launch_sweep_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     case SW_RD:      return launch_p2p<SW_RD, false>(a, g, s);
     case SW_GS_FWD:  return launch_p2p<SW_GS_FWD, false>(a, g, s);
     case SW_GS_BWD:  return launch_p2p<SW_GS_BWD, true>(a, g, s);
+    case SW_TRI_FWD_T: return launch_p2p<SW_TRI_FWD_T, false>(a, g, s);
+    case SW_TRI_BWD_T: return launch_p2p<SW_TRI_BWD_T, true>(a, g, s);
+    case SW_RD_T:      return launch_p2p<SW_RD_T, false>(a, g, s);
+    case SW_GS_FWD_T:  return launch_p2p<SW_GS_FWD_T, false>(a, g, s);
     }
     return -1;
 }
@@ -1536,8 +1570,9 @@ int k_sweep(ldu_addr* a, const SweepArgs& g)
     ldu_ctx* ctx = a->ctx;
     hipStream_t s = g.stream ? g.stream : ctx->stream;
     if (a->nCells == 0) return 0;
-    const int cat = (g.mode == SW_GS_FWD || g.mode == SW_GS_BWD) ? LDU_PROF_GS_SWEEP
-                    : (g.mode == SW_RD ? 7 : LDU_PROF_TRI_SWEEP);
+    const int bm = sw_base(g.mode);
+    const int cat = (bm == SW_GS_FWD || bm == SW_GS_BWD) ? LDU_PROF_GS_SWEEP
+                    : (bm == SW_RD ? 7 : LDU_PROF_TRI_SWEEP);
     if (ctx->sweepP2P)
     {
         if (s == ctx->stream) ctx->profStart(a, cat);

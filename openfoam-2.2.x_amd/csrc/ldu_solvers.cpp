@@ -68,7 +68,7 @@ static int dev_write_scalar(ldu_ctx* ctx, int slot, double v)
 // initMatrixInterfaces -> pack + exchange ; interior rows ; updateMatrixInterfaces -> apply
 // (lduMatrixUpdateMatrixInterfaces.C:30-266)
 
-static int halo_start(ldu_matrix* m, const double* x)
+int dev_halo_start(ldu_matrix* m, const double* x)
 {
     ldu_addr* a = m->a;
     if (!a->nPatchFaces) return 0;
@@ -79,7 +79,7 @@ static int halo_start(ldu_matrix* m, const double* x)
 int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStream_t s2)
 {
     hipStream_t s = s2 ? s2 : m->a->ctx->stream;
-    if (halo_start(m, x)) return -1;
+    if (dev_halo_start(m, x)) return -1;
     if (k_amul(m, y, x, transpose, s)) return -1;
     if (m->a->nPatchFaces) return k_apply_patches(m->a, y, transpose ? m->d_int : m->d_bou, 1.0, s);
     return 0;
@@ -88,7 +88,7 @@ int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStrea
 int dev_residual(ldu_matrix* m, double* r, const double* x, const double* b)
 {
     hipStream_t s = m->a->ctx->stream;
-    if (halo_start(m, x)) return -1;
+    if (dev_halo_start(m, x)) return -1;
     if (k_residual_rows(m, r, x, b, s)) return -1;
     if (m->a->nPatchFaces) return k_apply_patches(m->a, r, m->d_bou, -1.0, s);
     return 0;
@@ -215,7 +215,7 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         {
             // bPrime = source; coupled boundaries Jacobi-style with negated coefficients
             // (GaussSeidelSmoother.C:98-145)
-            if (halo_start(m, psi)) return -1;
+            if (dev_halo_start(m, psi)) return -1;
             if (k_ew(a->nCells, EW_COPY, bPrime, source, nullptr, s)) return -1;
             if (k_apply_patches(a, bPrime, m->d_bou, -1.0, s)) return -1;
             rhs = bPrime;
@@ -270,7 +270,7 @@ int dev_smooth(ldu_matrix* m, int smoother, double* psi, const double* source, i
         {
             for (int sweep = 0; sweep < nSweeps; sweep++)
             {
-                if (halo_start(m, psi)) return -1;
+                if (dev_halo_start(m, psi)) return -1;
                 if (k_sweep_gs_nonblocking(m->a, psi, source, m->d_diag, m->d_valA, m->d_bou)) return -1;
             }
             return 0;

@@ -19,6 +19,21 @@ PRECONDS = {"none": 0, "diagonal": 1, "DIC": 2, "FDIC": 3, "DILU": 4, "GAMG": 5}
 SMOOTHERS = {"GaussSeidel": 0, "symGaussSeidel": 1, "DIC": 2, "DILU": 3,
              "DICGaussSeidel": 4, "DILUGaussSeidel": 5, "FDIC": 6, "nonBlockingGaussSeidel": 7}
 AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
+# coupled family LduMatrix<Type, scalar, scalar> (ldu_oracle_coupled.c)
+CSOLVERS = {"PCICG": 0, "PBiCCCG": 1, "PBiCICG": 2, "SmoothSolver": 3, "diagonal": 4}
+CPRECONDS = {"none": 0, "diagonal": 1, "DILU": 2}
+
+
+class COpts(C.Structure):
+    _fields_ = [("solver", C.c_int), ("precond", C.c_int), ("smoother", C.c_int), ("nc", C.c_int),
+                ("maxIter", C.c_int), ("nSweeps", C.c_int),
+                ("tolerance", C.c_double * 9), ("relTol", C.c_double * 9)]
+
+
+class CPerf(C.Structure):
+    _fields_ = [("initialResidual", C.c_double * 9), ("finalResidual", C.c_double * 9),
+                ("normFactor", C.c_double * 9), ("singular", C.c_int * 9),
+                ("nIterations", C.c_int), ("converged", C.c_int)]
 
 
 class Patch(C.Structure):
@@ -221,6 +236,51 @@ class System:
         lib().orc_smooth(C.byref(self.sys), SMOOTHERS[smoother], _p(x), _p(b), int(nSweeps))
         return x
 
+    # --- coupled family: fields are (nCells, nc) arrays (Field<Type> images)
+    def _fld(self, x, nc):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.n, nc).copy()
+        return x
+
+    def c_ATmul(self, psi, transpose=False):
+        nc = np.asarray(psi).reshape(self.n, -1).shape[1]
+        x = self._fld(psi, nc); y = np.zeros_like(x)
+        lib().orc_c_ATmul(C.byref(self.sys), nc, _p(y), _p(x), int(transpose)); return y
+
+    def c_residual(self, psi, source):
+        nc = np.asarray(psi).reshape(self.n, -1).shape[1]
+        x = self._fld(psi, nc); b = self._fld(source, nc); y = np.zeros_like(x)
+        lib().orc_c_residual(C.byref(self.sys), nc, _p(y), _p(x), _p(b)); return y
+
+    def c_precondition(self, kind, r, transpose=False):
+        nc = np.asarray(r).reshape(self.n, -1).shape[1]
+        rr = self._fld(r, nc); w = np.zeros_like(rr)
+        lib().orc_c_precondition(C.byref(self.sys), CPRECONDS[kind], nc, _p(w), _p(rr), int(transpose)); return w
+
+    def c_smooth(self, psi, source, nSweeps):
+        nc = np.asarray(psi).reshape(self.n, -1).shape[1]
+        x = self._fld(psi, nc); b = self._fld(source, nc)
+        lib().orc_c_smooth(C.byref(self.sys), nc, _p(x), _p(b), int(nSweeps)); return x
+
+    def c_solve(self, psi, source, solver="PBiCCCG", preconditioner="DILU", tolerance=1e-6, relTol=0.0,
+                maxIter=1000, nSweeps=1):
+        nc = np.asarray(psi).reshape(self.n, -1).shape[1]
+        o = COpts()
+        o.solver, o.precond, o.smoother, o.nc = CSOLVERS[solver], CPRECONDS[preconditioner], 0, nc
+        o.maxIter, o.nSweeps = int(maxIter), int(nSweeps)
+        tol = np.broadcast_to(np.asarray(tolerance, dtype=np.float64), (nc,))
+        rel = np.broadcast_to(np.asarray(relTol, dtype=np.float64), (nc,))
+        for c in range(nc):
+            o.tolerance[c], o.relTol[c] = float(tol[c]), float(rel[c])
+        x = self._fld(psi, nc); b = self._fld(source, nc)
+        perf = CPerf()
+        rc = lib().orc_c_solve(C.byref(self.sys), C.byref(o), _p(x), _p(b), C.byref(perf))
+        if rc:
+            raise ValueError("coupled solver selection error %d (name not in the reference's table)" % rc)
+        return x, dict(initialResidual=np.array(perf.initialResidual[:nc]),
+                       finalResidual=np.array(perf.finalResidual[:nc]),
+                       normFactor=np.array(perf.normFactor[:nc]), nIterations=perf.nIterations,
+                       converged=bool(perf.converged), singular=[bool(v) for v in perf.singular[:nc]])
+
     def face_weights(self):
         ws = [np.ascontiguousarray(p.get("faceWeights", np.zeros(len(p["lowerAddr"]))), dtype=np.float64)
               for p in self.problems]
@@ -308,7 +368,8 @@ def run_ref(mode, problem, dict_str=""):
     spec.loader.exec_module(ldub)
     d = tempfile.mkdtemp(prefix="ldu_ref_")
     arrays = {"nCells": np.array([problem["nCells"]], dtype=np.int32)}
-    for k in ("lowerAddr", "upperAddr", "diag", "upper", "lower", "source", "psi", "faceWeights"):
+    for k in ("lowerAddr", "upperAddr", "diag", "upper", "lower", "source", "psi", "faceWeights", "psiV",
+              "sourceV"):
         if k in problem:
             arrays[k] = problem[k]
     ldub.write(os.path.join(d, "p.ldub"), arrays)

@@ -14,6 +14,8 @@
  *   mode = time    : the same, twice, timed, silent (bench.py cpu_baseline kind "reference")
  *          ops     : Amul/Tmul/sumA/residual/preconditioners/smoothers on psi, source
  *          agglom  : GAMG agglomeration + level matrices dump
+ *          cops    : LduMatrix<vector,scalar,scalar> Amul/Tmul/residual/preconditioners/smoother on psiV, sourceV
+ *          csolve  : LduMatrix<vector,scalar,scalar>::solver::New(...)->solve(psiV)   ("type coupled")
  *
  * Container format ("LDUB"): records {char name[32]; int32 dtype(0=i32,1=f64);
  * int64 count; payload}.
@@ -28,6 +30,9 @@
 #include "pairGAMGAgglomeration.H"
 #include "addToRunTimeSelectionTable.H"
 #include "DICPreconditioner.H"
+#include "LduMatrix.H"
+#include "vector.H"
+#include "vectorField.H"
 #include "OSspecific.H"
 
 #include <cstdio>
@@ -351,6 +356,79 @@ int main(int argc, char* argv[])
             if (cm.hasLower())
             {
                 sprintf(nm, "lower_%d", lev);    putS(nm, cm.lower());
+            }
+        }
+    }
+    else if (mode == "cops" || mode == "csolve")
+    {
+        // the templated coupled family on the same coefficients (fvMatrixSolve.C:222-277 builds exactly this)
+        typedef LduMatrix<vector, scalar, scalar> cMatrix;
+        cMatrix M(mesh);
+        M.diag() = A.diag();
+        M.upper() = A.upper();
+        if (A.hasLower()) M.lower() = A.lower();
+        vectorField psiV(nCells, vector::zero), sourceV(nCells, vector::zero);
+        for (label c = 0; c < nCells; c++)
+            for (direction k = 0; k < 3; k++)
+            {
+                if (P.count("psiV")) psiV[c][k] = P["psiV"].d[3*c + k];
+                if (P.count("sourceV")) sourceV[c][k] = P["sourceV"].d[3*c + k];
+            }
+        M.source() = sourceV;
+        if (mode == "csolve")
+        {
+            dictionary dict(mkDict(dictStr));
+            cMatrix::debug = 2;
+            SolverPerformance<vector>::debug = 2;
+            SolverPerformance<vector> perf = cMatrix::solver::New("U", M, dict)->solve(psiV);
+            perf.print(Info);
+            putD("psiV", reinterpret_cast<const double*>(psiV.begin()), 3*nCells);
+            double pv[11];
+            for (direction k = 0; k < 3; k++)
+            {
+                pv[k] = perf.initialResidual()[k];
+                pv[3 + k] = perf.finalResidual()[k];
+            }
+            pv[6] = perf.nIterations();
+            pv[7] = perf.converged();
+            pv[8] = perf.singular();
+            putD("perf", pv, 9);
+        }
+        else
+        {
+            vectorField y(nCells, vector::zero);
+            M.Amul(y, psiV);     putD("Amul", reinterpret_cast<const double*>(y.begin()), 3*nCells);
+            M.Tmul(y, psiV);     putD("Tmul", reinterpret_cast<const double*>(y.begin()), 3*nCells);
+            M.residual(y, psiV); putD("residual", reinterpret_cast<const double*>(y.begin()), 3*nCells);
+            const char* symPre[]  = {"diagonal", "none", 0};
+            const char* asymPre[] = {"DILU", "diagonal", "none", 0};
+            const char** pre = M.symmetric() ? symPre : asymPre;
+            const char* solName = M.symmetric() ? "PCICG" : "PBiCICG";
+            for (; *pre; ++pre)
+            {
+                std::string ds = std::string("solver ") + solName + "; preconditioner " + *pre + ";";
+                dictionary dict(mkDict(ds.c_str()));
+                autoPtr<cMatrix::solver> sol = cMatrix::solver::New("U", M, dict);
+                autoPtr<cMatrix::preconditioner> pc = cMatrix::preconditioner::New(sol(), dict);
+                vectorField w(nCells, vector::zero);
+                pc->precondition(w, sourceV);
+                putD((std::string("precond_") + *pre).c_str(), reinterpret_cast<const double*>(w.begin()), 3*nCells);
+                if (!M.symmetric())
+                {
+                    vectorField wT(nCells, vector::zero);
+                    pc->preconditionT(wT, sourceV);
+                    putD((std::string("precondT_") + *pre).c_str(), reinterpret_cast<const double*>(wT.begin()),
+                         3*nCells);
+                }
+            }
+            {
+                dictionary dict(mkDict("smoother GaussSeidel;"));
+                autoPtr<cMatrix::smoother> sm = cMatrix::smoother::New("U", M, dict);
+                vectorField x(psiV);
+                sm->smooth(x, 1);
+                putD("smooth1_GaussSeidel", reinterpret_cast<const double*>(x.begin()), 3*nCells);
+                sm->smooth(x, 2);
+                putD("smooth3_GaussSeidel", reinterpret_cast<const double*>(x.begin()), 3*nCells);
             }
         }
     }

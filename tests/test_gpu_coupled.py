@@ -1,0 +1,208 @@
+"""GPU (-m gpu): the coupled solvers LduMatrix<Type, scalar, scalar> (`type coupled;`)
+through the C ABI against the CPU oracle (oracle/ldu_oracle_coupled.c, pinned bit-for-bit against the real
+reference by tests/test_oracle_vs_ref.py) and the golden vectors of the real reference.
+
+Bars: Amul / Tmul / residual, the preconditioners (TDILU, diagonal, none) and the TGaussSeidel smoother are
+BIT-EXACT on every sweep engine; whole solves: same iteration count, residuals within 1e-6 relative (+1e-12),
+solution within 1e-9 of the reference's (only the reductions differ: tree vs left-to-right sums).  Krylov runs
+without an incomplete factorisation (none / diagonal) lose bi-orthogonality long before they converge and
+amplify those last-bit differences: they are stopped after 30 iterations and compared at 10 % / 1e-4, like the
+un-preconditioned cases of tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from openfoam_amd import capi, cases
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+PROBLEMS = {
+    "box_asym_9": lambda: cases.box3d(9, asym=True),
+    "box_asym_20x7x5": lambda: cases.box3d(20, 7, 5, asym=True),
+    "box_sym_8": lambda: cases.box3d(8),
+    "rand_asym_500": lambda: cases.random_graph(500, asym=True),
+    "rand_dense_asym_300": lambda: cases.random_graph(300, avg_deg=14, band=299, asym=True),
+    "tiny_asym_3": lambda: cases.box3d(3, 1, 1, asym=True),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _fields(p, nc, seed=5):
+    rng = np.random.RandomState(seed)
+    return rng.randn(p["nCells"], nc), rng.randn(p["nCells"], nc)
+
+
+@pytest.mark.parametrize("name", sorted(PROBLEMS))
+@pytest.mark.parametrize("nc", [3, 1, 6])
+def test_coupled_ops_bitexact(name, nc, ctx, oracle):
+    p = PROBLEMS[name]()
+    S = oracle.System(p)
+    a, m = capi.from_problem(ctx, p)
+    psi, src = _fields(p, nc)
+    assert np.array_equal(m.coupled_Amul(psi), S.c_ATmul(psi))
+    assert np.array_equal(m.coupled_Amul(psi, transpose=True), S.c_ATmul(psi, True))
+    assert np.array_equal(m.coupled_residual(psi, src), S.c_residual(psi, src))
+    for kind in ("none", "diagonal"):
+        assert np.array_equal(m.coupled_precondition(kind, src), S.c_precondition(kind, src)), kind
+    if not S.sym:
+        for rep in range(2):
+            assert np.array_equal(m.coupled_precondition("DILU", src), S.c_precondition("DILU", src))
+            assert np.array_equal(m.coupled_precondition("DILU", src, transpose=True),
+                                  S.c_precondition("DILU", src, True))
+    else:
+        # DILU is not in the symmetric-matrix table (lduPreconditioners.C:41-42)
+        with pytest.raises(capi.LduError):
+            m.coupled_precondition("DILU", src)
+    for k in (1, 3):
+        assert np.array_equal(m.coupled_smooth(psi, src, k), S.c_smooth(psi, src, k)), k
+    m.close(); a.close()
+
+
+def _bars(solver, pre):
+    strong = pre == "DILU" or solver == "SmoothSolver"
+    return (1e-6, 1e-9) if strong else (1e-1, 1e-4)
+
+
+SOLVES = [("PBiCCCG", "DILU"), ("PBiCCCG", "diagonal"), ("PBiCICG", "DILU"), ("PBiCICG", "none"),
+          ("SmoothSolver", "none"), ("PCICG", "diagonal"), ("PCICG", "none")]
+
+
+@pytest.mark.parametrize("solver,pre", SOLVES)
+@pytest.mark.parametrize("name", ["box_asym_9", "rand_asym_500", "box_sym_8"])
+def test_coupled_solve_matches_oracle(name, solver, pre, ctx, oracle):
+    p = PROBLEMS[name]()
+    S = oracle.System(p)
+    sym = S.sym
+    a, m = capi.from_problem(ctx, p)
+    psi, src = _fields(p, 3, seed=9)
+    kw = dict(solver=solver, preconditioner=pre, tolerance=[1e-8, 1e-7, 1e-9], relTol=0.0, maxIter=80, nSweeps=2)
+    if _bars(solver, pre)[0] > 1e-6:
+        kw["maxIter"] = 30   # before the lost bi-orthogonality dominates
+    if (sym and solver in ("PBiCCCG", "PBiCICG")) or (not sym and solver == "PCICG"):
+        # the name is not in the matrix's run-time selection table: FatalIOError in the reference
+        with pytest.raises(capi.LduError):
+            m.coupled_solve(psi, src, **kw)
+        with pytest.raises(ValueError):
+            S.c_solve(psi, src, **kw)
+        m.close(); a.close()
+        return
+    xo, po = S.c_solve(psi, src, **kw)
+    xg, pg = m.coupled_solve(psi, src, **kw)
+    assert pg["nIterations"] == po["nIterations"]
+    assert pg["converged"] == po["converged"]
+    assert pg["singular"] == po["singular"]
+    assert np.allclose(pg["initialResidual"], po["initialResidual"], rtol=1e-12, atol=0)
+    rt, xt = _bars(solver, pre)
+    assert np.allclose(pg["finalResidual"], po["finalResidual"], rtol=rt, atol=1e-12)
+    assert np.allclose(pg["normFactor"], po["normFactor"], rtol=1e-12, atol=0)
+    assert np.abs(xg - xo).max() <= xt * max(1.0, np.abs(xo).max())
+    m.close(); a.close()
+
+
+def test_coupled_fixed_sweeps_and_diagonal(ctx, oracle):
+    # SmoothSolver with nSweeps < 0: a fixed number of sweeps, no residual (SmoothSolver.C:74-86): bit-exact
+    p = PROBLEMS["box_asym_9"]()
+    S = oracle.System(p)
+    a, m = capi.from_problem(ctx, p)
+    psi, src = _fields(p, 3)
+    xo, po = S.c_solve(psi, src, solver="SmoothSolver", preconditioner="none", nSweeps=-3)
+    xg, pg = m.coupled_solve(psi, src, solver="SmoothSolver", preconditioner="none", nSweeps=-3)
+    assert np.array_equal(xg, xo)
+    assert pg["nIterations"] == po["nIterations"] == 3 and not pg["converged"]
+    m.close(); a.close()
+    # no faces: DiagonalSolver whatever the dictionary says (LduMatrixSolver.C:45-56)
+    d = dict(cases.box3d(4, 1, 1), lowerAddr=np.zeros(0, np.int32), upperAddr=np.zeros(0, np.int32),
+             upper=np.zeros(0), faceWeights=np.zeros(0))
+    S = oracle.System(d)
+    a, m = capi.from_problem(ctx, d)
+    psi, src = _fields(d, 3)
+    xo, po = S.c_solve(psi, src, solver="PBiCCCG")
+    xg, pg = m.coupled_solve(psi, src, solver="PBiCCCG")
+    assert np.array_equal(xg, xo) and pg["converged"] and pg["nIterations"] == 0
+    m.close(); a.close()
+
+
+GOLDEN = sorted(f for f in os.listdir(os.path.join(HERE, "golden")) if f.startswith("coupled_"))
+
+
+@pytest.mark.parametrize("fn", GOLDEN)
+def test_coupled_against_reference_golden(fn, ctx):
+    """Vectors written by the real reference (tests/golden/make_coupled_golden.py)."""
+    g = np.load(os.path.join(HERE, "golden", fn), allow_pickle=False)
+    p = {k[2:]: g[k] for k in g.files if k.startswith("p_")}
+    p["nCells"] = int(p["nCells"])
+    a, m = capi.from_problem(ctx, p)
+    n = p["nCells"]
+    psi, src = g["psiV"].reshape(n, 3), g["sourceV"].reshape(n, 3)
+    assert np.array_equal(m.coupled_Amul(psi).ravel(), g["Amul"])
+    assert np.array_equal(m.coupled_Amul(psi, True).ravel(), g["Tmul"])
+    assert np.array_equal(m.coupled_residual(psi, src).ravel(), g["residual"])
+    for kind in ("DILU", "diagonal", "none"):
+        if "precond_" + kind in g.files:
+            assert np.array_equal(m.coupled_precondition(kind, src).ravel(), g["precond_" + kind]), kind
+        if "precondT_" + kind in g.files:
+            assert np.array_equal(m.coupled_precondition(kind, src, True).ravel(), g["precondT_" + kind]), kind
+    x1 = m.coupled_smooth(psi, src, 1)
+    assert np.array_equal(x1.ravel(), g["smooth1_GaussSeidel"])
+    assert np.array_equal(m.coupled_smooth(x1, src, 2).ravel(), g["smooth3_GaussSeidel"])
+    for key in [k for k in g.files if k.startswith("solve_") and k.endswith("_psi")]:
+        _, solver, pre, _ = key.split("_")
+        perf = g["solve_%s_%s_perf" % (solver, pre)]
+        x, pg = m.coupled_solve(psi, src, solver=solver, preconditioner=pre, tolerance=g["tolerance"],
+                                relTol=0.0, maxIter=int(g["maxIter"]), nSweeps=2)
+        assert pg["nIterations"] == int(perf[6]), key
+        assert pg["converged"] == bool(perf[7]), key
+        assert np.allclose(pg["initialResidual"], perf[0:3], rtol=1e-12, atol=0), key
+        rt, xt = _bars(solver, pre)
+        assert np.allclose(pg["finalResidual"], perf[3:6], rtol=rt, atol=1e-12), key
+        assert np.abs(x.ravel() - g[key]).max() <= xt * max(1.0, np.abs(g[key]).max()), key
+    m.close(); a.close()
+
+
+ENGINES = {
+    "chip": {"LDU_P2P_SLABS": "0", "LDU_CLUSTER": "0"},
+    "slab3": {"LDU_P2P_SLABS": "3", "LDU_CLUSTER": "0"},
+    "slab8": {"LDU_P2P_SLABS": "8", "LDU_CLUSTER": "0"},
+    "levels": {"LDU_SWEEP": "levels"},
+    "cluster": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1"},
+    "auto": {},
+}
+KEYS = ("LDU_P2P_SLABS", "LDU_SWEEP", "LDU_CLUSTER", "LDU_CLUSTER_MIN")
+
+
+@pytest.mark.parametrize("engine", sorted(ENGINES))
+def test_coupled_sweeps_bitexact_on_every_engine(engine, oracle):
+    """TDILU forward/backward, its calcInvD and the TGaussSeidel sweep are separate sweep modes of every engine
+    (different association from the lduMatrix family): each engine must reproduce the sequential loops."""
+    probs = {"box_asym": cases.box3d(17, 30, 21, asym=True),
+             "graph_sparse": cases.random_graph(20000, 2, 60, asym=True),
+             "graph_wide": cases.random_graph(5000, 11, 300, asym=True)}
+    saved = {k: os.environ.pop(k, None) for k in KEYS}
+    os.environ.update(ENGINES[engine])
+    try:
+        ctx = capi.Context(0)
+        for name, p in probs.items():
+            S = oracle.System(p)
+            psi, src = _fields(p, 3, seed=21)
+            e_pre, e_preT = S.c_precondition("DILU", src), S.c_precondition("DILU", src, True)
+            e_gs = S.c_smooth(psi, src, 2)
+            a, m = capi.from_problem(ctx, p)
+            for rep in range(2):
+                assert np.array_equal(m.coupled_precondition("DILU", src), e_pre), (engine, name)
+                assert np.array_equal(m.coupled_precondition("DILU", src, True), e_preT), (engine, name)
+                assert np.array_equal(m.coupled_smooth(psi, src, 2), e_gs), (engine, name)
+            m.close(); a.close()
+        ctx.close()
+    finally:
+        for k in KEYS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
