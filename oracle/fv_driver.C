@@ -247,6 +247,26 @@ static int glueV(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
         put("ref_relax_diag", R.diag());
         put("ref_relax_source", R.source());
     }
+    // `type coupled;`: fvMatrix<vector>::solve -> solveCoupled (fvMatrixSolve.C:83-85, :222-277) builds an
+    // LduMatrix<vector, scalar, scalar> with the component-0 boundary coefficients on the cyclic interfaces
+    // and runs the templated solvers.  solveCoupled returns an empty solverPerformance: psi is the evidence.
+    {
+        const vectorField U0(U.internalField());
+        const char* names[3] = {"PBiCCCG", "PBiCICG", "SmoothSolver"};
+        for (int k = 0; k < 3; k++)
+        {
+            U.internalField() = U0;
+            U.correctBoundaryConditions();
+            fvVectorMatrix S(M);
+            std::string ds = std::string("type coupled; solver ") + names[k] + "; preconditioner DILU; "
+                "smoother GaussSeidel; nSweeps 2; tolerance (1e-9 1e-9 1e-9); relTol (0 0 0); maxIter 40;";
+            dictionary d(IStringStream(ds.c_str())());
+            S.solve(d);
+            put((std::string("ref_coupled_") + names[k]).c_str(), U.internalField());
+        }
+        U.internalField() = U0;
+        U.correctBoundaryConditions();
+    }
     fclose(out);
     return 0;
 }

@@ -286,6 +286,41 @@ def test_vector_fvmatrix_glue_oracle_matches_reference():
     assert eq(d, g["ref_relax_diag"]) and eq(s, g["ref_relax_source"])
 
 
+def coupled_problem(g):
+    """What fvMatrix<vector>::solveCoupled hands to the LduMatrix<vector,scalar,scalar> solvers
+    (fvMatrixSolve.C:236-249): diag + addBoundaryDiag(., 0), source + addBoundarySource(., false), and on the
+    coupled (cyclic) interfaces the component-0 boundary / internal coefficients."""
+    P = glue_patches(g)
+    diag = fv_oracle.add_boundary_diag_cmpt(g["diag"], P, 0)
+    source = fv_oracle.add_boundary_source_v(g["source"], P, couples=False)
+    cp = [i for i, q in enumerate(P) if q["coupled"]]
+    assert cp == [0, 1]
+    patches = [dict(faceCells=P[i]["faceCells"].astype(np.int32), bouCoeffs=np.ascontiguousarray(P[i]["boundaryCoeffs"][:, 0]),
+                    intCoeffs=np.ascontiguousarray(P[i]["internalCoeffs"][:, 0]), nbrDom=0, nbrRank=-1, nbrPatch=i ^ 1,
+                    cyclic=True) for i in cp]
+    return dict(nCells=int(g["nCells"]), lowerAddr=g["lowerAddr"], upperAddr=g["upperAddr"], diag=diag,
+                upper=g["upper"], lower=g["lower"], source=source, psi=g["psi"], patches=patches,
+                faceWeights=np.ones(g["lowerAddr"].size),
+                patches_dev=[dict(faceCells=q["faceCells"], nbrRank=-1, nbrPatch=q["nbrPatch"], cyclic=True)
+                             for q in patches])
+
+
+COUPLED_KW = dict(preconditioner="DILU", tolerance=1e-9, relTol=0.0, maxIter=40, nSweeps=2)
+
+
+def test_type_coupled_solve_oracle_matches_reference(oracle):
+    """8f rank 4 end to end: the reference's own fvVectorMatrix::solve with `type coupled;` (PBiCCCG, PBiCICG,
+    SmoothSolver on a convection-diffusion U equation with cyclic patches) against the coupled oracle fed by
+    the fvMatrix glue oracle - bit for bit."""
+    g = load("fvglueV_box_5x6x4_cyclic")
+    sp = coupled_problem(g)
+    S = oracle.System(sp)
+    for solver in ("PBiCCCG", "PBiCICG", "SmoothSolver"):
+        x, perf = S.c_solve(sp["psi"], sp["source"], solver=solver, **COUPLED_KW)
+        assert np.array_equal(x, g["ref_coupled_" + solver].reshape(-1, 3)), solver
+        assert perf["nIterations"] > 3
+
+
 def stencil_patches(g):
     return [dict(faceCells=g["ref_p%d_faceCells" % p], value=g["ref_p%d_value" % p], Cf=g["ref_p%d_Cf" % p])
             for p in range(int(g["ref_nPatches"][0]))]

@@ -206,3 +206,64 @@ def test_coupled_sweeps_bitexact_on_every_engine(engine, oracle):
             os.environ.pop(k, None)
             if saved[k] is not None:
                 os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("name", ["fvsolve3_chain_asym_5x7x6", "fvsolve2_halves_6x8x7"])
+def test_coupled_with_cyclic_patches(name, ctx, oracle):
+    """Coupled (cyclic) interfaces: every plane's coupled faces are added like the scalar family's
+    (LduMatrixUpdateMatrixInterfaces.C; cyclicFvPatchField::updateInterfaceMatrix(Field<Type>&, ...)):
+    Amul / Tmul / residual / TGaussSeidel bit-exact, solves to the usual bars."""
+    from test_fv_oracle_golden import load, cyclic_problem
+    sp = cyclic_problem(load(name))
+    S = oracle.System(sp)
+    a = capi.Addressing(ctx, sp["nCells"], sp["lowerAddr"], sp["upperAddr"], sp["faceWeights"],
+                        patches=sp["patches_dev"])
+    m = capi.Matrix(a)
+    m.set_coeffs(sp["diag"], sp["upper"], sp.get("lower"))
+    for i, q in enumerate(sp["patches"]):
+        m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+    psi, src = _fields(sp, 3, seed=2)
+    assert np.array_equal(m.coupled_Amul(psi), S.c_ATmul(psi))
+    assert np.array_equal(m.coupled_Amul(psi, True), S.c_ATmul(psi, True))
+    assert np.array_equal(m.coupled_residual(psi, src), S.c_residual(psi, src))
+    assert np.array_equal(m.coupled_smooth(psi, src, 3), S.c_smooth(psi, src, 3))
+    combos = [("PBiCCCG", "DILU"), ("PBiCICG", "DILU"), ("SmoothSolver", "none")] if not S.sym else \
+             [("PCICG", "diagonal"), ("SmoothSolver", "none")]
+    for solver, pre in combos:
+        kw = dict(solver=solver, preconditioner=pre, tolerance=1e-9, maxIter=40, nSweeps=2)
+        xo, po = S.c_solve(psi, src, **kw)
+        xg, pg = m.coupled_solve(psi, src, **kw)
+        rt, xt = _bars(solver, pre)
+        assert pg["nIterations"] == po["nIterations"] and pg["converged"] == po["converged"], (solver, pre)
+        assert np.allclose(pg["finalResidual"], po["finalResidual"], rtol=rt, atol=1e-12), (solver, pre)
+        assert np.abs(xg - xo).max() <= xt * max(1.0, np.abs(xo).max()), (solver, pre)
+    m.close(); a.close()
+
+
+def test_type_coupled_solve_against_reference(ctx):
+    """The reference's own fvVectorMatrix::solve with `type coupled;` (tests/golden/fvglueV_box_5x6x4_cyclic.npz:
+    convection-diffusion U equation, cyclic patches): the HIP fvMatrix glue builds what solveCoupled builds
+    (fvMatrixSolve.C:236-249), the coupled solvers solve it."""
+    from test_fv_oracle_golden import load, glue_patches, coupled_problem, COUPLED_KW
+    g = load("fvglueV_box_5x6x4_cyclic")
+    sp = coupled_problem(g)
+    a = capi.Addressing(ctx, sp["nCells"], sp["lowerAddr"], sp["upperAddr"], sp["faceWeights"],
+                        patches=sp["patches_dev"])
+    # the glue on the device: addBoundaryDiag(diag, 0) and addBoundarySource(source, couples = false)
+    P = glue_patches(g)
+    fb = capi.FvBoundary(a, [q["faceCells"] for q in P], coupled=[q["coupled"] for q in P])
+    iC3 = np.concatenate([q["internalCoeffs"] for q in P])
+    bC3 = np.concatenate([q["boundaryCoeffs"] for q in P])
+    pnf3 = np.concatenate([q["pnf"] for q in P])
+    diag = fb.addBoundaryDiagCmpt(iC3, 0, g["diag"])
+    source = fb.addBoundarySourceV(bC3, pnf3, g["source"], couples=False)
+    assert np.array_equal(diag, sp["diag"]) and np.array_equal(source, sp["source"])
+    m = capi.Matrix(a)
+    m.set_coeffs(diag, sp["upper"], sp["lower"])
+    for i, q in enumerate(sp["patches"]):
+        m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+    for solver in ("PBiCCCG", "PBiCICG", "SmoothSolver"):
+        x, perf = m.coupled_solve(sp["psi"], source, solver=solver, **COUPLED_KW)
+        ref = g["ref_coupled_" + solver].reshape(-1, 3)
+        assert np.abs(x - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), solver
+    fb.close(); m.close(); a.close()
