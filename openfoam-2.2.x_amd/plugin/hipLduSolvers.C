@@ -16,6 +16,8 @@
 \*---------------------------------------------------------------------------*/
 
 #include "lduMatrix.H"
+#include "LduMatrix.H"
+#include "fieldTypes.H"
 #include "processorLduInterface.H"
 #include "cyclicLduInterface.H"
 #include "addToRunTimeSelectionTable.H"
@@ -87,13 +89,13 @@ static ldu_ctx* hipContext()
 
 // Device image of (lduAddressing, coupled patches), built once per addressing like the
 // reference's lazily built losort/ownerStart.
-static hipLduEntry& hipLookup
+template<class InterfaceList>
+static hipLduEntry& hipLookupAddr
 (
-    const lduMatrix& matrix,
-    const lduInterfaceFieldPtrsList& interfaces
+    const lduAddressing& la,
+    const InterfaceList& interfaces
 )
 {
-    const lduAddressing& la = matrix.lduAddr();
     std::map<const lduAddressing*, hipLduEntry>::iterator it = hipEntries_.find(&la);
     const label nCells = la.size();
     const label nFaces = la.lowerAddr().size();
@@ -173,6 +175,15 @@ static hipLduEntry& hipLookup
         it->second.weightsSet = true;
     }
     return it->second;
+}
+
+static hipLduEntry& hipLookup
+(
+    const lduMatrix& matrix,
+    const lduInterfaceFieldPtrsList& interfaces
+)
+{
+    return hipLookupAddr(matrix.lduAddr(), interfaces);
 }
 
 // Coefficients are re-read every solve (fvScalarMatrix.C:152-174 changes diag around the call).
@@ -373,6 +384,161 @@ lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipSmoothSolver> addH
 lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipSmoothSolver> addHipSmoothAsym_(nSmooth);
 lduMatrix::solver::addRemovablesymMatrixConstructorToTable<hipSmoothSolver> addHipSmoothSym2_(nHipSmooth);
 lduMatrix::solver::addRemovableasymMatrixConstructorToTable<hipSmoothSolver> addHipSmoothAsym2_(nHipSmooth);
+
+
+// ------------------------------------------------------------------ coupled solvers (`type coupled;`)
+// LduMatrix<Type, scalar, scalar>::solver (fvMatrixSolve.C:222-277 builds the matrix): PCICG / PBiCCCG /
+// PBiCICG / SmoothSolver resolve to ldu_coupled_solve; the stock entries are replaced, hip* names added.
+
+static int hipCoupledPreconditionerKind(const word& n)
+{
+    if (n == "none") return LDU_CPRE_NONE;
+    if (n == "diagonal") return LDU_CPRE_DIAGONAL;
+    if (n == "DILU") return LDU_CPRE_DILU;
+    FatalErrorIn("hipCoupledPreconditionerKind") << "coupled preconditioner " << n
+        << " has no GPU implementation" << exit(FatalError);
+    return -1;
+}
+
+template<class Type, int Kind>
+class hipCoupledSolver
+:
+    public LduMatrix<Type, scalar, scalar>::solver
+{
+    typedef LduMatrix<Type, scalar, scalar> cMatrix;
+
+public:
+
+    static const word typeName;
+    virtual const word& type() const { return typeName; }
+
+    hipCoupledSolver(const word& fieldName, const cMatrix& matrix, const dictionary& solverDict)
+    :
+        cMatrix::solver(fieldName, matrix, solverDict)
+    {}
+
+    virtual ~hipCoupledSolver() {}
+
+    virtual SolverPerformance<Type> solve(Field<Type>& psi) const
+    {
+        const cMatrix& M = this->matrix_;
+        const direction nc = pTraits<Type>::nComponents;
+        ldu_coupled_controls c;
+        ldu_coupled_default_controls(&c, nc);
+        c.solver = Kind;
+        c.maxIter = this->maxIter_;
+        for (direction k = 0; k < nc; k++)
+        {
+            c.tolerance[k] = component(this->tolerance_, k);
+            c.relTol[k] = component(this->relTol_, k);
+        }
+        c.nSweeps = this->controlDict_.template lookupOrDefault<label>("nSweeps", 1);
+        if (Kind == LDU_CSOLVER_SMOOTHSOLVER)
+        {
+            const word sm(this->controlDict_.lookup("smoother"));   // LduMatrixSmoother.C:41
+            if (sm != "GaussSeidel")
+            {
+                FatalErrorIn("hipCoupledSolver::solve") << "coupled smoother " << sm
+                    << " has no GPU implementation" << exit(FatalError);
+            }
+        }
+        else
+        {
+            // LduMatrixPreconditioner.C:41: mandatory entry, read when the solver needs it
+            c.preconditioner = hipCoupledPreconditionerKind(word(this->controlDict_.lookup("preconditioner")));
+        }
+
+        hipLduEntry& e = hipLookupAddr(M.lduAddr(), M.interfaces());
+        hipCheck
+        (
+            ldu_matrix_set_coeffs
+            (
+                e.mat, M.diag().begin(), M.upper().begin(), M.asymmetric() ? M.lower().begin() : NULL
+            ),
+            "hipCoupledSolver::solve"
+        );
+        label k = 0;
+        forAll(M.interfaces(), patchi)
+        {
+            if (M.interfaces().set(patchi))
+            {
+                hipCheck
+                (
+                    ldu_matrix_set_patch_coeffs
+                    (
+                        e.mat, k++, M.interfacesUpper()[patchi].begin(), M.interfacesLower()[patchi].begin()
+                    ),
+                    "hipCoupledSolver::solve"
+                );
+            }
+        }
+
+        ldu_coupled_perf perf;
+        hipCheck
+        (
+            ldu_coupled_solve
+            (
+                e.mat, &c, reinterpret_cast<double*>(psi.begin()),
+                reinterpret_cast<const double*>(M.source().begin()), &perf
+            ),
+            "hipCoupledSolver::solve"
+        );
+        if (getenv("LDU_VERBOSE"))
+        {
+            Info<< "[hipLduSolvers] coupled " << typeName << " for " << this->fieldName_
+                << " solved on the GPU in " << perf.solveSeconds << " s, " << perf.nIterations
+                << " iterations" << endl;
+        }
+        Type iR(pTraits<Type>::zero), fR(pTraits<Type>::zero);
+        bool singular = true;
+        for (direction k2 = 0; k2 < nc; k2++)
+        {
+            setComponent(iR, k2) = perf.initialResidual[k2];
+            setComponent(fR, k2) = perf.finalResidual[k2];
+            singular = singular && perf.singular[k2];
+        }
+        return SolverPerformance<Type>
+        (
+            typeName, this->fieldName_, iR, fR, perf.nIterations, perf.converged, singular
+        );
+    }
+};
+
+#define makeHipCoupledSolvers(Type)                                                                     \
+    template<> const word hipCoupledSolver<Type, LDU_CSOLVER_PCICG>::typeName("PCICG");                 \
+    template<> const word hipCoupledSolver<Type, LDU_CSOLVER_PBICCCG>::typeName("PBiCCCG");             \
+    template<> const word hipCoupledSolver<Type, LDU_CSOLVER_PBICICG>::typeName("PBiCICG");             \
+    template<> const word hipCoupledSolver<Type, LDU_CSOLVER_SMOOTHSOLVER>::typeName("SmoothSolver");   \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovablesymMatrixConstructorToTable                   \
+        <hipCoupledSolver<Type, LDU_CSOLVER_PCICG> > addHipPCICG##Type##_(nPCICG);                      \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovablesymMatrixConstructorToTable                   \
+        <hipCoupledSolver<Type, LDU_CSOLVER_PCICG> > addHipPCICG2##Type##_(nHipPCICG);                  \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovableasymMatrixConstructorToTable                  \
+        <hipCoupledSolver<Type, LDU_CSOLVER_PBICCCG> > addHipPBiCCCG##Type##_(nPBiCCCG);                \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovableasymMatrixConstructorToTable                  \
+        <hipCoupledSolver<Type, LDU_CSOLVER_PBICCCG> > addHipPBiCCCG2##Type##_(nHipPBiCCCG);            \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovableasymMatrixConstructorToTable                  \
+        <hipCoupledSolver<Type, LDU_CSOLVER_PBICICG> > addHipPBiCICG##Type##_(nPBiCICG);                \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovableasymMatrixConstructorToTable                  \
+        <hipCoupledSolver<Type, LDU_CSOLVER_PBICICG> > addHipPBiCICG2##Type##_(nHipPBiCICG);            \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovablesymMatrixConstructorToTable                   \
+        <hipCoupledSolver<Type, LDU_CSOLVER_SMOOTHSOLVER> > addHipCSmoothSym##Type##_(nCSmooth);        \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovableasymMatrixConstructorToTable                  \
+        <hipCoupledSolver<Type, LDU_CSOLVER_SMOOTHSOLVER> > addHipCSmoothAsym##Type##_(nCSmooth);       \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovablesymMatrixConstructorToTable                   \
+        <hipCoupledSolver<Type, LDU_CSOLVER_SMOOTHSOLVER> > addHipCSmoothSym2##Type##_(nHipCSmooth);    \
+    LduMatrix<Type, scalar, scalar>::solver::addRemovableasymMatrixConstructorToTable                  \
+        <hipCoupledSolver<Type, LDU_CSOLVER_SMOOTHSOLVER> > addHipCSmoothAsym2##Type##_(nHipCSmooth);
+
+static const word nPCICG("PCICG"), nHipPCICG("hipPCICG"), nPBiCCCG("PBiCCCG"), nHipPBiCCCG("hipPBiCCCG"),
+    nPBiCICG("PBiCICG"), nHipPBiCICG("hipPBiCICG"), nCSmooth("SmoothSolver"), nHipCSmooth("hipSmoothSolver");
+
+// the Types the reference instantiates (Solvers/lduSolvers.C:54-58)
+makeHipCoupledSolvers(scalar)
+makeHipCoupledSolvers(vector)
+makeHipCoupledSolvers(sphericalTensor)
+makeHipCoupledSolvers(symmTensor)
+makeHipCoupledSolvers(tensor)
 
 
 // ------------------------------------------------------------------ preconditioners (hipDIC, hipDILU)

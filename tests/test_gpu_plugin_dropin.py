@@ -80,3 +80,60 @@ def test_fvmatrix_solve_through_plugin_with_cyclic_patches(name, tmp_path, monke
         np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-6)
         xr = g["ref_%s_psi" % key]
         assert np.max(np.abs(res["ref_%s_psi" % key] - xr)) <= 1e-8 * np.max(np.abs(xr)), key
+
+
+COUPLED = [("PBiCCCG", "DILU", True), ("PBiCICG", "DILU", True), ("SmoothSolver", "none", True),
+           ("PCICG", "diagonal", False)]
+
+
+@pytest.mark.parametrize("solver,pre,asym", COUPLED, ids=[c[0] for c in COUPLED])
+def test_plugin_replaces_stock_coupled_solver(solver, pre, asym, monkeypatch):
+    """`type coupled;` solvers: LduMatrix<vector,scalar,scalar>::solver::New of the reference (ref_driver mode
+    csolve) with and without the plugin - PCICG / PBiCCCG / PBiCICG / SmoothSolver resolve to the GPU classes."""
+    p = cases.box3d(11, 9, 8, asym=asym)
+    rng = np.random.RandomState(6)
+    p["psiV"], p["sourceV"] = rng.randn(p["nCells"] * 3), rng.randn(p["nCells"] * 3)
+    ds = ("solver %s; preconditioner %s; smoother GaussSeidel; nSweeps 2; tolerance (1e-8 1e-9 1e-8); "
+          "relTol (0 0 0); maxIter 60;" % (solver, pre))
+    ref, out_ref = oracle_py.run_ref("csolve", p, ds)
+    monkeypatch.setenv("LDU_PLUGIN_LIB", os.path.abspath(PLUGIN))
+    monkeypatch.setenv("LDU_VERBOSE", "1")
+    gpu, out_gpu = oracle_py.run_ref("csolve", p, ds)
+    assert "[hipLduSolvers] coupled " + solver in out_gpu and "[hipLduSolvers]" not in out_ref
+    # SolverPerformance<vector>::print: one line per component in both runs
+    assert [l for l in out_gpu.splitlines() if l.startswith(solver + ":  Solving for Ux")], out_gpu[-500:]
+    strong = pre == "DILU" or solver == "SmoothSolver"
+    assert int(gpu["perf"][6]) == int(ref["perf"][6]) and gpu["perf"][7] == ref["perf"][7]
+    np.testing.assert_allclose(gpu["perf"][0:3], ref["perf"][0:3], rtol=1e-10)
+    np.testing.assert_allclose(gpu["perf"][3:6], ref["perf"][3:6], rtol=1e-6 if strong else 1e-1, atol=1e-12)
+    assert np.max(np.abs(gpu["psiV"] - ref["psiV"])) <= (1e-9 if strong else 1e-4) * np.max(np.abs(ref["psiV"]))
+
+
+def test_type_coupled_fvmatrix_solve_through_plugin(tmp_path, monkeypatch):
+    """The application-level boundary of the coupled path: the reference's own fvVectorMatrix::solve with
+    `type coupled;` (fv_driver glueV: real fvMesh, cyclic patches) and the plugin loaded through `libs (...)`:
+    solveCoupled -> LduMatrix<vector,scalar,scalar>::solver::New -> hipCoupledSolver -> GPU.  Must reproduce the
+    stock run stored in the golden fixture."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    import fv_case
+    import make_fv_golden
+    if not fv_case.driver_available():
+        pytest.skip("oracle/_ref/fv_driver not built")
+    name = "fvglueV_box_5x6x4_cyclic"
+    g = dict(np.load(os.path.join(HERE, "golden", name + ".npz")))
+    nx, ny, nz, seed, cyc = make_fv_golden.GLUEV_CASES[name]
+    mesh = fv_case.box_mesh(nx, ny, nz, seed=seed, cyclic_x=cyc)
+    rng = np.random.RandomState(200 + seed)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
+    case = str(tmp_path / "case")
+    fv_case.write_case(case, mesh, libs=[os.path.abspath(PLUGIN)])
+    monkeypatch.setenv("LDU_VERBOSE", "1")
+    res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="glueV")
+    out = fv_case.run_driver.last_stdout
+    for solver in ("PBiCCCG", "PBiCICG", "SmoothSolver"):
+        assert "[hipLduSolvers] coupled " + solver + " for U" in out
+        xr = g["ref_coupled_" + solver]
+        assert np.max(np.abs(res["ref_coupled_" + solver] - xr)) <= 1e-9 * np.max(np.abs(xr)), solver
