@@ -56,6 +56,12 @@ struct ClusterPlan {
     unsigned ticketBase1 = 0;
     unsigned epoch1 = 0;
     int gen1 = 0;
+    // component planes of the coupled (LduMatrix<Type,scalar,scalar>) sweeps: 3 granule planes, own tickets
+    uint4* d_granuleV = nullptr;      // [3][nRows+1]
+    unsigned* d_ticketV = nullptr;
+    unsigned ticketBaseV = 0;
+    unsigned epochV = 0;
+    int genV = 0;
     std::vector<int> levelStart;      // [nClusterLevels+1] clusters of one cluster level are contiguous
     std::vector<int> upLevel;         // [nClusterLevels] running max of the cluster level holding an upper neighbour
     struct Tasks { int* d = nullptr; int n = 0; };
@@ -78,7 +84,8 @@ void cluster_free(ldu_addr* a)
     ClusterPlan* P = a->cluster;
     if (!P) return;
     void* ptrs[] = {P->d_sliceEnt, P->d_sliceDepth, P->d_rowMeta,
-                    P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket, P->d_granule1, P->d_ticket1};
+                    P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket, P->d_granule1, P->d_ticket1,
+                    P->d_granuleV, P->d_ticketV};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : P->conv) if (kv.second.d) (void)hipFree(kv.second.d);
     for (auto& kv : P->tasks) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -274,6 +281,7 @@ static int cluster_build(ldu_addr* a)
     LDU_CHECK_HIP(hipMemset(P->d_granule, 0, sizeof(uint4) * (size_t)(P->nRows + 1)));
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned)));
     LDU_CHECK_HIP(hipMemset(P->d_ticket, 0, sizeof(unsigned)));
+    LDU_CHECK_HIP(hipDeviceSynchronize());
     P->gen = a->ctx->p2pGen;
     P->eligible = true;
     if (getenv("LDU_VERBOSE"))
@@ -297,7 +305,10 @@ __device__ __forceinline__ void cl_store(uint4* G, int row, double v, unsigned t
     cl_u32x4 d;
     d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
     uint4* p = G + row;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+    // s_nop: a VMEM store of more than 64 bits reads its upper data registers one cycle late; the hazard
+    // recognizer does not look inside inline asm, so the wait state before the next VALU write to those
+    // registers is spelled out (without it: three plane stores in a row published pointer bits as tags)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(d) : "memory");
 }
 
 __device__ __forceinline__ void cl_load3(const uint4* p0, const uint4* p1, const uint4* p2, cl_u32x4& g0,
@@ -567,6 +578,9 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
             LDU_CHECK_HIP(hipMemset(P.d_granule1, 0, sizeof(uint4) * (size_t)(P.nRows + 1)));
             LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticket1, sizeof(unsigned)));
             LDU_CHECK_HIP(hipMemset(P.d_ticket1, 0, sizeof(unsigned)));
+            // hipMemset on device memory may return before the fill ran, and the compute streams do not wait
+            // for the null stream: without this the first sweep can publish tags that the fill then erases
+            LDU_CHECK_HIP(hipDeviceSynchronize());
             P.gen1 = ctx->p2pGen;
         }
         G = P.d_granule1; ticket = P.d_ticket1; base = &P.ticketBase1; epoch = &P.epoch1; gen = &P.gen1;
@@ -593,7 +607,264 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     return 0;
 }
 
+// ---------------------------------------------------------------- component planes of the coupled family
+// One cluster sweep for NC component planes of a Field<Type> (LduMatrix<Type, scalar, scalar>): column
+// indices, coefficients, row metadata and the wait for the neighbouring clusters are shared by the planes,
+// only the values are per plane.  B: SW_TRI_FWD / SW_TRI_BWD / SW_GS_FWD, always with the family's association
+// (TDILUPreconditioner.C:108-124, TGaussSeidelSmoother.C:121-142): rD*(coeff*x), rD*acc.
+template <int B, int ND, int NC>
+__device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, double* __restrict__ lds,
+                                               uint4* __restrict__ G, size_t gStride, unsigned tag,
+                                               volatile int* abortFlag, double* __restrict__ w,
+                                               const double* __restrict__ rhs, size_t stride,
+                                               const double* __restrict__ scale, const double* __restrict__ val)
+{
+    constexpr bool FWD = (B == SW_TRI_FWD || B == SW_GS_FWD);
+    constexpr int LSZ = LDU_WAVE * (1 + ND);   // LDS doubles per plane
+    const int row0 = s * LDU_WAVE;
+    const int depth = T.sliceDepth[s];
+    const int r = row0 + lane;
+    const int2 rm = T.rowMeta[r];
+    const int myLv = (rm.y >> 16) & 255;
+    const bool on = myLv != 255;
+    const int lr = rm.x;
+    const int nl = on ? (rm.y & 255) : 0, nu = on ? ((rm.y >> 8) & 255) : 0;
+    const long ent = (long)T.sliceEnt[s] + lane;
+    const int nd = FWD ? nl : nu;
+    const int d0 = FWD ? 0 : nl;
+    int c[ND];
+    double v[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+    {
+        const bool need = k < nd;
+        const long e = ent + (long)(d0 + k) * LDU_WAVE;
+        c[k] = need ? T.colDep[e] : r;
+        v[k] = need ? val[e] : 0.0;
+    }
+    const double dd = scale[lr];
+    double acc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+    {
+        if (B == SW_TRI_FWD) acc[j] = dd * rhs[j * stride + lr];
+        else if (B == SW_TRI_BWD) acc[j] = w[j * stride + lr];
+        else acc[j] = rhs[j * stride + lr];
+    }
+    double pu[NC][ND];
+    if (B == SW_GS_FWD)
+    {
+        // old values of the upper neighbours (level rows), read before anything of this sweep is written
+#pragma unroll
+        for (int k = 0; k < ND; k++)
+        {
+            const bool need = k < nu;
+            const long e = ent + (long)(nl + k) * LDU_WAVE;
+            const double vu = need ? val[e] : 0.0;
+            const int cu = need ? T.colDep[e] : lr;
+#pragma unroll
+            for (int j = 0; j < NC; j++) pu[j][k] = need ? vu * w[j * stride + cu] : 0.0;
+        }
+    }
+    // slot < 64: the dependency is a row of this cluster; otherwise the lane's private copy of an outside value
+    // (lane-varying flags are kept as these integers, not as booleans: a boolean per dependency and plane is
+    // a 64-bit lane mask in scalar registers, and there are not enough of those at ND = 6)
+    int slot[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++)
+    {
+        const bool in = (k < nd) && (c[k] >= row0 && c[k] < row0 + LDU_WAVE);
+        slot[k] = in ? c[k] - row0 : LDU_WAVE + k * LDU_WAVE + lane;
+    }
+    // external dependencies: plane by plane (the planes of a row are published together, so after the first
+    // plane's wait the others are normally there)
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+    {
+        const uint4* Gj = G + j * gStride;
+#pragma unroll
+        for (int k0 = 0; k0 < ND; k0 += 3)
+        {
+            const bool e0 = (k0 < nd) && slot[k0] >= LDU_WAVE, e1 = (k0 + 1 < nd) && slot[k0 + 1] >= LDU_WAVE,
+                       e2 = (k0 + 2 < nd) && slot[k0 + 2] >= LDU_WAVE;
+            double x0 = 1.0, x1 = 1.0, x2 = 1.0;   // unused slots: finite, coefficient 0
+            if (__any(e0 | e1 | e2))
+            {
+                cl_u32x4 g0, g1, g2;
+                unsigned spins = 0;
+                for (;;)
+                {
+                    cl_load3(Gj + c[k0], Gj + c[k0 + 1], Gj + c[k0 + 2], g0, g1, g2);
+                    bool ok = true;
+                    if (e0) ok &= (g0.y == tag) & (g0.w == tag);
+                    if (e1) ok &= (g1.y == tag) & (g1.w == tag);
+                    if (e2) ok &= (g2.y == tag) & (g2.w == tag);
+                    if (ok) break;
+                    if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
+                    {
+                        *abortFlag = 1;
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (e0) x0 = cl_value(g0);
+                if (e1) x1 = cl_value(g1);
+                if (e2) x2 = cl_value(g2);
+            }
+            lds[j * LSZ + LDU_WAVE + k0 * LDU_WAVE + lane] = x0;
+            lds[j * LSZ + LDU_WAVE + (k0 + 1) * LDU_WAVE + lane] = x1;
+            lds[j * LSZ + LDU_WAVE + (k0 + 2) * LDU_WAVE + lane] = x2;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double res[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) res[j] = 0.0;
+    for (int st = 0; st < depth; st++)
+    {
+        const int lv = FWD ? st : depth - 1 - st;
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+        {
+            double t = acc[j];
+            if (B == SW_TRI_BWD)
+            {
+#pragma unroll
+                for (int k = ND - 1; k >= 0; k--) t -= dd * (v[k] * lds[j * LSZ + slot[k]]);
+            }
+            else if (B == SW_TRI_FWD)
+            {
+#pragma unroll
+                for (int k = 0; k < ND; k++) t -= dd * (v[k] * lds[j * LSZ + slot[k]]);
+            }
+            else
+            {
+#pragma unroll
+                for (int k = 0; k < ND; k++) t -= v[k] * lds[j * LSZ + slot[k]];
+            }
+            if (myLv == lv)
+            {
+                double out = t;
+                if (B == SW_GS_FWD)
+                {
+#pragma unroll
+                    for (int k = 0; k < ND; k++) t -= pu[j][k];   // unused entries hold 0.0: t - 0.0 == t
+                    out = dd * t;
+                }
+                lds[j * LSZ + lane] = out;
+                res[j] = out;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (on)
+    {
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+        {
+            w[j * stride + lr] = res[j];
+            cl_store(G + j * gStride, r, res[j], tag);
+        }
+    }
+}
+
+template <int B, bool DESC, int ND, int NC>
+__global__ void __launch_bounds__(CL_BLK)
+sweep_cluster_vec_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, uint4* G,
+                         size_t gStride, unsigned tag, int* abortFlag, double* w, const double* rhs, size_t stride,
+                         const double* scale, const double* val)
+{
+    __shared__ int s_chunk[2];
+    __shared__ double s_x[CL_WPB][NC * LDU_WAVE * (1 + ND)];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    int nextT = 0;
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    for (int it = 0;; it++)
+    {
+        if (threadIdx.x == 0)
+        {
+            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            s_chunk[it & 1] = t;
+            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+        }
+        __syncthreads();
+        const int chunk = s_chunk[it & 1];
+        if (chunk >= nChunks) return;
+        const int si = chunk * CL_WPB + wave;
+        if (si < nSlices)
+            cl_cluster_vec<B, ND, NC>(T, DESC ? nSlices - 1 - si : si, lane, s_x[wave], G, gStride, tag, abortFlag, w, rhs,
+                                      stride, scale, val);
+    }
+}
+
 static bool cluster_pays(const ldu_addr* a, int kind);
+
+template <int B, bool DESC>
+static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t stride, const double* scale,
+                              const double* levelVal, hipStream_t s)
+{
+    ldu_ctx* ctx = a->ctx;
+    ClusterPlan& P = *a->cluster;
+    const double* val = cluster_values(a, levelVal, s);
+    if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
+    constexpr bool FWD = (B == SW_TRI_FWD || B == SW_GS_FWD);
+    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB};
+    const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
+    int bpc = ctx->clusterBlocksPerCU;
+    if (!ctx->clusterBpcForced && P.nSlices < 150 * P.nClusterLevels) bpc = 1;
+    int grid = ctx->numCUs * bpc;
+    if (grid > nChunks) grid = nChunks;
+    if (grid < 1) grid = 1;
+    const size_t gStride = (size_t)P.nRows + 1;
+    if (!P.d_granuleV)
+    {
+        LDU_CHECK_HIP(hipMalloc((void**)&P.d_granuleV, sizeof(uint4) * 3 * gStride));
+        LDU_CHECK_HIP(hipMemset(P.d_granuleV, 0, sizeof(uint4) * 3 * gStride));
+        LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticketV, sizeof(unsigned)));
+        LDU_CHECK_HIP(hipMemset(P.d_ticketV, 0, sizeof(unsigned)));
+        LDU_CHECK_HIP(hipDeviceSynchronize());   // see d_granule1: the fill must have run before the first sweep
+        P.genV = ctx->p2pGen;
+    }
+    if (P.genV != ctx->p2pGen)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticketV, 0, sizeof(unsigned), s));
+        P.ticketBaseV = 0;
+        P.genV = ctx->p2pGen;
+    }
+    P.epochV++;
+    if (P.epochV == 0) P.epochV = 1;
+    if (P.maxDep <= 3)
+        sweep_cluster_vec_kernel<B, DESC, 3, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticketV, P.ticketBaseV,
+            P.d_granuleV, gStride, P.epochV, ctx->d_abort, w, rhs, stride, scale, val);
+    else
+        sweep_cluster_vec_kernel<B, DESC, 6, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticketV, P.ticketBaseV,
+            P.d_granuleV, gStride, P.epochV, ctx->d_abort, w, rhs, stride, scale, val);
+    P.ticketBaseV += (unsigned)(nChunks + grid);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Three component planes (w, rhs: plane p at + p*stride) in one cluster sweep.  mode: SW_TRI_FWD_T,
+// SW_TRI_BWD_T or SW_GS_FWD_T.  Returns 1 when the cluster engine does not take it (caller: plane by plane).
+int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, size_t stride, const double* scale,
+                         const double* val, hipStream_t s)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->clusterEngine || !ctx->sweepP2P || a->nCells < ctx->clusterMinCells) return 1;
+    if (cluster_build(a) < 0) return -1;
+    if (!a->cluster->eligible || a->cluster->maxDep > 6) return 1;
+    if (!cluster_pays(a, mode == SW_GS_FWD_T ? 1 : 0)) return 1;
+    if (!s) s = ctx->stream;
+    switch (mode)
+    {
+    case SW_TRI_FWD_T: return launch_cluster_vec<SW_TRI_FWD, false>(a, w, rhs, stride, scale, val, s);
+    case SW_TRI_BWD_T: return launch_cluster_vec<SW_TRI_BWD, true>(a, w, rhs, stride, scale, val, s);
+    case SW_GS_FWD_T:  return launch_cluster_vec<SW_GS_FWD, false>(a, w, rhs, stride, scale, val, s);
+    }
+    return 1;
+}
+
 
 // returns 1 when the cluster engine does not take this sweep
 int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)

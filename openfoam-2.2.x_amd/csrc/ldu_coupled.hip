@@ -435,7 +435,18 @@ static int c_precondition(ldu_matrix* m, CoupledWork* W, int pre, double* w, con
         // precondition: lower[] forward, upper[] backward (TDILUPreconditioner.C:108-124);
         // preconditionT: upper[] forward, lower[] backward (:154-175) = the transposed value array
         const double* val = (transpose && !m->sym) ? m->d_valT : m->d_valA;
-        for (int c = 0; c < W->nc; c++)
+        int c0 = 0;
+        // three planes per cluster sweep: indices, coefficients and the waits are shared (ldu_cluster.hip)
+        for (; c0 + 3 <= W->nc; c0 += 3)
+        {
+            double* wp = w + c0 * W->stride;
+            int rc = k_sweep_cluster_vec3(a, SW_TRI_FWD_T, wp, r + c0 * W->stride, W->stride, W->d_rDT, val, nullptr);
+            if (rc < 0) return -1;
+            if (rc > 0) break;
+            rc = k_sweep_cluster_vec3(a, SW_TRI_BWD_T, wp, nullptr, W->stride, W->d_rDT, val, nullptr);
+            if (rc) return -1;
+        }
+        for (int c = c0; c < W->nc; c++)
         {
             SweepArgs f{};
             f.mode = SW_TRI_FWD_T; f.w = w + c * W->stride; f.rhs = r + c * W->stride; f.scale = W->d_rDT; f.val = val;
@@ -461,7 +472,17 @@ static int c_smooth(ldu_matrix* m, CoupledWork* W, double* psi, const double* so
     double* bPrime = a->nPatchFaces ? field(W, 10) : nullptr;
     if (a->nPatchFaces && !bPrime) return -1;
     for (int sweep = 0; sweep < nSweeps; sweep++)
-        for (int c = 0; c < W->nc; c++)
+    {
+        int c0 = 0;
+        if (!a->nPatchFaces)
+            for (; c0 + 3 <= W->nc; c0 += 3)
+            {
+                const int rc = k_sweep_cluster_vec3(a, SW_GS_FWD_T, psi + c0 * W->stride, source + c0 * W->stride,
+                                                    W->stride, m->d_rDiag, m->d_valA, nullptr);
+                if (rc < 0) return -1;
+                if (rc > 0) break;
+            }
+        for (int c = c0; c < W->nc; c++)
         {
             const double* rhs = source + c * W->stride;
             if (a->nPatchFaces)
@@ -476,6 +497,7 @@ static int c_smooth(ldu_matrix* m, CoupledWork* W, double* psi, const double* so
             g.mode = SW_GS_FWD_T; g.w = psi + c * W->stride; g.rhs = rhs; g.scale = m->d_rDiag; g.val = m->d_valA;
             if (k_sweep(a, g)) return -1;
         }
+    }
     return 0;
 }
 

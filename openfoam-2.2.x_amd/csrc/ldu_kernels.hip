@@ -570,7 +570,7 @@ __device__ __forceinline__ void granule_store(uint4* G, int row, double v, unsig
     u32x4 d;
     d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
     uint4* p = G + row;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(d) : "memory");
 }
 
 // XCD-slab engine (see "XCD slabs" below): the granule stays in the producing XCD's L2 (plain store:
@@ -583,11 +583,11 @@ __device__ __forceinline__ void granule_store_slab(uint4* G, uint4* X, int row, 
     u32x4 d;
     d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
     uint4* p = G + row;
-    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(d) : "memory");
     if (exported)
     {
         uint4* q = X + row;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(q), "v"(d) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(q), "v"(d) : "memory");
     }
 }
 

@@ -35,6 +35,9 @@ ldu_addr::P2PLane* ldu_addr::lane(int i)
             if (hipMemset(P.d_ctl, 0, sizeof(unsigned) * 16) != hipSuccess) return nullptr;
             P.par = 0;
         }
+        // hipMemset on device memory may return before the fill ran and the compute streams do not wait for
+        // the null stream: the fills must be complete before the first sweep publishes its tags
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
         P.ticketBase = 0;
         P.epoch = 0;
         P.gen = ctx->p2pGen;
