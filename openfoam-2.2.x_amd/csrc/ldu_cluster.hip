@@ -324,6 +324,29 @@ __device__ __forceinline__ void cl_load3(const uint4* p0, const uint4* p1, const
         : "memory");
 }
 
+// nine granules in flight (three dependencies x three component planes), one wait
+__device__ __forceinline__ void cl_load9(const uint4* p0, const uint4* p1, const uint4* p2, size_t gStride,
+                                         cl_u32x4 (&g)[3][3])
+{
+    const uint4 *q0 = p0 + gStride, *q1 = p1 + gStride, *q2 = p2 + gStride;
+    const uint4 *r0 = q0 + gStride, *r1 = q1 + gStride, *r2 = q2 + gStride;
+    asm volatile(
+        "global_load_dwordx4 %0, %9, off sc1\n\t"
+        "global_load_dwordx4 %1, %10, off sc1\n\t"
+        "global_load_dwordx4 %2, %11, off sc1\n\t"
+        "global_load_dwordx4 %3, %12, off sc1\n\t"
+        "global_load_dwordx4 %4, %13, off sc1\n\t"
+        "global_load_dwordx4 %5, %14, off sc1\n\t"
+        "global_load_dwordx4 %6, %15, off sc1\n\t"
+        "global_load_dwordx4 %7, %16, off sc1\n\t"
+        "global_load_dwordx4 %8, %17, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[0][2]), "=&v"(g[1][0]), "=&v"(g[1][1]), "=&v"(g[1][2]),
+          "=&v"(g[2][0]), "=&v"(g[2][1]), "=&v"(g[2][2])
+        : "v"(p0), "v"(p1), "v"(p2), "v"(q0), "v"(q1), "v"(q2), "v"(r0), "v"(r1), "v"(r2)
+        : "memory");
+}
+
 __device__ __forceinline__ double cl_value(const cl_u32x4& g)
 {
     return __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
@@ -676,44 +699,50 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
         const bool in = (k < nd) && (c[k] >= row0 && c[k] < row0 + LDU_WAVE);
         slot[k] = in ? c[k] - row0 : LDU_WAVE + k * LDU_WAVE + lane;
     }
-    // external dependencies: plane by plane (the planes of a row are published together, so after the first
-    // plane's wait the others are normally there)
+    // external dependencies: the three planes of a dependency are polled together (nine granules in flight
+    // per round trip); the planes of a row are published together, so they normally arrive together
+    static_assert(NC == 3, "three planes");
 #pragma unroll
-    for (int j = 0; j < NC; j++)
+    for (int k0 = 0; k0 < ND; k0 += 3)
     {
-        const uint4* Gj = G + j * gStride;
+        const bool e0 = (k0 < nd) && slot[k0] >= LDU_WAVE, e1 = (k0 + 1 < nd) && slot[k0 + 1] >= LDU_WAVE,
+                   e2 = (k0 + 2 < nd) && slot[k0 + 2] >= LDU_WAVE;
+        double x[3][3];
 #pragma unroll
-        for (int k0 = 0; k0 < ND; k0 += 3)
+        for (int j = 0; j < 3; j++) { x[j][0] = 1.0; x[j][1] = 1.0; x[j][2] = 1.0; }   // unused: finite, coefficient 0
+        if (__any(e0 | e1 | e2))
         {
-            const bool e0 = (k0 < nd) && slot[k0] >= LDU_WAVE, e1 = (k0 + 1 < nd) && slot[k0 + 1] >= LDU_WAVE,
-                       e2 = (k0 + 2 < nd) && slot[k0 + 2] >= LDU_WAVE;
-            double x0 = 1.0, x1 = 1.0, x2 = 1.0;   // unused slots: finite, coefficient 0
-            if (__any(e0 | e1 | e2))
+            cl_u32x4 g[3][3];
+            unsigned spins = 0;
+            for (;;)
             {
-                cl_u32x4 g0, g1, g2;
-                unsigned spins = 0;
-                for (;;)
+                cl_load9(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], gStride, g);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
                 {
-                    cl_load3(Gj + c[k0], Gj + c[k0 + 1], Gj + c[k0 + 2], g0, g1, g2);
-                    bool ok = true;
-                    if (e0) ok &= (g0.y == tag) & (g0.w == tag);
-                    if (e1) ok &= (g1.y == tag) & (g1.w == tag);
-                    if (e2) ok &= (g2.y == tag) & (g2.w == tag);
-                    if (ok) break;
-                    if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
-                    {
-                        *abortFlag = 1;
-                        return;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
+                    if (e0) ok &= (g[j][0].y == tag) & (g[j][0].w == tag);
+                    if (e1) ok &= (g[j][1].y == tag) & (g[j][1].w == tag);
+                    if (e2) ok &= (g[j][2].y == tag) & (g[j][2].w == tag);
                 }
-                if (e0) x0 = cl_value(g0);
-                if (e1) x1 = cl_value(g1);
-                if (e2) x2 = cl_value(g2);
+                if (ok) break;
+                if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                __builtin_amdgcn_s_sleep(2);
             }
-            lds[j * LSZ + LDU_WAVE + k0 * LDU_WAVE + lane] = x0;
-            lds[j * LSZ + LDU_WAVE + (k0 + 1) * LDU_WAVE + lane] = x1;
-            lds[j * LSZ + LDU_WAVE + (k0 + 2) * LDU_WAVE + lane] = x2;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+            {
+                if (e0) x[j][0] = cl_value(g[j][0]);
+                if (e1) x[j][1] = cl_value(g[j][1]);
+                if (e2) x[j][2] = cl_value(g[j][2]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+        {
+            lds[j * LSZ + LDU_WAVE + k0 * LDU_WAVE + lane] = x[j][0];
+            lds[j * LSZ + LDU_WAVE + (k0 + 1) * LDU_WAVE + lane] = x[j][1];
+            lds[j * LSZ + LDU_WAVE + (k0 + 2) * LDU_WAVE + lane] = x[j][2];
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
