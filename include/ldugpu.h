@@ -313,6 +313,30 @@ int ldu_coupled_precondition(ldu_matrix* m, int32_t preconditioner, int32_t nCmp
 int ldu_coupled_smooth(ldu_matrix* m, int32_t smoother, int32_t nCmpt, double* psi, const double* source,
                        int32_t nSweeps);
 
+/* ---- mesh side: polyMesh arrays -> geometric fields, renumbering ----------------
+ * Faces as a CSR of point labels (faceStart[nFaces+1], facePoints), all faces (internal first, then the
+ * patches, as in constant/polyMesh/faces); owner for every face, neighbour for the internal ones.
+ * primitiveMesh::makeFaceCentresAndAreas (primitiveMeshFaceCentresAndAreas.C:73-131) and
+ * makeCellCentresAndVols (primitiveMeshCellCentresAndVols.C:72-147); arrays host or device. */
+int ldu_mesh_geometry(ldu_ctx* ctx, int32_t nPoints, const double* points, int32_t nFaces, const int32_t* faceStart,
+                      const int32_t* facePoints, int32_t nCells, int32_t nInternalFaces, const int32_t* owner,
+                      const int32_t* neighbour, double* faceCentres /* nFaces*3 */, double* faceAreas /* nFaces*3 */,
+                      double* cellCentres /* nCells*3 */, double* cellVolumes /* nCells */);
+/* surfaceInterpolation::makeWeights / makeDeltaCoeffs, internal faces (surfaceInterpolation.C:163-185, :227-231)
+ * and fvMesh::magSf; any output may be NULL */
+int ldu_mesh_interpolation_factors(ldu_ctx* ctx, int32_t nCells, int32_t nInternalFaces, const int32_t* owner,
+                                   const int32_t* neighbour, const double* faceCentres, const double* faceAreas,
+                                   const double* cellCentres, double* weights, double* deltaCoeffs, double* magSf);
+/* Foam::bandCompression (meshes/bandCompression/bandCompression.C:43-146) on the cell-cell addressing of the
+ * internal faces: newOrder[i] = old label of the cell that becomes cell i (what renumberMesh applies) */
+int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
+                         int32_t* newOrder);
+/* the matrix addressing under such a renumbering, back in upper-triangular order (lduAddressing.C:92-126 needs
+ * it): faceMap[newFace] = old face, flip[newFace] = 1 when lower/upper of that face swap (may be NULL) */
+int ldu_renumber_addressing(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
+                            const int32_t* newOrder, int32_t* newLower, int32_t* newUpper, int32_t* faceMap,
+                            uint8_t* flip);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,7 @@ EXPORTS = [
     "ldu_fv_linearUpwindCorrection", "ldu_fvc_cellLimitedGrad",
     "ldu_coupled_default_controls", "ldu_coupled_solve", "ldu_coupled_amul", "ldu_coupled_residual",
     "ldu_coupled_precondition", "ldu_coupled_smooth",
+    "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
 ]
 
 # LduMatrix<Type, scalar, scalar> run-time selection names (Solvers/*/*.H TypeName)
@@ -544,3 +545,63 @@ class FvBoundary:
         if self.h:
             lib().ldu_fv_boundary_destroy(self.h)
             self.h = C.c_void_p()
+
+
+# ---------------------------------------------------------------- mesh side
+
+def _i32(x):
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def faces_csr(faces):
+    """list of per-face point-label lists -> (faceStart, facePoints)"""
+    n = np.array([len(f) for f in faces], dtype=np.int64)
+    start = np.zeros(len(faces) + 1, dtype=np.int32)
+    start[1:] = np.cumsum(n)
+    pts = np.fromiter((p for f in faces for p in f), dtype=np.int32, count=int(start[-1]))
+    return start, pts
+
+
+def mesh_geometry(ctx, points, faceStart, facePoints, owner, neighbour, nCells):
+    """primitiveMesh face centres / area vectors (all faces) and cell centres / volumes on the device."""
+    points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    faceStart, facePoints, owner, neighbour = _i32(faceStart), _i32(facePoints), _i32(owner), _i32(neighbour)
+    nF = owner.size
+    Cf, Sf = np.zeros((nF, 3)), np.zeros((nF, 3))
+    C, V = np.zeros((int(nCells), 3)), np.zeros(int(nCells))
+    _chk(lib().ldu_mesh_geometry(ctx.h, points.shape[0], _ptr(points), nF, _ptr(faceStart), _ptr(facePoints),
+                                 int(nCells), neighbour.size, _ptr(owner), _ptr(neighbour), _ptr(Cf), _ptr(Sf),
+                                 _ptr(C), _ptr(V)))
+    return Cf, Sf, C, V
+
+
+def mesh_interpolation_factors(ctx, owner, neighbour, Cf, Sf, C):
+    """linear weights, deltaCoeffs and magSf of the internal faces"""
+    neighbour = _i32(neighbour)
+    nI = neighbour.size
+    owner = _i32(np.asarray(owner)[:nI])
+    Cf = np.ascontiguousarray(np.asarray(Cf, dtype=np.float64)[:nI])
+    Sf = np.ascontiguousarray(np.asarray(Sf, dtype=np.float64)[:nI])
+    C = np.ascontiguousarray(C, dtype=np.float64)
+    w, d, m = np.zeros(nI), np.zeros(nI), np.zeros(nI)
+    _chk(lib().ldu_mesh_interpolation_factors(ctx.h, C.shape[0], nI, _ptr(owner), _ptr(neighbour), _ptr(Cf), _ptr(Sf),
+                                              _ptr(C), _ptr(w), _ptr(d), _ptr(m)))
+    return w, d, m
+
+
+def band_compression(nCells, lowerAddr, upperAddr):
+    """Foam::bandCompression order (host code in the library): newOrder[i] = old label of new cell i"""
+    l, u = _i32(lowerAddr), _i32(upperAddr)
+    out = np.zeros(int(nCells), dtype=np.int32)
+    _chk(lib().ldu_band_compression(int(nCells), l.size, _ptr(l), _ptr(u), _ptr(out)))
+    return out
+
+
+def renumber_addressing(nCells, lowerAddr, upperAddr, newOrder):
+    """-> (newLower, newUpper, faceMap, flip): the addressing after renumbering, upper-triangular order"""
+    l, u, o = _i32(lowerAddr), _i32(upperAddr), _i32(newOrder)
+    nl, nu, fm = np.zeros_like(l), np.zeros_like(l), np.zeros_like(l)
+    fl = np.zeros(l.size, dtype=np.uint8)
+    _chk(lib().ldu_renumber_addressing(int(nCells), l.size, _ptr(l), _ptr(u), _ptr(o), _ptr(nl), _ptr(nu), _ptr(fm),
+                                       _ptr(fl)))
+    return nl, nu, fm, fl

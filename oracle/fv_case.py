@@ -105,7 +105,7 @@ def write_case(case, mesh, libs=None):
         f.write(HEADER % ("faceList", "constant/polyMesh", "faces"))
         f.write("%d\n(\n" % len(mesh["faces"]))
         for fv in mesh["faces"]:
-            f.write("4(%d %d %d %d)\n" % tuple(fv))
+            f.write("%d(%s)\n" % (len(fv), " ".join(str(int(v)) for v in fv)))
         f.write(")\n")
     for name, arr in (("owner", mesh["owner"]), ("neighbour", mesh["neighbour"])):
         with open(os.path.join(pm, name), "w") as f:
@@ -276,3 +276,76 @@ def chain_box_mesh(nBoxes, nxh, ny, nz, seed=4, jitter=0.15, axis="x"):
     return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32),
                 neighbour=np.array(nei, dtype=np.int32), nInternalFaces=nInt, patches=patches,
                 nCells=nBoxes * nA, nHalf=nA, nBoxes=nBoxes)
+
+
+def prism_box_mesh(nx, ny, nz, seed=5, jitter=0.15):
+    """Every hex of a perturbed box split along its x-y diagonal into two prisms: triangular faces (the direct
+    formulas of primitiveMesh::makeFaceCentresAndAreas) next to quads, 5-face cells.  Faces in upper-triangular
+    order, oriented owner -> neighbour / outwards."""
+    base = box_mesh(nx, ny, nz, seed=seed, jitter=jitter, grading=(1.0, 1.5, 0.8))
+    pts = base["points"]
+
+    def pid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    def cid(i, j, k, h):
+        return 2 * (i + nx * (j + ny * k)) + h
+
+    cellPts = {}
+    internal, boundary = [], {n: [] for n in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")}
+
+    def add(verts, a, b=None, patch=None):
+        if b is None:
+            boundary[patch].append((verts, a))
+        else:
+            internal.append((min(a, b), max(a, b), verts))
+
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                p00, p10, p11, p01 = pid(i, j, k), pid(i + 1, j, k), pid(i + 1, j + 1, k), pid(i, j + 1, k)
+                q00, q10, q11, q01 = pid(i, j, k + 1), pid(i + 1, j, k + 1), pid(i + 1, j + 1, k + 1), pid(i, j + 1, k + 1)
+                A, B = cid(i, j, k, 0), cid(i, j, k, 1)
+                cellPts[A] = [p00, p10, p11, q00, q10, q11]
+                cellPts[B] = [p00, p11, p01, q00, q11, q01]
+                add([p00, p11, q11, q00], A, B)                                   # the diagonal
+                if i + 1 < nx: add([p10, p11, q11, q10], A, cid(i + 1, j, k, 1))  # x+ of A meets B of the next hex
+                else: add([p10, p11, q11, q10], A, patch="xmax")
+                if i == 0: add([p00, p01, q01, q00], B, patch="xmin")
+                if j + 1 < ny: add([p01, p11, q11, q01], B, cid(i, j + 1, k, 0))  # y+ of B meets A above
+                else: add([p01, p11, q11, q01], B, patch="ymax")
+                if j == 0: add([p00, p10, q10, q00], A, patch="ymin")
+                if k + 1 < nz:
+                    add([q00, q10, q11], A, cid(i, j, k + 1, 0))
+                    add([q00, q11, q01], B, cid(i, j, k + 1, 1))
+                else:
+                    add([q00, q10, q11], A, patch="zmax")
+                    add([q00, q11, q01], B, patch="zmax")
+                if k == 0:
+                    add([p00, p10, p11], A, patch="zmin")
+                    add([p00, p11, p01], B, patch="zmin")
+
+    def centroid(c):
+        return pts[cellPts[c]].mean(axis=0)
+
+    def oriented(verts, frm, to_point):
+        v = pts[verts]
+        fc = v.mean(axis=0)
+        n = np.zeros(3)
+        for q in range(len(verts)):
+            n += np.cross(v[q] - fc, v[(q + 1) % len(verts)] - fc)
+        return verts if np.dot(n, to_point - centroid(frm)) > 0 else verts[::-1]
+
+    internal.sort(key=lambda t: (t[0], t[1]))
+    faces, owner, nei = [], [], []
+    for a, b, verts in internal:
+        faces.append(oriented(verts, a, centroid(b))); owner.append(a); nei.append(b)
+    nInt = len(faces)
+    patches = []
+    for name in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"):
+        start = len(faces)
+        for verts, a in boundary[name]:
+            faces.append(oriented(verts, a, pts[verts].mean(axis=0))); owner.append(a)
+        patches.append((name, len(boundary[name]), start, ""))
+    return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32), neighbour=np.array(nei, dtype=np.int32),
+                nInternalFaces=nInt, patches=patches, nCells=2 * nx * ny * nz)

@@ -14,6 +14,7 @@
  *   mode = time    : the same, twice, timed, silent (bench.py cpu_baseline kind "reference")
  *          ops     : Amul/Tmul/sumA/residual/preconditioners/smoothers on psi, source
  *          agglom  : GAMG agglomeration + level matrices dump
+ *          rcm     : Foam::bandCompression on the cell-cell addressing of the faces (what renumberMesh applies)
  *          cops    : LduMatrix<vector,scalar,scalar> Amul/Tmul/residual/preconditioners/smoother on psiV, sourceV
  *          csolve  : LduMatrix<vector,scalar,scalar>::solver::New(...)->solve(psiV)   ("type coupled")
  *
@@ -31,6 +32,7 @@
 #include "addToRunTimeSelectionTable.H"
 #include "DICPreconditioner.H"
 #include "LduMatrix.H"
+#include "bandCompression.H"
 #include "vector.H"
 #include "vectorField.H"
 #include "OSspecific.H"
@@ -358,6 +360,22 @@ int main(int argc, char* argv[])
                 sprintf(nm, "lower_%d", lev);    putS(nm, cm.lower());
             }
         }
+    }
+    else if (mode == "rcm")
+    {
+        // primitiveMesh::calcCellCells (primitiveMeshCellCells.C): face order, own learns nei, nei learns own
+        labelList n(nCells, 0);
+        for (label f = 0; f < nFaces; f++) { n[l[f]]++; n[u[f]]++; }
+        labelListList cc(nCells);
+        for (label c = 0; c < nCells; c++) cc[c].setSize(n[c]);
+        n = 0;
+        for (label f = 0; f < nFaces; f++)
+        {
+            cc[l[f]][n[l[f]]++] = u[f];
+            cc[u[f]][n[u[f]]++] = l[f];
+        }
+        labelList order(bandCompression(cc));
+        putL("newOrder", order);
     }
     else if (mode == "cops" || mode == "csolve")
     {
