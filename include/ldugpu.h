@@ -262,6 +262,14 @@ int ldu_fv_linearUpwindCorrection(ldu_addr* a, const double* faceFlux, const dou
  * b may be NULL (no boundary faces). */
 int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf, const double* boundaryValues,
                             const double* C3, const double* Cf3, const double* boundaryCf3, double* grad3);
+/* vector forms (what motorBike's fvSchemes selects for U: `div(phi,U) bounded Gauss linearUpwindV grad(U)`,
+ * `grad(U) cellLimited Gauss linear 1`): linearUpwindV<vector>::correction (linearUpwindV.C:87-140, internal
+ * faces; weights = linear weights, gradVf9 = [nCells][9] tensors xx xy xz yx ...) and
+ * cellLimitedGrad<vector>::calcGrad (cellLimitedGrads.C:200-360; grad9 in/out) */
+int ldu_fv_linearUpwindVCorrection(ldu_addr* a, const double* faceFlux, const double* weights, const double* vf3,
+                                   const double* C3, const double* Cf3, const double* gradVf9, double* corr3);
+int ldu_fvc_cellLimitedGradV(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf3, const double* boundaryValues3,
+                             const double* C3, const double* Cf3, const double* boundaryCf3, double* grad9);
 
 /* ---- coupled solvers: LduMatrix<Type, scalar, scalar> (src/OpenFOAM/matrices/LduMatrix) -------------
  * `type coupled;` in fvSolution (fvMatrixSolve.C:83-85, solveCoupled :222-277) solves every component

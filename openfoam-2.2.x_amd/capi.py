@@ -33,6 +33,7 @@ EXPORTS = [
     "ldu_fv_linearUpwindCorrection", "ldu_fvc_cellLimitedGrad",
     "ldu_coupled_default_controls", "ldu_coupled_solve", "ldu_coupled_amul", "ldu_coupled_residual",
     "ldu_coupled_precondition", "ldu_coupled_smooth",
+    "ldu_fv_linearUpwindVCorrection", "ldu_fvc_cellLimitedGradV",
     "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
 ]
 
@@ -192,6 +193,12 @@ class Addressing:
         out = np.zeros(self.nFaces)
         _chk(lib().ldu_fv_linearUpwindCorrection(self.h, _ptr(_f64(phi)), _ptr(_f64(C3)), _ptr(_f64(Cf3)),
                                                  _ptr(_f64(grad3)), _ptr(out)))
+        return out
+
+    def linearUpwindVCorrection(self, phi, w, vf3, C3, Cf3, grad9):
+        out = np.zeros((self.nFaces, 3))
+        _chk(lib().ldu_fv_linearUpwindVCorrection(self.h, _ptr(_f64(phi)), _ptr(_f64(w)), _ptr(_f64(vf3)), _ptr(_f64(C3)),
+                                                  _ptr(_f64(Cf3)), _ptr(_f64(grad9)), _ptr(out)))
         return out
 
     ENGINES = ("chip-wide point-to-point", "XCD slabs", "clusters", "single wavefront", "level kernels")
@@ -508,6 +515,12 @@ class FvBoundary:
         g = np.array(grad3, dtype=np.float64, copy=True)
         _chk(lib().ldu_fvc_cellLimitedGrad(self.addr.h, self.h, C.c_double(k), _ptr(_f64(vsf)), _ptr(_f64(bVal)),
                                            _ptr(_f64(C3)), _ptr(_f64(Cf3)), _ptr(_f64(bCf3)), _ptr(g)))
+        return g
+
+    def cellLimitedGradV(self, k, vsf3, bVal3, C3, Cf3, bCf3, grad9):
+        g = np.array(grad9, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvc_cellLimitedGradV(self.addr.h, self.h, C.c_double(k), _ptr(_f64(vsf3)), _ptr(_f64(bVal3)),
+                                            _ptr(_f64(C3)), _ptr(_f64(Cf3)), _ptr(_f64(bCf3)), _ptr(g)))
         return g
 
     # ---- vector matrices: coefficient arrays [n][3]

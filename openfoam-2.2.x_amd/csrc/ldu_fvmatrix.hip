@@ -429,6 +429,131 @@ fv_cellLimitedGrad_kernel(int nCells, double k, const int* __restrict__ cs, cons
     g3[3 * c] = gx * lim; g3[3 * c + 1] = gy * lim; g3[3 * c + 2] = gz * lim;
 }
 
+// vector & tensor (TensorI.H operator&(Vector, Tensor)): component j = v.x*t.xj + v.y*t.yj + v.z*t.zj
+__device__ __forceinline__ void vec_dot_tensor(double dx, double dy, double dz, const double* __restrict__ t,
+                                               double& ex, double& ey, double& ez)
+{
+    ex = dx * t[0] + dy * t[3] + dz * t[6];
+    ey = dx * t[1] + dy * t[4] + dz * t[7];
+    ez = dx * t[2] + dy * t[5] + dz * t[8];
+}
+
+// linearUpwindV<vector>::correction, schemes/linearUpwind/linearUpwindV.C:87-140 (internal faces): the upwind
+// cell's gradient extrapolation, limited against the linear (central) correction maxCorr
+__global__ void __launch_bounds__(GLUE_BLK)
+fv_linearUpwindV_kernel(int nFaces, const int* __restrict__ l, const int* __restrict__ u,
+                        const double* __restrict__ phi, const double* __restrict__ w, const double* __restrict__ vf3,
+                        const double* __restrict__ C3, const double* __restrict__ Cf3,
+                        const double* __restrict__ grad9, double* __restrict__ corr3)
+{
+    const int f = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (f >= nFaces) return;
+    const int o = l[f], n = u[f];
+    double mx, my, mz;
+    int c;
+    if (phi[f] > 0.0)
+    {
+        const double a = 1.0 - w[f];
+        mx = a * (vf3[3 * n] - vf3[3 * o]); my = a * (vf3[3 * n + 1] - vf3[3 * o + 1]); mz = a * (vf3[3 * n + 2] - vf3[3 * o + 2]);
+        c = o;
+    }
+    else
+    {
+        const double a = w[f];
+        mx = a * (vf3[3 * o] - vf3[3 * n]); my = a * (vf3[3 * o + 1] - vf3[3 * n + 1]); mz = a * (vf3[3 * o + 2] - vf3[3 * n + 2]);
+        c = n;
+    }
+    double sx, sy, sz;
+    vec_dot_tensor(Cf3[3 * f] - C3[3 * c], Cf3[3 * f + 1] - C3[3 * c + 1], Cf3[3 * f + 2] - C3[3 * c + 2], grad9 + 9 * (size_t)c,
+                   sx, sy, sz);
+    const double sfCorrs = sx * sx + sy * sy + sz * sz;
+    const double maxCorrs = sx * mx + sy * my + sz * mz;
+    if (sfCorrs > 0)
+    {
+        if (maxCorrs < 0) { sx = 0.0; sy = 0.0; sz = 0.0; }
+        else if (sfCorrs > maxCorrs)
+        {
+            const double r = maxCorrs / (sfCorrs + 1.0e-300);
+            sx *= r; sy *= r; sz *= r;
+        }
+    }
+    else if (sfCorrs < 0)
+    {
+        if (maxCorrs > 0) { sx = 0.0; sy = 0.0; sz = 0.0; }
+        else if (sfCorrs < maxCorrs)
+        {
+            const double r = maxCorrs / (sfCorrs - 1.0e-300);
+            sx *= r; sy *= r; sz *= r;
+        }
+    }
+    corr3[3 * f] = sx; corr3[3 * f + 1] = sy; corr3[3 * f + 2] = sz;
+}
+
+// cellLimitedGrad<vector>::calcGrad, cellLimitedGrads.C:200-360: the scalar algorithm per component
+// (limitFace, cellLimitedGrad.H:155-174); the limiter of component j scales column j of the gradient tensor
+__global__ void __launch_bounds__(GLUE_BLK)
+fv_cellLimitedGradV_kernel(int nCells, double k, const int* __restrict__ cs, const int* __restrict__ cf,
+                           const int* __restrict__ losortStart, const int* __restrict__ losort,
+                           const int* __restrict__ ownerStart, const int* __restrict__ l, const int* __restrict__ u,
+                           const double* __restrict__ vsf3, const double* __restrict__ bVal3,
+                           const double* __restrict__ C3, const double* __restrict__ Cf3,
+                           const double* __restrict__ bCf3, double* __restrict__ g9)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    double v[3], mx[3], mn[3];
+    for (int j = 0; j < 3; j++) { v[j] = vsf3[3 * c + j]; mx[j] = v[j]; mn[j] = v[j]; }
+    for (int q = losortStart[c]; q < losortStart[c + 1]; q++)
+    {
+        const int o = l[losort[q]];
+        for (int j = 0; j < 3; j++) { const double x = vsf3[3 * o + j]; mx[j] = fmax(mx[j], x); mn[j] = fmin(mn[j], x); }
+    }
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+    {
+        const int o = u[f];
+        for (int j = 0; j < 3; j++) { const double x = vsf3[3 * o + j]; mx[j] = fmax(mx[j], x); mn[j] = fmin(mn[j], x); }
+    }
+    const int b = cs ? cs[c] : 0, e = cs ? cs[c + 1] : 0;
+    for (int q = b; q < e; q++)
+    {
+        const int f = cf[q];
+        for (int j = 0; j < 3; j++) { const double x = bVal3[3 * f + j]; mx[j] = fmax(mx[j], x); mn[j] = fmin(mn[j], x); }
+    }
+    for (int j = 0; j < 3; j++)
+    {
+        mx[j] -= v[j]; mn[j] -= v[j];
+        if (k < 1.0)
+        {
+            const double mm = (1.0 / k - 1.0) * (mx[j] - mn[j]);
+            mx[j] += mm; mn[j] -= mm;
+        }
+    }
+    double t[9];
+    for (int j = 0; j < 9; j++) t[j] = g9[9 * (size_t)c + j];
+    const double cx = C3[3 * c], cy = C3[3 * c + 1], cz = C3[3 * c + 2];
+    double lim[3] = {1.0, 1.0, 1.0};
+    double ex[3];
+    for (int q = losortStart[c]; q < losortStart[c + 1]; q++)
+    {
+        const int f = losort[q];
+        vec_dot_tensor(Cf3[3 * f] - cx, Cf3[3 * f + 1] - cy, Cf3[3 * f + 2] - cz, t, ex[0], ex[1], ex[2]);
+        for (int j = 0; j < 3; j++) limit_face(lim[j], mx[j], mn[j], ex[j]);
+    }
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+    {
+        vec_dot_tensor(Cf3[3 * f] - cx, Cf3[3 * f + 1] - cy, Cf3[3 * f + 2] - cz, t, ex[0], ex[1], ex[2]);
+        for (int j = 0; j < 3; j++) limit_face(lim[j], mx[j], mn[j], ex[j]);
+    }
+    for (int q = b; q < e; q++)
+    {
+        const int f = cf[q];
+        vec_dot_tensor(bCf3[3 * f] - cx, bCf3[3 * f + 1] - cy, bCf3[3 * f + 2] - cz, t, ex[0], ex[1], ex[2]);
+        for (int j = 0; j < 3; j++) limit_face(lim[j], mx[j], mn[j], ex[j]);
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) g9[9 * (size_t)c + 3 * i + j] = lim[j] * t[3 * i + j];
+}
+
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -735,6 +860,42 @@ int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const dou
         bcf, g);
     LDU_CHECK_HIP(hipGetLastError());
     return B.finish(grad3, g, 3 * (size_t)a->nCells);
+}
+
+int ldu_fv_linearUpwindVCorrection(ldu_addr* a, const double* faceFlux, const double* weights, const double* vf3,
+                                   const double* C3, const double* Cf3, const double* gradVf9, double* corr3)
+{
+    GlueBuf B(a->ctx->stream);
+    const double* phi = B.in(faceFlux, a->nFaces);
+    const double* w = B.in(weights, a->nFaces);
+    const double* v = B.in(vf3, 3 * (size_t)a->nCells);
+    const double* c = B.in(C3, 3 * (size_t)a->nCells);
+    const double* cf = B.in(Cf3, 3 * (size_t)a->nFaces);
+    const double* g = B.in(gradVf9, 9 * (size_t)a->nCells);
+    double* o = B.inout(corr3, 3 * (size_t)a->nFaces, false);
+    fv_linearUpwindV_kernel<<<glue_grid(a->nFaces), GLUE_BLK, 0, B.s>>>(a->nFaces, a->d_l, a->d_u, phi, w, v, c, cf, g, o);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(corr3, o, 3 * (size_t)a->nFaces);
+}
+
+int ldu_fvc_cellLimitedGradV(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf3, const double* boundaryValues3,
+                             const double* C3, const double* Cf3, const double* boundaryCf3, double* grad9)
+{
+    if (k < 1.0e-15) return 0;   // cellLimitedGrads.C:212-215 (k_ < SMALL: unlimited)
+    if (b && b->a != a) { ldu_set_error("ldu_fvc_cellLimitedGradV: boundary belongs to another addressing"); return -2; }
+    GlueBuf B(a->ctx->stream);
+    const size_t nB = b ? (size_t)b->nFacesTotal : 0;
+    const double* v = B.in(vsf3, 3 * (size_t)a->nCells);
+    const double* bv = B.in(boundaryValues3, 3 * nB);
+    const double* c = B.in(C3, 3 * (size_t)a->nCells);
+    const double* cf = B.in(Cf3, 3 * (size_t)a->nFaces);
+    const double* bcf = B.in(boundaryCf3, 3 * nB);
+    double* g = B.inout(grad9, 9 * (size_t)a->nCells, true);
+    fv_cellLimitedGradV_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, k, b ? b->d_cellStart : nullptr,
+        b ? b->d_cellFace : nullptr, a->d_losortStart, a->d_losort, a->d_ownerStart, a->d_l, a->d_u, v, bv, c, cf,
+        bcf, g);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(grad9, g, 9 * (size_t)a->nCells);
 }
 
 }  // extern "C"

@@ -166,8 +166,12 @@ def run_driver(case, mesh, vf, U, phi, gamma, mode="stencils", controls=None):
             name, n = hdr.split(b"\0", 1)[0].decode().split()
             a = np.fromfile(f, dtype=np.float64, count=int(n))
             res[name] = a
+    for k in ("gaussLinearGradU", "cellLimitedGradV_k1", "cellLimitedGradV_k05"):
+        if k in res:
+            res[k] = res[k].reshape(-1, 9)
     for k in ("Sf", "interpolate_v", "surfaceIntegrate_v", "gaussGrad", "phiU", "C", "Cf", "gaussLinearGrad",
-              "cellLimitedGrad_k1", "cellLimitedGrad_k05") + tuple(k for k in res if k.endswith("_Cf") and mode == "stencils"):
+              "cellLimitedGrad_k1", "cellLimitedGrad_k05", "linearUpwindV_correction") + tuple(
+                  k for k in res if k.endswith("_valueU")) + tuple(k for k in res if k.endswith("_Cf") and mode == "stencils"):
         if k in res:
             res[k] = res[k].reshape(-1, 3)
     if mode == "glueV":

@@ -20,6 +20,7 @@
 #include "gaussLaplacianScheme.H"
 #include "gaussConvectionScheme.H"
 #include "linearUpwind.H"
+#include "linearUpwindV.H"
 #include "cellLimitedGrad.H"
 #include "fvcSurfaceIntegrate.H"
 #include "fvMatrices.H"
@@ -51,6 +52,10 @@ static void put(const char* name, const scalarField& f) { put(name, f.begin(), f
 static void put(const char* name, const vectorField& f)
 {
     put(name, reinterpret_cast<const double*>(f.begin()), 3L * f.size());
+}
+static void put(const char* name, const tensorField& f)
+{
+    put(name, reinterpret_cast<const double*>(f.begin()), 9L * f.size());
 }
 
 // fvMatrix glue: a scalar transport matrix with fixedValue / zeroGradient / cyclic
@@ -551,6 +556,36 @@ int main(int argc, char* argv[])
             fv::cellLimitedGrad<scalar> clg(mesh, cl);
             tmp<volVectorField> g = clg.calcGrad(vf, "g");
             put(i ? "cellLimitedGrad_k05" : "cellLimitedGrad_k1", g().internalField());
+        }
+    }
+    // ---- 8f rank 2, vector forms (what motorBike's fvSchemes selects for U): linearUpwindV correction and
+    //      cellLimited Gauss linear gradient of a vector field, non-zero boundary values
+    {
+        forAll(U.boundaryField(), p)
+        {
+            forAll(U.boundaryField()[p], i)
+            {
+                U.boundaryField()[p][i] = vector(0.3*((i % 4) - 1.5), 0.2*((i % 3) - 1.0), 0.1*((i + p) % 5));
+            }
+            char nm[64];
+            snprintf(nm, sizeof(nm), "p%d_valueU", p); put(nm, U.boundaryField()[p]);
+        }
+        {
+            IStringStream gs("Gauss linear");
+            tmp<volTensorField> g0 = fv::gradScheme<vector>::New(mesh, gs)().calcGrad(U, "g0U");
+            put("gaussLinearGradU", g0().internalField());
+        }
+        IStringStream lu("grad(U)");
+        linearUpwindV<vector> sch(mesh, phi, lu);
+        tmp<surfaceVectorField> corr = sch.correction(U);
+        put("linearUpwindV_correction", corr().internalField());
+        const char* ks[2] = {"1", "0.5"};
+        for (int i = 0; i < 2; i++)
+        {
+            IStringStream cl((std::string("Gauss linear ") + ks[i]).c_str());
+            fv::cellLimitedGrad<vector> clg(mesh, cl);
+            tmp<volTensorField> g = clg.calcGrad(U, "gU");
+            put(i ? "cellLimitedGradV_k05" : "cellLimitedGradV_k1", g().internalField());
         }
     }
     // addressing as the reference sees it (must equal the generator's)

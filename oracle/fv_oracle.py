@@ -306,3 +306,81 @@ def cell_limited_grad(k, l, u, vsf, C, Cf, grad, patches):
         for i, c in enumerate(p["faceCells"]):
             limit(c, dot(p["Cf"][i] - C[c], g[c]))
     return g * lim[:, None]
+
+
+def linear_upwind_v_correction(l, u, phi, w, vf, C, Cf, gradT):
+    """linearUpwindV<vector>::correction, interpolation/surfaceInterpolation/schemes/linearUpwind/linearUpwindV.C:
+    87-140 (internal faces).  gradT: [nCells, 9] tensors (xx xy xz yx ...), vector & tensor = TensorI.H."""
+    VSMALL = 1.0e-300
+    out = np.zeros((l.size, 3))
+    for f in range(l.size):
+        o, n = l[f], u[f]
+        if phi[f] > 0.0:
+            maxCorr = (1.0 - w[f]) * (vf[n] - vf[o])
+            d, g = Cf[f] - C[o], gradT[o]
+        else:
+            maxCorr = w[f] * (vf[o] - vf[n])
+            d, g = Cf[f] - C[n], gradT[n]
+        s = np.array([d[0] * g[0] + d[1] * g[3] + d[2] * g[6],
+                      d[0] * g[1] + d[1] * g[4] + d[2] * g[7],
+                      d[0] * g[2] + d[1] * g[5] + d[2] * g[8]])
+        sfCorrs = s[0] * s[0] + s[1] * s[1] + s[2] * s[2]
+        maxCorrs = s[0] * maxCorr[0] + s[1] * maxCorr[1] + s[2] * maxCorr[2]
+        if sfCorrs > 0:
+            if maxCorrs < 0:
+                s = np.zeros(3)
+            elif sfCorrs > maxCorrs:
+                s = s * (maxCorrs / (sfCorrs + VSMALL))
+        elif sfCorrs < 0:
+            if maxCorrs > 0:
+                s = np.zeros(3)
+            elif sfCorrs < maxCorrs:
+                s = s * (maxCorrs / (sfCorrs - VSMALL))
+        out[f] = s
+    return out
+
+
+def cell_limited_grad_v(k, l, u, vsf, C, Cf, gradT, patches):
+    """cellLimitedGrad<vector>::calcGrad, cellLimitedGrads.C:200-360 (component-wise limitFace,
+    cellLimitedGrad.H:155-174; the limiter of component j scales column j of the gradient tensor).
+    patches: dicts faceCells, value [n,3], Cf"""
+    VSMALL = 1.0e-300
+    g = gradT.copy()
+    mx, mn = vsf.copy(), vsf.copy()
+    for f in range(l.size):
+        o, n = l[f], u[f]
+        mx[o] = np.maximum(mx[o], vsf[n]); mn[o] = np.minimum(mn[o], vsf[n])
+        mx[n] = np.maximum(mx[n], vsf[o]); mn[n] = np.minimum(mn[n], vsf[o])
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            mx[c] = np.maximum(mx[c], p["value"][i]); mn[c] = np.minimum(mn[c], p["value"][i])
+    mx = mx - vsf
+    mn = mn - vsf
+    if k < 1.0:
+        mm = (1.0 / k - 1.0) * (mx - mn)
+        mx = mx + mm
+        mn = mn - mm
+    lim = np.ones_like(vsf)
+
+    def limit(c, d):
+        t = g[c]
+        ex = (d[0] * t[0] + d[1] * t[3] + d[2] * t[6], d[0] * t[1] + d[1] * t[4] + d[2] * t[7],
+              d[0] * t[2] + d[1] * t[5] + d[2] * t[8])
+        for j in range(3):
+            if ex[j] > mx[c, j] + VSMALL:
+                lim[c, j] = min(lim[c, j], mx[c, j] / ex[j])
+            elif ex[j] < mn[c, j] - VSMALL:
+                lim[c, j] = min(lim[c, j], mn[c, j] / ex[j])
+
+    for f in range(l.size):
+        limit(l[f], Cf[f] - C[l[f]])
+        limit(u[f], Cf[f] - C[u[f]])
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            limit(c, p["Cf"][i] - C[c])
+    out = g.copy()
+    for j in range(3):
+        out[:, j] = lim[:, j] * g[:, j]
+        out[:, 3 + j] = lim[:, j] * g[:, 3 + j]
+        out[:, 6 + j] = lim[:, j] * g[:, 6 + j]
+    return out

@@ -340,3 +340,12 @@ def test_higher_order_schemes_oracle_matches_reference(name):
     assert np.array_equal(lim1, g["ref_cellLimitedGrad_k1"])
     assert not np.array_equal(lim1, g0)               # the limiter is active somewhere
     assert np.array_equal(fv_oracle.cell_limited_grad(0.5, l, u, g["vf"], C, Cf, g0, P), g["ref_cellLimitedGrad_k05"])
+    # vector forms: linearUpwindV<vector>::correction and cellLimitedGrad<vector> on U with non-zero patch values
+    gU = g["ref_gaussLinearGradU"]
+    assert np.array_equal(fv_oracle.linear_upwind_v_correction(l, u, g["phi"], g["ref_weights"], g["U"], C, Cf, gU),
+                          g["ref_linearUpwindV_correction"])
+    PU = [dict(faceCells=g["ref_p%d_faceCells" % p].astype(int), value=g["ref_p%d_valueU" % p], Cf=g["ref_p%d_Cf" % p])
+          for p in range(int(g["ref_nPatches"][0]))]
+    limV = fv_oracle.cell_limited_grad_v(1.0, l, u, g["U"], C, Cf, gU, PU)
+    assert np.array_equal(limV, g["ref_cellLimitedGradV_k1"]) and not np.array_equal(limV, gU)
+    assert np.array_equal(fv_oracle.cell_limited_grad_v(0.5, l, u, g["U"], C, Cf, gU, PU), g["ref_cellLimitedGradV_k05"])

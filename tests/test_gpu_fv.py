@@ -222,4 +222,12 @@ def test_higher_order_schemes_against_reference_vectors(ctx, name):
     bCf = np.concatenate([g["ref_p%d_Cf" % p] for p in range(nP)])
     assert np.array_equal(B.cellLimitedGrad(1.0, g["vf"], bVal, C, Cf, bCf, g0), g["ref_cellLimitedGrad_k1"])
     assert np.array_equal(B.cellLimitedGrad(0.5, g["vf"], bVal, C, Cf, bCf, g0), g["ref_cellLimitedGrad_k05"])
+    # vector forms (linearUpwindV, cellLimitedGrad<vector>): what motorBike's fvSchemes selects for U
+    gU = g["ref_gaussLinearGradU"]
+    corr = a.linearUpwindVCorrection(g["phi"], g["ref_weights"], g["U"], C, Cf, gU)
+    assert np.array_equal(corr, g["ref_linearUpwindV_correction"]) and np.count_nonzero(corr)
+    bValU = np.concatenate([g["ref_p%d_valueU" % p] for p in range(nP)])
+    lim1 = B.cellLimitedGradV(1.0, g["U"], bValU, C, Cf, bCf, gU)
+    assert np.array_equal(lim1, g["ref_cellLimitedGradV_k1"]) and not np.array_equal(lim1, gU)
+    assert np.array_equal(B.cellLimitedGradV(0.5, g["U"], bValU, C, Cf, bCf, gU), g["ref_cellLimitedGradV_k05"])
     B.close(); a.close()
