@@ -9,6 +9,7 @@
 // cell order), so it stays a host algorithm run once per addressing ("cacheAgglomeration");
 // everything executed per solve or per cycle runs on the device.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -571,7 +572,18 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
         if (k_restrict(C.addr->nCells, C.d_childStart, C.d_child, L.d_src, C.d_src, s)) return -1;
     }
 
-    if (solve_coarsest(Lv[coarsestLevel].mat, c, Lv[coarsestLevel].d_corr, Lv[coarsestLevel].d_src)) return -1;
+    {
+        static const bool timeCoarsest = getenv("LDU_GAMG_TIME") != nullptr;
+        std::chrono::steady_clock::time_point t0;
+        if (timeCoarsest) { (void)hipStreamSynchronize(s); t0 = std::chrono::steady_clock::now(); }
+        if (solve_coarsest(Lv[coarsestLevel].mat, c, Lv[coarsestLevel].d_corr, Lv[coarsestLevel].d_src)) return -1;
+        if (timeCoarsest)
+        {
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "[ldugpu] coarsest level (%d cells): %.3f ms\n", Lv[coarsestLevel].addr->nCells,
+                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+    }
 
     for (int leveli = coarsestLevel - 1; leveli >= 0; leveli--)
     {
