@@ -1,0 +1,166 @@
+// The coarsest GAMG level (GAMGSolverSolve.C:430-487: PCG+DIC or PBiCG+DILU on ~10-60 cells with the outer
+// tolerances) as ONE single-wavefront kernel.  Through the general solver the 17-cell system of the 216^3
+// hierarchy cost 0.24 ms per V-cycle - a dozen launches and one host round trip per Krylov iteration.  Here
+// the matrix is staged in LDS and one lane runs the reference's loops literally (face loops in face / losort
+// order, left-to-right sums: PCG.C:65-182, PBiCG.C:65-198, DICPreconditioner.C:57-123,
+// DILUPreconditioner.C:57-185, lduMatrixSolver.C:179-197), so this level is now also bit-identical to the CPU
+// reference (the general path sums by a tree).  Vectors come in and go out in the plan's numbering.
+#include "ldu_internal.hpp"
+
+#define CO_MAXC 64
+#define CO_MAXF 512
+
+template <bool BI>
+__global__ void __launch_bounds__(LDU_WAVE)
+coarsest_krylov_kernel(int n, int nF, const int* __restrict__ gl, const int* __restrict__ gu,
+                       const int* __restrict__ glosort, const double* __restrict__ gdiag,
+                       const double* __restrict__ gupper, const double* __restrict__ glower,
+                       const int* __restrict__ perm, double* __restrict__ psiNew, const double* __restrict__ srcNew,
+                       double tolerance, double relTol, int maxIter)
+{
+    __shared__ int l[CO_MAXF], u[CO_MAXF], losort[CO_MAXF];
+    __shared__ double upper[CO_MAXF], lower[CO_MAXF];
+    __shared__ double diag[CO_MAXC], psi[CO_MAXC], b[CO_MAXC], pA[CO_MAXC], wA[CO_MAXC], rA[CO_MAXC], rD[CO_MAXC];
+    __shared__ double pT[BI ? CO_MAXC : 1], wT[BI ? CO_MAXC : 1], rT[BI ? CO_MAXC : 1];
+    const int lane = threadIdx.x;
+    for (int f = lane; f < nF; f += LDU_WAVE)
+    {
+        l[f] = gl[f]; u[f] = gu[f];
+        upper[f] = gupper[f]; lower[f] = glower[f];
+        if (BI) losort[f] = glosort[f];
+    }
+    for (int i = lane; i < n; i += LDU_WAVE)
+    {
+        const int o = perm[i];   // perm[new] = old
+        psi[o] = psiNew[i];
+        b[o] = srcNew[i];
+    }
+    for (int c = lane; c < n; c += LDU_WAVE) diag[c] = gdiag[c];
+    __syncthreads();
+    if (lane == 0)
+    {
+        const double great_ = 1e20, small_ = 1e-20, vsmall_ = 1e-300;
+        // wA = A psi (wT = T psi), residuals
+        for (int c = 0; c < n; c++) { wA[c] = diag[c] * psi[c]; if (BI) wT[c] = wA[c]; }
+        for (int f = 0; f < nF; f++)
+        {
+            wA[u[f]] += lower[f] * psi[l[f]];
+            wA[l[f]] += upper[f] * psi[u[f]];
+            if (BI)
+            {
+                wT[u[f]] += upper[f] * psi[l[f]];
+                wT[l[f]] += lower[f] * psi[u[f]];
+            }
+        }
+        for (int c = 0; c < n; c++) { rA[c] = b[c] - wA[c]; if (BI) rT[c] = b[c] - wT[c]; }
+        // normFactor (pA as the temporary, like the reference)
+        for (int c = 0; c < n; c++) pA[c] = diag[c];
+        for (int f = 0; f < nF; f++) { pA[u[f]] += lower[f]; pA[l[f]] += upper[f]; }
+        double sum = 0.0;
+        for (int c = 0; c < n; c++) sum += psi[c];
+        const double avg = sum / (double)n;
+        for (int c = 0; c < n; c++) pA[c] *= avg;
+        double nf = 0.0;
+        for (int c = 0; c < n; c++) nf += fabs(wA[c] - pA[c]) + fabs(b[c] - pA[c]);
+        nf += small_;
+        double res = 0.0;
+        for (int c = 0; c < n; c++) res += fabs(rA[c]);
+        const double initial = res / nf;
+        double final_ = initial;
+        bool converged = final_ < tolerance || (relTol > small_ && final_ < relTol * initial);
+        if (!converged)
+        {
+            // calcReciprocalD
+            for (int c = 0; c < n; c++) rD[c] = diag[c];
+            for (int f = 0; f < nF; f++) rD[u[f]] -= upper[f] * lower[f] / rD[l[f]];
+            for (int c = 0; c < n; c++) rD[c] = 1.0 / rD[c];
+            if (BI) for (int c = 0; c < n; c++) pT[c] = 0.0;
+            double wArA = great_, wArAold;
+            int nIterations = 0;
+            do
+            {
+                wArAold = wArA;
+                // precondition (DIC: lower == upper; DILU: the lower sweep runs in losort order)
+                for (int c = 0; c < n; c++) wA[c] = rD[c] * rA[c];
+                for (int f = 0; f < nF; f++)
+                {
+                    const int sf = BI ? losort[f] : f;
+                    wA[u[sf]] -= rD[u[sf]] * lower[sf] * wA[l[sf]];
+                }
+                for (int f = nF - 1; f >= 0; f--) wA[l[f]] -= rD[l[f]] * upper[f] * wA[u[f]];
+                if (BI)
+                {
+                    for (int c = 0; c < n; c++) wT[c] = rD[c] * rT[c];
+                    for (int f = 0; f < nF; f++) wT[u[f]] -= rD[u[f]] * upper[f] * wT[l[f]];
+                    for (int f = nF - 1; f >= 0; f--)
+                    {
+                        const int sf = losort[f];
+                        wT[l[sf]] -= rD[l[sf]] * lower[sf] * wT[u[sf]];
+                    }
+                }
+                wArA = 0.0;
+                for (int c = 0; c < n; c++) wArA += wA[c] * (BI ? rT[c] : rA[c]);
+                if (nIterations == 0)
+                {
+                    for (int c = 0; c < n; c++) { pA[c] = wA[c]; if (BI) pT[c] = wT[c]; }
+                }
+                else
+                {
+                    const double beta = wArA / wArAold;
+                    for (int c = 0; c < n; c++)
+                    {
+                        pA[c] = wA[c] + beta * pA[c];
+                        if (BI) pT[c] = wT[c] + beta * pT[c];
+                    }
+                }
+                for (int c = 0; c < n; c++) { wA[c] = diag[c] * pA[c]; if (BI) wT[c] = diag[c] * pT[c]; }
+                for (int f = 0; f < nF; f++)
+                {
+                    wA[u[f]] += lower[f] * pA[l[f]];
+                    wA[l[f]] += upper[f] * pA[u[f]];
+                    if (BI)
+                    {
+                        wT[u[f]] += upper[f] * pT[l[f]];
+                        wT[l[f]] += lower[f] * pT[u[f]];
+                    }
+                }
+                double wApA = 0.0;
+                for (int c = 0; c < n; c++) wApA += wA[c] * (BI ? pT[c] : pA[c]);
+                if (fabs(wApA) / nf < vsmall_) break;   // checkSingularity
+                const double alpha = wArA / wApA;
+                for (int c = 0; c < n; c++)
+                {
+                    psi[c] += alpha * pA[c];
+                    rA[c] -= alpha * wA[c];
+                    if (BI) rT[c] -= alpha * wT[c];
+                }
+                res = 0.0;
+                for (int c = 0; c < n; c++) res += fabs(rA[c]);
+                final_ = res / nf;
+                converged = final_ < tolerance || (relTol > small_ && final_ < relTol * initial);
+            } while (nIterations++ < maxIter && !converged);
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += LDU_WAVE) psiNew[i] = psi[perm[i]];
+}
+
+// 1 = not taken (too large, coupled patches, several ranks, switched off)
+int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src)
+{
+    ldu_addr* a = A->a;
+    ldu_ctx* ctx = a->ctx;
+    static const bool off = getenv("LDU_COARSEST_KERNEL") && !atoi(getenv("LDU_COARSEST_KERNEL"));
+    if (off || a->nCells > CO_MAXC || a->nFaces > CO_MAXF || a->nCells == 0 || a->nFaces == 0 || a->nPatchFaces
+        || ctx->nRanks > 1)
+        return 1;
+    hipStream_t s = ctx->stream;
+    if (A->sym)
+        coarsest_krylov_kernel<false><<<1, LDU_WAVE, 0, s>>>(a->nCells, a->nFaces, a->d_l, a->d_u, a->d_losort, A->d_diagO,
+            A->d_upperO, A->d_upperO, a->d_perm, corr, src, tolerance, relTol, maxIter);
+    else
+        coarsest_krylov_kernel<true><<<1, LDU_WAVE, 0, s>>>(a->nCells, a->nFaces, a->d_l, a->d_u, a->d_losort, A->d_diagO,
+            A->d_upperO, A->d_lowerO, a->d_perm, corr, src, tolerance, relTol, maxIter);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -521,6 +521,11 @@ static int solve_coarsest(ldu_matrix* A, const ldu_controls* c, double* corr, co
 {
     hipStream_t s = A->a->ctx->stream;
     if (k_ew(A->a->nCells, EW_ZERO, corr, nullptr, nullptr, s)) return -1;
+    {
+        // the whole Krylov solve of a tiny level in one single-wavefront kernel (ldu_coarsest.hip)
+        const int rc = k_coarsest_solve(A, c->tolerance, c->relTol, 1000, corr, src);
+        if (rc <= 0) return rc;
+    }
     ldu_controls cc;
     ldu_default_controls(&cc);
     cc.tolerance = c->tolerance;
