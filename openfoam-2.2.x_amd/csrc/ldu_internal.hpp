@@ -75,7 +75,7 @@ struct ldu_ctx {
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
-    int smallMaxCells = 256;         // LDU_SMALL_MAX (<= 8192); measured: wins up to ~200 cells, loses above
+    int smallMaxCells = 3000;        // LDU_SMALL_MAX (<= 8192); measured: wins up to ~2500 cells, loses at 4900
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
     int p2pMaxBlocksPerCU = 5;       // register-limited residency of the sweep kernels

@@ -1274,10 +1274,11 @@ sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0
 // The coefficients of the next two slices are in flight while a slice is computed (they do not
 // depend on the sweep).  Arithmetic per row = GaussSeidelSmoother.C:151-176, identical to the
 // other engines (bit-exact).
-// Measured (216^3 GAMG hierarchy, 4 sweeps): 36 cells 0.067 ms (slab engine 0.095), 150 cells 0.121
-// (0.140), 608 cells 0.182 (0.185), 4908 cells 0.467 (0.259): ~0.8-1.1 us per slice - one exposed
-// global-load round trip, the 4+2W loads of two slices do not fit the 63-deep vmcnt window - so it
-// is only used up to ctx->smallMaxCells (256) cells.
+// Measured (216^3 GAMG hierarchy, 4 sweeps; chip-wide engines in brackets): 36 cells 0.049 ms (0.095), 150 cells
+// 0.084 (0.140), 302 cells 0.102 (0.137), 608 cells 0.120 (0.182), 1220 cells 0.186 (0.236), 2454 cells 0.179
+// (0.247), 4908 cells 0.319 (0.265): ~0.6-0.7 us per slice, so it is used up to ctx->smallMaxCells (3000) cells.
+// (Until the accumulation was written branch-free - see SMALL_STEP - it cost 0.8-1.1 us per slice and lost
+//  above ~200 cells.)
 // (A 512/1024-thread version with a workgroup barrier per level measured 1.2-2.3 us per level: idle
 //  waves either issue the same loads - the CU's address pipeline becomes the bound - or skip them
 //  behind a branch, after which the compiler must drain all prefetches at the join.)
@@ -1342,11 +1343,17 @@ gs_small_kernel(SliceTab T, int nSlices, int nCells, int k, double* __restrict__
         {                                                                                 \
             double acc = (CUR).b;                                                         \
             const int nn = (int)(CUR).nl + (int)(CUR).nu;                                 \
+            /* all W LDS reads in flight, then the products, then ONE dependent subtraction per entry;  \
+               entries beyond the row subtract +0.0 (identity for every acc, also -0.0).  Written as   \
+               `if (q < nn) acc -= v*x[c]` the compiler sinks each read into its branch: W serial      \
+               read-wait-multiply-subtract round trips (ISA checked; 1.4-1.5x slower) */               \
+            double xv[W], pr[W];                                                          \
             _Pragma("unroll") for (int q = 0; q < W; q++)                                 \
-            {                                                                             \
-                const double xq = x[(CUR).c[q] & (SMALL_MAX_CELLS - 1)];                  \
-                if (q < nn) acc -= (CUR).v[q] * xq;                                       \
-            }                                                                             \
+                xv[q] = x[(CUR).c[q] & (SMALL_MAX_CELLS - 1)];                            \
+            _Pragma("unroll") for (int q = 0; q < W; q++) asm volatile("" : "+v"(xv[q])); \
+            _Pragma("unroll") for (int q = 0; q < W; q++)                                 \
+                pr[q] = q < nn ? (CUR).v[q] * xv[q] : 0.0;                                \
+            _Pragma("unroll") for (int q = 0; q < W; q++) acc -= pr[q];                   \
             if ((CUR).r >= 0) x[(CUR).r] = acc / (CUR).d;                                 \
         }                                                                                 \
         /* the next slice may read what this one wrote: LDS is in order within a wave */  \

@@ -42,7 +42,7 @@ def _problems():
     p = cases.random_graph(30000, 9, 400)
     p["psi"] = rng.randn(p["nCells"])
     out["graph"] = p
-    # <= 8192 cells: the single-wavefront LDS kernel (engine "small8192"; default limit 256 cells: "chain")
+    # <= 8192 cells: the single-wavefront LDS kernel (engine "small8192"; default limit 3000 cells: "chain")
     p = cases.box3d(19, 20, 21)
     p["psi"] = rng.randn(p["nCells"])
     out["box_small"] = p
