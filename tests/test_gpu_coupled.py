@@ -267,3 +267,41 @@ def test_type_coupled_solve_against_reference(ctx):
         ref = g["ref_coupled_" + solver].reshape(-1, 3)
         assert np.abs(x - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), solver
     fb.close(); m.close(); a.close()
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_coupled_on_n_ranks(n, oracle):
+    """The coupled family across N ranks (processor patches, rank-ordered reductions): N host threads in a local
+    communicator group against the oracle's serial emulation of the same N-rank run - operators and the
+    TGaussSeidel sweep bit-exact, PBiCCCG / PBiCICG / SmoothSolver to the usual bars on every rank."""
+    from test_gpu_multidomain import run_ranks, _case
+    p, subs, maps = _case(n, asym=True, size=10)
+    rng = np.random.RandomState(31)
+    xs = [rng.randn(s["nCells"], 3) for s in subs]
+    bs = [rng.randn(s["nCells"], 3) for s in subs]
+    S = oracle.System(subs)
+    X, B = np.concatenate(xs), np.concatenate(bs)
+    kws = [dict(solver="PBiCCCG", preconditioner="DILU", tolerance=1e-9, maxIter=60),
+           dict(solver="PBiCICG", preconditioner="DILU", tolerance=[1e-9, 1e-8, 1e-9], maxIter=60),
+           dict(solver="SmoothSolver", preconditioner="none", tolerance=1e-7, maxIter=40, nSweeps=2)]
+
+    def fn(r, ctx, a, m):
+        out = dict(Amul=m.coupled_Amul(xs[r]), Tmul=m.coupled_Amul(xs[r], True), res=m.coupled_residual(xs[r], bs[r]),
+                   gs=m.coupled_smooth(xs[r], bs[r], 2), pre=m.coupled_precondition("DILU", bs[r]))
+        out["solves"] = [m.coupled_solve(xs[r], bs[r], **kw) for kw in kws]
+        return out
+    res = run_ranks(subs, fn)
+    cat = lambda k: np.concatenate([r[k] for r in res])
+    assert np.array_equal(cat("Amul"), S.c_ATmul(X))
+    assert np.array_equal(cat("Tmul"), S.c_ATmul(X, True))
+    assert np.array_equal(cat("res"), S.c_residual(X, B))
+    assert np.array_equal(cat("gs"), S.c_smooth(X, B, 2))
+    assert np.array_equal(cat("pre"), S.c_precondition("DILU", B))
+    for i, kw in enumerate(kws):
+        xo, po = S.c_solve(X, B, **kw)
+        xg = np.concatenate([r["solves"][i][0] for r in res])
+        for r in res:
+            pg = r["solves"][i][1]
+            assert pg["nIterations"] == po["nIterations"] and pg["converged"] == po["converged"], kw
+            assert np.allclose(pg["finalResidual"], po["finalResidual"], rtol=1e-6, atol=1e-12), kw
+        assert np.abs(xg - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max()), kw
