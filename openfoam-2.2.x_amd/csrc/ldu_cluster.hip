@@ -21,6 +21,7 @@
 #include <vector>
 
 #include <chrono>
+#include <thread>
 
 #include "ldu_internal.hpp"
 
@@ -186,6 +187,7 @@ static int cluster_build(ldu_addr* a)
         cDepth.push_back(depth);
     }
     const int nCl = (int)members.size();
+    const auto tGreedy = std::chrono::steady_clock::now();
     // ---- schedule order: by cluster level (ties: creation order) = a topological order of the quotient
     std::vector<int> order(nCl);
     for (int i = 0; i < nCl; i++) order[i] = i;
@@ -249,7 +251,9 @@ static int cluster_build(ldu_addr* a)
             for (int r = lvlSliceRow[s]; r < lvlSliceRow[s + 1]; r++) lvlSliceOfRow[r] = s;
     }
     std::vector<int> colF((size_t)P->nEntries, 0), colB((size_t)P->nEntries, 0), src((size_t)P->nEntries, 0);
-    for (int s = 0; s < nCl; s++)
+    // the clusters write disjoint ranges of the tables: host threads over cluster ranges
+    auto fillRange = [&](int s0, int s1) {
+    for (int s = s0; s < s1; s++)
     {
         const int id = order[s];
         for (size_t i = 0; i < members[id].size(); i++)
@@ -283,6 +287,19 @@ static int cluster_build(ldu_addr* a)
             (void)r;
         }
     }
+    };
+    {
+        const int nT = nCl >= 4096 ? (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        if (nT == 1) fillRange(0, nCl);
+        else
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nT; t++)
+                th.emplace_back(fillRange, (int)((long)nCl * t / nT), (int)((long)nCl * (t + 1) / nT));
+            for (auto& t : th) t.join();
+        }
+    }
+    const auto tTables = std::chrono::steady_clock::now();
     if (cl_upload(&P->d_sliceEnt, sliceEnt) || cl_upload(&P->d_sliceDepth, sliceDepth) || cl_upload(&P->d_rowMeta, rowMeta)
         || cl_upload(&P->d_colF, colF) || cl_upload(&P->d_colB, colB) || cl_upload(&P->d_src, src))
         return -1;
@@ -295,9 +312,12 @@ static int cluster_build(ldu_addr* a)
     P->eligible = true;
     if (getenv("LDU_VERBOSE"))
         fprintf(stderr, "[ldugpu] cluster plan: %d cells -> %d clusters (avg %.1f cells, avg %.1f internal steps), "
-                        "%d cluster levels (dependency levels: %d), built in %.3f s\n",
+                        "%d cluster levels (dependency levels: %d), built in %.3f s (greedy %.3f, tables %.3f, upload %.3f)\n",
                 nC, nCl, (double)nC / std::max(1, nCl), P->avgDepth, P->nClusterLevels, a->nLevels,
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count());
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count(),
+                std::chrono::duration<double>(tGreedy - tBuild0).count(),
+                std::chrono::duration<double>(tTables - tGreedy).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tTables).count());
     return 0;
 }
 
