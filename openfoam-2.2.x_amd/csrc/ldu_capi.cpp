@@ -9,6 +9,7 @@
 
 static thread_local std::string g_err;
 void ldu_set_error(const std::string& msg) { g_err = msg; }
+std::string ldu_last_error_string() { return g_err; }
 
 static double now_s()
 {

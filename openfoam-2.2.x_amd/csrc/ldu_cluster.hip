@@ -21,6 +21,7 @@
 #include <vector>
 
 #include <chrono>
+#include <string>
 #include <thread>
 
 #include "ldu_internal.hpp"
@@ -924,6 +925,30 @@ int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, si
     return 1;
 }
 
+
+// Build the cluster plans of several addressings at once (one host thread each): the greedy clustering is
+// sequential per addressing but the levels of a GAMG hierarchy are independent.
+int k_cluster_prebuild(const std::vector<ldu_addr*>& addrs)
+{
+    std::vector<ldu_addr*> todo;
+    for (ldu_addr* a : addrs)
+        if (a && !a->cluster && a->ctx->clusterEngine && a->ctx->sweepP2P && a->nCells >= a->ctx->clusterMinCells)
+            todo.push_back(a);
+    if (todo.size() < 2) return 0;
+    std::vector<int> rc(todo.size(), 0);
+    std::vector<std::string> err(todo.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < todo.size(); i++)
+        th.emplace_back([&, i]() {
+            if (hipSetDevice(todo[i]->ctx->device) != hipSuccess) { rc[i] = -1; err[i] = "hipSetDevice failed"; return; }
+            rc[i] = cluster_build(todo[i]) < 0 ? -1 : 0;
+            if (rc[i]) err[i] = ldu_last_error_string();
+        });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < todo.size(); i++)
+        if (rc[i]) { ldu_set_error("cluster plan: " + err[i]); return -1; }
+    return 0;
+}
 
 // returns 1 when the cluster engine does not take this sweep
 int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <string>
+#include <thread>
 
 #include "ldu_internal.hpp"
 
@@ -413,6 +415,24 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             return -8;
         }
         g->levels.resize(hl.size());
+        const bool parallelPlans = !getenv("LDU_NO_PARALLEL_PLANS");
+        if (parallelPlans)
+        {
+            // the level plans (dependency levels, sliced-ELL tables) are independent: one host thread each
+            std::vector<int> rcs(hl.size(), 0);
+            std::vector<std::string> errs(hl.size());
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < hl.size(); i++)
+                th.emplace_back([&, i]() {
+                    if (hipSetDevice(a->ctx->device) != hipSuccess) { rcs[i] = -1; errs[i] = "hipSetDevice failed"; return; }
+                    rcs[i] = addr_create_internal(a->ctx, &g->levels[i].addr, hl[i].nCells, (int)hl[i].lower.size(),
+                                                  hl[i].lower.data(), hl[i].upper.data());
+                    if (rcs[i]) errs[i] = ldu_last_error_string();
+                });
+            for (auto& t : th) t.join();
+            for (size_t i = 0; i < hl.size(); i++)
+                if (rcs[i]) { ldu_set_error("GAMG level plan: " + errs[i]); return -1; }
+        }
         const ldu_addr* fineA = a;
         for (size_t i = 0; i < hl.size(); i++)
         {
@@ -421,8 +441,9 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             L.nFineFaces = fineA->nFaces;
             L.restrictAddr.swap(hl[i].restrictAddr);
             L.faceRestrictAddr.swap(hl[i].faceRestrictAddr);
-            if (addr_create_internal(a->ctx, &L.addr, hl[i].nCells, (int)hl[i].lower.size(),
-                                     hl[i].lower.data(), hl[i].upper.data()))
+            if (!parallelPlans
+                && addr_create_internal(a->ctx, &L.addr, hl[i].nCells, (int)hl[i].lower.size(),
+                                        hl[i].lower.data(), hl[i].upper.data()))
                 return -1;
             // coarse processor patches + the lists that agglomerate their coefficients
             // (GAMGInterface::agglomerateCoeffs, GAMGInterface.C:61-75) in ascending fine-face order
@@ -455,6 +476,13 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 fprintf(stderr, "[ldugpu] GAMG level %2zu: %9d cells %9d faces  %5d dependency levels  %7d slices\n",
                         i + 1, L.addr->nCells, L.addr->nFaces, L.addr->nLevels, L.addr->nSlices);
             fineA = L.addr;
+        }
+        if (!getenv("LDU_NO_CLUSTER_PREBUILD"))
+        {
+            // the cluster plans of the large levels (and of the finest matrix), one host thread each
+            std::vector<ldu_addr*> big{a};
+            for (auto& L : g->levels) big.push_back(L.addr);
+            if (k_cluster_prebuild(big)) return -1;
         }
         const size_t n = (size_t)a->nCells + 1;
         LDU_CHECK_HIP(hipMalloc((void**)&g->d_Apsi, sizeof(double) * n));

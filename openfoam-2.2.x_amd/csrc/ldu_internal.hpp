@@ -282,6 +282,8 @@ int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
 int k_xcd_census(ldu_ctx* ctx);
 int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s);   // 1 = not taken
+int k_cluster_prebuild(const std::vector<ldu_addr*>& addrs);            // cluster plans of several addressings, in parallel
+std::string ldu_last_error_string();
 int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, size_t stride, const double* scale,
                          const double* val, hipStream_t s);   // three component planes at once; 1 = not taken
 bool k_cluster_active(ldu_addr* a);
