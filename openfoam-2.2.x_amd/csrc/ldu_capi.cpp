@@ -102,13 +102,14 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * 2 * (size_t)c->maxRedBlocks));
-    LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * S_NSLOTS));
-    LDU_CHECK_HIP(hipMemset(c->d_scalars, 0, sizeof(double) * S_NSLOTS));
-    LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * S_NSLOTS, hipHostMallocDefault));
-    LDU_CHECK_HIP(hipMalloc((void**)&c->d_abort, sizeof(int)));
-    LDU_CHECK_HIP(hipMemset(c->d_abort, 0, sizeof(int)));
-    LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_abort, sizeof(int), hipHostMallocDefault));
+    // the abort flag lives behind the scalar slots so that ONE device-to-host copy brings both
+    LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * (S_NSLOTS + 1)));
+    LDU_CHECK_HIP(hipMemset(c->d_scalars, 0, sizeof(double) * (S_NSLOTS + 1)));
+    LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * (S_NSLOTS + 1), hipHostMallocDefault));
+    c->d_abort = (int*)(c->d_scalars + S_NSLOTS);
+    c->h_abort = (int*)(c->h_scalars + S_NSLOTS);
     *c->h_abort = 0;
+    LDU_CHECK_HIP(hipDeviceSynchronize());
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -166,8 +167,6 @@ int ldu_ctx_destroy(ldu_ctx* c)
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_scalars);
     (void)hipHostFree(c->h_scalars);
-    (void)hipFree(c->d_abort);
-    (void)hipHostFree(c->h_abort);
     (void)hipEventDestroy(c->evFork);
     (void)hipEventDestroy(c->evJoin);
     (void)hipStreamDestroy(c->stream);
