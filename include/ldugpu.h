@@ -266,6 +266,11 @@ int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const dou
  * `grad(U) cellLimited Gauss linear 1`): linearUpwindV<vector>::correction (linearUpwindV.C:87-140, internal
  * faces; weights = linear weights, gradVf9 = [nCells][9] tensors xx xy xz yx ...) and
  * cellLimitedGrad<vector>::calcGrad (cellLimitedGrads.C:200-360; grad9 in/out) */
+/* the `bounded` wrapper of those div schemes (boundedConvectionScheme.C:60-77): fvmDiv - fvm::Sp(fvc::
+ * surfaceIntegrate(phi), vf), i.e. diag -= V*surfaceIntegrate(phi) (fvcSurfaceIntegrate.C:43-76; boundaryFlux:
+ * the patch values of phi concatenated in patch order, b may be NULL for a mesh without patches) */
+int ldu_fvm_boundedSp(ldu_addr* a, ldu_fv_boundary* b, const double* faceFlux, const double* boundaryFlux,
+                      const double* V, double* diag);
 int ldu_fv_linearUpwindVCorrection(ldu_addr* a, const double* faceFlux, const double* weights, const double* vf3,
                                    const double* C3, const double* Cf3, const double* gradVf9, double* corr3);
 int ldu_fvc_cellLimitedGradV(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf3, const double* boundaryValues3,

@@ -33,7 +33,7 @@ EXPORTS = [
     "ldu_fv_linearUpwindCorrection", "ldu_fvc_cellLimitedGrad",
     "ldu_coupled_default_controls", "ldu_coupled_solve", "ldu_coupled_amul", "ldu_coupled_residual",
     "ldu_coupled_precondition", "ldu_coupled_smooth",
-    "ldu_fv_linearUpwindVCorrection", "ldu_fvc_cellLimitedGradV",
+    "ldu_fv_linearUpwindVCorrection", "ldu_fvc_cellLimitedGradV", "ldu_fvm_boundedSp",
     "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
 ]
 
@@ -516,6 +516,11 @@ class FvBoundary:
         _chk(lib().ldu_fvc_cellLimitedGrad(self.addr.h, self.h, C.c_double(k), _ptr(_f64(vsf)), _ptr(_f64(bVal)),
                                            _ptr(_f64(C3)), _ptr(_f64(Cf3)), _ptr(_f64(bCf3)), _ptr(g)))
         return g
+
+    def boundedSp(self, phi, bPhi, V, diag):
+        d = np.array(diag, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_boundedSp(self.addr.h, self.h, _ptr(_f64(phi)), _ptr(_f64(bPhi)), _ptr(_f64(V)), _ptr(d)))
+        return d
 
     def cellLimitedGradV(self, k, vsf3, bVal3, C3, Cf3, bCf3, grad9):
         g = np.array(grad9, dtype=np.float64, copy=True)

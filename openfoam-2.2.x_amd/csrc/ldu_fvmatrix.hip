@@ -554,6 +554,26 @@ fv_cellLimitedGradV_kernel(int nCells, double k, const int* __restrict__ cs, con
         for (int j = 0; j < 3; j++) g9[9 * (size_t)c + 3 * i + j] = lim[j] * t[3 * i + j];
 }
 
+// the `bounded` convection wrapper (boundedConvectionScheme.C:60-77): diag -= V * surfaceIntegrate(phi),
+// surfaceIntegrate as fvcSurfaceIntegrate.C:43-76 - the cell's neighbour faces (-=) and owned faces (+=) in face
+// order, then its patch faces in (patch, face) order, then / V
+__global__ void __launch_bounds__(GLUE_BLK)
+fv_boundedSp_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                    const int* __restrict__ losortStart, const int* __restrict__ losort,
+                    const int* __restrict__ ownerStart, const double* __restrict__ phi,
+                    const double* __restrict__ bPhi, const double* __restrict__ V, double* __restrict__ diag)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    double acc = 0.0;
+    for (int t = losortStart[c]; t < losortStart[c + 1]; t++) acc -= phi[losort[t]];
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++) acc += phi[f];
+    if (cs)
+        for (int j = cs[c]; j < cs[c + 1]; j++) acc += bPhi[cf[j]];
+    const double v = V[c];
+    diag[c] -= v * (acc / v);
+}
+
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -860,6 +880,22 @@ int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const dou
         bcf, g);
     LDU_CHECK_HIP(hipGetLastError());
     return B.finish(grad3, g, 3 * (size_t)a->nCells);
+}
+
+int ldu_fvm_boundedSp(ldu_addr* a, ldu_fv_boundary* b, const double* faceFlux, const double* boundaryFlux,
+                      const double* V, double* diag)
+{
+    if (b && b->a != a) { ldu_set_error("ldu_fvm_boundedSp: boundary belongs to another addressing"); return -2; }
+    GlueBuf B(a->ctx->stream);
+    const size_t nB = b ? (size_t)b->nFacesTotal : 0;
+    const double* phi = B.in(faceFlux, a->nFaces);
+    const double* bphi = B.in(boundaryFlux, nB);
+    const double* v = B.in(V, a->nCells);
+    double* d = B.inout(diag, a->nCells, true);
+    fv_boundedSp_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b ? b->d_cellStart : nullptr,
+        b ? b->d_cellFace : nullptr, a->d_losortStart, a->d_losort, a->d_ownerStart, phi, bphi, v, d);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(diag, d, a->nCells);
 }
 
 int ldu_fv_linearUpwindVCorrection(ldu_addr* a, const double* faceFlux, const double* weights, const double* vf3,

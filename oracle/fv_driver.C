@@ -20,6 +20,8 @@
 #include "gaussLaplacianScheme.H"
 #include "gaussConvectionScheme.H"
 #include "linearUpwind.H"
+#include "fvmSup.H"
+#include "fvcSurfaceIntegrate.H"
 #include "linearUpwindV.H"
 #include "cellLimitedGrad.H"
 #include "fvcSurfaceIntegrate.H"
@@ -587,6 +589,23 @@ int main(int argc, char* argv[])
             tmp<volTensorField> g = clg.calcGrad(U, "gU");
             put(i ? "cellLimitedGradV_k05" : "cellLimitedGradV_k1", g().internalField());
         }
+    }
+    // ---- the `bounded` wrapper of motorBike's div schemes (boundedConvectionScheme.C:60-77):
+    //      scheme.fvmDiv(phi, vf) - fvm::Sp(fvc::surfaceIntegrate(phi), vf), with non-zero boundary fluxes
+    {
+        dimensionSet::debug = 0;
+        forAll(phi.boundaryField(), p)
+        {
+            forAll(phi.boundaryField()[p], i) phi.boundaryField()[p][i] = 0.04*((i % 5) - 2) + 0.01*p;
+            char nm[64];
+            snprintf(nm, sizeof(nm), "p%d_phi", p); put(nm, phi.boundaryField()[p]);
+        }
+        fv::gaussConvectionScheme<scalar> cu(mesh, phi,
+            tmp<surfaceInterpolationScheme<scalar> >(new upwind<scalar>(mesh, phi)));
+        tmp<fvScalarMatrix> Mu = cu.fvmDiv(phi, vfz);
+        put("div_upwind_diag_bphi", Mu().diag());
+        fvScalarMatrix Mb(Mu() - fvm::Sp(fvc::surfaceIntegrate(phi), vfz));
+        put("div_bounded_upwind_diag", Mb.diag());
     }
     // addressing as the reference sees it (must equal the generator's)
     {

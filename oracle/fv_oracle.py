@@ -384,3 +384,19 @@ def cell_limited_grad_v(k, l, u, vsf, C, Cf, gradT, patches):
         out[:, 3 + j] = lim[:, j] * g[:, 3 + j]
         out[:, 6 + j] = lim[:, j] * g[:, 6 + j]
     return out
+
+
+def bounded_sp(diag, l, u, phi, patches, V):
+    """the `bounded` convection wrapper's implicit term, boundedConvectionScheme.C:60-77:
+    fvmDiv - fvm::Sp(fvc::surfaceIntegrate(phi), vf)  ->  diag -= V * (surfaceIntegrate(phi)) with
+    fvcSurfaceIntegrate.C:43-76 (own += / nei -= in face order, then the patch fluxes, then / V).
+    patches: dicts faceCells, phi"""
+    ivf = np.zeros(diag.size)
+    for f in range(l.size):
+        ivf[l[f]] += phi[f]
+        ivf[u[f]] -= phi[f]
+    for p in patches:
+        for i, c in enumerate(p["faceCells"]):
+            ivf[c] += p["phi"][i]
+    ivf = ivf / V
+    return diag - V * ivf

@@ -349,3 +349,8 @@ def test_higher_order_schemes_oracle_matches_reference(name):
     limV = fv_oracle.cell_limited_grad_v(1.0, l, u, g["U"], C, Cf, gU, PU)
     assert np.array_equal(limV, g["ref_cellLimitedGradV_k1"]) and not np.array_equal(limV, gU)
     assert np.array_equal(fv_oracle.cell_limited_grad_v(0.5, l, u, g["U"], C, Cf, gU, PU), g["ref_cellLimitedGradV_k05"])
+    # the `bounded` wrapper
+    PP = [dict(faceCells=g["ref_p%d_faceCells" % p].astype(int), phi=g["ref_p%d_phi" % p])
+          for p in range(int(g["ref_nPatches"][0]))]
+    assert np.array_equal(fv_oracle.bounded_sp(g["ref_div_upwind_diag_bphi"], l, u, g["phi"], PP, g["ref_V"]),
+                          g["ref_div_bounded_upwind_diag"])

@@ -230,4 +230,8 @@ def test_higher_order_schemes_against_reference_vectors(ctx, name):
     lim1 = B.cellLimitedGradV(1.0, g["U"], bValU, C, Cf, bCf, gU)
     assert np.array_equal(lim1, g["ref_cellLimitedGradV_k1"]) and not np.array_equal(lim1, gU)
     assert np.array_equal(B.cellLimitedGradV(0.5, g["U"], bValU, C, Cf, bCf, gU), g["ref_cellLimitedGradV_k05"])
+    # the `bounded` wrapper: fvmDiv - fvm::Sp(fvc::surfaceIntegrate(phi)) with non-zero boundary fluxes
+    bPhi = np.concatenate([g["ref_p%d_phi" % p] for p in range(nP)])
+    bd = B.boundedSp(g["phi"], bPhi, g["ref_V"], g["ref_div_upwind_diag_bphi"])
+    assert np.array_equal(bd, g["ref_div_bounded_upwind_diag"]) and not np.array_equal(bd, g["ref_div_upwind_diag_bphi"])
     B.close(); a.close()
