@@ -61,11 +61,12 @@ struct ClusterPlan {
     unsigned epoch1 = 0;
     int gen1 = 0;
     // component planes of the coupled (LduMatrix<Type,scalar,scalar>) sweeps: 3 granule planes, own tickets
-    uint4* d_granuleV = nullptr;      // [3][nRows+1]
-    unsigned* d_ticketV = nullptr;
-    unsigned ticketBaseV = 0;
-    unsigned epochV = 0;
-    int genV = 0;
+    // (two lanes: the transposed system of PBiCCCG / PBiCICG runs concurrently on the second stream)
+    uint4* d_granuleV[2] = {nullptr, nullptr};      // [3][nRows+1]
+    unsigned* d_ticketV[2] = {nullptr, nullptr};
+    unsigned ticketBaseV[2] = {0, 0};
+    unsigned epochV[2] = {0, 0};
+    int genV[2] = {0, 0};
     std::vector<int> levelStart;      // [nClusterLevels+1] clusters of one cluster level are contiguous
     std::vector<int> upLevel;         // [nClusterLevels] running max of the cluster level holding an upper neighbour
     struct Tasks { int* d = nullptr; int n = 0; };
@@ -89,7 +90,7 @@ void cluster_free(ldu_addr* a)
     if (!P) return;
     void* ptrs[] = {P->d_sliceEnt, P->d_sliceDepth, P->d_rowMeta,
                     P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket, P->d_granule1, P->d_ticket1,
-                    P->d_granuleV, P->d_ticketV};
+                    P->d_granuleV[0], P->d_ticketV[0], P->d_granuleV[1], P->d_ticketV[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : P->conv) if (kv.second.d) (void)hipFree(kv.second.d);
     for (auto& kv : P->tasks) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -862,7 +863,7 @@ static bool cluster_pays(const ldu_addr* a, int kind);
 
 template <int B, bool DESC>
 static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t stride, const double* scale,
-                              const double* levelVal, hipStream_t s)
+                              const double* levelVal, int lane, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
     ClusterPlan& P = *a->cluster;
@@ -877,30 +878,30 @@ static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t 
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
     const size_t gStride = (size_t)P.nRows + 1;
-    if (!P.d_granuleV)
+    if (!P.d_granuleV[lane])
     {
-        LDU_CHECK_HIP(hipMalloc((void**)&P.d_granuleV, sizeof(uint4) * 3 * gStride));
-        LDU_CHECK_HIP(hipMemset(P.d_granuleV, 0, sizeof(uint4) * 3 * gStride));
-        LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticketV, sizeof(unsigned)));
-        LDU_CHECK_HIP(hipMemset(P.d_ticketV, 0, sizeof(unsigned)));
+        LDU_CHECK_HIP(hipMalloc((void**)&P.d_granuleV[lane], sizeof(uint4) * 3 * gStride));
+        LDU_CHECK_HIP(hipMemset(P.d_granuleV[lane], 0, sizeof(uint4) * 3 * gStride));
+        LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticketV[lane], sizeof(unsigned)));
+        LDU_CHECK_HIP(hipMemset(P.d_ticketV[lane], 0, sizeof(unsigned)));
         LDU_CHECK_HIP(hipDeviceSynchronize());   // see d_granule1: the fill must have run before the first sweep
-        P.genV = ctx->p2pGen;
+        P.genV[lane] = ctx->p2pGen;
     }
-    if (P.genV != ctx->p2pGen)
+    if (P.genV[lane] != ctx->p2pGen)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticketV, 0, sizeof(unsigned), s));
-        P.ticketBaseV = 0;
-        P.genV = ctx->p2pGen;
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticketV[lane], 0, sizeof(unsigned), s));
+        P.ticketBaseV[lane] = 0;
+        P.genV[lane] = ctx->p2pGen;
     }
-    P.epochV++;
-    if (P.epochV == 0) P.epochV = 1;
+    P.epochV[lane]++;
+    if (P.epochV[lane] == 0) P.epochV[lane] = 1;
     if (P.maxDep <= 3)
-        sweep_cluster_vec_kernel<B, DESC, 3, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticketV, P.ticketBaseV,
-            P.d_granuleV, gStride, P.epochV, ctx->d_abort, w, rhs, stride, scale, val);
+        sweep_cluster_vec_kernel<B, DESC, 3, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticketV[lane], P.ticketBaseV[lane],
+            P.d_granuleV[lane], gStride, P.epochV[lane], ctx->d_abort, w, rhs, stride, scale, val);
     else
-        sweep_cluster_vec_kernel<B, DESC, 6, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticketV, P.ticketBaseV,
-            P.d_granuleV, gStride, P.epochV, ctx->d_abort, w, rhs, stride, scale, val);
-    P.ticketBaseV += (unsigned)(nChunks + grid);
+        sweep_cluster_vec_kernel<B, DESC, 6, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticketV[lane], P.ticketBaseV[lane],
+            P.d_granuleV[lane], gStride, P.epochV[lane], ctx->d_abort, w, rhs, stride, scale, val);
+    P.ticketBaseV[lane] += (unsigned)(nChunks + grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -908,7 +909,7 @@ static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t 
 // Three component planes (w, rhs: plane p at + p*stride) in one cluster sweep.  mode: SW_TRI_FWD_T,
 // SW_TRI_BWD_T or SW_GS_FWD_T.  Returns 1 when the cluster engine does not take it (caller: plane by plane).
 int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, size_t stride, const double* scale,
-                         const double* val, hipStream_t s)
+                         const double* val, int lane, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
     if (!ctx->clusterEngine || !ctx->sweepP2P || a->nCells < ctx->clusterMinCells) return 1;
@@ -916,11 +917,12 @@ int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, si
     if (!a->cluster->eligible || a->cluster->maxDep > 6) return 1;
     if (!cluster_pays(a, mode == SW_GS_FWD_T ? 1 : 0)) return 1;
     if (!s) s = ctx->stream;
+    if (lane < 0 || lane > 1) return 1;
     switch (mode)
     {
-    case SW_TRI_FWD_T: return launch_cluster_vec<SW_TRI_FWD, false>(a, w, rhs, stride, scale, val, s);
-    case SW_TRI_BWD_T: return launch_cluster_vec<SW_TRI_BWD, true>(a, w, rhs, stride, scale, val, s);
-    case SW_GS_FWD_T:  return launch_cluster_vec<SW_GS_FWD, false>(a, w, rhs, stride, scale, val, s);
+    case SW_TRI_FWD_T: return launch_cluster_vec<SW_TRI_FWD, false>(a, w, rhs, stride, scale, val, lane, s);
+    case SW_TRI_BWD_T: return launch_cluster_vec<SW_TRI_BWD, true>(a, w, rhs, stride, scale, val, lane, s);
+    case SW_GS_FWD_T:  return launch_cluster_vec<SW_GS_FWD, false>(a, w, rhs, stride, scale, val, lane, s);
     }
     return 1;
 }

@@ -419,9 +419,12 @@ static int ensure_rDT(ldu_matrix* m, CoupledWork* W)
     return 0;
 }
 
-static int c_precondition(ldu_matrix* m, CoupledWork* W, int pre, double* w, const double* r, bool transpose)
+static int c_precondition(ldu_matrix* m, CoupledWork* W, int pre, double* w, const double* r, bool transpose,
+                          hipStream_t st = nullptr)
 {
     ldu_addr* a = m->a;
+    if (!st) st = a->ctx->stream;
+    const int lane = st == a->ctx->stream2 ? 1 : 0;   // second concurrent sweep: own hand-off state
     switch (pre)
     {
     case LDU_CPRE_NONE:       // NoPreconditioner.C:49-56
@@ -440,19 +443,21 @@ static int c_precondition(ldu_matrix* m, CoupledWork* W, int pre, double* w, con
         for (; c0 + 3 <= W->nc; c0 += 3)
         {
             double* wp = w + c0 * W->stride;
-            int rc = k_sweep_cluster_vec3(a, SW_TRI_FWD_T, wp, r + c0 * W->stride, W->stride, W->d_rDT, val, nullptr);
+            int rc = k_sweep_cluster_vec3(a, SW_TRI_FWD_T, wp, r + c0 * W->stride, W->stride, W->d_rDT, val, lane, st);
             if (rc < 0) return -1;
             if (rc > 0) break;
-            rc = k_sweep_cluster_vec3(a, SW_TRI_BWD_T, wp, nullptr, W->stride, W->d_rDT, val, nullptr);
+            rc = k_sweep_cluster_vec3(a, SW_TRI_BWD_T, wp, nullptr, W->stride, W->d_rDT, val, lane, st);
             if (rc) return -1;
         }
         for (int c = c0; c < W->nc; c++)
         {
             SweepArgs f{};
             f.mode = SW_TRI_FWD_T; f.w = w + c * W->stride; f.rhs = r + c * W->stride; f.scale = W->d_rDT; f.val = val;
+            f.lane = lane; f.stream = st;
             if (k_sweep(a, f)) return -1;
             SweepArgs b{};
             b.mode = SW_TRI_BWD_T; b.w = w + c * W->stride; b.scale = W->d_rDT; b.val = val;
+            b.lane = lane; b.stream = st;
             if (k_sweep(a, b)) return -1;
         }
         return 0;
@@ -478,7 +483,7 @@ static int c_smooth(ldu_matrix* m, CoupledWork* W, double* psi, const double* so
             for (; c0 + 3 <= W->nc; c0 += 3)
             {
                 const int rc = k_sweep_cluster_vec3(a, SW_GS_FWD_T, psi + c0 * W->stride, source + c0 * W->stride,
-                                                    W->stride, m->d_rDiag, m->d_valA, nullptr);
+                                                    W->stride, m->d_rDiag, m->d_valA, 0, nullptr);
                 if (rc < 0) return -1;
                 if (rc > 0) break;
             }
@@ -588,8 +593,24 @@ static int solve_krylov(ldu_matrix* m, CoupledWork* W, const ldu_coupled_control
     for (;;)
     {
         for (int i = 0; i < nc; i++) wArAold[i] = wArA[i];
-        if (c_precondition(m, W, c->preconditioner, wA, rA, false)) return -1;
-        if (bi && c_precondition(m, W, c->preconditioner, wT, rT, true)) return -1;
+        // the transposed system is independent until the dot product: second stream, own hand-off lane
+        const bool dual = bi && c->preconditioner == LDU_CPRE_DILU && !m->a->nPatchFaces && m->a->ctx->dualStream;
+        if (dual)
+        {
+            ldu_ctx* ctx = m->a->ctx;
+            if (ensure_rDT(m, W)) return -1;
+            LDU_CHECK_HIP(hipEventRecord(ctx->evFork, ctx->stream));
+            LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+            if (c_precondition(m, W, c->preconditioner, wT, rT, true, ctx->stream2)) return -1;
+            LDU_CHECK_HIP(hipEventRecord(ctx->evJoin, ctx->stream2));
+            if (c_precondition(m, W, c->preconditioner, wA, rA, false)) return -1;
+            LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+        }
+        else
+        {
+            if (c_precondition(m, W, c->preconditioner, wA, rA, false)) return -1;
+            if (bi && c_precondition(m, W, c->preconditioner, wT, rT, true)) return -1;
+        }
         if (bi == 2)
         {
             if (cred<CR_DOTALL>(m, W, wA, rT, nullptr, nullptr, wArA)) return -1;

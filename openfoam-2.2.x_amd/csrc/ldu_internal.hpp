@@ -285,7 +285,7 @@ int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s);   // 1 = no
 int k_cluster_prebuild(const std::vector<ldu_addr*>& addrs);            // cluster plans of several addressings, in parallel
 std::string ldu_last_error_string();
 int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, size_t stride, const double* scale,
-                         const double* val, hipStream_t s);   // three component planes at once; 1 = not taken
+                         const double* val, int lane, hipStream_t s);   // three component planes at once; 1 = not taken
 bool k_cluster_active(ldu_addr* a);
 bool k_cluster_kind_active(ldu_addr* a, int kind);
 int k_engine_of(ldu_addr* a, int kind);
