@@ -70,7 +70,7 @@ struct ldu_ctx {
     int clusterEngine = 1;           // LDU_CLUSTER=0: off
     int clusterMinCells = 50000;     // LDU_CLUSTER_MIN
     int clusterBlocksPerCU = 2;      // LDU_CLUSTER_BPC
-    int clusterBlocksPerCUMulti = 2; // LDU_CLUSTER_BPC_MULTI (pipelined sweeps)
+    int clusterBlocksPerCUMulti = 3; // LDU_CLUSTER_BPC_MULTI (pipelined sweeps; 216^3 bench: 106 / 118.4 / 119.8 / 119.1 V-cycles/s at 1 / 2 / 3 / 4)
     int clusterBpcForced = 0;
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
