@@ -300,6 +300,11 @@ typedef struct ldu_coupled_controls {
     int32_t nCmpt;
     int32_t maxIter, nSweeps;
     double tolerance[LDU_MAX_CMPT], relTol[LDU_MAX_CMPT];
+    /* PBiCCCG's gSumProd is the Type's double inner product `&&` per cell: weight of component k =
+     * (unit_k && unit_k): all 1 for vector / tensor, 1 2 2 1 2 1 for symmTensor (SymmTensorI.H:212-220),
+     * 3 for sphericalTensor (SphericalTensorI.H:130-133).  ldu_coupled_default_controls sets them from nCmpt
+     * (6 = symmTensor; 1 = scalar). */
+    double innerProductWeights[LDU_MAX_CMPT];
 } ldu_coupled_controls;
 
 /* SolverPerformance<Type> (LduMatrix/SolverPerformance.H) */

@@ -46,7 +46,7 @@ COUPLED_SMOOTHERS = {"GaussSeidel": 0}
 class CoupledControls(C.Structure):
     _fields_ = [("solver", C.c_int32), ("preconditioner", C.c_int32), ("smoother", C.c_int32),
                 ("nCmpt", C.c_int32), ("maxIter", C.c_int32), ("nSweeps", C.c_int32),
-                ("tolerance", C.c_double * 9), ("relTol", C.c_double * 9)]
+                ("tolerance", C.c_double * 9), ("relTol", C.c_double * 9), ("innerProductWeights", C.c_double * 9)]
 
 
 class CoupledPerf(C.Structure):

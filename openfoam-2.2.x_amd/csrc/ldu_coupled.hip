@@ -346,8 +346,9 @@ cred_partial_kernel(int n, int nc, size_t stride, const double* __restrict__ a, 
         }
         else
         {
-            double d = 0.0;
-            for (int j = 0; j < nc; j++) d += a[(size_t)j * stride + i] * b[(size_t)j * stride + i];
+            // Type && Type: weight*a*b per component, summed in component order (k.v = the weights)
+            double d = (k.v[0] * a[i]) * b[i];
+            for (int j = 1; j < nc; j++) d += (k.v[j] * a[(size_t)j * stride + i]) * b[(size_t)j * stride + i];
             acc += d;
         }
     }
@@ -575,6 +576,8 @@ static int solve_krylov(ldu_matrix* m, CoupledWork* W, const ldu_coupled_control
 
     double wArA[LDU_MAX_CMPT], wArAold[LDU_MAX_CMPT], wApA[LDU_MAX_CMPT], res[LDU_MAX_CMPT];
     for (int i = 0; i < nc; i++) wArA[i] = bi == 2 ? 1e15 : kGreat;   // PBiCCCG.C:81
+    Cmpts ipw{};
+    for (int i = 0; i < nc; i++) ipw.v[i] = c->innerProductWeights[i];
 
     if (c_amul(m, W, wA, psi, false)) return -1;
     if (cew<CEW_SUB>(m, W, rA, source, wA)) return -1;
@@ -613,7 +616,7 @@ static int solve_krylov(ldu_matrix* m, CoupledWork* W, const ldu_coupled_control
         }
         if (bi == 2)
         {
-            if (cred<CR_DOTALL>(m, W, wA, rT, nullptr, nullptr, wArA)) return -1;
+            if (cred<CR_DOTALL>(m, W, wA, rT, nullptr, &ipw, wArA)) return -1;
             for (int i = 1; i < nc; i++) wArA[i] = wArA[0];
         }
         else if (cred<CR_DOT>(m, W, wA, bi ? rT : rA, nullptr, nullptr, wArA)) return -1;
@@ -635,7 +638,7 @@ static int solve_krylov(ldu_matrix* m, CoupledWork* W, const ldu_coupled_control
         if (bi && c_amul(m, W, wT, pT, true)) return -1;
         if (bi == 2)
         {
-            if (cred<CR_DOTALL>(m, W, wA, pT, nullptr, nullptr, wApA)) return -1;
+            if (cred<CR_DOTALL>(m, W, wA, pT, nullptr, &ipw, wApA)) return -1;
             for (int i = 1; i < nc; i++) wApA[i] = wApA[0];
         }
         else if (cred<CR_DOT>(m, W, wA, bi ? pT : pA, nullptr, nullptr, wApA)) return -1;
@@ -713,7 +716,8 @@ void ldu_coupled_default_controls(ldu_coupled_controls* c, int32_t nCmpt)
     c->nCmpt = nCmpt;
     c->maxIter = 1000;    // LduMatrixSolver.C:134-136
     c->nSweeps = 1;       // SmoothSolver.C:41
-    for (int i = 0; i < LDU_MAX_CMPT; i++) { c->tolerance[i] = 1e-6; c->relTol[i] = 0.0; }
+    for (int i = 0; i < LDU_MAX_CMPT; i++) { c->tolerance[i] = 1e-6; c->relTol[i] = 0.0; c->innerProductWeights[i] = 1.0; }
+    if (nCmpt == 6) { c->innerProductWeights[1] = c->innerProductWeights[2] = c->innerProductWeights[4] = 2.0; }
 }
 
 int ldu_coupled_solve(ldu_matrix* m, const ldu_coupled_controls* c, double* psi, const double* source,

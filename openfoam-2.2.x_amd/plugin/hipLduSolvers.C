@@ -431,6 +431,10 @@ public:
         {
             c.tolerance[k] = component(this->tolerance_, k);
             c.relTol[k] = component(this->relTol_, k);
+            // weight of component k in the Type's double inner product (PBiCCCG's gSumProd): unit_k && unit_k
+            Type e(pTraits<Type>::zero);
+            setComponent(e, k) = 1;
+            c.innerProductWeights[k] = (e && e);
         }
         c.nSweeps = this->controlDict_.template lookupOrDefault<label>("nSweeps", 1);
         if (Kind == LDU_CSOLVER_SMOOTHSOLVER)

@@ -23,6 +23,7 @@ enum { ORC_CPRE_NONE = 0, ORC_CPRE_DIAGONAL = 1, ORC_CPRE_DILU = 2 };
 typedef struct orc_copts {
     int solver, precond, smoother, nc, maxIter, nSweeps;
     double tolerance[MAXC], relTol[MAXC];
+    double ipw[MAXC];   /* weights of the Type's `&&`: SymmTensorI.H:212-220 (1 2 2 1 2 1), SphericalTensorI.H:130-133 (3) */
 } orc_copts;
 
 typedef struct orc_cperf {
@@ -146,7 +147,7 @@ static void c_sumCmptMag(const orc_sys* s, int nc, const double* a, double* out)
     }
 }
 /* gSumProd of two Field<Type>: sum over cells of the double inner product (FieldFunctions.C sumProd, `&&`) */
-static double c_sumProd(const orc_sys* s, int nc, const double* a, const double* b)
+static double c_sumProd(const orc_sys* s, int nc, const double* ipw, const double* a, const double* b)
 {
     double out = 0.0;
     for (int d = 0; d < s->nDom; d++)
@@ -155,8 +156,8 @@ static double c_sumProd(const orc_sys* s, int nc, const double* a, const double*
         double loc = 0.0;
         for (int i = D->cellOffset; i < D->cellOffset + D->nCells; i++)
         {
-            double dot = a[(size_t)i * nc] * b[(size_t)i * nc];
-            for (int c = 1; c < nc; c++) dot += a[(size_t)i * nc + c] * b[(size_t)i * nc + c];
+            double dot = (ipw[0] * a[(size_t)i * nc]) * b[(size_t)i * nc];
+            for (int c = 1; c < nc; c++) dot += (ipw[c] * a[(size_t)i * nc + c]) * b[(size_t)i * nc + c];
             loc += dot;
         }
         out += loc;
@@ -371,7 +372,7 @@ static void c_krylov(const orc_sys* s, const orc_copts* o, double* psi, const do
             if (bi) orc_c_precondition(s, o->precond, nc, wT, rT, 1);
             if (bi == 2)
             {
-                const double v = c_sumProd(s, nc, wA, rT);
+                const double v = c_sumProd(s, nc, o->ipw, wA, rT);
                 for (int c = 0; c < nc; c++) wArA[c] = v;
             }
             else c_sumCmptProd(s, nc, wA, bi ? rT : rA, wArA);
@@ -397,7 +398,7 @@ static void c_krylov(const orc_sys* s, const orc_copts* o, double* psi, const do
             if (bi) orc_c_ATmul(s, nc, wT, pT, 1);
             if (bi == 2)
             {
-                const double v = c_sumProd(s, nc, wA, pT);
+                const double v = c_sumProd(s, nc, o->ipw, wA, pT);
                 for (int c = 0; c < nc; c++) wApA[c] = v;
             }
             else c_sumCmptProd(s, nc, wA, bi ? pT : pA, wApA);

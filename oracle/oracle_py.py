@@ -27,7 +27,7 @@ CPRECONDS = {"none": 0, "diagonal": 1, "DILU": 2}
 class COpts(C.Structure):
     _fields_ = [("solver", C.c_int), ("precond", C.c_int), ("smoother", C.c_int), ("nc", C.c_int),
                 ("maxIter", C.c_int), ("nSweeps", C.c_int),
-                ("tolerance", C.c_double * 9), ("relTol", C.c_double * 9)]
+                ("tolerance", C.c_double * 9), ("relTol", C.c_double * 9), ("ipw", C.c_double * 9)]
 
 
 class CPerf(C.Structure):
@@ -271,6 +271,8 @@ class System:
         rel = np.broadcast_to(np.asarray(relTol, dtype=np.float64), (nc,))
         for c in range(nc):
             o.tolerance[c], o.relTol[c] = float(tol[c]), float(rel[c])
+        for c, wgt in enumerate([1, 2, 2, 1, 2, 1] if nc == 6 else [1] * 9):   # the `&&` of symmTensor / vector, tensor
+            o.ipw[c] = float(wgt)
         x = self._fld(psi, nc); b = self._fld(source, nc)
         perf = CPerf()
         rc = lib().orc_c_solve(C.byref(self.sys), C.byref(o), _p(x), _p(b), C.byref(perf))

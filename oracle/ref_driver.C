@@ -35,6 +35,7 @@
 #include "bandCompression.H"
 #include "vector.H"
 #include "vectorField.H"
+#include "symmTensorField.H"
 #include "OSspecific.H"
 
 #include <cstdio>
@@ -376,6 +377,36 @@ int main(int argc, char* argv[])
         }
         labelList order(bandCompression(cc));
         putL("newOrder", order);
+    }
+    else if (mode == "csolve6")
+    {
+        // the same family on a symmTensor field (six components): LduMatrix<symmTensor, scalar, scalar>
+        typedef LduMatrix<symmTensor, scalar, scalar> sMatrix;
+        sMatrix M(mesh);
+        M.diag() = A.diag();
+        M.upper() = A.upper();
+        if (A.hasLower()) M.lower() = A.lower();
+        symmTensorField psiS(nCells, symmTensor::zero), sourceS(nCells, symmTensor::zero);
+        for (label c = 0; c < nCells; c++)
+            for (direction k = 0; k < 6; k++)
+            {
+                if (P.count("psiV")) psiS[c][k] = P["psiV"].d[6*c + k];
+                if (P.count("sourceV")) sourceS[c][k] = P["sourceV"].d[6*c + k];
+            }
+        M.source() = sourceS;
+        dictionary dict(mkDict(dictStr));
+        SolverPerformance<symmTensor> perf = sMatrix::solver::New("R", M, dict)->solve(psiS);
+        putD("psiV", reinterpret_cast<const double*>(psiS.begin()), 6*nCells);
+        double pv[15];
+        for (direction k = 0; k < 6; k++)
+        {
+            pv[k] = perf.initialResidual()[k];
+            pv[6 + k] = perf.finalResidual()[k];
+        }
+        pv[12] = perf.nIterations();
+        pv[13] = perf.converged();
+        pv[14] = perf.singular();
+        putD("perf", pv, 15);
     }
     else if (mode == "cops" || mode == "csolve")
     {

@@ -97,3 +97,22 @@ def test_coupled_selection_tables(oracle):
                 with pytest.raises(RuntimeError):
                     oracle.run_ref("csolve", q, "solver %s; preconditioner %s; tolerance (1e-6 1e-6 1e-6); "
                                    "relTol (0 0 0);" % (solver, pre))
+
+
+def test_coupled_oracle_symmtensor_vs_reference(oracle):
+    """Six components: LduMatrix<symmTensor, scalar, scalar>.  PBiCCCG's scalar products are the symmTensor
+    double inner product (off-diagonal components count twice, SymmTensorI.H:212-220) - bit for bit."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    p = cases.box3d(7, 6, 5, asym=True)
+    n = p["nCells"]
+    rng = np.random.RandomState(8)
+    p["psiV"], p["sourceV"] = rng.randn(n * 6), rng.randn(n * 6)
+    tol = [1e-8, 1e-8, 1e-7, 1e-8, 1e-9, 1e-8]
+    for solver in ("PBiCCCG", "PBiCICG", "SmoothSolver"):
+        r, _ = oracle.run_ref("csolve6", p, "solver %s; preconditioner DILU; smoother GaussSeidel; nSweeps 2; "
+                              "tolerance (1e-8 1e-8 1e-7 1e-8 1e-9 1e-8); relTol (0 0 0 0 0 0); maxIter 50;" % solver)
+        x, perf = oracle.System(p).c_solve(p["psiV"].reshape(n, 6), p["sourceV"].reshape(n, 6), solver=solver,
+                                           preconditioner="DILU", tolerance=tol, maxIter=50, nSweeps=2)
+        assert np.array_equal(x.ravel(), r["psiV"]), solver
+        assert perf["nIterations"] == int(r["perf"][12]) and np.array_equal(perf["finalResidual"], r["perf"][6:12])

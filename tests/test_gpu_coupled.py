@@ -305,3 +305,22 @@ def test_coupled_on_n_ranks(n, oracle):
             assert pg["nIterations"] == po["nIterations"] and pg["converged"] == po["converged"], kw
             assert np.allclose(pg["finalResidual"], po["finalResidual"], rtol=1e-6, atol=1e-12), kw
         assert np.abs(xg - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max()), kw
+
+
+@pytest.mark.parametrize("nc", [6, 9, 1])
+def test_coupled_solve_other_types(nc, ctx, oracle):
+    """symmTensor (6), tensor (9) and scalar (1) fields: PBiCCCG's scalar products are the Type's double inner
+    product - for symmTensor the off-diagonal components count twice (pinned on the reference by
+    test_coupled_oracle_symmtensor_vs_reference)."""
+    p = cases.box3d(9, 8, 7, asym=True)
+    S = oracle.System(p)
+    a, m = capi.from_problem(ctx, p)
+    psi, src = _fields(p, nc, seed=13)
+    for solver in ("PBiCCCG", "PBiCICG"):
+        kw = dict(solver=solver, preconditioner="DILU", tolerance=1e-9, maxIter=60)
+        xo, po = S.c_solve(psi, src, **kw)
+        xg, pg = m.coupled_solve(psi, src, **kw)
+        assert pg["nIterations"] == po["nIterations"] and pg["converged"] == po["converged"], (nc, solver)
+        assert np.allclose(pg["finalResidual"], po["finalResidual"], rtol=1e-6, atol=1e-12), (nc, solver)
+        assert np.abs(xg - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max()), (nc, solver)
+    m.close(); a.close()
