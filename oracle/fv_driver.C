@@ -271,6 +271,16 @@ static int glueV(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
             S.solve(d);
             put((std::string("ref_coupled_") + names[k]).c_str(), U.internalField());
         }
+        // the default (segregated) path of a vector equation: three scalar solves with the component's
+        // boundary coefficients (fvMatrixSolve.C:103-218)
+        {
+            U.internalField() = U0;
+            U.correctBoundaryConditions();
+            fvVectorMatrix S(M);
+            dictionary d(IStringStream("solver PBiCG; preconditioner DILU; tolerance 1e-10; relTol 0; maxIter 60;")());
+            S.solve(d);
+            put("ref_segregated_PBiCG", U.internalField());
+        }
         U.internalField() = U0;
         U.correctBoundaryConditions();
     }

@@ -137,3 +137,9 @@ def test_type_coupled_fvmatrix_solve_through_plugin(tmp_path, monkeypatch):
         assert "[hipLduSolvers] coupled " + solver + " for U" in out
         xr = g["ref_coupled_" + solver]
         assert np.max(np.abs(res["ref_coupled_" + solver] - xr)) <= 1e-9 * np.max(np.abs(xr)), solver
+    # the default segregated path of the same vector equation: three scalar PBiCG/DILU solves (Ux, Uy, Uz) with
+    # the component's interface coefficients, each through hipLduSolver (fvMatrixSolve.C:103-218)
+    for cmpt in ("Ux", "Uy", "Uz"):
+        assert "[hipLduSolvers] DILUPBiCG for " + cmpt in out
+    xr = g["ref_segregated_PBiCG"]
+    assert np.max(np.abs(res["ref_segregated_PBiCG"] - xr)) <= 1e-9 * np.max(np.abs(xr))
