@@ -266,6 +266,11 @@ int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const dou
  * `grad(U) cellLimited Gauss linear 1`): linearUpwindV<vector>::correction (linearUpwindV.C:87-140, internal
  * faces; weights = linear weights, gradVf9 = [nCells][9] tensors xx xy xz yx ...) and
  * cellLimitedGrad<vector>::calcGrad (cellLimitedGrads.C:200-360; grad9 in/out) */
+/* fv::gaussGrad<Type>::gradf with the patch faces (gaussGrad.C:41-110): nComp = 1 -> grad[nCells][3],
+ * nComp = 3 (vector field) -> grad[nCells][9] (xx xy xz yx ..., component 3i+j = d_i U_j); ssf = the face values
+ * (e.g. from ldu_fv_interpolate), boundarySf3 / boundarySsf concatenated in patch order */
+int ldu_fvc_gaussGradFull(ldu_addr* a, ldu_fv_boundary* b, int32_t nComp, const double* Sf3, const double* ssf,
+                          const double* boundarySf3, const double* boundarySsf, const double* V, double* grad);
 /* the `bounded` wrapper of those div schemes (boundedConvectionScheme.C:60-77): fvmDiv - fvm::Sp(fvc::
  * surfaceIntegrate(phi), vf), i.e. diag -= V*surfaceIntegrate(phi) (fvcSurfaceIntegrate.C:43-76; boundaryFlux:
  * the patch values of phi concatenated in patch order, b may be NULL for a mesh without patches) */

@@ -33,7 +33,7 @@ EXPORTS = [
     "ldu_fv_linearUpwindCorrection", "ldu_fvc_cellLimitedGrad",
     "ldu_coupled_default_controls", "ldu_coupled_solve", "ldu_coupled_amul", "ldu_coupled_residual",
     "ldu_coupled_precondition", "ldu_coupled_smooth",
-    "ldu_fv_linearUpwindVCorrection", "ldu_fvc_cellLimitedGradV", "ldu_fvm_boundedSp",
+    "ldu_fv_linearUpwindVCorrection", "ldu_fvc_cellLimitedGradV", "ldu_fvm_boundedSp", "ldu_fvc_gaussGradFull",
     "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
 ]
 
@@ -516,6 +516,14 @@ class FvBoundary:
         _chk(lib().ldu_fvc_cellLimitedGrad(self.addr.h, self.h, C.c_double(k), _ptr(_f64(vsf)), _ptr(_f64(bVal)),
                                            _ptr(_f64(C3)), _ptr(_f64(Cf3)), _ptr(_f64(bCf3)), _ptr(g)))
         return g
+
+    def gaussGradFull(self, Sf3, ssf, bSf3, bssf, V):
+        ssf = np.ascontiguousarray(ssf, dtype=np.float64)
+        nComp = 1 if ssf.ndim == 1 else ssf.shape[1]
+        out = np.zeros((self.addr.nCells, 3 * nComp))
+        _chk(lib().ldu_fvc_gaussGradFull(self.addr.h, self.h, nComp, _ptr(_f64(Sf3)), _ptr(ssf), _ptr(_f64(bSf3)),
+                                         _ptr(_f64(bssf)), _ptr(_f64(V)), _ptr(out)))
+        return out
 
     def boundedSp(self, phi, bPhi, V, diag):
         d = np.array(diag, dtype=np.float64, copy=True)

@@ -554,6 +554,52 @@ fv_cellLimitedGradV_kernel(int nCells, double k, const int* __restrict__ cs, con
         for (int j = 0; j < 3; j++) g9[9 * (size_t)c + 3 * i + j] = lim[j] * t[3 * i + j];
 }
 
+// fv::gaussGrad<Type>::gradf (gaussGrad.C:41-110) with the patch faces: grad = (sum_f +-Sf*ssf_f + sum_b Sf_b*ssf_b)/V,
+// Sf*ssf the outer product for a vector field (tensor component 3i+j = Sf_i*ssf_j).  Per cell and component the
+// products are added in the reference's order: neighbour faces (-=) and owned faces (+=) in face order, then the
+// patch faces in (patch, face) order.
+template <int NC>
+__global__ void __launch_bounds__(GLUE_BLK)
+fv_gaussGradFull_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                        const int* __restrict__ losortStart, const int* __restrict__ losort,
+                        const int* __restrict__ ownerStart, const double* __restrict__ Sf3,
+                        const double* __restrict__ ssf, const double* __restrict__ bSf3,
+                        const double* __restrict__ bssf, const double* __restrict__ V, double* __restrict__ grad)
+{
+    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    if (c >= nCells) return;
+    double acc[3 * NC];
+#pragma unroll
+    for (int q = 0; q < 3 * NC; q++) acc[q] = 0.0;
+    for (int t = losortStart[c]; t < losortStart[c + 1]; t++)
+    {
+        const int f = losort[t];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < NC; j++) acc[NC * i + j] -= Sf3[3 * (size_t)f + i] * ssf[NC * (size_t)f + j];
+    }
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < NC; j++) acc[NC * i + j] += Sf3[3 * (size_t)f + i] * ssf[NC * (size_t)f + j];
+    }
+    if (cs)
+        for (int q = cs[c]; q < cs[c + 1]; q++)
+        {
+            const int f = cf[q];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < NC; j++) acc[NC * i + j] += bSf3[3 * (size_t)f + i] * bssf[NC * (size_t)f + j];
+        }
+    const double v = V[c];
+#pragma unroll
+    for (int q = 0; q < 3 * NC; q++) grad[3 * NC * (size_t)c + q] = acc[q] / v;
+}
+
 // the `bounded` convection wrapper (boundedConvectionScheme.C:60-77): diag -= V * surfaceIntegrate(phi),
 // surfaceIntegrate as fvcSurfaceIntegrate.C:43-76 - the cell's neighbour faces (-=) and owned faces (+=) in face
 // order, then its patch faces in (patch, face) order, then / V
@@ -880,6 +926,29 @@ int ldu_fvc_cellLimitedGrad(ldu_addr* a, ldu_fv_boundary* b, double k, const dou
         bcf, g);
     LDU_CHECK_HIP(hipGetLastError());
     return B.finish(grad3, g, 3 * (size_t)a->nCells);
+}
+
+int ldu_fvc_gaussGradFull(ldu_addr* a, ldu_fv_boundary* b, int32_t nComp, const double* Sf3, const double* ssf,
+                          const double* boundarySf3, const double* boundarySsf, const double* V, double* grad)
+{
+    if (nComp != 1 && nComp != 3) { ldu_set_error("ldu_fvc_gaussGradFull: nComp must be 1 or 3"); return -2; }
+    if (b && b->a != a) { ldu_set_error("ldu_fvc_gaussGradFull: boundary belongs to another addressing"); return -2; }
+    GlueBuf B(a->ctx->stream);
+    const size_t nB = b ? (size_t)b->nFacesTotal : 0;
+    const double* sf = B.in(Sf3, 3 * (size_t)a->nFaces);
+    const double* f = B.in(ssf, (size_t)nComp * a->nFaces);
+    const double* bsf = B.in(boundarySf3, 3 * nB);
+    const double* bf = B.in(boundarySsf, (size_t)nComp * nB);
+    const double* v = B.in(V, a->nCells);
+    double* g = B.inout(grad, 3 * (size_t)nComp * a->nCells, false);
+    if (nComp == 1)
+        fv_gaussGradFull_kernel<1><<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b ? b->d_cellStart : nullptr,
+            b ? b->d_cellFace : nullptr, a->d_losortStart, a->d_losort, a->d_ownerStart, sf, f, bsf, bf, v, g);
+    else
+        fv_gaussGradFull_kernel<3><<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b ? b->d_cellStart : nullptr,
+            b ? b->d_cellFace : nullptr, a->d_losortStart, a->d_losort, a->d_ownerStart, sf, f, bsf, bf, v, g);
+    LDU_CHECK_HIP(hipGetLastError());
+    return B.finish(grad, g, 3 * (size_t)nComp * a->nCells);
 }
 
 int ldu_fvm_boundedSp(ldu_addr* a, ldu_fv_boundary* b, const double* faceFlux, const double* boundaryFlux,

@@ -230,6 +230,22 @@ def test_higher_order_schemes_against_reference_vectors(ctx, name):
     lim1 = B.cellLimitedGradV(1.0, g["U"], bValU, C, Cf, bCf, gU)
     assert np.array_equal(lim1, g["ref_cellLimitedGradV_k1"]) and not np.array_equal(lim1, gU)
     assert np.array_equal(B.cellLimitedGradV(0.5, g["U"], bValU, C, Cf, bCf, gU), g["ref_cellLimitedGradV_k05"])
+    # the basic gradient of U that feeds those schemes: linear interpolation to the faces, then Gauss with the
+    # patch faces (their area vectors come from the device geometry of the generating mesh)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import fv_case
+    import make_fv_golden
+    nx, ny, nz, seed = make_fv_golden.CASES[name]
+    mesh = fv_case.box_mesh(nx, ny, nz, seed=seed)
+    start, pts = capi.faces_csr(mesh["faces"])
+    _, SfAll, _, _ = capi.mesh_geometry(ctx, mesh["points"], start, pts, mesh["owner"], mesh["neighbour"], nC)
+    nI = l.size
+    assert np.array_equal(SfAll[:nI], g["ref_Sf"])
+    Uf = a.interpolate(g["ref_weights"], g["U"])
+    gradU = B.gaussGradFull(g["ref_Sf"], Uf, SfAll[nI:], bValU, g["ref_V"])
+    assert np.array_equal(gradU, gU)
     # the `bounded` wrapper: fvmDiv - fvm::Sp(fvc::surfaceIntegrate(phi)) with non-zero boundary fluxes
     bPhi = np.concatenate([g["ref_p%d_phi" % p] for p in range(nP)])
     bd = B.boundedSp(g["phi"], bPhi, g["ref_V"], g["ref_div_upwind_diag_bphi"])
