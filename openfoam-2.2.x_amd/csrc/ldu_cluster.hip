@@ -1200,6 +1200,13 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
                 progress = true;
             }
         }
+        if (getenv("LDU_VERBOSE"))
+        {
+            int mx = 0; double sum = 0;
+            for (int L = 0; L < nLev; L++) { mx = std::max(mx, P.upLevel[L] - L); sum += P.upLevel[L] - L; }
+            fprintf(stderr, "[ldugpu] cluster multi-sweep order: %d cells, %d cluster levels, k = %d, sweep lag (upLevel - level) "
+                            "avg %.1f max %d\n", a->nCells, nLev, k, sum / std::max(1, nLev), mx);
+        }
         ClusterPlan::Tasks T;
         T.n = (int)tasks.size();
         LDU_CHECK_HIP(hipMalloc((void**)&T.d, sizeof(int) * (tasks.size() + 1)));
