@@ -343,40 +343,58 @@ __device__ __forceinline__ void cl_store(uint4* G, int row, double v, unsigned t
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(d) : "memory");
 }
 
-__device__ __forceinline__ void cl_load3(const uint4* p0, const uint4* p1, const uint4* p2, cl_u32x4& g0,
-                                         cl_u32x4& g1, cl_u32x4& g2)
+// Three polls in flight, one wait.  Only the lanes that have that dependency outside the cluster issue the
+// load (e0..e2 -> exec masks): in a 4x4x4 cluster 48 of the 192 (lane, dependency) pairs are external, and
+// the polls of the whole chip are what fills the L2 request queues.  The other lanes' registers keep garbage
+// that the callers never look at.
+__device__ __forceinline__ void cl_load3(const uint4* p0, const uint4* p1, const uint4* p2, bool e0, bool e1,
+                                         bool e2, cl_u32x4& g0, cl_u32x4& g1, cl_u32x4& g2)
 {
+    const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1), m2 = __ballot(e2);
+    unsigned long long sv;
     asm volatile(
-        "global_load_dwordx4 %0, %3, off sc1\n\t"
-        "global_load_dwordx4 %1, %4, off sc1\n\t"
-        "global_load_dwordx4 %2, %5, off sc1\n\t"
+        "s_mov_b64 %3, exec\n\t"
+        "s_and_b64 exec, %3, %7\n\t"
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "s_and_b64 exec, %3, %8\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "s_and_b64 exec, %3, %9\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "s_mov_b64 exec, %3\n\t"
         "s_waitcnt vmcnt(0)"
-        : "=&v"(g0), "=&v"(g1), "=&v"(g2)
-        : "v"(p0), "v"(p1), "v"(p2)
-        : "memory");
+        : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&s"(sv)
+        : "v"(p0), "v"(p1), "v"(p2), "s"(m0), "s"(m1), "s"(m2)
+        : "memory", "scc");
 }
 
 // nine granules in flight (three dependencies x three component planes), one wait
-__device__ __forceinline__ void cl_load9(const uint4* p0, const uint4* p1, const uint4* p2, size_t gStride,
-                                         cl_u32x4 (&g)[3][3])
+__device__ __forceinline__ void cl_load9(const uint4* p0, const uint4* p1, const uint4* p2, size_t gStride, bool e0,
+                                         bool e1, bool e2, cl_u32x4 (&g)[3][3])
 {
     const uint4 *q0 = p0 + gStride, *q1 = p1 + gStride, *q2 = p2 + gStride;
     const uint4 *r0 = q0 + gStride, *r1 = q1 + gStride, *r2 = q2 + gStride;
+    const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1), m2 = __ballot(e2);
+    unsigned long long sv;
     asm volatile(
-        "global_load_dwordx4 %0, %9, off sc1\n\t"
-        "global_load_dwordx4 %1, %10, off sc1\n\t"
-        "global_load_dwordx4 %2, %11, off sc1\n\t"
-        "global_load_dwordx4 %3, %12, off sc1\n\t"
-        "global_load_dwordx4 %4, %13, off sc1\n\t"
-        "global_load_dwordx4 %5, %14, off sc1\n\t"
-        "global_load_dwordx4 %6, %15, off sc1\n\t"
-        "global_load_dwordx4 %7, %16, off sc1\n\t"
-        "global_load_dwordx4 %8, %17, off sc1\n\t"
+        "s_mov_b64 %9, exec\n\t"
+        "s_and_b64 exec, %9, %19\n\t"
+        "global_load_dwordx4 %0, %10, off sc1\n\t"
+        "global_load_dwordx4 %3, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %16, off sc1\n\t"
+        "s_and_b64 exec, %9, %20\n\t"
+        "global_load_dwordx4 %1, %11, off sc1\n\t"
+        "global_load_dwordx4 %4, %14, off sc1\n\t"
+        "global_load_dwordx4 %7, %17, off sc1\n\t"
+        "s_and_b64 exec, %9, %21\n\t"
+        "global_load_dwordx4 %2, %12, off sc1\n\t"
+        "global_load_dwordx4 %5, %15, off sc1\n\t"
+        "global_load_dwordx4 %8, %18, off sc1\n\t"
+        "s_mov_b64 exec, %9\n\t"
         "s_waitcnt vmcnt(0)"
         : "=&v"(g[0][0]), "=&v"(g[0][1]), "=&v"(g[0][2]), "=&v"(g[1][0]), "=&v"(g[1][1]), "=&v"(g[1][2]),
-          "=&v"(g[2][0]), "=&v"(g[2][1]), "=&v"(g[2][2])
-        : "v"(p0), "v"(p1), "v"(p2), "v"(q0), "v"(q1), "v"(q2), "v"(r0), "v"(r1), "v"(r2)
-        : "memory");
+          "=&v"(g[2][0]), "=&v"(g[2][1]), "=&v"(g[2][2]), "=&s"(sv)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(q0), "v"(q1), "v"(q2), "v"(r0), "v"(r1), "v"(r2), "s"(m0), "s"(m1), "s"(m2)
+        : "memory", "scc");
 }
 
 __device__ __forceinline__ double cl_value(const cl_u32x4& g)
@@ -460,7 +478,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
             unsigned spins = 0;
             for (;;)
             {
-                cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], g0, g1, g2);
+                cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], e0, e1, e2, g0, g1, g2);
                 bool ok = true;
                 if (e0) ok &= (g0.y == tag) & (g0.w == tag);
                 if (e1) ok &= (g1.y == tag) & (g1.w == tag);
@@ -748,7 +766,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
             unsigned spins = 0;
             for (;;)
             {
-                cl_load9(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], gStride, g);
+                cl_load9(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], gStride, e0, e1, e2, g);
                 bool ok = true;
 #pragma unroll
                 for (int j = 0; j < 3; j++)
@@ -1059,7 +1077,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                 unsigned spins = 0;
                 for (;;)
                 {
-                    cl_load3(G + cu[k0], G + cu[k0 + 1], G + cu[k0 + 2], g0, g1, g2);
+                    cl_load3(G + cu[k0], G + cu[k0 + 1], G + cu[k0 + 2], e0, e1, e2, g0, g1, g2);
                     bool ok = true;
                     if (e0) ok &= (g0.y == t) & (g0.w == t);
                     if (e1) ok &= (g1.y == t) & (g1.w == t);
@@ -1090,7 +1108,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
             unsigned spins = 0;
             for (;;)
             {
-                cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], g0, g1, g2);
+                cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], e0, e1, e2, g0, g1, g2);
                 bool ok = true;
                 if (e0) ok &= (g0.y == tagNew) & (g0.w == tagNew);
                 if (e1) ok &= (g1.y == tagNew) & (g1.w == tagNew);
@@ -1189,11 +1207,16 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
         while (progress)
         {
             progress = false;
-            for (int j = 0; j < k; j++)
+            // One round = the tasks that can run at the same time.  Sweep j may take cluster level L once sweep
+            // j-1 has emitted every level <= upLevel[L] IN AN EARLIER ROUND (those tasks must have finished, not
+            // just started): going through the sweeps from the last to the first makes next[j-1] the count
+            // before this round.  With the sweeps ascending, a round held tasks that wait for each other, the
+            // tasks runnable at one time lay (k-1) rounds apart and the workgroups' ticket window (grid chunks)
+            // no longer covered them: k sweeps cost k/2 times two sweeps.
+            for (int j = k - 1; j >= 0; j--)
             {
                 const int L = next[j];
                 if (L >= nLev) continue;
-                // sweep j may take cluster level L once sweep j-1 has emitted every level <= upLevel[L]
                 if (j > 0 && next[j - 1] <= P.upLevel[L]) continue;
                 for (int sl = P.levelStart[L]; sl < P.levelStart[L + 1]; sl++) tasks.push_back((j << 28) | sl);
                 next[j]++;

@@ -1459,11 +1459,13 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         while (progress)
         {
             progress = false;
-            for (int j = 0; j < k; j++)
+            // one round = tasks that can run at the same time: sweep j may take level L once sweep j-1 has
+            // emitted every level <= M[L] in an EARLIER round (last sweep first, so that next[j-1] is the count
+            // before this round; see k_sweep_cluster_gs_multi)
+            for (int j = k - 1; j >= 0; j--)
             {
                 const int L = next[j];
                 if (L >= nLev) continue;
-                // sweep j may take level L once sweep j-1 has emitted every level <= M[L]
                 if (j > 0 && next[j - 1] <= M[L]) continue;
                 for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++)
                     tasks.push_back((j << 28) | sl);
