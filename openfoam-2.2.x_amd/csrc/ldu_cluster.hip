@@ -1230,6 +1230,11 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
             fprintf(stderr, "[ldugpu] cluster multi-sweep order: %d cells, %d cluster levels, k = %d, sweep lag (upLevel - level) "
                             "avg %.1f max %d\n", a->nCells, nLev, k, sum / std::max(1, nLev), mx);
         }
+        if (tasks.size() != (size_t)k * (size_t)P.nSlices)
+        {
+            ldu_set_error("cluster engine: the pipelined task order does not cover every (sweep, cluster) pair");
+            return -1;
+        }
         ClusterPlan::Tasks T;
         T.n = (int)tasks.size();
         LDU_CHECK_HIP(hipMalloc((void**)&T.d, sizeof(int) * (tasks.size() + 1)));

@@ -1473,6 +1473,11 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
                 progress = true;
             }
         }
+        if (tasks.size() != (size_t)k * (size_t)a->nSlices)
+        {
+            ldu_set_error("GS pipeline: the task order does not cover every (sweep, slice) pair");
+            return -1;
+        }
         ldu_addr::GsTasks gt;
         gt.n = (int)tasks.size();
         LDU_CHECK_HIP(hipMalloc((void**)&gt.d_tasks, sizeof(int) * (tasks.size() + 1)));
