@@ -28,6 +28,26 @@
 
 #define CL_BLK 256
 #define CL_WPB (CL_BLK / LDU_WAVE)
+// Ticket counters.  One counter for the whole chip caps the engine at ~70 M tickets/s (one device-scope atomic on
+// one address every ~14 ns: 216^3, 157 464 clusters = 39 366 tickets per sweep -> 0.55 ms, whatever else is done).
+// CL_NQ counters on their own cache lines, workgroup b draws from counter b % CL_NQ (normally its XCD) and counter
+// q hands out the chunks q, q + CL_NQ, ...: every counter still hands out its chunks in ascending order, and the
+// lowest unfinished chunk is either held or the next ticket of its counter, so the sweep cannot deadlock as long
+// as each counter has one workgroup that gets to run (grids this small to use one counter only).
+#define CL_NQ 8
+#define CL_QSTRIDE 32
+struct ClBase { unsigned b[CL_NQ]; };
+static inline int cl_nq(int grid) { return grid >= 8 * CL_NQ ? CL_NQ : 1; }
+static inline void cl_advance(ClBase& B, int nChunks, int grid)
+{
+    const int nq = cl_nq(grid);
+    for (int q = 0; q < nq; q++)
+    {
+        const int nCh = nChunks > q ? (nChunks - q + nq - 1) / nq : 0;
+        const int nBl = grid > q ? (grid - q + nq - 1) / nq : 0;
+        B.b[q] += (unsigned)(nCh + nBl);   // every workgroup overshoots its counter exactly once
+    }
+}
 #define CL_MAXD 12     // dependencies (lower resp. upper neighbours) per row held in registers (variants 3 / 6 / 12)
 #define CL_SPIN_LIMIT (1u << 22)
 
@@ -51,20 +71,20 @@ struct ClusterPlan {
     int* d_src = nullptr;             // [nEntries] index of the entry in the level-ordered SELL arrays
     uint4* d_granule = nullptr;       // [nCells+1]
     unsigned* d_ticket = nullptr;
-    unsigned ticketBase = 0;
+    ClBase ticketBase{};
     unsigned epoch = 0;
     int gen = 0;
     // second lane: a concurrent sweep of the same addressing on the second stream (PBiCG's transposed system)
     uint4* d_granule1 = nullptr;
     unsigned* d_ticket1 = nullptr;
-    unsigned ticketBase1 = 0;
+    ClBase ticketBase1{};
     unsigned epoch1 = 0;
     int gen1 = 0;
     // component planes of the coupled (LduMatrix<Type,scalar,scalar>) sweeps: 3 granule planes, own tickets
     // (two lanes: the transposed system of PBiCCCG / PBiCICG runs concurrently on the second stream)
     uint4* d_granuleV[2] = {nullptr, nullptr};      // [3][nRows+1]
     unsigned* d_ticketV[2] = {nullptr, nullptr};
-    unsigned ticketBaseV[2] = {0, 0};
+    ClBase ticketBaseV[2]{};
     unsigned epochV[2] = {0, 0};
     int genV[2] = {0, 0};
     std::vector<int> levelStart;      // [nClusterLevels+1] clusters of one cluster level are contiguous
@@ -307,8 +327,8 @@ static int cluster_build(ldu_addr* a)
         return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(P->nRows + 1)));
     LDU_CHECK_HIP(hipMemset(P->d_granule, 0, sizeof(uint4) * (size_t)(P->nRows + 1)));
-    LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned)));
-    LDU_CHECK_HIP(hipMemset(P->d_ticket, 0, sizeof(unsigned)));
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
+    LDU_CHECK_HIP(hipMemset(P->d_ticket, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
     LDU_CHECK_HIP(hipDeviceSynchronize());
     P->gen = a->ctx->p2pGen;
     P->eligible = true;
@@ -575,7 +595,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
 
 template <int MODE, bool DESC, int ND>
 __global__ void __launch_bounds__(CL_BLK)
-sweep_cluster_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, uint4* G, unsigned tag,
+sweep_cluster_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, ClBase ticketBase, uint4* G, unsigned tag,
                      int* abortFlag, double* w, const double* rhs, const double* scale, const double* val,
                      const double* val2, double* aux)
 {
@@ -584,14 +604,18 @@ sweep_cluster_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, unsign
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     int nextT = 0;
-    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    const int nq = gridDim.x >= 8 * CL_NQ ? CL_NQ : 1;
+    const int tq = blockIdx.x % nq;
+    unsigned* const tk = ticket + tq * CL_QSTRIDE;
+    const unsigned tb = ticketBase.b[tq];
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
     for (int it = 0;; it++)
     {
         if (threadIdx.x == 0)
         {
             const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
             s_chunk[it & 1] = t;
-            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+            if (t < nChunks) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
         }
         __syncthreads();
         const int chunk = s_chunk[it & 1];
@@ -640,7 +664,7 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     if (grid < 1) grid = 1;
     uint4* G = P.d_granule;
     unsigned* ticket = P.d_ticket;
-    unsigned* base = &P.ticketBase;
+    ClBase* base = &P.ticketBase;
     unsigned* epoch = &P.epoch;
     int* gen = &P.gen;
     if (g.lane == 1)
@@ -649,8 +673,8 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
         {
             LDU_CHECK_HIP(hipMalloc((void**)&P.d_granule1, sizeof(uint4) * (size_t)(P.nRows + 1)));
             LDU_CHECK_HIP(hipMemset(P.d_granule1, 0, sizeof(uint4) * (size_t)(P.nRows + 1)));
-            LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticket1, sizeof(unsigned)));
-            LDU_CHECK_HIP(hipMemset(P.d_ticket1, 0, sizeof(unsigned)));
+            LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticket1, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
+            LDU_CHECK_HIP(hipMemset(P.d_ticket1, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
             // hipMemset on device memory may return before the fill ran, and the compute streams do not wait
             // for the null stream: without this the first sweep can publish tags that the fill then erases
             LDU_CHECK_HIP(hipDeviceSynchronize());
@@ -660,8 +684,8 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     }
     if (*gen != ctx->p2pGen)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), s));
-        *base = 0;
+        LDU_CHECK_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE, s));
+        *base = ClBase{};
         *gen = ctx->p2pGen;
     }
     (*epoch)++;
@@ -675,7 +699,7 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     else
         sweep_cluster_kernel<MODE, DESC, CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, ticket, *base,
             G, *epoch, ctx->d_abort, g.w, g.rhs, g.scale, val, val2, g.aux);
-    *base += (unsigned)(nChunks + grid);
+    cl_advance(*base, nChunks, grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -849,7 +873,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
 
 template <int B, bool DESC, int ND, int NC>
 __global__ void __launch_bounds__(CL_BLK)
-sweep_cluster_vec_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, uint4* G,
+sweep_cluster_vec_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, ClBase ticketBase, uint4* G,
                          size_t gStride, unsigned tag, int* abortFlag, double* w, const double* rhs, size_t stride,
                          const double* scale, const double* val)
 {
@@ -858,14 +882,18 @@ sweep_cluster_vec_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, un
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     int nextT = 0;
-    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    const int nq = gridDim.x >= 8 * CL_NQ ? CL_NQ : 1;
+    const int tq = blockIdx.x % nq;
+    unsigned* const tk = ticket + tq * CL_QSTRIDE;
+    const unsigned tb = ticketBase.b[tq];
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
     for (int it = 0;; it++)
     {
         if (threadIdx.x == 0)
         {
             const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
             s_chunk[it & 1] = t;
-            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+            if (t < nChunks) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
         }
         __syncthreads();
         const int chunk = s_chunk[it & 1];
@@ -900,15 +928,15 @@ static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t 
     {
         LDU_CHECK_HIP(hipMalloc((void**)&P.d_granuleV[lane], sizeof(uint4) * 3 * gStride));
         LDU_CHECK_HIP(hipMemset(P.d_granuleV[lane], 0, sizeof(uint4) * 3 * gStride));
-        LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticketV[lane], sizeof(unsigned)));
-        LDU_CHECK_HIP(hipMemset(P.d_ticketV[lane], 0, sizeof(unsigned)));
+        LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticketV[lane], sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
+        LDU_CHECK_HIP(hipMemset(P.d_ticketV[lane], 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
         LDU_CHECK_HIP(hipDeviceSynchronize());   // see d_granule1: the fill must have run before the first sweep
         P.genV[lane] = ctx->p2pGen;
     }
     if (P.genV[lane] != ctx->p2pGen)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticketV[lane], 0, sizeof(unsigned), s));
-        P.ticketBaseV[lane] = 0;
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticketV[lane], 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE, s));
+        P.ticketBaseV[lane] = ClBase{};
         P.genV[lane] = ctx->p2pGen;
     }
     P.epochV[lane]++;
@@ -919,7 +947,7 @@ static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t 
     else
         sweep_cluster_vec_kernel<B, DESC, 6, 3><<<grid, CL_BLK, 0, s>>>(T, P.nSlices, nChunks, P.d_ticketV[lane], P.ticketBaseV[lane],
             P.d_granuleV[lane], gStride, P.epochV[lane], ctx->d_abort, w, rhs, stride, scale, val);
-    P.ticketBaseV[lane] += (unsigned)(nChunks + grid);
+    cl_advance(P.ticketBaseV[lane], nChunks, grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1159,7 +1187,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
 template <int ND>
 __global__ void __launch_bounds__(CL_BLK)
 sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int* __restrict__ tasks, int nTasks,
-                              int nChunks, int k, unsigned* ticket, unsigned ticketBase, uint4* G, unsigned tag0,
+                              int nChunks, int k, unsigned* ticket, ClBase ticketBase, uint4* G, unsigned tag0,
                               int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
 {
     __shared__ int s_chunk[2];
@@ -1167,14 +1195,18 @@ sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int*
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     int nextT = 0;
-    if (threadIdx.x == 0) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+    const int nq = gridDim.x >= 8 * CL_NQ ? CL_NQ : 1;
+    const int tq = blockIdx.x % nq;
+    unsigned* const tk = ticket + tq * CL_QSTRIDE;
+    const unsigned tb = ticketBase.b[tq];
+    if (threadIdx.x == 0) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
     for (int it = 0;; it++)
     {
         if (threadIdx.x == 0)
         {
             const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
             s_chunk[it & 1] = t;
-            if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
+            if (t < nChunks) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
         }
         __syncthreads();
         const int chunk = s_chunk[it & 1];
@@ -1235,6 +1267,11 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
             ldu_set_error("cluster engine: the pipelined task order does not cover every (sweep, cluster) pair");
             return -1;
         }
+        if (tasks.size() != (size_t)k * (size_t)P.nSlices)
+        {
+            ldu_set_error("cluster engine: the pipelined task order does not cover every (sweep, cluster) pair");
+            return -1;
+        }
         ClusterPlan::Tasks T;
         T.n = (int)tasks.size();
         LDU_CHECK_HIP(hipMalloc((void**)&T.d, sizeof(int) * (tasks.size() + 1)));
@@ -1252,8 +1289,8 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     if (grid < 1) grid = 1;
     if (P.gen != ctx->p2pGen)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
-        P.ticketBase = 0;
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE, s));
+        P.ticketBase = ClBase{};
         P.gen = ctx->p2pGen;
     }
     if (P.epoch > 0xffffff00u)
@@ -1274,7 +1311,7 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
         sweep_cluster_gs_multi_kernel<CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     ctx->profStop(a, 4);
-    P.ticketBase += (unsigned)(nChunks + grid);
+    cl_advance(P.ticketBase, nChunks, grid);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
