@@ -26,7 +26,9 @@
 
 #include "ldu_internal.hpp"
 
+#ifndef CL_BLK
 #define CL_BLK 256
+#endif
 #define CL_WPB (CL_BLK / LDU_WAVE)
 // Ticket counters.  One counter for the whole chip caps the engine at ~70 M tickets/s (one device-scope atomic on
 // one address every ~14 ns: 216^3, 157 464 clusters = 39 366 tickets per sweep -> 0.55 ms, whatever else is done).
@@ -34,7 +36,9 @@
 // q hands out the chunks q, q + CL_NQ, ...: every counter still hands out its chunks in ascending order, and the
 // lowest unfinished chunk is either held or the next ticket of its counter, so the sweep cannot deadlock as long
 // as each counter has one workgroup that gets to run (grids this small to use one counter only).
+#ifndef CL_NQ
 #define CL_NQ 8
+#endif
 #define CL_QSTRIDE 32
 struct ClBase { unsigned b[CL_NQ]; };
 static inline int cl_nq(int grid) { return grid >= 8 * CL_NQ ? CL_NQ : 1; }
@@ -600,7 +604,7 @@ sweep_cluster_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, ClBase
                      const double* val2, double* aux)
 {
     __shared__ int s_chunk[2];
-    __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + CL_MAXD)];
+    __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + ND)];   // slots 0..63: the cluster's rows, then ND x 64 outside values
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     int nextT = 0;
@@ -658,6 +662,7 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     // one workgroup per CU while a cluster level holds few clusters (fewer waiting waves: faster hand-offs),
     // two when it is wide (tools/det_probe.py: 64^3 .104 / .114 ms, 216^3 .763 / .603 ms at 1 / 2 per CU)
     int bpc = ctx->clusterBlocksPerCU;
+    if (!ctx->clusterBpcForced && ctx->dualActive && bpc > 2) bpc = 2;   // two sweeps at once (PBiCG): 2 + 2 per CU
     if (!ctx->clusterBpcForced && P.nSlices < 150 * P.nClusterLevels) bpc = 1;
     int grid = ctx->numCUs * bpc;
     if (grid > nChunks) grid = nChunks;
@@ -919,6 +924,7 @@ static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t 
     ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB};
     const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
     int bpc = ctx->clusterBlocksPerCU;
+    if (!ctx->clusterBpcForced && ctx->dualActive && bpc > 2) bpc = 2;   // two sweeps at once (PBiCG): 2 + 2 per CU
     if (!ctx->clusterBpcForced && P.nSlices < 150 * P.nClusterLevels) bpc = 1;
     int grid = ctx->numCUs * bpc;
     if (grid > nChunks) grid = nChunks;
@@ -1191,7 +1197,7 @@ sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int*
                               int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
 {
     __shared__ int s_chunk[2];
-    __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + CL_MAXD)];
+    __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + ND)];   // slots 0..63: the cluster's rows, then ND x 64 outside values
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     int nextT = 0;

@@ -604,9 +604,12 @@ static int solve_krylov(ldu_matrix* m, CoupledWork* W, const ldu_coupled_control
             if (ensure_rDT(m, W)) return -1;
             LDU_CHECK_HIP(hipEventRecord(ctx->evFork, ctx->stream));
             LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
-            if (c_precondition(m, W, c->preconditioner, wT, rT, true, ctx->stream2)) return -1;
+            ctx->dualActive = 1;
+            if (c_precondition(m, W, c->preconditioner, wT, rT, true, ctx->stream2)) { ctx->dualActive = 0; return -1; }
             LDU_CHECK_HIP(hipEventRecord(ctx->evJoin, ctx->stream2));
-            if (c_precondition(m, W, c->preconditioner, wA, rA, false)) return -1;
+            const int rcA = c_precondition(m, W, c->preconditioner, wA, rA, false);
+            ctx->dualActive = 0;
+            if (rcA) return -1;
             LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
         }
         else

@@ -63,13 +63,14 @@ struct ldu_ctx {
     int p2pGate = 0;                 // slice-completion gate before granule polling (measured slower: off)
     int p2pTrace = 0;                // diagnostic kernels with per-slice tracing
     int dualStream = 1;              // PBiCG: A system and transposed system on two streams
+    int dualActive = 0;              // two cluster sweeps share the chip right now: two workgroups per CU each
     int gsPipeline = 1;
     int gsPipelineMaxSkew = 4;       // pipeline sweeps only if upper neighbours are <= this many levels ahead              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
     // cluster (row-blocking) sweep engine, ldu_cluster.hip
     int clusterEngine = 1;           // LDU_CLUSTER=0: off
     int clusterMinCells = 50000;     // LDU_CLUSTER_MIN
-    int clusterBlocksPerCU = 2;      // LDU_CLUSTER_BPC
+    int clusterBlocksPerCU = 3;      // LDU_CLUSTER_BPC (216^3 DIC half sweep: 0.494 / 0.467 / 0.487 / 0.526 ms at 2 / 3 / 4 / 6)
     int clusterBlocksPerCUMulti = 3; // LDU_CLUSTER_BPC_MULTI (pipelined sweeps; 216^3 bench: 106 / 118.4 / 119.8 / 119.1 V-cycles/s at 1 / 2 / 3 / 4)
     int clusterBpcForced = 0;
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)

@@ -402,14 +402,17 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
             {
                 // PBiCG: the transposed system is independent until the dot product -> second
                 // stream, own point-to-point lane (both are latency-bound: they overlap fully)
+                ctx->dualActive = dual ? 1 : 0;
                 if (dual)
                 {
                     LDU_CHECK_HIP(hipEventRecord(ctx->evFork, s));
                     LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
-                    if (dev_precondition(m, pre, wT, rT, true, ctx->stream2)) return -1;
+                    if (dev_precondition(m, pre, wT, rT, true, ctx->stream2)) { ctx->dualActive = 0; return -1; }
                     LDU_CHECK_HIP(hipEventRecord(ctx->evJoin, ctx->stream2));
                 }
-                if (dev_precondition(m, pre, wA, rA, false, s)) return -1;
+                const int rcA = dev_precondition(m, pre, wA, rA, false, s);
+                ctx->dualActive = 0;
+                if (rcA) return -1;
                 if (bi && !dual && dev_precondition(m, pre, wT, rT, true, s)) return -1;
                 if (dual) LDU_CHECK_HIP(hipStreamWaitEvent(s, ctx->evJoin, 0));
             }
