@@ -30,6 +30,12 @@
 #define CL_BLK 256
 #endif
 #define CL_WPB (CL_BLK / LDU_WAVE)
+#ifndef CL_NAP
+#define CL_NAP 2      // x64 clocks between two polls of the dependencies of this sweep
+#endif
+#ifndef CL_NAP_UP
+#define CL_NAP_UP 1   // ... of the previous sweep's values (pipelined GaussSeidel)
+#endif
 // Ticket counters.  One counter for the whole chip caps the engine at ~70 M tickets/s (one device-scope atomic on
 // one address every ~14 ns: 216^3, 157 464 clusters = 39 366 tickets per sweep -> 0.55 ms, whatever else is done).
 // CL_NQ counters on their own cache lines, workgroup b draws from counter b % CL_NQ (normally its XCD) and counter
@@ -509,7 +515,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
                 if (e2) ok &= (g2.y == tag) & (g2.w == tag);
                 if (ok) break;
                 if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);
             if (e1) xe[k0 + 1] = cl_value(g1);
@@ -806,7 +812,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
                 }
                 if (ok) break;
                 if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(CL_NAP);
             }
 #pragma unroll
             for (int j = 0; j < 3; j++)
@@ -1118,7 +1124,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                     if (e2) ok &= (g2.y == t) & (g2.w == t);
                     if (ok) break;
                     if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(CL_NAP_UP);
                 }
                 if (e0) xu[k0] = cl_value(g0);
                 if (e1) xu[k0 + 1] = cl_value(g1);
@@ -1149,7 +1155,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                 if (e2) ok &= (g2.y == tagNew) & (g2.w == tagNew);
                 if (ok) break;
                 if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);
             if (e1) xe[k0 + 1] = cl_value(g1);

@@ -71,7 +71,7 @@ struct ldu_ctx {
     int clusterEngine = 1;           // LDU_CLUSTER=0: off
     int clusterMinCells = 50000;     // LDU_CLUSTER_MIN
     int clusterBlocksPerCU = 3;      // LDU_CLUSTER_BPC (216^3 DIC half sweep: 0.494 / 0.467 / 0.487 / 0.526 ms at 2 / 3 / 4 / 6)
-    int clusterBlocksPerCUMulti = 3; // LDU_CLUSTER_BPC_MULTI (pipelined sweeps; 216^3 bench: 106 / 118.4 / 119.8 / 119.1 V-cycles/s at 1 / 2 / 3 / 4)
+    int clusterBlocksPerCUMulti = 3; // LDU_CLUSTER_BPC_MULTI (pipelined sweeps; 216^3 bench with one ticket counter: 106 / 118.4 / 119.8 / 119.1 V-cycles/s at 1 / 2 / 3 / 4; with eight: 133.2 / 132.6 at 3 / 4)
     int clusterBpcForced = 0;
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
