@@ -3,8 +3,8 @@
  *
  * Drop-in boundary = OpenFOAM-2.2.x's lduMatrix::solver / preconditioner /
  * smoother interface (src/OpenFOAM/matrices/lduMatrix/lduMatrix/lduMatrix.H:91-506).
- * The OpenFOAM-side shim (openfoam-2.2.x_amd/plugin/) and the
- * host mirror (openfoam-2.2.x_amd/host/) are the only callers; both hand over
+ * The OpenFOAM-side shim (openfoam-2.2.x_amd/plugin/hipLduSolvers.C) and the
+ * Python host mirror (openfoam-2.2.x_amd/capi.py, tests and bench) are the only callers; both hand over
  * exactly what the reference hands to its solvers (SURVEY.md 8b "data handed over"):
  * raw contiguous f64 coefficient arrays, int32 addressing, psi and source.
  *
@@ -76,6 +76,13 @@ void ldu_default_controls(ldu_controls* c);
 int ldu_ctx_create(ldu_ctx** ctx, int device);
 int ldu_ctx_destroy(ldu_ctx* ctx);
 int ldu_ctx_sync(ldu_ctx* ctx);
+/* The sequential sweeps of the reference (DICPreconditioner.C:87-123, GaussSeidelSmoother.C:66-187) always
+ * complete.  Here the point-to-point / cluster sweep engines bound every dependency wait (`polls` granule
+ * polls, default 2^22, env LDU_SPIN_LIMIT); an operation in which a wait expired is re-run from its inputs on
+ * the level-kernel engine (bit-identical results) instead of failing.  ldu_ctx_fallback_count = how many
+ * operations of this context took that path.  polls = 0 restores the default. */
+int ldu_ctx_set_spin_limit(ldu_ctx* ctx, uint32_t polls);
+int64_t ldu_ctx_fallback_count(const ldu_ctx* ctx);
 /* Multi-GPU: RCCL communicator from a 128-byte unique id shared out-of-band
  * (replaces UPstream::init / MPI_COMM_WORLD, src/Pstream/mpi/UPstream.C). */
 int ldu_comm_unique_id(uint8_t id[128]);
@@ -109,6 +116,14 @@ int ldu_addr_sweep_engine(ldu_addr* a, int32_t kind);
 /* Face weights for the geometric agglomerator (faceAreaPairGAMGAgglomeration.C:48-73
  * computes them from Sf; the shim passes mag(cmptMultiply(Sf/sqrt(magSf),(1,1.01,1.02)))). */
 int ldu_addr_set_face_weights(ldu_addr* a, const double* faceWeights);
+/* The same from the face area vectors themselves, as faceAreaPairGAMGAgglomeration.C:48-73 does with
+ * fvMesh::Sf() / magSf() (= mag(Sf) + VSMALL, fvMeshGeometry.C:101-114): Sf = nFaces*3 doubles (internal
+ * faces = the first nInternalFaces entries of primitiveMesh::faceAreas()), host or device.  The weights are
+ * computed on the device; ldu_addr_get_face_weights returns them (host or device destination). */
+int ldu_addr_set_face_areas(ldu_addr* a, const double* Sf);
+int ldu_addr_get_face_weights(const ldu_addr* a, double* faceWeights);
+/* number of HIP devices visible to this process (rank -> GPU binding of the shim) */
+int ldu_device_count(void);
 
 /* ---- matrix (lduMatrix.H:82-85; symmetric <=> lower == NULL, lduMatrix.C:198-215) -- */
 int ldu_matrix_create(ldu_addr* a, ldu_matrix** m);
@@ -280,6 +295,61 @@ int ldu_fv_linearUpwindVCorrection(ldu_addr* a, const double* faceFlux, const do
                                    const double* C3, const double* Cf3, const double* gradVf9, double* corr3);
 int ldu_fvc_cellLimitedGradV(ldu_addr* a, ldu_fv_boundary* b, double k, const double* vsf3, const double* boundaryValues3,
                              const double* C3, const double* Cf3, const double* boundaryCf3, double* grad9);
+
+/* ---- non-orthogonal correction, gaussDiv, patch halves ---------------
+ * What motorBike's fvSchemes adds to the uncorrected stencils above (`laplacianSchemes default Gauss linear
+ * corrected; snGradSchemes default corrected; div((nuEff*dev(T(grad(U))))) Gauss linear;`).  Vectors [n][3], tensors
+ * [n][9] (xx xy xz yx ...), symmTensors [n][6] (xx xy xz yy yz zz); patch-face arrays concatenated in
+ * ldu_fv_boundary order; every pointer host or device; results bit-identical to the reference's loops.
+ *
+ * surfaceInterpolation::makeNonOrthDeltaCoeffs / makeNonOrthCorrectionVectors, internal faces
+ * (surfaceInterpolation.C:289-305, :346-352): 1/max(unitArea & delta, 0.05*mag(delta)); unitArea -
+ * delta*nonOrthDeltaCoeffs.  magSf may be NULL (= mag(Sf) + VSMALL, fvMeshGeometry.C:101-114); outputs may be NULL. */
+int ldu_mesh_nonorth_factors(ldu_ctx* ctx, int32_t nCells, int32_t nInternalFaces, const int32_t* owner,
+                             const int32_t* neighbour, const double* faceAreas, const double* magSf,
+                             const double* cellCentres, double* nonOrthDeltaCoeffs, double* nonOrthCorrectionVectors);
+/* the faces of one patch (surfaceInterpolation.C:307-313, :362-390): patchDelta = fvPatch::delta(); correction
+ * vectors are zero unless the patch is coupled */
+int ldu_mesh_patch_nonorth_factors(ldu_ctx* ctx, int32_t nPatchFaces, const double* patchSf, const double* patchMagSf,
+                                   const double* patchDelta, int32_t coupled, double* nonOrthDeltaCoeffs,
+                                   double* nonOrthCorrectionVectors);
+/* vec & linear.interpolate(field) on the internal faces, field = cell vectors (nComp 3 -> scalar per face) or cell
+ * tensors (nComp 9 -> vector per face).  With vec = nonOrthCorrectionVectors and field = grad(vf) this is
+ * correctedSnGrad<Type>::correction (correctedSnGrad.C:44-107, correctedSnGrads.C); with vec = Sf the face field of
+ * gaussDivScheme::fvcDiv (gaussDivScheme.C:60-63); with vec = SfGammaCorr gammaSnGradCorr (gaussLaplacianScheme.C:92-128) */
+int ldu_fv_interpolateDot(ldu_addr* a, int32_t nComp, const double* vec, const double* weights, const double* field,
+                          double* out);
+/* the same inner product for face values already at hand (patch faces): out = vec & field per face */
+int ldu_fv_faceDot(ldu_ctx* ctx, int32_t nFaces, int32_t nComp, const double* vec, const double* field, double* out);
+/* out = scale*field (accumulate 0) or out += scale*field (accumulate 1), scale per face: gammaMagSf*correction
+ * (gaussLaplacianSchemes.C:64-66), tfaceFluxCorrection += SfGammaSn*correction (gaussLaplacianScheme.C:182-185) */
+int ldu_fv_faceScale(ldu_ctx* ctx, int32_t nFaces, int32_t nComp, const double* scale, const double* field,
+                     int32_t accumulate, double* out);
+/* snGradScheme::snGrad(vf) of a corrected scheme (snGradScheme.C:168-186): nonOrthDeltaCoeffs*(vf[N]-vf[P]) +
+ * correction (NULL: none) */
+int ldu_fvc_correctedSnGrad(ldu_addr* a, int32_t nComp, const double* nonOrthDeltaCoeffs, const double* vf,
+                            const double* correction, double* ssf);
+/* surfaceInterpolationScheme::interpolate on the patch faces (surfaceInterpolationScheme.C:298-314): coupled faces
+ * get w*vf[faceCells] + (1-w)*patchNeighbourField, the others patchValues (NULL: left as they are in out) */
+int ldu_fv_interpolateBoundary(ldu_fv_boundary* b, int32_t nComp, const double* patchWeights, const double* vf,
+                               const double* patchNeighbourField, const double* patchValues, double* out);
+/* gaussGrad::correctBoundaryConditions (gaussGrad.C:144-170) on the ordinary patches: boundaryGrad = g +
+ * n*(snGrad - (n & g)), g = grad[faceCells]; nComp 1 (grad [nCells][3]) or 3 ([nCells][9]).  Coupled faces of
+ * boundaryGrad are not touched (ldu_fv_interpolateBoundary fills them). */
+int ldu_fvc_gaussGradBoundary(ldu_fv_boundary* b, int32_t nComp, const double* patchNf, const double* grad,
+                              const double* patchSnGrad, double* boundaryGrad);
+/* fvc::surfaceIntegrate (= fvc::div of a face field) with its patch faces (fvcSurfaceIntegrate.C:43-76); nComp 1 or 3;
+ * b / boundarySsf may be NULL.  Together with ldu_fv_interpolateDot(Sf, ...) this is gaussDivScheme::fvcDiv. */
+int ldu_fvc_surfaceIntegrateFull(ldu_addr* a, ldu_fv_boundary* b, int32_t nComp, const double* ssf,
+                                 const double* boundarySsf, const double* V, double* out);
+/* the explicit non-orthogonal source of fvm::laplacian: source -= V*fvc::div(faceFluxCorrection)
+ * (gaussLaplacianSchemes.C:74-88, gaussLaplacianScheme.C:187) */
+int ldu_fvm_sourceMinusVDiv(ldu_addr* a, ldu_fv_boundary* b, int32_t nComp, const double* faceFluxCorrection,
+                            const double* boundaryFaceFluxCorrection, const double* V, double* source);
+/* tensor diffusivity (gaussLaplacianScheme.C:165-173): Sn = Sf/magSf; SfGammaSn = (Sf & gamma) & Sn (feeds
+ * ldu_fvm_laplacian in place of gammaMagSf); SfGammaCorr = (Sf & gamma) - SfGammaSn*Sn.  nGammaCmpt 6 | 9. */
+int ldu_fv_tensorGammaFactors(ldu_ctx* ctx, int32_t nFaces, int32_t nGammaCmpt, const double* Sf, const double* magSf,
+                              const double* gamma, double* SfGammaSn, double* SfGammaCorr);
 
 /* ---- coupled solvers: LduMatrix<Type, scalar, scalar> (src/OpenFOAM/matrices/LduMatrix) -------------
  * `type coupled;` in fvSolution (fvMatrixSolve.C:83-85, solveCoupled :222-277) solves every component

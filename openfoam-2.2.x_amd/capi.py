@@ -20,8 +20,10 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
+    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
+    "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
     "ldu_gSumProd", "ldu_gSumMag", "ldu_precondition", "ldu_smooth", "ldu_solve", "ldu_gamg_levels",
@@ -34,6 +36,9 @@ EXPORTS = [
     "ldu_coupled_default_controls", "ldu_coupled_solve", "ldu_coupled_amul", "ldu_coupled_residual",
     "ldu_coupled_precondition", "ldu_coupled_smooth",
     "ldu_fv_linearUpwindVCorrection", "ldu_fvc_cellLimitedGradV", "ldu_fvm_boundedSp", "ldu_fvc_gaussGradFull",
+    "ldu_mesh_nonorth_factors", "ldu_mesh_patch_nonorth_factors", "ldu_fv_interpolateDot", "ldu_fv_faceDot",
+    "ldu_fv_faceScale", "ldu_fvc_correctedSnGrad", "ldu_fv_interpolateBoundary", "ldu_fvc_gaussGradBoundary",
+    "ldu_fvc_surfaceIntegrateFull", "ldu_fvm_sourceMinusVDiv", "ldu_fv_tensorGammaFactors",
     "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
 ]
 
@@ -160,6 +165,15 @@ class Context:
     def sync(self):
         _chk(lib().ldu_ctx_sync(self.h))
 
+    def set_spin_limit(self, polls):
+        """bound of the sweep engines' dependency waits (0 = default); tiny values force the engine fallback"""
+        _chk(lib().ldu_ctx_set_spin_limit(self.h, C.c_uint32(int(polls))))
+
+    def fallback_count(self):
+        f = lib().ldu_ctx_fallback_count
+        f.restype = C.c_int64
+        return int(f(self.h))
+
     def close(self):
         if self.h:
             lib().ldu_ctx_destroy(self.h)
@@ -200,6 +214,47 @@ class Addressing:
         _chk(lib().ldu_fv_linearUpwindVCorrection(self.h, _ptr(_f64(phi)), _ptr(_f64(w)), _ptr(_f64(vf3)), _ptr(_f64(C3)),
                                                   _ptr(_f64(Cf3)), _ptr(_f64(grad9)), _ptr(out)))
         return out
+
+    # ---- non-orthogonal correction / gaussDiv (include/ldugpu.h; ldu_fvschemes.hip)
+    def interpolateDot(self, vec, weights, field):
+        fld = np.ascontiguousarray(field, dtype=np.float64).reshape(self.nCells, -1)
+        nc = fld.shape[1]
+        out = np.zeros(self.nFaces) if nc == 3 else np.zeros((self.nFaces, 3))
+        _chk(lib().ldu_fv_interpolateDot(self.h, nc, _ptr(_f64(vec)), _ptr(_f64(weights)), _ptr(fld), _ptr(out)))
+        return out
+
+    def correctedSnGrad(self, nonOrthDelta, vf, corr=None):
+        v = np.ascontiguousarray(vf, dtype=np.float64)
+        nc = 1 if v.ndim == 1 else v.shape[1]
+        out = np.zeros(self.nFaces) if nc == 1 else np.zeros((self.nFaces, nc))
+        _chk(lib().ldu_fvc_correctedSnGrad(self.h, nc, _ptr(_f64(nonOrthDelta)), _ptr(v), _ptr(_f64(corr)), _ptr(out)))
+        return out
+
+    def surfaceIntegrateFull(self, ssf, V, boundary=None, boundarySsf=None):
+        f = np.ascontiguousarray(ssf, dtype=np.float64)
+        nc = 1 if f.ndim == 1 else f.shape[1]
+        out = np.zeros(self.nCells) if nc == 1 else np.zeros((self.nCells, nc))
+        _chk(lib().ldu_fvc_surfaceIntegrateFull(self.h, boundary.h if boundary else None, nc, _ptr(f),
+                                                _ptr(_f64(boundarySsf)), _ptr(_f64(V)), _ptr(out)))
+        return out
+
+    def sourceMinusVDiv(self, source, ffc, V, boundary=None, boundaryFfc=None):
+        f = np.ascontiguousarray(ffc, dtype=np.float64)
+        nc = 1 if f.ndim == 1 else f.shape[1]
+        s = np.array(source, dtype=np.float64, copy=True)
+        _chk(lib().ldu_fvm_sourceMinusVDiv(self.h, boundary.h if boundary else None, nc, _ptr(f),
+                                           _ptr(_f64(boundaryFfc)), _ptr(_f64(V)), _ptr(s)))
+        return s
+
+    def set_face_areas(self, Sf):
+        """faceAreaPair weights from the internal faces' area vectors, computed on the device
+        (faceAreaPairGAMGAgglomeration.C:48-73); returns them"""
+        sf = np.ascontiguousarray(Sf, dtype=np.float64).reshape(-1, 3)
+        assert sf.shape[0] == self.nFaces
+        _chk(lib().ldu_addr_set_face_areas(self.h, _ptr(sf)))
+        w = np.zeros(self.nFaces)
+        _chk(lib().ldu_addr_get_face_weights(self.h, _ptr(w)))
+        return w
 
     ENGINES = ("chip-wide point-to-point", "XCD slabs", "clusters", "single wavefront", "level kernels")
 
@@ -450,6 +505,50 @@ def from_problem(ctx, p):
     return a, m
 
 
+def mesh_nonorth_factors(ctx, nCells, owner, neighbour, Sf, magSf, C):
+    """nonOrthDeltaCoeffs, nonOrthCorrectionVectors of the internal faces (surfaceInterpolation.C:289-352)"""
+    o = np.ascontiguousarray(owner, dtype=np.int32)
+    n = np.ascontiguousarray(neighbour, dtype=np.int32)
+    nF = o.size
+    nod, cv = np.zeros(nF), np.zeros((nF, 3))
+    _chk(lib().ldu_mesh_nonorth_factors(ctx.h, int(nCells), nF, _ptr(o), _ptr(n), _ptr(_f64(Sf)), _ptr(_f64(magSf)),
+                                        _ptr(_f64(C)), _ptr(nod), _ptr(cv)))
+    return nod, cv
+
+
+def mesh_patch_nonorth_factors(ctx, Sf, magSf, delta, coupled):
+    n = np.asarray(Sf).reshape(-1, 3).shape[0]
+    nod, cv = np.zeros(n), np.zeros((n, 3))
+    _chk(lib().ldu_mesh_patch_nonorth_factors(ctx.h, n, _ptr(_f64(Sf)), _ptr(_f64(magSf)), _ptr(_f64(delta)),
+                                              int(bool(coupled)), _ptr(nod), _ptr(cv)))
+    return nod, cv
+
+
+def fv_face_dot(ctx, vec, field):
+    f = np.ascontiguousarray(field, dtype=np.float64)
+    n, nc = f.shape
+    out = np.zeros(n) if nc == 3 else np.zeros((n, 3))
+    _chk(lib().ldu_fv_faceDot(ctx.h, n, nc, _ptr(_f64(vec)), _ptr(f), _ptr(out)))
+    return out
+
+
+def fv_face_scale(ctx, scale, field, accumulate_into=None):
+    f = np.ascontiguousarray(field, dtype=np.float64)
+    n = f.shape[0]
+    nc = 1 if f.ndim == 1 else f.shape[1]
+    out = np.zeros_like(f) if accumulate_into is None else np.array(accumulate_into, dtype=np.float64, copy=True)
+    _chk(lib().ldu_fv_faceScale(ctx.h, n, nc, _ptr(_f64(scale)), _ptr(f), int(accumulate_into is not None), _ptr(out)))
+    return out
+
+
+def fv_tensor_gamma_factors(ctx, Sf, magSf, gamma):
+    g = np.ascontiguousarray(gamma, dtype=np.float64)
+    n, ng = g.shape
+    sn, sc = np.zeros(n), np.zeros((n, 3))
+    _chk(lib().ldu_fv_tensorGammaFactors(ctx.h, n, ng, _ptr(_f64(Sf)), _ptr(_f64(magSf)), _ptr(g), _ptr(sn), _ptr(sc)))
+    return sn, sc
+
+
 class FvBoundary:
     """ldu_fv_boundary: the patches of an fvMesh (sizes, faceCells, coupled flags) for the fvMatrix glue
     (fvMatrix.C addBoundaryDiag/addBoundarySource/relax/A/H/flux).  Coefficient arrays are concatenated
@@ -471,6 +570,25 @@ class FvBoundary:
         d = np.array(diag, dtype=np.float64, copy=True)
         _chk(lib().ldu_fvm_addBoundaryDiag(self.h, _ptr(_f64(iC)), _ptr(d)))
         return d
+
+    def interpolateBoundary(self, patchWeights, vf, pnf, values):
+        """surfaceInterpolationScheme::interpolate on the patch faces (coupled: w*pif + (1-w)*pnf)"""
+        v = np.ascontiguousarray(vf, dtype=np.float64).reshape(self.addr.nCells, -1)
+        nc = v.shape[1]
+        out = np.zeros((self.n, nc))
+        _chk(lib().ldu_fv_interpolateBoundary(self.h, nc, _ptr(_f64(patchWeights)), _ptr(v),
+                                              _ptr(np.ascontiguousarray(pnf, dtype=np.float64)),
+                                              _ptr(np.ascontiguousarray(values, dtype=np.float64)), _ptr(out)))
+        return out[:, 0] if np.asarray(vf).ndim == 1 else out
+
+    def gaussGradBoundary(self, patchNf, grad, patchSnGrad, boundaryGrad):
+        """gaussGrad::correctBoundaryConditions on the ordinary patches; coupled faces keep boundaryGrad's values"""
+        g = np.ascontiguousarray(grad, dtype=np.float64).reshape(self.addr.nCells, -1)
+        nc = g.shape[1] // 3
+        out = np.array(boundaryGrad, dtype=np.float64, copy=True).reshape(self.n, 3 * nc)
+        _chk(lib().ldu_fvc_gaussGradBoundary(self.h, nc, _ptr(_f64(patchNf)), _ptr(g),
+                                             _ptr(np.ascontiguousarray(patchSnGrad, dtype=np.float64)), _ptr(out)))
+        return out
 
     def addBoundarySource(self, bC, pnf, source, couples=True):
         s = np.array(source, dtype=np.float64, copy=True)

@@ -153,6 +153,9 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->smallMaxCells = std::min(atoi(e), 8192);
     e = getenv("LDU_P2P_SLABS");
     if (e) c->p2pSlabs = atoi(e);
+    e = getenv("LDU_SPIN_LIMIT");
+    if (e && (k_set_spin_limit((unsigned)strtoul(e, nullptr, 10)) || k_cluster_set_spin_limit((unsigned)strtoul(e, nullptr, 10))))
+        return -1;
     if (c->sweepP2P && c->p2pSlabs != 0 && k_xcd_census(c)) return -1;
     *out = c;
     return 0;
@@ -174,6 +177,16 @@ int ldu_ctx_destroy(ldu_ctx* c)
     delete c;
     return 0;
 }
+
+int ldu_ctx_set_spin_limit(ldu_ctx* c, uint32_t polls)
+{
+    LDU_CHECK_HIP(hipSetDevice(c->device));
+    LDU_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (k_set_spin_limit(polls) || k_cluster_set_spin_limit(polls)) return -1;
+    return 0;
+}
+
+int64_t ldu_ctx_fallback_count(const ldu_ctx* c) { return c ? (int64_t)c->nFallbacks : 0; }
 
 int ldu_ctx_sync(ldu_ctx* c)
 {
@@ -591,25 +604,29 @@ int ldu_precondition(ldu_matrix* m, int32_t pre, double* wA, const double* rA, i
         return -16;
     }
     if (pre == LDU_PRE_GAMG) { ldu_set_error("use ldu_solve with preconditioner GAMG"); return -16; }
-    Stager S(m);
-    double* r = S.in(rA);
-    double* w = S.tmp();
-    if (!r || !w) return -1;
-    if (dev_precondition(m, pre, w, r, transpose != 0, S.s)) return -1;
-    if (int rc = dev_check_abort(m->a->ctx)) return rc;
-    return S.out(wA, w);
+    return run_with_fallback(m, [&]() -> int {
+        Stager S(m);
+        double* r = S.in(rA);
+        double* w = S.tmp();
+        if (!r || !w) return -1;
+        if (dev_precondition(m, pre, w, r, transpose != 0, S.s)) return -1;
+        if (int rc = dev_check_abort(m->a->ctx)) return rc;
+        return S.out(wA, w);
+    });
 }
 
 int ldu_smooth(ldu_matrix* m, int32_t smoother, double* psi, const double* source, int32_t nSweeps)
 {
     NEED_COEFFS(m);
-    Stager S(m);
-    double* x = S.in(psi);
-    double* b = S.in(source);
-    if (!x || !b) return -1;
-    if (dev_smooth(m, smoother, x, b, nSweeps)) return -1;
-    if (int rc = dev_check_abort(m->a->ctx)) return rc;
-    return S.out(psi, x);
+    return run_with_fallback(m, [&]() -> int {
+        Stager S(m);
+        double* x = S.in(psi);
+        double* b = S.in(source);
+        if (!x || !b) return -1;
+        if (dev_smooth(m, smoother, x, b, nSweeps)) return -1;
+        if (int rc = dev_check_abort(m->a->ctx)) return rc;
+        return S.out(psi, x);
+    });
 }
 
 int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
@@ -621,19 +638,21 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
         ldu_set_error("directSolveCoarsest is not supported");
         return -17;
     }
-    memset(perf, 0, sizeof(*perf));
-    Stager S(m);
-    double* x = S.in(psi);
-    double* b = S.in(source);
-    if (!x || !b) return -1;
-    LDU_CHECK_HIP(hipStreamSynchronize(S.s));
-    const double t0 = now_s();
-    int rc = dev_solve(m, c, x, b, perf, resHistory);
-    LDU_CHECK_HIP(hipStreamSynchronize(S.s));
-    perf->solveSeconds = now_s() - t0;
-    if (rc) return rc;
-    if (int rc2 = dev_check_abort(m->a->ctx)) return rc2;
-    return S.out(psi, x);
+    return run_with_fallback(m, [&]() -> int {
+        memset(perf, 0, sizeof(*perf));
+        Stager S(m);
+        double* x = S.in(psi);
+        double* b = S.in(source);
+        if (!x || !b) return -1;
+        LDU_CHECK_HIP(hipStreamSynchronize(S.s));
+        const double t0 = now_s();
+        int rc = dev_solve(m, c, x, b, perf, resHistory);
+        LDU_CHECK_HIP(hipStreamSynchronize(S.s));
+        perf->solveSeconds = now_s() - t0;
+        if (rc) return rc;
+        if (int rc2 = dev_check_abort(m->a->ctx)) return rc2;
+        return S.out(psi, x);
+    });
 }
 
 int ldu_debug_granule_tags(ldu_matrix* m, int32_t* tags /* nCells, level order */, int32_t* perm)

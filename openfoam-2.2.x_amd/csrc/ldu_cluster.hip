@@ -59,9 +59,18 @@ static inline void cl_advance(ClBase& B, int nChunks, int grid)
     }
 }
 #define CL_MAXD 12     // dependencies (lower resp. upper neighbours) per row held in registers (variants 3 / 6 / 12)
-#define CL_SPIN_LIMIT (1u << 22)
+#define CL_SPIN_LIMIT_DEFAULT (1u << 22)
 
 typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
+
+// bound of every dependency wait, in polls (run-time overridable: ldu_ctx_set_spin_limit / LDU_SPIN_LIMIT)
+__device__ unsigned g_cl_spin_limit = CL_SPIN_LIMIT_DEFAULT;
+int k_cluster_set_spin_limit(unsigned polls)
+{
+    if (!polls) polls = CL_SPIN_LIMIT_DEFAULT;
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cl_spin_limit), &polls, sizeof(unsigned)));
+    return 0;
+}
 
 struct ClusterPlan {
     int nSlices = 0;
@@ -367,10 +376,13 @@ __device__ __forceinline__ void cl_store(uint4* G, int row, double v, unsigned t
     cl_u32x4 d;
     d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
     uint4* p = G + row;
-    // s_nop: a VMEM store of more than 64 bits reads its upper data registers one cycle late; the hazard
-    // recognizer does not look inside inline asm, so the wait state before the next VALU write to those
-    // registers is spelled out (without it: three plane stores in a row published pointer bits as tags)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(d) : "memory");
+    // s_nop 1: a VMEM store of more than 64 bits reads its upper data registers late; the hazard recognizer
+    // does not look inside inline asm, so the wait states before the next VALU write to those registers are
+    // spelled out.  gfx940+ needs TWO (what the compiler inserts after its own dwordx4 stores on gfx950 is
+    // `s_nop 1`); with `s_nop 0` the next pointer computation (v_lshl_add_u64 into the store's z,w
+    // registers) could still win the race and publish pointer bits as the second tag - a consumer then
+    // spins until its bound (round-1 fuzz case 8723: three plane stores in a row, under load)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
 }
 
 // Three polls in flight, one wait.  Only the lanes that have that dependency outside the cluster issue the
@@ -506,6 +518,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
         {
             cl_u32x4 g0, g1, g2;
             unsigned spins = 0;
+            const unsigned spinLimit = g_cl_spin_limit;
             for (;;)
             {
                 cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], e0, e1, e2, g0, g1, g2);
@@ -514,7 +527,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
                 if (e1) ok &= (g1.y == tag) & (g1.w == tag);
                 if (e2) ok &= (g2.y == tag) & (g2.w == tag);
                 if (ok) break;
-                if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);
@@ -799,6 +812,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
         {
             cl_u32x4 g[3][3];
             unsigned spins = 0;
+            const unsigned spinLimit = g_cl_spin_limit;
             for (;;)
             {
                 cl_load9(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], gStride, e0, e1, e2, g);
@@ -811,7 +825,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
                     if (e2) ok &= (g[j][2].y == tag) & (g[j][2].w == tag);
                 }
                 if (ok) break;
-                if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
 #pragma unroll
@@ -1115,6 +1129,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
             {
                 cl_u32x4 g0, g1, g2;
                 unsigned spins = 0;
+                const unsigned spinLimit = g_cl_spin_limit;
                 for (;;)
                 {
                     cl_load3(G + cu[k0], G + cu[k0 + 1], G + cu[k0 + 2], e0, e1, e2, g0, g1, g2);
@@ -1123,7 +1138,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                     if (e1) ok &= (g1.y == t) & (g1.w == t);
                     if (e2) ok &= (g2.y == t) & (g2.w == t);
                     if (ok) break;
-                    if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                    if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
                     __builtin_amdgcn_s_sleep(CL_NAP_UP);
                 }
                 if (e0) xu[k0] = cl_value(g0);
@@ -1146,6 +1161,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
         {
             cl_u32x4 g0, g1, g2;
             unsigned spins = 0;
+            const unsigned spinLimit = g_cl_spin_limit;
             for (;;)
             {
                 cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], e0, e1, e2, g0, g1, g2);
@@ -1154,7 +1170,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                 if (e1) ok &= (g1.y == tagNew) & (g1.w == tagNew);
                 if (e2) ok &= (g2.y == tagNew) & (g2.w == tagNew);
                 if (ok) break;
-                if (++spins > CL_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);

@@ -50,6 +50,11 @@ void coupled_free(ldu_matrix* m)
     m->coupled = nullptr;
 }
 
+void coupled_invalidate(ldu_matrix* m)
+{
+    if (m->coupled) m->coupled->rDTEpoch = ~0ull;
+}
+
 static CoupledWork* work_of(ldu_matrix* m, int nc)
 {
     if (!m->coupled) m->coupled = new CoupledWork;
@@ -762,6 +767,8 @@ int ldu_coupled_solve(ldu_matrix* m, const ldu_coupled_controls* c, double* psi,
         ldu_set_error("unknown coupled smoother");
         return -3;
     }
+    return run_with_fallback(m, [&]() -> int {
+    memset(perf, 0, sizeof(*perf));
     CoupledWork* W = work_of(m, c->nCmpt);
     if (!W) { ldu_set_error("coupled work allocation failed"); return -1; }
     double* x = field_in(m, W, 0, 0, psi);
@@ -787,6 +794,7 @@ int ldu_coupled_solve(ldu_matrix* m, const ldu_coupled_controls* c, double* psi,
     if (rc) return rc;
     if (int rc2 = dev_check_abort(a->ctx)) return rc2;
     return field_out(m, W, psi, x);
+    });
 }
 
 int ldu_coupled_amul(ldu_matrix* m, int32_t nCmpt, double* Apsi, const double* psi, int32_t transpose)
@@ -823,14 +831,16 @@ int ldu_coupled_precondition(ldu_matrix* m, int32_t pre, int32_t nCmpt, double* 
         ldu_set_error("Unknown symmetric matrix preconditioner DILU (lduPreconditioners.C:41-42)");
         return -16;
     }
-    CoupledWork* W = work_of(m, nCmpt);
-    if (!W) return -1;
-    double* r = field_in(m, W, 1, 1, rA);
-    double* w = field(W, 3);
-    if (!r || !w) return -1;
-    if (c_precondition(m, W, pre, w, r, transpose != 0)) return -1;
-    if (int rc = dev_check_abort(m->a->ctx)) return rc;
-    return field_out(m, W, wA, w);
+    return run_with_fallback(m, [&]() -> int {
+        CoupledWork* W = work_of(m, nCmpt);
+        if (!W) return -1;
+        double* r = field_in(m, W, 1, 1, rA);
+        double* w = field(W, 3);
+        if (!r || !w) return -1;
+        if (c_precondition(m, W, pre, w, r, transpose != 0)) return -1;
+        if (int rc = dev_check_abort(m->a->ctx)) return rc;
+        return field_out(m, W, wA, w);
+    });
 }
 
 int ldu_coupled_smooth(ldu_matrix* m, int32_t smoother, int32_t nCmpt, double* psi, const double* source,
@@ -843,14 +853,16 @@ int ldu_coupled_smooth(ldu_matrix* m, int32_t smoother, int32_t nCmpt, double* p
         ldu_set_error("cannot solve incomplete matrix, no off-diagonal coefficients (LduMatrixSmoother.C:96-104)");
         return -16;
     }
-    CoupledWork* W = work_of(m, nCmpt);
-    if (!W) return -1;
-    double* x = field_in(m, W, 0, 0, psi);
-    double* b = field_in(m, W, 1, 1, source);
-    if (!x || !b) return -1;
-    if (c_smooth(m, W, x, b, nSweeps)) return -1;
-    if (int rc = dev_check_abort(m->a->ctx)) return rc;
-    return field_out(m, W, psi, x);
+    return run_with_fallback(m, [&]() -> int {
+        CoupledWork* W = work_of(m, nCmpt);
+        if (!W) return -1;
+        double* x = field_in(m, W, 0, 0, psi);
+        double* b = field_in(m, W, 1, 1, source);
+        if (!x || !b) return -1;
+        if (c_smooth(m, W, x, b, nSweeps)) return -1;
+        if (int rc = dev_check_abort(m->a->ctx)) return rc;
+        return field_out(m, W, psi, x);
+    });
 }
 
 }  // extern "C"

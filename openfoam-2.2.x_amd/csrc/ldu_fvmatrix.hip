@@ -12,17 +12,6 @@
 
 #include "ldu_internal.hpp"
 
-struct ldu_fv_boundary {
-    ldu_addr* a = nullptr;
-    int nPatches = 0;
-    int nFacesTotal = 0;
-    std::vector<int> sizes, offsets, coupled;
-    int* d_cellStart = nullptr;        // [nCells+1] CSR over cells
-    int* d_cellFace = nullptr;         // [nFacesTotal] index into the concatenated patch-face arrays
-    int* d_faceCells = nullptr;        // [nFacesTotal]
-    unsigned char* d_coupled = nullptr;  // [nFacesTotal] per patch face: its patch is coupled
-};
-
 static bool dev_ptr(const void* p)
 {
     hipPointerAttribute_t at;

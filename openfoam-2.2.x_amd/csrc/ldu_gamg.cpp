@@ -82,6 +82,12 @@ void gamg_free(GamgHierarchy* g)
     delete g;
 }
 
+void gamg_invalidate_factors(GamgHierarchy* g)
+{
+    for (auto& L : g->levels)
+        if (L.mat) { L.mat->rDKind = -1; coupled_invalidate(L.mat); }
+}
+
 // ---------------------------------------------------------------- pair agglomeration (host)
 
 // One pairing pass (pairGAMGAgglomerate.C:31-198).  cellFaces order = faces where the cell is

@@ -86,6 +86,8 @@ struct ldu_ctx {
     int* d_abort = nullptr;          // set by a sweep whose bounded spin expired
     int* h_abort = nullptr;          // pinned mirror
     int p2pGen = 0;                  // bumped when a sweep aborted: addressings reset their tickets
+    int abortSeen = 0;               // an aborted sweep was detected since run_with_fallback() cleared this
+    long nFallbacks = 0;             // operations re-run on the level-kernel engine after an aborted sweep
     // communicator
     int rank = 0, nRanks = 1;
     ldu_comm_impl* comm = nullptr;
@@ -212,6 +214,19 @@ struct ldu_addr {
 };
 
 struct GamgHierarchy;  // ldu_gamg.cpp
+
+// the patches of an fvMesh for the fvMatrix glue and the fv schemes (ldu_fvmatrix.hip, ldu_fvschemes.hip)
+struct ldu_fv_boundary {
+    ldu_addr* a = nullptr;
+    int nPatches = 0;
+    int nFacesTotal = 0;
+    std::vector<int> sizes, offsets, coupled;
+    int* d_cellStart = nullptr;        // [nCells+1] CSR over cells
+    int* d_cellFace = nullptr;         // [nFacesTotal] index into the concatenated patch-face arrays
+    int* d_faceCells = nullptr;        // [nFacesTotal]
+    unsigned char* d_coupled = nullptr;  // [nFacesTotal] per patch face: its patch is coupled
+};
+
 
 struct ldu_matrix {
     ldu_addr* a = nullptr;
@@ -393,6 +408,29 @@ int dev_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
               double* hist);
 int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out);
 int dev_check_abort(ldu_ctx* ctx);
+// Engine fallback.  The point-to-point / cluster engines bound every dependency wait; a sweep whose bound
+// expires drains and flags the context (the reference's sweeps simply always complete,
+// DICPreconditioner.C:87-123, GaussSeidelSmoother.C:66-187).  An operation that saw such an abort is run
+// again from its (untouched) inputs on the level-kernel engine, whose results are bit-identical.
+int fallback_prepare(ldu_matrix* m);           // drain, clear the flag, drop sweep-built caches; 0 = ok
+template <class F>
+static inline int run_with_fallback(ldu_matrix* m, F&& op)
+{
+    ldu_ctx* ctx = m->a->ctx;
+    ctx->abortSeen = 0;
+    int rc = op();
+    if (!ctx->abortSeen) return rc;
+    if (fallback_prepare(m)) return -1;
+    const int p2p = ctx->sweepP2P;
+    ctx->sweepP2P = 0;
+    rc = op();
+    ctx->sweepP2P = p2p;
+    return rc;
+}
+int k_set_spin_limit(unsigned polls);          // ldu_kernels.hip (0 = default)
+int k_cluster_set_spin_limit(unsigned polls);  // ldu_cluster.hip
+void gamg_invalidate_factors(GamgHierarchy* g);
+void coupled_invalidate(ldu_matrix* m);
 
 // GAMG (ldu_gamg.cpp)
 int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,

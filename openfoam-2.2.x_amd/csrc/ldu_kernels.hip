@@ -514,7 +514,16 @@ int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const
 #define P2P_BLK 256
 #endif
 #define P2P_CHUNK (P2P_BLK / LDU_WAVE)   // slices per ticket: one per wave of the workgroup
-#define P2P_SPIN_LIMIT (1u << 22)
+#define P2P_SPIN_LIMIT_DEFAULT (1u << 22)
+// bound of every dependency wait, in polls; run-time overridable (ldu_ctx_set_spin_limit / LDU_SPIN_LIMIT) so that
+// the abort -> engine-fallback path can be forced in tests
+__device__ unsigned g_p2p_spin_limit = P2P_SPIN_LIMIT_DEFAULT;
+int k_set_spin_limit(unsigned polls)
+{
+    if (!polls) polls = P2P_SPIN_LIMIT_DEFAULT;
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_spin_limit), &polls, sizeof(unsigned)));
+    return 0;
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -570,7 +579,7 @@ __device__ __forceinline__ void granule_store(uint4* G, int row, double v, unsig
     u32x4 d;
     d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
     uint4* p = G + row;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
 }
 
 // XCD-slab engine (see "XCD slabs" below): the granule stays in the producing XCD's L2 (plain store:
@@ -583,11 +592,11 @@ __device__ __forceinline__ void granule_store_slab(uint4* G, uint4* X, int row, 
     u32x4 d;
     d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
     uint4* p = G + row;
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
     if (exported)
     {
         uint4* q = X + row;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(q), "v"(d) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(q), "v"(d) : "memory");
     }
 }
 
@@ -651,11 +660,12 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             // fine-grained polling below runs for ~1 hand-off instead of the whole look-ahead.
             const unsigned* gp = waitEst.sliceDone + waitEst.gateSlice;
             unsigned gspins = 0;
+            const unsigned spinLimit = g_p2p_spin_limit;
             for (;;)
             {
                 const unsigned gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(gv - tag) >= 0) break;
-                if (++gspins > P2P_SPIN_LIMIT || ((gspins & 255u) == 0 && *abortFlag)) break;
+                if (++gspins > spinLimit || ((gspins & 255u) == 0 && *abortFlag)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
             waitEst.gateSlice = -1;
@@ -663,6 +673,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
         u32x4 g0, g1, g2, g3;
         unsigned spins = 0;
         const int sleepN = g_p2p_sleep;
+        const unsigned spinLimit = g_p2p_spin_limit;
         for (;; waitEst.polls += DIAG ? 1u : 0u)
         {
             if (SLAB) granule_load4(gp[0], gp[1], gp[2], gp[3], g0, g1, g2, g3);
@@ -673,7 +684,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             if (i0 + 2 < n) ok &= (g2.y == tag) & (g2.w == tag);
             if (i0 + 3 < n) ok &= (g3.y == tag) & (g3.w == tag);
             if (ok) break;
-            if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
+            if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag))
             {
                 *abortFlag = 1;
                 return false;
@@ -1084,6 +1095,7 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
     for (int q = 0; q < 4; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
     u32x4 g0, g1, g2, g3;
     unsigned spins = 0;
+    const unsigned spinLimit = g_p2p_spin_limit;
     for (;;)
     {
         granule_load4(gp[0], gp[1], gp[2], gp[3], g0, g1, g2, g3);
@@ -1093,7 +1105,7 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
         if (BASE + 2 < nu) ok &= (g2.y == t) & (g2.w == t);
         if (BASE + 3 < nu) ok &= (g3.y == t) & (g3.w == t);
         if (ok) break;
-        if (++spins > P2P_SPIN_LIMIT || ((spins & 255u) == 0 && *abortFlag))
+        if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag))
         {
             *abortFlag = 1;
             return false;

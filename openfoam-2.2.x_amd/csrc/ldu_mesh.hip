@@ -107,7 +107,7 @@ mesh_cell_kernel(int nCells, const int* __restrict__ cStart, const int* __restri
     }
 }
 
-// surfaceInterpolation.C:163-185 (weights), :227-231 (deltaCoeffs); fvMesh::magSf = mag(Sf)
+// surfaceInterpolation.C:163-185 (weights), :227-231 (deltaCoeffs); fvMesh::magSf = mag(Sf) + VSMALL (fvMeshGeometry.C:113)
 __global__ void __launch_bounds__(BLK)
 mesh_factors_kernel(int nInternal, const int* __restrict__ owner, const int* __restrict__ neighbour,
                     const double* __restrict__ Cf, const double* __restrict__ Sf, const double* __restrict__ C,
@@ -121,7 +121,22 @@ mesh_factors_kernel(int nInternal, const int* __restrict__ owner, const int* __r
         const double SfdNei = fabs(dot(sf, sub(cn, cf)));
         if (w) w[facei] = SfdNei / (SfdOwn + SfdNei);
         if (delta) delta[facei] = 1.0 / mag(sub(cn, co));
-        if (magSf) magSf[facei] = mag(sf);
+        if (magSf) magSf[facei] = mag(sf) + kVSmall;
+    }
+}
+
+// faceAreaPairGAMGAgglomeration.C:48-73: mag(cmptMultiply(Sf/sqrt(magSf), vector(1, 1.01, 1.02))) with
+// magSf = mag(Sf) + VSMALL (fvMeshGeometry.C:101-114)
+__global__ void __launch_bounds__(BLK)
+mesh_faceAreaPair_kernel(int nInternal, const double* __restrict__ Sf, double* __restrict__ w)
+{
+    for (int facei = blockIdx.x * BLK + threadIdx.x; facei < nInternal; facei += gridDim.x * BLK)
+    {
+        const V3 sf = ld3(Sf, facei);
+        const double r = sqrt(mag(sf) + kVSmall);
+        V3 t;
+        t.x = sf.x / r; t.y = (sf.y / r) * 1.01; t.z = (sf.z / r) * 1.02;
+        w[facei] = mag(t);
     }
 }
 
@@ -259,6 +274,37 @@ int ldu_mesh_interpolation_factors(ldu_ctx* ctx, int32_t nCells, int32_t nIntern
     if (dev_back(dW, s) || dev_back(dD, s) || dev_back(dM, s)) return -1;
     LDU_CHECK_HIP(hipStreamSynchronize(s));
     return 0;
+}
+
+int ldu_addr_set_face_areas(ldu_addr* a, const double* Sf)
+{
+    if (!a || (!Sf && a->nFaces)) { ldu_set_error("ldu_addr_set_face_areas: null argument"); return -14; }
+    LDU_CHECK_HIP(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    const size_t nF = (size_t)a->nFaces;
+    a->faceWeights.resize(nF);
+    if (!nF) return 0;
+    DevBuf<double> dSf, dW;
+    if (dev_in(dSf, Sf, 3 * nF, s) || dev_out(dW, a->faceWeights.data(), nF)) return -1;
+    mesh_faceAreaPair_kernel<<<ewGrid(a->nFaces), BLK, 0, s>>>(a->nFaces, dSf.d, dW.d);
+    LDU_CHECK_HIP(hipGetLastError());
+    if (dev_back(dW, s)) return -1;
+    LDU_CHECK_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ldu_addr_get_face_weights(const ldu_addr* a, double* w)
+{
+    if ((int)a->faceWeights.size() != a->nFaces) { ldu_set_error("no face weights set"); return -7; }
+    if (a->nFaces) LDU_CHECK_HIP(hipMemcpy(w, a->faceWeights.data(), sizeof(double) * a->nFaces, hipMemcpyDefault));
+    return 0;
+}
+
+int ldu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
 }
 
 // bandCompression.C:43-146 on the cell-cell addressing of the internal faces (primitiveMeshCellCells.C: face

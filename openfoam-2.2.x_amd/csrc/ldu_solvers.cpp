@@ -34,6 +34,7 @@ int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
         // a point-to-point sweep gave up waiting (bounded spin): fail loudly, never hang
         (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), ctx->stream);
         ctx->p2pGen++;
+        ctx->abortSeen = 1;
         ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
         return -20;
     }
@@ -49,9 +50,32 @@ int dev_check_abort(ldu_ctx* ctx)
     {
         (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), ctx->stream);
         ctx->p2pGen++;
+        ctx->abortSeen = 1;
         ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
         return -20;
     }
+    return 0;
+}
+
+int fallback_prepare(ldu_matrix* m)
+{
+    ldu_ctx* ctx = m->a->ctx;
+    // whatever the failed attempt left in flight (the second stream of PBiCG included) has to end first
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream2));
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    LDU_CHECK_HIP(hipMemset(ctx->d_abort, 0, sizeof(int)));
+    *ctx->h_abort = 0;
+    ctx->dualActive = 0;
+    ctx->sb = 0;
+    ctx->abortSeen = 0;
+    // factors a broken sweep may have written (calcReciprocalD runs as a sweep): this matrix, its GAMG levels,
+    // the coupled family's rD
+    m->rDKind = -1;
+    if (m->gamg) gamg_invalidate_factors(m->gamg);
+    coupled_invalidate(m);
+    if (ctx->nFallbacks++ == 0 || getenv("LDU_VERBOSE"))
+        fprintf(stderr, "[ldugpu] warning: a point-to-point sweep exceeded its dependency-wait bound; the operation is "
+                        "re-run on the level-kernel engine (fallback %ld of this context)\n", ctx->nFallbacks);
     return 0;
 }
 
@@ -507,10 +531,12 @@ int dev_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
     switch (c->solver)
     {
     case LDU_SOLVER_PCG:
-        if (!m->sym && c->preconditioner != LDU_PRE_NONE && c->preconditioner != LDU_PRE_DIAGONAL
-            && c->preconditioner != LDU_PRE_GAMG)
+        if (!m->sym)
         {
-            // the reference has no DIC for asymmetric matrices (lduMatrixPreconditioner.C:98-124)
+            // PCG is registered in the symmetric table only (PCG.C:34-35): on an asymmetric matrix the reference
+            // aborts in lduMatrix::solver::New (lduMatrixSolver.C:96-110)
+            ldu_set_error("Unknown asymmetric matrix solver PCG (lduMatrixSolver.C:96-110)");
+            return -16;
         }
         return solve_krylov(m, c, psi, source, perf, hist, false);
     case LDU_SOLVER_PBICG:

@@ -24,6 +24,7 @@
 #include "Pstream.H"
 #include "Switch.H"
 #include "labelList.H"
+#include "polyMesh.H"
 
 #include <cstring>
 #include <cstdlib>
@@ -32,23 +33,33 @@
 
 #include <map>
 #include <vector>
+#include <stdint.h>
 
 namespace Foam
 {
 
 // ------------------------------------------------------------------ device registry
 
+// One entry per lduAddressing the solvers have seen.  The key is the address of the addressing object; an
+// entry is only reused when its fingerprint still matches: the two address arrays (pointer, size, a strided
+// sample of their contents) and every coupled patch's faceCells (size + sample).  An lduAddressing freed and
+// re-allocated at the same address (GAMG levels without cacheAgglomeration, a topology change that keeps the
+// cell and face counts) therefore rebuilds its device plan instead of silently reusing a stale one.
+// Entries are evicted least-recently-used beyond hipMaxEntries_ and all freed when the library is unloaded.
 struct hipLduEntry
 {
     ldu_addr* addr;
     ldu_matrix* mat;
     label nCells, nFaces;
+    uint64_t fingerprint;
+    uint64_t lastUse;
     bool weightsSet;
 };
 
 static ldu_ctx* hipCtx_ = NULL;
 static std::map<const lduAddressing*, hipLduEntry> hipEntries_;
-static std::vector<double> hipFaceWeights_;
+static uint64_t hipUseClock_ = 0;
+static const size_t hipMaxEntries_ = 64;
 
 static void hipCheck(int rc, const char* where)
 {
@@ -58,12 +69,94 @@ static void hipCheck(int rc, const char* where)
     }
 }
 
+static inline void hipMix(uint64_t& h, uint64_t v)
+{
+    h ^= v + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
+}
+
+static void hipMixList(uint64_t& h, const labelUList& l)
+{
+    hipMix(h, uint64_t(l.size()));
+    hipMix(h, uint64_t(reinterpret_cast<uintptr_t>(l.begin())));
+    const label n = l.size();
+    const label step = n > 4096 ? n/4096 : 1;
+    for (label i = 0; i < n; i += step) hipMix(h, uint64_t(l[i]));
+    if (n) hipMix(h, uint64_t(l[n - 1]));
+}
+
+template<class InterfaceList>
+static uint64_t hipFingerprint(const lduAddressing& la, const InterfaceList& interfaces)
+{
+    uint64_t h = 0x243F6A8885A308D3ULL;
+    hipMix(h, uint64_t(la.size()));
+    hipMixList(h, la.lowerAddr());
+    hipMixList(h, la.upperAddr());
+    forAll(interfaces, patchi)
+    {
+        hipMix(h, interfaces.set(patchi) ? 1 : 0);
+        if (interfaces.set(patchi)) hipMixList(h, la.patchAddr(patchi));
+    }
+    return h;
+}
+
+static void hipFreeEntry(hipLduEntry& e)
+{
+    ldu_matrix_destroy(e.mat);
+    ldu_addr_destroy(e.addr);
+}
+
+static void hipEvictOldest()
+{
+    std::map<const lduAddressing*, hipLduEntry>::iterator old = hipEntries_.begin();
+    for (std::map<const lduAddressing*, hipLduEntry>::iterator i = hipEntries_.begin(); i != hipEntries_.end(); ++i)
+    {
+        if (i->second.lastUse < old->second.lastUse) old = i;
+    }
+    hipFreeEntry(old->second);
+    hipEntries_.erase(old);
+}
+
+// device memory is returned when the library is unloaded (dlclose / exit)
+struct hipLduRegistryCleaner
+{
+    ~hipLduRegistryCleaner()
+    {
+        for (std::map<const lduAddressing*, hipLduEntry>::iterator i = hipEntries_.begin(); i != hipEntries_.end(); ++i)
+        {
+            hipFreeEntry(i->second);
+        }
+        hipEntries_.clear();
+        if (hipCtx_) { ldu_ctx_destroy(hipCtx_); hipCtx_ = NULL; }
+    }
+};
+static hipLduRegistryCleaner hipLduRegistryCleaner_;
+
+// rank -> GPU: the rank's position within its node (what the MPI launchers export) modulo the devices this
+// process can see (HIP_VISIBLE_DEVICES respected); without a launcher hint, the global rank modulo the count
+static int hipDeviceForRank()
+{
+    const int nDev = ldu_device_count();
+    if (nDev <= 0)
+    {
+        FatalErrorIn("hipDeviceForRank()") << "no HIP device visible to this process" << exit(FatalError);
+    }
+    if (!Pstream::parRun()) return 0;
+    const char* vars[] = {"OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID",
+                          "SLURM_LOCALID", "PMI_LOCAL_RANK"};
+    for (unsigned i = 0; i < sizeof(vars)/sizeof(vars[0]); i++)
+    {
+        const char* v = getenv(vars[i]);
+        if (v && *v) return atoi(v) % nDev;
+    }
+    return Pstream::myProcNo() % nDev;
+}
+
 static ldu_ctx* hipContext()
 {
     if (!hipCtx_)
     {
-        // one rank per GPU: device = rank within the node
-        int dev = Pstream::parRun() ? Pstream::myProcNo() % 8 : 0;
+        // one rank per GPU
+        const int dev = hipDeviceForRank();
         hipCheck(ldu_ctx_create(&hipCtx_, dev), "hipContext()");
         if (Pstream::parRun())
         {
@@ -99,18 +192,21 @@ static hipLduEntry& hipLookupAddr
     std::map<const lduAddressing*, hipLduEntry>::iterator it = hipEntries_.find(&la);
     const label nCells = la.size();
     const label nFaces = la.lowerAddr().size();
-    if (it != hipEntries_.end() && (it->second.nCells != nCells || it->second.nFaces != nFaces))
+    const uint64_t fp = hipFingerprint(la, interfaces);
+    if (it != hipEntries_.end() && it->second.fingerprint != fp)
     {
-        ldu_matrix_destroy(it->second.mat);
-        ldu_addr_destroy(it->second.addr);
+        hipFreeEntry(it->second);
         hipEntries_.erase(it);
         it = hipEntries_.end();
     }
     if (it == hipEntries_.end())
     {
+        while (hipEntries_.size() >= hipMaxEntries_) hipEvictOldest();
         hipLduEntry e;
         e.nCells = nCells;
         e.nFaces = nFaces;
+        e.fingerprint = fp;
+        e.lastUse = 0;
         e.weightsSet = false;
         hipCheck
         (
@@ -138,6 +234,16 @@ static hipLduEntry& hipLookupAddr
                 const labelUList& fc = la.patchAddr(patchi);
                 if (pp)
                 {
+                    // processorFvPatchField::updateInterfaceMatrix applies transformCoupleField(pnf, cmpt)
+                    // (processorFvPatchScalarField.C / processorFvPatchField.C): non-trivial on processorCyclic
+                    // patches with a rotation.  Not implemented here: refuse instead of computing a wrong halo.
+                    if (pp->forwardT().size())
+                    {
+                        FatalErrorIn("hipLookup")
+                            << "processor patch " << patchi << " carries a transformation (processorCyclic with "
+                            << "rotation): only untransformed processor patches are supported on the GPU path"
+                            << exit(FatalError);
+                    }
                     hipCheck(ldu_addr_add_patch(e.addr, fc.size(), fc.begin(), pp->neighbProcNo()), "hipLookup");
                 }
                 else if (cp)
@@ -169,11 +275,7 @@ static hipLduEntry& hipLookupAddr
         hipCheck(ldu_matrix_create(e.addr, &e.mat), "hipLookup");
         it = hipEntries_.insert(std::make_pair(&la, e)).first;
     }
-    if (!it->second.weightsSet && label(hipFaceWeights_.size()) == nFaces && nFaces)
-    {
-        hipCheck(ldu_addr_set_face_weights(it->second.addr, &hipFaceWeights_[0]), "hipLookup");
-        it->second.weightsSet = true;
-    }
+    it->second.lastUse = ++hipUseClock_;
     return it->second;
 }
 
@@ -287,8 +389,40 @@ static void hipReadControls(const dictionary& dict, int solverKind, ldu_controls
     if (gd->found("agglomerator"))
     {
         const word ag(gd->lookup("agglomerator"));
-        c.agglomerator = (ag == "algebraicPair") ? LDU_AGG_ALGEBRAICPAIR : LDU_AGG_FACEAREAPAIR;
+        if (ag == "algebraicPair") c.agglomerator = LDU_AGG_ALGEBRAICPAIR;
+        else if (ag == "faceAreaPair") c.agglomerator = LDU_AGG_FACEAREAPAIR;
+        else
+        {
+            FatalErrorIn("hipReadControls") << "agglomerator " << ag << " has no GPU implementation "
+                << "(available: faceAreaPair, algebraicPair)" << exit(FatalError);
+        }
     }
+}
+
+
+// Geometric agglomeration weights, obtained the way faceAreaPairGAMGAgglomeration.C:48-73 obtains them: from
+// the mesh behind matrix.mesh().  The reference refCasts the lduMesh to fvMesh and uses Sf() / magSf(); the
+// internal field of fvMesh::Sf() is the first nInternalFaces entries of primitiveMesh::faceAreas()
+// (fvMeshGeometry.C:52-76: a sliced field over faceAreas()) and magSf = mag(Sf) + VSMALL (:101-114), so the
+// polyMesh base of the same object (libOpenFOAM - the shim does not link libfiniteVolume) gives the same numbers.
+// mag(cmptMultiply(Sf/sqrt(magSf), (1, 1.01, 1.02))) itself is evaluated on the device (ldu_addr_set_face_areas).
+static void hipEnsureFaceWeights(hipLduEntry& e, const lduMatrix& matrix)
+{
+    if (e.weightsSet) return;
+    const polyMesh* pm = dynamic_cast<const polyMesh*>(&matrix.mesh());
+    if (!pm) pm = dynamic_cast<const polyMesh*>(&matrix.mesh().thisDb());
+    if (!pm || pm->nInternalFaces() != e.nFaces)
+    {
+        // the reference: refCast<const fvMesh>(mesh) fails the same way on anything that is not an fvMesh
+        FatalErrorIn("hipEnsureFaceWeights")
+            << "agglomerator faceAreaPair needs the face areas of the finite-volume mesh behind the matrix "
+            << "(faceAreaPairGAMGAgglomeration.C:56); this matrix's lduMesh is " << (pm ? "a polyMesh whose internal "
+               "faces do not match the matrix addressing" : "not a polyMesh") << ". Use agglomerator algebraicPair."
+            << exit(FatalError);
+    }
+    const vectorField& Sf = pm->faceAreas();
+    hipCheck(ldu_addr_set_face_areas(e.addr, reinterpret_cast<const double*>(Sf.begin())), "hipEnsureFaceWeights");
+    e.weightsSet = true;
 }
 
 
@@ -341,6 +475,14 @@ public:
 
         hipLduEntry& e = hipLookup(matrix_, interfaces_);
         hipSetCoeffs(e, matrix_, interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_);
+        if
+        (
+            (SolverKind == LDU_SOLVER_GAMG || c.preconditioner == LDU_PRE_GAMG)
+         && c.agglomerator == LDU_AGG_FACEAREAPAIR
+        )
+        {
+            hipEnsureFaceWeights(e, matrix_);
+        }
 
         ldu_perf perf;
         hipCheck(ldu_solve(e.mat, &c, psi.begin(), source.begin(), &perf, NULL), "hipLduSolver::solve");
@@ -632,12 +774,3 @@ lduMatrix::smoother::addRemovablesymMatrixConstructorToTable<hipGaussSeidelSmoot
 lduMatrix::smoother::addRemovableasymMatrixConstructorToTable<hipGaussSeidelSmoother> addHipGSAsym_;
 
 } // End namespace Foam
-
-
-// Geometric agglomeration weights: faceAreaPairGAMGAgglomeration (libfiniteVolume) computes
-// mag(cmptMultiply(Sf/sqrt(magSf), (1,1.01,1.02))) from fvMesh::Sf(); a finiteVolume-aware
-// caller hands them over here once per mesh.
-extern "C" void hipLduSetFaceWeights(const double* w, int n)
-{
-    Foam::hipFaceWeights_.assign(w, w + n);
-}

@@ -84,6 +84,12 @@ CXXFLAGS="-m64 -std=gnu++98 -Dlinux64 -DWM_DP -DNoRepository -ftemplate-depth-10
     echo "all: \$(OBJS)"
 } > "$W/Makefile"
 
+if [ -n "$DRIVERS_ONLY" ] && [ -f "$OUT/libOpenFOAM.so" ]; then
+    # re-link only the driver (our code) against the reference library already built
+    g++ $CXXFLAGS -o "$OUT/ref_driver" "$HERE/ref_driver.C" -L"$OUT" -lOpenFOAM -ldl -lm -Wl,-rpath,'$ORIGIN'
+    echo "build_ref.sh: OK (driver only) -> $OUT/ref_driver"
+    exit 0
+fi
 make -s -C "$W" -f "$W/Makefile" -j"$JOBS" all
 
 # 4. link

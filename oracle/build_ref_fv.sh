@@ -57,9 +57,11 @@ CXXFLAGS="-m64 -std=gnu++98 -Dlinux64 -DWM_DP -DNoRepository -ftemplate-depth-10
     echo "all: \$(OBJS)"
 } > "$W/Makefile.fv"
 rm -f "$W/fvfailed.txt"
+if [ -z "$DRIVERS_ONLY" ] || [ ! -f "$W/libfiniteVolume.a" ]; then
 make -s -k -C "$W" -f "$W/Makefile.fv" -j"$JOBS" all || true
 rm -f "$W/libfiniteVolume.a"
 ar rcs "$W/libfiniteVolume.a" "$W"/fvobj/*.o
+fi
 echo "build_ref_fv.sh: $(ls "$W"/fvobj/*.o | wc -l) units archived; failed: $(cat "$W/fvfailed.txt" 2>/dev/null | wc -l)"
 # units whose only entry point is a static registration object (run-time selection of the cyclic patch
 # and its patch fields) are not reachable through symbols: name them explicitly

@@ -17,6 +17,10 @@
 #include "gaussGrad.H"
 #include "snGradScheme.H"
 #include "uncorrectedSnGrad.H"
+#include "correctedSnGrad.H"
+#include "gaussDivScheme.H"
+#include "fvcGrad.H"
+#include "symmTensorField.H"
 #include "gaussLaplacianScheme.H"
 #include "gaussConvectionScheme.H"
 #include "linearUpwind.H"
@@ -34,7 +38,6 @@
 #include "cyclicFvsPatchFields.H"
 #include "fixedValueFvPatchFields.H"
 #include <cstdio>
-#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -58,6 +61,16 @@ static void put(const char* name, const vectorField& f)
 static void put(const char* name, const tensorField& f)
 {
     put(name, reinterpret_cast<const double*>(f.begin()), 9L * f.size());
+}
+static void put(const char* name, const symmTensorField& f)
+{
+    put(name, reinterpret_cast<const double*>(f.begin()), 6L * f.size());
+}
+static std::string pname(label p, const char* what)
+{
+    char nm[64];
+    snprintf(nm, sizeof(nm), "p%d_%s", int(p), what);
+    return std::string(nm);
 }
 
 // fvMatrix glue: a scalar transport matrix with fixedValue / zeroGradient / cyclic
@@ -311,11 +324,6 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
         scalarField w(mag(cmptMultiply(mesh.Sf().internalField() / sqrt(mesh.magSf().internalField()),
                                        vector(1, 1.01, 1.02))));
         put("faceAreaPairWeights", w);
-        // when the product's plugin is loaded (libs (...) in controlDict): hand it the geometric
-        // agglomeration weights
-        typedef void (*setw_t)(const double*, int);
-        setw_t fn = (setw_t)dlsym(RTLD_DEFAULT, "hipLduSetFaceWeights");
-        if (fn) fn(w.begin(), w.size());
     }
     const bool ownSmoother = std::string(extraControls).find("smoother ") != std::string::npos;
     std::string d0 = std::string("solver GAMG; ") + (ownSmoother ? "" : "smoother GaussSeidel; ")
@@ -410,6 +418,266 @@ static int solveMode(fvMesh& mesh, Time& runTime, const std::vector<double>& in,
     return 0;
 }
 
+// SURVEY.md 8a rows a36 / a37 / a39 and the patch halves of a34 / a35 on a non-orthogonal mesh:
+// nonOrthDeltaCoeffs / nonOrthCorrectionVectors (surfaceInterpolation.C:252-391), correctedSnGrad (correction, full
+// snGrad), the corrected gaussLaplacianScheme with scalar / symmTensor / tensor gamma (fvm and fvc), gaussDivScheme of
+// a vector and of a tensor field, interpolation on the patch faces (coupled and not) and gaussGrad's boundary
+// correction - all computed by the reference's own classes; fixedValue / zeroGradient / cyclic patches.
+static int nonorth(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
+{
+    const label nC = mesh.nCells();
+    const label nF = mesh.nInternalFaces();
+    dimensionSet::debug = 0;
+    wordList types(mesh.boundary().size());
+    forAll(types, p)
+    {
+        types[p] = mesh.boundary()[p].coupled() ? word("cyclic") : (p % 2 ? word("zeroGradient") : word("fixedValue"));
+    }
+    volScalarField T(IOobject("T", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0), types);
+    volVectorField U(IOobject("U", runTime.timeName(), mesh), mesh, dimensionedVector("0", dimless, vector::zero), types);
+    for (label c = 0; c < nC; c++)
+    {
+        T.internalField()[c] = in[c];
+        U.internalField()[c] = vector(in[nC + 3 * c], in[nC + 3 * c + 1], in[nC + 3 * c + 2]);
+    }
+    forAll(types, p)
+    {
+        if (types[p] == "fixedValue")
+        {
+            scalarField tv(mesh.boundary()[p].size());
+            vectorField uv(mesh.boundary()[p].size());
+            forAll(tv, i)
+            {
+                tv[i] = 0.7 + 0.1 * p + 0.03 * (i % 5);
+                uv[i] = vector(0.3 + 0.1 * p, -0.2 + 0.02 * (i % 3), 0.05 * p);
+            }
+            T.boundaryField()[p] == tv;
+            U.boundaryField()[p] == uv;
+        }
+    }
+    T.correctBoundaryConditions();
+    U.correctBoundaryConditions();
+    surfaceScalarField gamma(IOobject("gamma", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0));
+    for (label f = 0; f < nF; f++) gamma.internalField()[f] = in[(size_t)4 * nC + nF + f];
+    forAll(gamma.boundaryField(), p)
+        forAll(gamma.boundaryField()[p], i) gamma.boundaryField()[p][i] = 0.8 + 0.01 * (i % 7);
+    // cyclic halves must carry the same face value
+    forAll(gamma.boundaryField(), p)
+        if (mesh.boundary()[p].coupled())
+            forAll(gamma.boundaryField()[p], i) gamma.boundaryField()[p][i] = 0.9 + 0.02 * (i % 4);
+
+    // ---- geometry
+    put("V", mesh.V().field());
+    put("C", mesh.C().internalField());
+    put("Sf", mesh.Sf().internalField());
+    put("magSf", mesh.magSf().internalField());
+    put("weights", mesh.weights().internalField());
+    put("deltaCoeffs", mesh.deltaCoeffs().internalField());
+    put("nonOrthDeltaCoeffs", mesh.nonOrthDeltaCoeffs().internalField());
+    put("nonOrthCorrectionVectors", mesh.nonOrthCorrectionVectors().internalField());
+    put("T", T.internalField());
+    put("U", U.internalField());
+    put("gamma", gamma.internalField());
+    {
+        scalarField np(1, scalar(mesh.boundary().size()));
+        put("nPatches", np);
+    }
+    forAll(mesh.boundary(), p)
+    {
+        const fvPatch& fp = mesh.boundary()[p];
+        const labelUList& fc = fp.faceCells();
+        scalarField fcd(fc.size());
+        forAll(fc, i) fcd[i] = fc[i];
+        put(pname(p, "faceCells").c_str(), fcd);
+        scalarField cp(1, fp.coupled() ? 1.0 : 0.0);
+        put(pname(p, "coupled").c_str(), cp);
+        put(pname(p, "Sf").c_str(), mesh.Sf().boundaryField()[p]);
+        put(pname(p, "magSf").c_str(), mesh.magSf().boundaryField()[p]);
+        vectorField d(fp.delta());
+        put(pname(p, "delta").c_str(), d);
+        vectorField nf(fp.nf());
+        put(pname(p, "nf").c_str(), nf);
+        put(pname(p, "weights").c_str(), mesh.weights().boundaryField()[p]);
+        put(pname(p, "deltaCoeffs").c_str(), mesh.deltaCoeffs().boundaryField()[p]);
+        put(pname(p, "nonOrthDeltaCoeffs").c_str(), mesh.nonOrthDeltaCoeffs().boundaryField()[p]);
+        put(pname(p, "nonOrthCorrectionVectors").c_str(), mesh.nonOrthCorrectionVectors().boundaryField()[p]);
+        put(pname(p, "gamma").c_str(), gamma.boundaryField()[p]);
+        put(pname(p, "T").c_str(), T.boundaryField()[p]);
+        put(pname(p, "U").c_str(), U.boundaryField()[p]);
+        scalarField tpnf(fc.size(), 0.0);
+        vectorField upnf(fc.size(), vector::zero);
+        if (fp.coupled())
+        {
+            tpnf = T.boundaryField()[p].patchNeighbourField();
+            upnf = U.boundaryField()[p].patchNeighbourField();
+        }
+        put(pname(p, "T_pnf").c_str(), tpnf);
+        put(pname(p, "U_pnf").c_str(), upnf);
+        // fvPatchField::snGrad() = deltaCoeffs*(*this - patchInternalField()) (coupled patches have none without
+        // an explicit deltaCoeffs argument, coupledFvPatchField.H:150)
+        scalarField tsg(fc.size(), 0.0);
+        vectorField usg(fc.size(), vector::zero);
+        if (!fp.coupled())
+        {
+            tsg = T.boundaryField()[p].snGrad();
+            usg = U.boundaryField()[p].snGrad();
+        }
+        put(pname(p, "T_snGrad").c_str(), tsg);
+        put(pname(p, "U_snGrad").c_str(), usg);
+    }
+
+    // ---- a35 patch half: surfaceInterpolationScheme::interpolate on the patch faces (surfaceInterpolationScheme.C:298-314)
+    {
+        tmp<surfaceScalarField> s = linear<scalar>(mesh).interpolate(T);
+        tmp<surfaceVectorField> v = linear<vector>(mesh).interpolate(U);
+        put("ref_interpolate_T", s().internalField());
+        put("ref_interpolate_U", v().internalField());
+        forAll(mesh.boundary(), p)
+        {
+            put(pname(p, "ref_interpolate_T").c_str(), s().boundaryField()[p]);
+            put(pname(p, "ref_interpolate_U").c_str(), v().boundaryField()[p]);
+        }
+    }
+    // ---- a34 with its boundary correction (gaussGrad.C:123-170): Gauss linear gradients, internal and patch fields
+    volVectorField gradT(fvc::grad(T));
+    volTensorField gradU(fvc::grad(U));
+    put("ref_gradT", gradT.internalField());
+    put("ref_gradU", gradU.internalField());
+    forAll(mesh.boundary(), p)
+    {
+        put(pname(p, "ref_gradT").c_str(), gradT.boundaryField()[p]);
+        put(pname(p, "ref_gradU").c_str(), gradU.boundaryField()[p]);
+        vectorField gpnf(mesh.boundary()[p].size(), vector::zero);
+        tensorField gupnf(mesh.boundary()[p].size(), tensor::zero);
+        if (mesh.boundary()[p].coupled())
+        {
+            gpnf = gradT.boundaryField()[p].patchNeighbourField();
+            gupnf = gradU.boundaryField()[p].patchNeighbourField();
+        }
+        put(pname(p, "gradT_pnf").c_str(), gpnf);
+        put(pname(p, "gradU_pnf").c_str(), gupnf);
+    }
+    // ---- a36: correctedSnGrad (correctedSnGrad.C:44-107, correctedSnGrads.C), snGradScheme::snGrad (snGradScheme.C:104-186)
+    {
+        fv::correctedSnGrad<scalar> cs(mesh);
+        fv::correctedSnGrad<vector> cv(mesh);
+        tmp<surfaceScalarField> c1 = cs.correction(T);
+        tmp<surfaceVectorField> c3 = cv.correction(U);
+        tmp<surfaceScalarField> g1 = cs.snGrad(T);
+        tmp<surfaceVectorField> g3 = cv.snGrad(U);
+        put("ref_snGradCorrection_T", c1().internalField());
+        put("ref_snGradCorrection_U", c3().internalField());
+        put("ref_correctedSnGrad_T", g1().internalField());
+        put("ref_correctedSnGrad_U", g3().internalField());
+        forAll(mesh.boundary(), p)
+        {
+            put(pname(p, "ref_snGradCorrection_T").c_str(), c1().boundaryField()[p]);
+            put(pname(p, "ref_snGradCorrection_U").c_str(), c3().boundaryField()[p]);
+        }
+    }
+    // ---- a37: gaussLaplacianScheme with the corrected snGrad, scalar gamma (gaussLaplacianSchemes.C:43-114)
+    {
+        fv::gaussLaplacianScheme<scalar, scalar> ls
+        (
+            mesh, tmp<surfaceInterpolationScheme<scalar> >(new linear<scalar>(mesh)),
+            tmp<fv::snGradScheme<scalar> >(new fv::correctedSnGrad<scalar>(mesh))
+        );
+        tmp<fvScalarMatrix> M = ls.fvmLaplacian(gamma, T);
+        put("ref_lap_upper", M().upper());
+        put("ref_lap_diag", M().diag());
+        put("ref_lap_source", M().source());
+        forAll(mesh.boundary(), p)
+        {
+            put(pname(p, "ref_lap_internalCoeffs").c_str(), M().internalCoeffs()[p]);
+            put(pname(p, "ref_lap_boundaryCoeffs").c_str(), M().boundaryCoeffs()[p]);
+        }
+        if (M().faceFluxCorrectionPtr())
+        {
+            put("ref_lap_faceFluxCorrection", M().faceFluxCorrectionPtr()->internalField());
+            forAll(mesh.boundary(), p)
+                put(pname(p, "ref_lap_faceFluxCorrection").c_str(), M().faceFluxCorrectionPtr()->boundaryField()[p]);
+        }
+        tmp<volScalarField> L = ls.fvcLaplacian(gamma, T);
+        put("ref_fvcLaplacian", L().internalField());
+
+        fv::gaussLaplacianScheme<vector, scalar> lv
+        (
+            mesh, tmp<surfaceInterpolationScheme<scalar> >(new linear<scalar>(mesh)),
+            tmp<fv::snGradScheme<vector> >(new fv::correctedSnGrad<vector>(mesh))
+        );
+        tmp<fvVectorMatrix> MV = lv.fvmLaplacian(gamma, U);
+        put("ref_lapU_upper", MV().upper());
+        put("ref_lapU_diag", MV().diag());
+        put("ref_lapU_source", MV().source());
+    }
+    // ---- a37: tensor-gamma path (gaussLaplacianScheme.C:92-231), symmTensor and tensor diffusivities
+    {
+        surfaceSymmTensorField gS
+        (
+            IOobject("gS", runTime.timeName(), mesh), mesh, dimensionedSymmTensor("0", dimless, symmTensor::zero)
+        );
+        surfaceTensorField gT
+        (
+            IOobject("gT", runTime.timeName(), mesh), mesh, dimensionedTensor("0", dimless, tensor::zero)
+        );
+        for (label f = 0; f < nF; f++)
+        {
+            const scalar g = gamma.internalField()[f];
+            const scalar a = 0.1 * in[(size_t)4 * nC + f];
+            gS.internalField()[f] = symmTensor(g, 0.1 * a, -0.05 * a, 1.2 * g, 0.07 * a, 0.9 * g);
+            gT.internalField()[f] = tensor(g, 0.1 * a, -0.05 * a, 0.02 * a, 1.2 * g, 0.07 * a, 0.03 * a, -0.04 * a, 0.9 * g);
+        }
+        forAll(gS.boundaryField(), p)
+            forAll(gS.boundaryField()[p], i)
+            {
+                const scalar g = gamma.boundaryField()[p][i];
+                const scalar a = 0.01 * (1 + (i % 3));
+                gS.boundaryField()[p][i] = symmTensor(g, a, -a, 1.2 * g, 0.5 * a, 0.9 * g);
+                gT.boundaryField()[p][i] = tensor(g, a, -a, a, 1.2 * g, 0.5 * a, -0.5 * a, 0.25 * a, 0.9 * g);
+            }
+        put("gammaS", gS.internalField());
+        put("gammaT", gT.internalField());
+        forAll(mesh.boundary(), p)
+        {
+            put(pname(p, "gammaS").c_str(), gS.boundaryField()[p]);
+            put(pname(p, "gammaT").c_str(), gT.boundaryField()[p]);
+        }
+        fv::gaussLaplacianScheme<scalar, symmTensor> lS
+        (
+            mesh, tmp<surfaceInterpolationScheme<symmTensor> >(new linear<symmTensor>(mesh)),
+            tmp<fv::snGradScheme<scalar> >(new fv::correctedSnGrad<scalar>(mesh))
+        );
+        tmp<fvScalarMatrix> MS = lS.fvmLaplacian(gS, T);
+        put("ref_lapS_upper", MS().upper());
+        put("ref_lapS_diag", MS().diag());
+        put("ref_lapS_source", MS().source());
+        forAll(mesh.boundary(), p)
+        {
+            put(pname(p, "ref_lapS_internalCoeffs").c_str(), MS().internalCoeffs()[p]);
+            put(pname(p, "ref_lapS_boundaryCoeffs").c_str(), MS().boundaryCoeffs()[p]);
+        }
+        put("ref_fvcLaplacianS", lS.fvcLaplacian(gS, T)().internalField());
+        fv::gaussLaplacianScheme<scalar, tensor> lT
+        (
+            mesh, tmp<surfaceInterpolationScheme<tensor> >(new linear<tensor>(mesh)),
+            tmp<fv::snGradScheme<scalar> >(new fv::correctedSnGrad<scalar>(mesh))
+        );
+        tmp<fvScalarMatrix> MT = lT.fvmLaplacian(gT, T);
+        put("ref_lapT_upper", MT().upper());
+        put("ref_lapT_diag", MT().diag());
+        put("ref_lapT_source", MT().source());
+    }
+    // ---- a39: gaussDivScheme::fvcDiv (gaussDivScheme.C:48-68) of a vector and of a tensor field
+    {
+        fv::gaussDivScheme<vector> dv(mesh);
+        put("ref_divU", dv.fvcDiv(U)().internalField());
+        fv::gaussDivScheme<tensor> dt(mesh);
+        put("ref_divGradU", dt.fvcDiv(gradU)().internalField());
+    }
+    fclose(out);
+    return 0;
+}
+
 int main(int argc, char* argv[])
 {
     if (argc < 4 || argc > 6) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|glueV|solve|solve2] [extra GAMG controls for solve]\n"); return 2; }
@@ -432,6 +700,7 @@ int main(int argc, char* argv[])
     out = fopen(argv[3], "wb");
     if (argc >= 5 && std::string(argv[4]) == "glue") return glue(mesh, runTime, in);
     if (argc >= 5 && std::string(argv[4]) == "glueV") return glueV(mesh, runTime, in);
+    if (argc >= 5 && std::string(argv[4]) == "nonorth") return nonorth(mesh, runTime, in);
     if (argc == 5 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in, "nCellsInCoarsestLevel 10;");
     if (argc == 6 && std::string(argv[4]) == "solve") return solveMode(mesh, runTime, in, argv[5]);
     // two identical halves coupled by a cyclic pair = serial emulation of a 2-rank run: the combined

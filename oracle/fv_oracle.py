@@ -400,3 +400,127 @@ def bounded_sp(diag, l, u, phi, patches, V):
             ivf[c] += p["phi"][i]
     ivf = ivf / V
     return diag - V * ivf
+
+
+# ---------------------------------------------------------------- non-orthogonal correction (a36, a37), gaussDiv (a39)
+# and the patch halves of interpolate (a35) / gaussGrad (a34).  Vectors are [n,3]; tensors [n,9] in the reference's
+# component order xx xy xz yx yy yz zx zy zz; symmTensors [n,6] xx xy xz yy yz zz.
+
+def _dot(a, b):
+    """Vector & Vector (VectorI.H): a.x*b.x + a.y*b.y + a.z*b.z, left to right"""
+    return a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1] + a[:, 2] * b[:, 2]
+
+
+def _mag(a):
+    """mag(Vector) = sqrt(magSqr), magSqr = x*x + y*y + z*z"""
+    return np.sqrt(a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1] + a[:, 2] * a[:, 2])
+
+
+def vec_dot_field(v, g):
+    """Vector & Type per face: Type = vector ([n,3] -> [n]) or tensor ([n,9] -> [n,3], TensorI.H
+    operator&(Vector, Tensor): (v.x*t.xj + v.y*t.yj + v.z*t.zj))"""
+    if g.shape[1] == 3:
+        return _dot(v, g)
+    return np.stack([v[:, 0] * g[:, j] + v[:, 1] * g[:, 3 + j] + v[:, 2] * g[:, 6 + j] for j in range(3)], axis=1)
+
+
+def nonorth_factors(l, u, C, Sf, magSf):
+    """surfaceInterpolation::makeNonOrthDeltaCoeffs / makeNonOrthCorrectionVectors, internal faces,
+    interpolation/surfaceInterpolation/surfaceInterpolation/surfaceInterpolation.C:289-305, :346-352:
+    delta = C[nei]-C[own]; unitArea = Sf/magSf; nonOrthDeltaCoeffs = 1/max(unitArea & delta, 0.05*mag(delta));
+    corrVecs = unitArea - delta*nonOrthDeltaCoeffs"""
+    delta = C[u] - C[l]
+    unitArea = Sf / magSf[:, None]
+    nod = 1.0 / np.maximum(_dot(unitArea, delta), 0.05 * _mag(delta))
+    return nod, unitArea - delta * nod[:, None]
+
+
+def nonorth_factors_patch(Sf, magSf, delta, coupled):
+    """the patch faces, surfaceInterpolation.C:307-313 (1/max(nf & delta, 0.05*mag(delta)), nf = Sf/magSf:
+    fvPatch.C nf()) and :362-390 (correction vectors: zero on ordinary patches, unitArea - delta*nonOrthDeltaCoeffs on
+    coupled ones)"""
+    nf = Sf / magSf[:, None]
+    nod = 1.0 / np.maximum(_dot(nf, delta), 0.05 * _mag(delta))
+    corr = nf - delta * nod[:, None] if coupled else np.zeros_like(Sf)
+    return nod, corr
+
+
+def interpolate_patch(w, vf, faceCells, pnf, values, coupled):
+    """surfaceInterpolationScheme::interpolate on a patch, surfaceInterpolationScheme.C:298-314: coupled ->
+    pLambda*patchInternalField + (1 - pLambda)*patchNeighbourField, otherwise the patch values"""
+    if not coupled:
+        return values.copy()
+    lam = w if vf.ndim == 1 else w[:, None]
+    return lam * vf[faceCells] + (1.0 - lam) * pnf
+
+
+def gauss_grad_boundary(nf, gradInternalAtFaceCells, snGrad):
+    """gaussGrad::correctBoundaryConditions, finiteVolume/gradSchemes/gaussGrad/gaussGrad.C:144-170, on an ordinary
+    (not coupled) patch whose gradient patch field is zeroGradient (= the face cell's gradient):
+    g += n*(snGrad - (n & g)); scalar field: g [n,3], snGrad [n]; vector field: g [n,9], snGrad [n,3]"""
+    g = gradInternalAtFaceCells
+    if g.shape[1] == 3:
+        d = snGrad - _dot(nf, g)
+        return g + nf * d[:, None]
+    d = snGrad - vec_dot_field(nf, g)            # vector
+    outer = np.stack([nf[:, i] * d[:, j] for i in range(3) for j in range(3)], axis=1)   # Vector * Vector (outer)
+    return g + outer
+
+
+def sn_grad_correction(l, u, w, corrVecs, grad):
+    """correctedSnGrad<Type>::fullGradCorrection, snGradSchemes/correctedSnGrad/correctedSnGrad.C:44-66 (and the
+    scalar / vector specialisations of correction(), correctedSnGrads.C:44-62): nonOrthCorrectionVectors &
+    linear.interpolate(grad(vf)), internal faces"""
+    return vec_dot_field(corrVecs, interpolate(l, u, w, grad))
+
+
+def corrected_sn_grad(l, u, nonOrthDelta, vf, corr):
+    """snGradScheme::snGrad(vf), snGradScheme.C:168-186: snGrad(vf, deltaCoeffs(vf)) += correction(vf) with
+    deltaCoeffs = nonOrthDeltaCoeffs (correctedSnGrad.H:98-104)"""
+    d = nonOrthDelta if vf.ndim == 1 else nonOrthDelta[:, None]
+    return d * (vf[u] - vf[l]) + corr
+
+
+def surface_integrate_full(l, u, ssf, patches, V):
+    """fvc::surfaceIntegrate with its patch faces, fvcSurfaceIntegrate.C:43-76; patches: list of (faceCells, pssf)"""
+    out = np.zeros((V.size,) + ssf.shape[1:])
+    for f in range(l.size):
+        out[l[f]] += ssf[f]
+        out[u[f]] -= ssf[f]
+    for fc, pssf in patches:
+        for i, c in enumerate(fc):
+            out[c] += pssf[i]
+    return out / (V if ssf.ndim == 1 else V[:, None])
+
+
+def source_minus_V_div(source, l, u, ffc, patches, V):
+    """fvm.source() -= mesh.V()*fvc::div(faceFluxCorrection)().internalField(), gaussLaplacianSchemes.C:74-88 /
+    gaussLaplacianScheme.C:187"""
+    div = surface_integrate_full(l, u, ffc, patches, V)
+    return source - (V if ffc.ndim == 1 else V[:, None]) * div
+
+
+def face_scale(scale, field):
+    """surfaceScalarField * surfaceField<Type>: s*v per face and component"""
+    return scale * field if field.ndim == 1 else scale[:, None] * field
+
+
+def tensor_gamma_factors(Sf, magSf, gamma):
+    """gaussLaplacianScheme<Type, GType>::fvmLaplacian, gaussLaplacianScheme.C:165-173: Sn = Sf/magSf;
+    SfGamma = Sf & gamma; SfGammaSn = SfGamma & Sn; SfGammaCorr = SfGamma - SfGammaSn*Sn.  gamma [n,6] (symmTensor,
+    SymmTensorI.H operator&(Vector, SymmTensor)) or [n,9] (tensor)"""
+    Sn = Sf / magSf[:, None]
+    x, y, z = Sf[:, 0], Sf[:, 1], Sf[:, 2]
+    if gamma.shape[1] == 6:
+        xx, xy, xz, yy, yz, zz = (gamma[:, i] for i in range(6))
+        SfGamma = np.stack([x * xx + y * xy + z * xz, x * xy + y * yy + z * yz, x * xz + y * yz + z * zz], axis=1)
+    else:
+        SfGamma = vec_dot_field(Sf, gamma)
+    SfGammaSn = _dot(SfGamma, Sn)
+    return SfGammaSn, SfGamma - SfGammaSn[:, None] * Sn
+
+
+def gauss_div_faces(l, u, w, Sf, vf):
+    """gaussDivScheme::fvcDiv, divSchemes/gaussDivScheme/gaussDivScheme.C:48-68: the face field
+    Sf & linear.interpolate(vf) (vf vector -> scalar, tensor -> vector), internal faces"""
+    return vec_dot_field(Sf, interpolate(l, u, w, vf))

@@ -230,14 +230,6 @@ int main(int argc, char* argv[])
     FieldField<Field, scalar> bc(0), ic(0);
     lduInterfaceFieldPtrsList ifs(0);
 
-    if (getenv("LDU_PLUGIN_LIB") && suppliedWeights)
-    {
-        // hand the geometric agglomeration weights to the plugin
-        typedef void (*setw_t)(const double*, int);
-        setw_t fn = (setw_t)dlsym(RTLD_DEFAULT, "hipLduSetFaceWeights");
-        if (fn) fn(weights.begin(), weights.size());
-    }
-
     if (mode == "solve")
     {
         dictionary dict(mkDict(dictStr));

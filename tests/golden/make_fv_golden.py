@@ -106,9 +106,45 @@ def generate_chain(name):
     return out
 
 
+NONORTH_CASES = {"fvnonorth_box_6x5x4": ("box", (6, 5, 4), 21, False), "fvnonorth_box_5x4x6_cyclic": ("box", (5, 4, 6), 22, True),
+                 "fvnonorth_prism_5x4x3": ("prism", (5, 4, 3), 23, False)}
+
+
+def nonorth_mesh(name):
+    kind, dims, seed, cyc = NONORTH_CASES[name]
+    if kind == "box":
+        return fv_case.box_mesh(*dims, seed=seed, cyclic_x=cyc)
+    return fv_case.prism_box_mesh(*dims)
+
+
+def generate_nonorth(name):
+    """a36 / a37 / a39 and the patch halves of a34 / a35 on non-orthogonal meshes (fv_driver mode nonorth): jittered
+    graded hex boxes (one with a cyclic pair) and a prism mesh; fixedValue / zeroGradient / cyclic patches"""
+    kind, dims, seed, cyc = NONORTH_CASES[name]
+    mesh = nonorth_mesh(name)
+    rng = np.random.RandomState(400 + seed)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
+    with tempfile.TemporaryDirectory() as d:
+        case = os.path.join(d, "case")
+        fv_case.write_case(case, mesh)
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="nonorth")
+    out = dict(nCells=nC, lowerAddr=mesh["owner"][:nF].astype(np.int32), upperAddr=mesh["neighbour"].astype(np.int32))
+    for k, v in res.items():
+        out[k] = v.astype(np.int32) if k.endswith("_faceCells") else v
+    return out
+
+
 if __name__ == "__main__":
     if not fv_case.driver_available():
         raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
+    for name in NONORTH_CASES:
+        data = generate_nonorth(name)
+        np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+        print(name, "cells", data["nCells"], "faces", data["lowerAddr"].size, "patches", int(data["nPatches"][0]),
+              "max |corrVec|", float(np.abs(data["nonOrthCorrectionVectors"]).max()))
+    if len(sys.argv) > 1 and sys.argv[1] == "nonorth":
+        raise SystemExit(0)
     for name in CASES:
         data = generate(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)

@@ -70,6 +70,9 @@ def test_fv_kernels_against_reference_vectors(ctx, name):
         diag, upper, lower = a.fvmDiv(wk, g["phi"])
         assert eq(lower, g["ref_div_%s_lower" % kind]) and eq(upper, g["ref_div_%s_upper" % kind])
         assert eq(diag, g["ref_div_%s_diag" % kind])
+    # a30: the geometric agglomeration weights from Sf alone, on the device, vs the reference's
+    # mag(cmptMultiply(mesh.Sf()/sqrt(mesh.magSf()), (1, 1.01, 1.02))) (faceAreaPairGAMGAgglomeration.C:48-73)
+    assert eq(a.set_face_areas(Sf), g["ref_faceAreaPairWeights"])
     a.close()
 
 

@@ -22,7 +22,9 @@ pytestmark = [pytest.mark.gpu,
 CASES = [
     ("box3d_12", lambda: cases.box3d(12), dict(solver="PCG", preconditioner="DIC", tolerance=1e-9, relTol=0), "DICPCG"),
     ("box3d_asym", lambda: cases.box3d(10, asym=True), dict(solver="PBiCG", preconditioner="DILU", tolerance=1e-9, relTol=0), "DILUPBiCG"),
-    ("box3d_gamg", lambda: cases.box3d(14), dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+    # ref_driver's mesh is an lduPrimitiveMesh (no geometry): the agglomerator that needs none.  faceAreaPair goes
+    # through a real fvMesh below (test_fvmatrix_solve_through_plugin_with_cyclic_patches).
+    ("box3d_gamg", lambda: cases.box3d(14), dict(solver="GAMG", smoother="GaussSeidel", agglomerator="algebraicPair",
                                                  nCellsInCoarsestLevel=10, mergeLevels=1, cacheAgglomeration=True,
                                                  tolerance=1e-8, relTol=0), "GAMG"),
     ("rand_gs", lambda: cases.random_graph(500), dict(solver="smoothSolver", smoother="GaussSeidel", nSweeps=2,
@@ -49,9 +51,31 @@ def test_plugin_replaces_stock_solver(name, gen, kw, logname, monkeypatch):
     assert np.max(np.abs(gpu["psi"] - ref["psi"])) <= 1e-8 * np.max(np.abs(ref["psi"]))
 
 
+def test_drivers_do_not_know_the_plugin():
+    """The drop-in claim: the applications that load the plugin contain no product symbol - the shim finds what
+    it needs (coefficients, interfaces, face areas for faceAreaPair) behind the reference's own interfaces."""
+    for f in ("ref_driver.C", "fv_driver.C"):
+        src = open(os.path.join(HERE, "..", "oracle", f)).read()
+        assert "hipLdu" not in src and "dlsym" not in src, f
+
+
+def test_face_area_pair_without_a_mesh_is_fatal_like_the_reference(monkeypatch):
+    """faceAreaPairGAMGAgglomeration.C:56 refCasts the lduMesh to fvMesh: on an lduPrimitiveMesh the reference
+    aborts; the shim aborts too (FatalError, non-zero exit) instead of inventing weights."""
+    p = cases.box3d(8)
+    p.pop("faceWeights")
+    ds = oracle_py.dict_string(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                               nCellsInCoarsestLevel=10, tolerance=1e-8, relTol=0)
+    monkeypatch.setenv("LDU_PLUGIN_LIB", os.path.abspath(PLUGIN))
+    with pytest.raises(Exception) as ei:
+        oracle_py.run_ref("solve", p, ds)
+    assert "faceAreaPair" in str(ei.value)
+
+
 @pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve3_chain_asym_5x7x6"])
 def test_fvmatrix_solve_through_plugin_with_cyclic_patches(name, tmp_path, monkeypatch):
-    """The application-level boundary: the reference's own fvScalarMatrix::solve (oracle/_ref/fv_driver,
+    """The application-level boundary (and the faceAreaPair drop-in: nobody hands the shim any weights - it reads
+    the face areas of the fvMesh behind matrix.mesh() as faceAreaPairGAMGAgglomeration.C:48-73 does): the reference's own fvScalarMatrix::solve (oracle/_ref/fv_driver,
     real fvMesh with cyclic patches, fixedValue / zeroGradient boundaries) with the plugin loaded through
     `libs (...)`: solveSegregated -> lduMatrix::solver::New -> hipLduSolver -> ldu_addr_add_cyclic_patch ->
     GPU.  Must reproduce the stock run stored in the golden fixture."""
