@@ -44,6 +44,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
+    ap.add_argument("--mesh", choices=["box", "renumbered", "random"], default="box",
+                    help="box: the SURVEY 8d C3 stand-in in blockMesh's natural ordering (the metric's workload); "
+                         "renumbered: the same matrix under Foam::bandCompression (what renumberMesh applies); "
+                         "random: an irregular 5-9-neighbour graph of the same size (unstructured stand-in)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCG / asymmetric / host-path legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=0, help="box edge of the CPU sample (0 = same)")
     args = ap.parse_args()
@@ -69,9 +74,18 @@ def main():
 
     n = args.n
     t_gen = time.perf_counter()
-    p = cases.box3d(n)
+    if args.mesh == "random":
+        p = cases.random_graph_fast(n ** 3, 7.0, 600)
+    else:
+        p = cases.box3d(n)
+        if args.mesh == "renumbered":
+            order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+            nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+            p = cases.renumbered(p, order, fmap, flip, nl, nu)
     t_gen = time.perf_counter() - t_gen
     nC_total, nF_total = p["nCells"], int(p["lowerAddr"].size)
+    if world > 1 and args.mesh != "box":
+        raise SystemExit("bench.py: --mesh %s is a single-GPU measurement" % args.mesh)
 
     if world > 1:
         # 2x2x2 blocks at 8 ranks, slabs/blocks otherwise
@@ -163,17 +177,22 @@ def main():
         kname = ("%s (%s engine): %d pipelined GaussSeidel sweeps of the finest level per launch"
                  % (kernels[0], eng, per_launch)) if key == "gs_multi" else \
             "%s (%s engine): one GaussSeidel sweep of the rank's finest level" % (kernels[1], eng)
-        traffic = None
+        # traffic: HBM bytes per launch from the PMC counters.  NOT measured by this run: counters need their own
+        # rocprofv3 --pmc passes (MI355X_MICROARCH.md); the recorded value is only quoted when kernel, size and mesh
+        # are the ones it was recorded for, and the line says where it comes from.
+        traffic, traffic_source = None, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if key == "gs_multi" and n == 216 and world == 1 and pj.get("kernel", "") == kernels[0]:
-                traffic = pj["bytes_per_launch"]   # separate rocprofv3 --pmc passes, see profiles/r01_pmc_traffic.md
+            if (key == "gs_multi" and n == 216 and world == 1 and args.mesh == "box"
+                    and pj.get("kernel", "") == kernels[0]):
+                traffic = pj["bytes_per_launch"]
+                traffic_source = pj.get("source", "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)")
         except Exception:
             pass
         roof = dict(bound="hbm", kernel=kname + " (%d dependency levels)" % info["nLevels"],
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                    traffic=traffic, avg_launch_ms=round(ms, 4), bytes_per_launch=per_launch * gs_bytes,
-                    launches=prof[key]["count"])
+                    traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
+                    bytes_per_launch=per_launch * gs_bytes, launches=prof[key]["count"])
     amul = None
     if "amul" in prof and prof["amul"]["count"]:
         ms = prof["amul"]["ms"] / prof["amul"]["count"]
@@ -182,9 +201,50 @@ def main():
                     frac=round(ach / HBM_PEAK_GBS, 4), avg_launch_ms=round(ms, 4),
                     bytes_per_launch=amul_bytes, launches=prof["amul"]["count"])
 
+    # the reported metric itself against the roofline: one V-cycle by SURVEY.md 8d's formulas with the REAL level
+    # sizes (finest 312 nC + 56 nF; every coarse level but the coarsest 232 nC_l + 40 nF_l), over the time of a
+    # V-cycle including its share of the per-solve work (coefficient hand-over, level matrices)
+    roof_v = None
+    levels = []
+    try:
+        levels = mat.gamg_level_sizes(**GAMG_CONTROLS)
+        vbytes = 312.0 * nC + 56.0 * nF + sum(232.0 * L["nCells"] + 40.0 * L["nFaces"] for L in levels[:-1])
+        vsec = elapsed / max(1, iters)
+        roof_v = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, bytes_per_vcycle=vbytes,
+                      ms_per_vcycle=round(vsec * 1e3, 4), achieved=round(vbytes / vsec / 1e9, 1),
+                      frac=round(vbytes / vsec / 1e9 / HBM_PEAK_GBS, 4),
+                      levels=[[L["nCells"], L["nFaces"], L["nLevels"], L["engine_gs_multi"]] for L in levels],
+                      finest=[nC, nF, info["nLevels"], addr.sweep_engine(2)],
+                      cluster_levels_fraction=round(
+                          (sum(L["engine_gs_multi"] == "clusters" for L in levels) + (addr.sweep_engine(2) == "clusters"))
+                          / float(len(levels) + 1), 3))
+    except Exception as e:  # pragma: no cover
+        roof_v = dict(error=str(e))
+
     # extra: PCG+DIC iterations/s on the same matrix (fixed 40 iterations)
     extra = {}
+    if args.no_extras:
+        extra["skipped"] = True
+    else:
+      try:
+        # what the OpenFOAM shim pays today: diag/upper/source/psi handed over as pageable HOST arrays every solve
+        # (PCIe-inclusive; never `value`)
+        if world == 1:
+            h_psi = np.zeros(lp["nCells"])
+            t0 = time.perf_counter()
+            itsH = 0
+            for _ in range(2):
+                h_psi[:] = 0.0
+                mat.set_coeffs(lp["diag"], lp["upper"])
+                _, ph = mat.solve(h_psi, lp["source"], history=False, **GAMG_CONTROLS)
+                itsH += ph["nIterations"]
+            barrier()
+            extra["host_pointer_path_vcycles_per_s"] = round(itsH / (time.perf_counter() - t0), 2)
+            mat.set_coeffs(d_diag, d_upper)
+      except Exception as e:  # pragma: no cover
+        extra["host_path_error"] = str(e)
     try:
+      if not args.no_extras:
         d_psi.zero_()
         torch.cuda.synchronize()
         mat.profile_begin()
@@ -201,6 +261,33 @@ def main():
             extra["dic_sweep_avg_ms"] = round(pprof["tri_sweep"]["ms"] / pprof["tri_sweep"]["count"], 4)
     except Exception as e:  # pragma: no cover
         extra["pcg_error"] = str(e)
+    # config C3's other half: the U-equation solvers of the motorBike case on the ASYMMETRIC matrix of the same box
+    # (lower = upper - phi): PBiCG/DILU and the tutorial's own smoothSolver/GaussSeidel
+    # (motorBike/system/fvSolution:33-40); fixed iteration counts, it/s and algorithmic GB/s
+    if world == 1 and args.mesh == "box" and not args.no_extras:
+        try:
+            pa = cases.box3d(n, asym=True)
+            mat.set_coeffs(torch.from_numpy(pa["diag"]).to(dev), torch.from_numpy(pa["upper"]).to(dev),
+                           torch.from_numpy(pa["lower"]).to(dev))
+            d_srcA = torch.from_numpy(pa["source"]).to(dev)
+            for nm, kw, bytes_it in (
+                    ("pbicg_dilu", dict(solver="PBiCG", preconditioner="DILU", tolerance=0.0, relTol=0.0, maxIter=19),
+                     256.0 * nC + 120.0 * nF),
+                    ("smoothsolver_gs", dict(solver="smoothSolver", smoother="GaussSeidel", nSweeps=1, tolerance=0.0,
+                                            relTol=0.0, maxIter=20), (60.0 + 24.0 + 8.0) * nC + (20.0 + 24.0) * nF)):
+                mat.solve(d_psi.zero_(), d_srcA, history=False, **dict(kw, maxIter=2))     # factors / plans
+                d_psi.zero_()
+                barrier()
+                t0 = time.perf_counter()
+                _, pq = mat.solve(d_psi, d_srcA, history=False, **kw)
+                barrier()
+                tq = time.perf_counter() - t0
+                extra[nm + "_iterations_per_s"] = round(pq["nIterations"] / tq, 2)
+                extra[nm + "_GBs_algorithmic"] = round(bytes_it * pq["nIterations"] / tq / 1e9, 1)
+            del pa, d_srcA
+            mat.set_coeffs(d_diag, d_upper)
+        except Exception as e:  # pragma: no cover
+            extra["asym_error"] = str(e)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:   # the CPU leg is timed at N=1 only
@@ -234,6 +321,26 @@ def main():
                               "(%.1f s; agglomeration %.1f s excluded, cached like cacheAgglomeration)"
                               % (cn, secs, setup) + note)
 
+    # the same solve on ALL host cores: the C restatement, box decomposed into one sub-domain per
+    # core, one thread per sub-domain emulating the reference's MPI ranks (oracle/time_allcores.py); a port, never
+    # the reference itself (no MPI in this image)
+    cpu_all = None
+    if cpu is not None and not args.no_extras:
+        import subprocess
+        cores = max(1, min(os.cpu_count() or 1, 64))
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_allcores.py"), str(args.cpu_n or n),
+                                str(cores), "2"], capture_output=True, text=True, timeout=420)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            sc = ((args.cpu_n or n) ** 3) / float(n ** 3)
+            cpu_all = dict(value=round(j["vcycles_per_s"] * sc, 4), unit="V-cycles/s", cores=cores, kind="port",
+                           sample="oracle (C restatement, gcc -O2 -fopenmp): %d^3 box decomposed %dx%dx%d, one thread per "
+                                  "sub-domain (rank-local GaussSeidel / agglomeration, processor patches, rank-ordered sums): "
+                                  "2 GAMG V-cycles in %.2f s (agglomeration %.1f s excluded, cached like cacheAgglomeration)"
+                                  % (j["n"], j["blocks"][0], j["blocks"][1], j["blocks"][2], j["seconds"], j["setup_s"]))
+        except Exception as e:  # pragma: no cover
+            cpu_all = dict(error=str(e)[:300], cores=cores)
+
     if rank == 0:
         out = {
             "metric": "GAMG p-solve iterations/sec (V-cycles/s) + achieved HBM GB/s, 10M-cell motorBike stand-in",
@@ -248,14 +355,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "simpleFoam motorBike ~10M-cell p-solve stand-in: %d^3 hex box "
-                                   "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
-                                   "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total),
+            "config": {"workload": ("simpleFoam motorBike ~10M-cell p-solve stand-in: %d^3 hex box "
+                                    "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
+                                    "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total))
+                                   + ({"box": "", "renumbered": "; cells renumbered by Foam::bandCompression",
+                                       "random": "; NOT the box: irregular random graph, 5-9 neighbours per cell"}[args.mesh]),
+                       "mesh": args.mesh,
                        "parallelism": "domain decomposition x%d" % world,
                        "vcycles_per_solve": perf["nIterations"],
                        "dependency_levels_finest": info["nLevels"]},
             "roofline": roof,
+            "roofline_vcycle": roof_v,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "amul": amul,
             "extra": dict(extra, first_solve_s=round(t_first, 3), addressing_setup_s=round(t_addr, 3),
                           problem_generation_s=round(t_gen, 3),

@@ -83,6 +83,10 @@ int ldu_ctx_sync(ldu_ctx* ctx);
  * operations of this context took that path.  polls = 0 restores the default. */
 int ldu_ctx_set_spin_limit(ldu_ctx* ctx, uint32_t polls);
 int64_t ldu_ctx_fallback_count(const ldu_ctx* ctx);
+/* RCCL halo exchanges that ran on the communication stream, overlapped with the interior rows of the operator
+ * (between initMatrixInterfaces and updateMatrixInterfaces, lduMatrixUpdateMatrixInterfaces.C:30-93, 127-160);
+ * LDU_HALO_OVERLAP=0 puts them back on the compute stream. */
+int64_t ldu_ctx_overlapped_halo_count(const ldu_ctx* ctx);
 /* Multi-GPU: RCCL communicator from a 128-byte unique id shared out-of-band
  * (replaces UPstream::init / MPI_COMM_WORLD, src/Pstream/mpi/UPstream.C). */
 int ldu_comm_unique_id(uint8_t id[128]);
@@ -164,6 +168,10 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* controls, double* psi, const do
 /* GAMG hierarchy introspection (tests): level sizes and restrict maps */
 int ldu_gamg_levels(ldu_matrix* m, const ldu_controls* controls, int32_t* nLevels,
                     int32_t* nCellsPerLevel /* [50] */, int32_t* nFacesPerLevel /* [50] */);
+/* measurement introspection of a built hierarchy: info = {nCells, nFaces, dependency levels, widest row,
+ * engine of the triangular sweeps, of one GaussSeidel sweep, of pipelined GaussSeidel sweeps (codes of
+ * ldu_addr_sweep_engine), slices} of coarse level `level` (0 = first coarse level) */
+int ldu_gamg_level_info(ldu_matrix* m, int32_t level, int32_t info[8]);
 int ldu_gamg_level_data(ldu_matrix* m, int32_t level, int32_t* restrictAddr /* fine nCells */,
                         double* diag, double* upper, double* lower /* may be NULL */);
 

@@ -20,14 +20,14 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
-    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count",
+    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
     "ldu_gSumProd", "ldu_gSumMag", "ldu_precondition", "ldu_smooth", "ldu_solve", "ldu_gamg_levels",
-    "ldu_gamg_level_data", "ldu_fv_interpolate", "ldu_fvc_surfaceIntegrate", "ldu_fvc_gaussGrad",
+    "ldu_gamg_level_data", "ldu_gamg_level_info", "ldu_fv_interpolate", "ldu_fvc_surfaceIntegrate", "ldu_fvc_gaussGrad",
     "ldu_fvc_snGrad", "ldu_fvm_laplacian", "ldu_fvm_div", "ldu_profile_begin", "ldu_profile_end",
     "ldu_fv_boundary_create", "ldu_fv_boundary_destroy", "ldu_fvm_addBoundaryDiag", "ldu_fvm_addBoundarySource",
     "ldu_fvm_relax", "ldu_fvm_setReference", "ldu_fvm_A", "ldu_fvm_H", "ldu_fvm_flux",
@@ -168,6 +168,11 @@ class Context:
     def set_spin_limit(self, polls):
         """bound of the sweep engines' dependency waits (0 = default); tiny values force the engine fallback"""
         _chk(lib().ldu_ctx_set_spin_limit(self.h, C.c_uint32(int(polls))))
+
+    def overlapped_halo_count(self):
+        f = lib().ldu_ctx_overlapped_halo_count
+        f.restype = C.c_int64
+        return int(f(self.h))
 
     def fallback_count(self):
         f = lib().ldu_ctx_fallback_count
@@ -471,6 +476,22 @@ class Matrix:
         _chk(lib().ldu_profile_end(self.h, ms, cnt))
         names = ["amul", "gs_sweep", "tri_sweep", "residual", "gs_multi", "c5", "c6", "rd_sweep"]
         return {n: dict(ms=ms[i], count=cnt[i]) for i, n in enumerate(names) if cnt[i]}
+
+    def gamg_level_sizes(self, **controls):
+        """[(nCells, nFaces, dependency levels, widest row, engine of one GS sweep, engine of pipelined sweeps)] of the
+        coarse levels (builds the hierarchy when needed)"""
+        c = make_controls(**controls)
+        nl = C.c_int32()
+        nc = (C.c_int32 * 50)()
+        nf = (C.c_int32 * 50)()
+        _chk(lib().ldu_gamg_levels(self.h, C.byref(c), C.byref(nl), nc, nf))
+        out = []
+        for i in range(nl.value):
+            info = (C.c_int32 * 8)()
+            _chk(lib().ldu_gamg_level_info(self.h, i, info))
+            out.append(dict(nCells=info[0], nFaces=info[1], nLevels=info[2], maxRowWidth=info[3],
+                            engine_gs=Addressing.ENGINES[info[5]], engine_gs_multi=Addressing.ENGINES[info[6]]))
+        return out
 
     def gamg_levels(self, **controls):
         c = make_controls(**controls)

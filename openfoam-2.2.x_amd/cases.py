@@ -160,6 +160,46 @@ def random_graph(nC, avg_deg=4, band=50, asym=False, seed=7):
     return p
 
 
+def random_graph_fast(nC, avg_deg=7.0, band=600, seed=11):
+    """Large irregular addressing, vectorised (random_graph above is a Python loop): cell c draws Poisson(avg_deg/2)
+    higher-numbered neighbours within `band`; duplicates are dropped; faces come out in upper-triangular order.
+    Symmetric M-matrix coefficients, b = A x* with x*_i = sin(1e-3 i).  The stand-in for an unstructured (snappyHexMesh-
+    like) matrix in bench.py --mesh random: 5-9 neighbours per cell for avg_deg 7."""
+    rng = np.random.RandomState(seed)
+    k = rng.poisson(avg_deg / 2.0, size=nC).astype(np.int64)
+    k[k > band] = band
+    own = np.repeat(np.arange(nC, dtype=np.int64), k)
+    nbr = own + rng.randint(1, band + 1, size=own.size)
+    keep = nbr < nC
+    key = np.unique(own[keep] * np.int64(nC) + nbr[keep])     # sorted by (owner, neighbour), duplicates removed
+    l = (key // nC).astype(np.int32)
+    u = (key % nC).astype(np.int32)
+    nF = l.size
+    upper = -(0.5 + u01(seed, nF))
+    diag = _neg_sum_diag(nC, l, u, upper, upper)
+    diag += 0.05
+    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, upper=upper, diag=diag, faceWeights=0.5 + u01(seed + 1, nF))
+    p["source"] = amul(p, np.sin(1e-3 * np.arange(nC)))
+    p["psi"] = np.zeros(nC)
+    return p
+
+
+def renumbered(p, order, faceMap, flip, newLower, newUpper):
+    """the same matrix after a cell renumbering (capi.renumber_addressing): cell order[i] becomes cell i"""
+    q = dict(nCells=p["nCells"], lowerAddr=newLower, upperAddr=newUpper, diag=p["diag"][order],
+             source=p["source"][order], psi=p["psi"][order])
+    up = p["upper"][faceMap]
+    if "lower" in p:
+        lo = p["lower"][faceMap]
+        q["upper"] = np.where(flip == 1, lo, up)
+        q["lower"] = np.where(flip == 1, up, lo)
+    else:
+        q["upper"] = up
+    if "faceWeights" in p:
+        q["faceWeights"] = p["faceWeights"][faceMap]
+    return q
+
+
 def to_ldub_dict(p):
     out = {"nCells": np.array([p["nCells"]], dtype=np.int32)}
     for k in ("lowerAddr", "upperAddr", "diag", "upper", "lower", "source", "psi", "faceWeights"):

@@ -101,6 +101,9 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->streamComm, hipStreamNonBlocking));
+    LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evPacked, hipEventDisableTiming));
+    LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming));
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * 2 * (size_t)c->maxRedBlocks));
     // the abort flag lives behind the scalar slots so that ONE device-to-host copy brings both
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * (S_NSLOTS + 1)));
@@ -150,9 +153,13 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     e = getenv("LDU_SMALL");
     if (e) c->smallKernels = atoi(e);
     e = getenv("LDU_SMALL_MAX");
-    if (e) c->smallMaxCells = std::min(atoi(e), 8192);
+    if (e) c->smallMaxCells = std::min(atoi(e), 16384);
+    e = getenv("LDU_SMALL_PIPE");
+    if (e) c->smallPipe = atoi(e);
     e = getenv("LDU_P2P_SLABS");
     if (e) c->p2pSlabs = atoi(e);
+    e = getenv("LDU_HALO_OVERLAP");
+    if (e) c->haloOverlap = atoi(e);
     e = getenv("LDU_SPIN_LIMIT");
     if (e && (k_set_spin_limit((unsigned)strtoul(e, nullptr, 10)) || k_cluster_set_spin_limit((unsigned)strtoul(e, nullptr, 10))))
         return -1;
@@ -172,6 +179,10 @@ int ldu_ctx_destroy(ldu_ctx* c)
     (void)hipHostFree(c->h_scalars);
     (void)hipEventDestroy(c->evFork);
     (void)hipEventDestroy(c->evJoin);
+    (void)hipStreamSynchronize(c->streamComm);
+    (void)hipEventDestroy(c->evPacked);
+    (void)hipEventDestroy(c->evHalo);
+    (void)hipStreamDestroy(c->streamComm);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -187,6 +198,7 @@ int ldu_ctx_set_spin_limit(ldu_ctx* c, uint32_t polls)
 }
 
 int64_t ldu_ctx_fallback_count(const ldu_ctx* c) { return c ? (int64_t)c->nFallbacks : 0; }
+int64_t ldu_ctx_overlapped_halo_count(const ldu_ctx* c) { return c ? (int64_t)c->nHaloOverlapped : 0; }
 
 int ldu_ctx_sync(ldu_ctx* c)
 {
@@ -720,6 +732,8 @@ int ldu_gamg_levels(ldu_matrix* m, const ldu_controls* c, int32_t* nLevels, int3
     if (gamg_build_for_query(m, c)) return -1;
     return gamg_query(m, nLevels, nCells, nFaces);
 }
+
+int ldu_gamg_level_info(ldu_matrix* m, int32_t level, int32_t info[8]) { return gamg_level_info(m, level, info); }
 
 int ldu_gamg_level_data(ldu_matrix* m, int32_t level, int32_t* restrictAddr, double* diag, double* upper,
                         double* lower)

@@ -190,14 +190,40 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
         G->barrier();
         return 0;
     }
+    // the exchange runs on the comm stream: it starts when the send buffers are packed (event on the compute stream)
+    // and the compute stream only waits for it where the received values are consumed (comm_wait_halo, before
+    // apply_patches) - the interior rows of Amul / residual run meanwhile
+    hipStream_t cs = s;
+    if (ctx->haloOverlap)
+    {
+        if (ctx->haloInFlight) LDU_CHECK_HIP(hipStreamWaitEvent(s, ctx->evHalo, 0));   // never two exchanges in flight
+        LDU_CHECK_HIP(hipEventRecord(ctx->evPacked, s));
+        LDU_CHECK_HIP(hipStreamWaitEvent(ctx->streamComm, ctx->evPacked, 0));
+        cs = ctx->streamComm;
+    }
     LDU_CHECK_NCCL(ncclGroupStart());
     for (auto& p : a->patches)
     {
         if (p.n == 0 || p.nbrPatch >= 0) continue;
-        LDU_CHECK_NCCL(ncclSend(p.d_send, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, s));
-        LDU_CHECK_NCCL(ncclRecv(p.d_recv, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, s));
+        LDU_CHECK_NCCL(ncclSend(p.d_send, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, cs));
+        LDU_CHECK_NCCL(ncclRecv(p.d_recv, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, cs));
     }
     LDU_CHECK_NCCL(ncclGroupEnd());
+    if (ctx->haloOverlap)
+    {
+        LDU_CHECK_HIP(hipEventRecord(ctx->evHalo, cs));
+        ctx->haloInFlight = true;
+        ctx->nHaloOverlapped++;
+    }
+    return 0;
+}
+
+// the compute stream waits for the exchange started by the last comm_exchange (no-op when none is in flight)
+int comm_wait_halo(ldu_ctx* ctx, hipStream_t s)
+{
+    if (!ctx->haloInFlight) return 0;
+    LDU_CHECK_HIP(hipStreamWaitEvent(s, ctx->evHalo, 0));
+    if (s == ctx->stream) ctx->haloInFlight = false;
     return 0;
 }
 

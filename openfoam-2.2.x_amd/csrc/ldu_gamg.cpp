@@ -776,6 +776,18 @@ int gamg_query(ldu_matrix* m, int32_t* nLevels, int32_t* nCells, int32_t* nFaces
     return 0;
 }
 
+// per-level facts for measurement reports: cells, faces, dependency levels, widest row, the engine that serves
+// one GaussSeidel sweep / k pipelined sweeps on that level's addressing
+int gamg_level_info(ldu_matrix* m, int level, int32_t out[8])
+{
+    GamgHierarchy* g = m->gamg;
+    if (!g || level < 0 || level >= (int)g->levels.size()) { ldu_set_error("bad GAMG level"); return -9; }
+    ldu_addr* a = g->levels[level].addr;
+    out[0] = a->nCells; out[1] = a->nFaces; out[2] = a->nLevels; out[3] = a->maxRowWidth;
+    out[4] = k_engine_of(a, 0); out[5] = k_engine_of(a, 1); out[6] = k_engine_of(a, 2); out[7] = a->nSlices;
+    return 0;
+}
+
 int gamg_level_data(ldu_matrix* m, int level, int32_t* restrictAddr, double* diag, double* upper,
                     double* lower)
 {

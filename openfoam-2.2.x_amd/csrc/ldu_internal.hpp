@@ -48,8 +48,16 @@ enum {
 struct ldu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // second stream (PBiCG transpose system, halo overlap)
+    hipStream_t stream2 = nullptr;   // second stream (PBiCG transpose system)
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // halo exchange overlapped with the interior rows: the send/recv of an operator application runs on its own
+    // stream between pack (initMatrixInterfaces) and apply (updateMatrixInterfaces) - the window the reference
+    // itself leaves for the interior loops (lduMatrixUpdateMatrixInterfaces.C:30-93, 127-160; lduMatrixATmul.C:62-89)
+    hipStream_t streamComm = nullptr;
+    hipEvent_t evPacked = nullptr, evHalo = nullptr;
+    bool haloInFlight = false;       // an exchange was started and nobody waited for it yet
+    int haloOverlap = 1;             // LDU_HALO_OVERLAP=0: exchange on the compute stream (round-1 behaviour)
+    long nHaloOverlapped = 0;        // exchanges that ran on the comm stream (test / report introspection)
     double* d_partials = nullptr;    // reduction scratch [2 * maxBlocks]
     int maxRedBlocks = 1024;
     double* d_scalars = nullptr;     // [S_NSLOTS] = banks of S_BANK slots
@@ -76,7 +84,8 @@ struct ldu_ctx {
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
-    int smallMaxCells = 3000;        // LDU_SMALL_MAX (<= 8192); measured: wins up to ~2500 cells, loses at 4900
+    int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
+    int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
     int p2pMaxBlocksPerCU = 5;       // register-limited residency of the sweep kernels
@@ -200,6 +209,10 @@ struct ldu_addr {
     unsigned char* d_xflag = nullptr;      // [nCells] 1 = has a neighbour in another slab
 
     ClusterPlan* cluster = nullptr;        // secondary structure of the cluster sweep engine (lazy)
+    // single-workgroup pipelined GaussSeidel sweeps of small matrices (gs_small_pipe_kernel): per slice, how many
+    // slices the PREVIOUS sweep must have finished before this slice may run (all its upper neighbours done)
+    int* d_smallNeed = nullptr;            // [nSlices] (lazy)
+    double smallLag = 0;                   // average need[s] - s: how far a sweep trails the previous one
 
     // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
     struct GsTasks { int* d_tasks = nullptr; int n = 0; int* d_slabTasks = nullptr; int slabStart[9] = {0}; };
@@ -389,7 +402,8 @@ int plan_finalize_patches(ldu_addr* a);
 void plan_free(ldu_addr* a);
 
 int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s);   // ldu_comm.cpp
-int comm_exchange(ldu_addr* a, hipStream_t s);                                   // halo send/recv
+int comm_exchange(ldu_addr* a, hipStream_t s);                                   // halo send/recv (may return before it ran)
+int comm_wait_halo(ldu_ctx* ctx, hipStream_t s);                                 // s waits for the exchange started last
 int comm_allreduce_min_int(ldu_ctx* ctx, int* v);
 int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
                        const std::vector<std::vector<int>>& send, std::vector<std::vector<int>>& recv);
@@ -440,6 +454,7 @@ int gamg_precondition(ldu_matrix* m, const ldu_controls* c, double* wA, const do
 void gamg_free(GamgHierarchy* g);
 int gamg_build_for_query(ldu_matrix* m, const ldu_controls* c);
 int gamg_query(ldu_matrix* m, int32_t* nLevels, int32_t* nCells, int32_t* nFaces);
+int gamg_level_info(ldu_matrix* m, int level, int32_t out[8]);
 int gamg_level_data(ldu_matrix* m, int level, int32_t* restrictAddr, double* diag, double* upper,
                     double* lower);
 

@@ -485,6 +485,7 @@ int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const
 {
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
     hipStream_t s = a->ctx->stream;
+    if (comm_wait_halo(a->ctx, s)) return -1;
     for (int L = 0; L < a->nLevels; L++)
     {
         const int s0 = a->levelSliceStart[L], s1 = a->levelSliceStart[L + 1];
@@ -1001,7 +1002,8 @@ int k_engine_of(ldu_addr* a, int kind /* 0 triangular, 1 one GaussSeidel sweep, 
 {
     ldu_ctx* ctx = a->ctx;
     if (!ctx->sweepP2P) return 4;
-    if (kind >= 1 && ctx->smallKernels && a->nCells <= ctx->smallMaxCells && a->maxRowWidth <= 16 && !a->nPatchFaces)
+    if (kind >= 1 && ctx->smallKernels && a->maxRowWidth <= 16 && !a->nPatchFaces
+        && a->nCells <= ((kind == 2 && ctx->smallPipe) ? ctx->smallMaxCells : std::min(ctx->smallMaxCells, 3000)))
         return 3;
     if (kind == 2 ? (ctx->clusterMulti && k_cluster_active(a)) : k_cluster_kind_active(a, kind)) return 2;
     return use_slab(a, kind, 2) ? 1 : 0;
@@ -1294,7 +1296,7 @@ sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0
 // (A 512/1024-thread version with a workgroup barrier per level measured 1.2-2.3 us per level: idle
 //  waves either issue the same loads - the CU's address pipeline becomes the bound - or skip them
 //  behind a branch, after which the compiler must drain all prefetches at the join.)
-#define SMALL_MAX_CELLS 8192
+#define SMALL_MAX_CELLS 16384
 #define SMALL_MAX_LDS (144 * 1024)
 
 template <int W> struct SmallRow { int r; unsigned char nl, nu; int c[W]; double v[W]; double b, d; };
@@ -1387,6 +1389,148 @@ gs_small_kernel(SliceTab T, int nSlices, int nCells, int k, double* __restrict__
     for (int i = lane; i < nCells; i += LDU_WAVE) psi[i] = x[i];
 }
 
+// k sweeps PIPELINED inside one workgroup: wavefront j runs sweep j over the slices in order and trails sweep j-1 by
+// exactly what the data dependence asks for - sweep j may take a slice once sweep j-1 has finished every slice that
+// holds an upper neighbour of its rows (need[s] slices; in the reference's sequential loop those are the values of
+// the previous sweep, GaussSeidelSmoother.C:151-176).  ONE solution vector in LDS, updated in place by every sweep:
+// a row's lower neighbours already hold this sweep's values (same wavefront, program order), its upper neighbours
+// still hold the previous sweep's (sweep j+1 cannot have reached them: it waits for sweep j on THIS row first).
+// Progress words in LDS (one per sweep, written after the slice's values are in LDS); wavefront 0 never waits, so
+// the workgroup cannot deadlock.  nSlices + (k-1)*lag steps instead of k*nSlices: the coarse GAMG levels
+// (36 ... 4908 cells of the 216^3 hierarchy) spend their time in this kernel.
+template <int W, int NW>
+__global__ void __launch_bounds__(LDU_WAVE * NW)
+gs_small_pipe_kernel(SliceTab T, int nSlices, int nCells, const int* __restrict__ need, double* __restrict__ psi,
+                     const double* __restrict__ rhs, const double* __restrict__ diag, const double* __restrict__ val)
+{
+    extern __shared__ double smem[];
+    double* x = smem;
+    int* sRow = (int*)(x + nCells);
+    int* sEnt = sRow + nSlices + 1;
+    int* sNeed = sEnt + nSlices;
+    unsigned* prog = (unsigned*)(sNeed + nSlices);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < nCells; i += LDU_WAVE * NW) x[i] = psi[i];
+    for (int i = tid; i <= nSlices; i += LDU_WAVE * NW) sRow[i] = T.sliceRow[i];
+    for (int i = tid; i < nSlices; i += LDU_WAVE * NW) { sEnt[i] = T.sliceEnt[i]; sNeed[i] = need[i]; }
+    if (tid < NW) prog[tid] = 0u;
+    __syncthreads();
+    {
+        SmallRow<W> R0, R1, R2;
+        int sNext = 0;
+        int left = nSlices, sCur = 0;
+#define PIPE_FILL(R)                                                                      \
+    do {                                                                                  \
+        small_load<W>(sRow, sEnt, T, sNext < nSlices, sNext, lane, rhs, diag, val, (R));  \
+        ++sNext;                                                                          \
+    } while (0)
+#define PIPE_STEP(CUR, FILL)                                                              \
+    do {                                                                                  \
+        PIPE_FILL(FILL);                                                                  \
+        if (wave > 0)                                                                     \
+        {                                                                                 \
+            const unsigned want = (unsigned)sNeed[sCur];                                  \
+            while (__hip_atomic_load(prog + wave - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) \
+                __builtin_amdgcn_s_sleep(1);                                              \
+        }                                                                                 \
+        {                                                                                 \
+            double acc = (CUR).b;                                                         \
+            const int nn = (int)(CUR).nl + (int)(CUR).nu;                                 \
+            double xv[W], pr[W];                                                          \
+            _Pragma("unroll") for (int q = 0; q < W; q++)                                 \
+                xv[q] = x[(CUR).c[q] & (SMALL_MAX_CELLS - 1)];                            \
+            _Pragma("unroll") for (int q = 0; q < W; q++) asm volatile("" : "+v"(xv[q])); \
+            _Pragma("unroll") for (int q = 0; q < W; q++)                                 \
+                pr[q] = q < nn ? (CUR).v[q] * xv[q] : 0.0;                                \
+            _Pragma("unroll") for (int q = 0; q < W; q++) acc -= pr[q];                   \
+            if ((CUR).r >= 0) x[(CUR).r] = acc / (CUR).d;                                 \
+        }                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+        ++sCur;                                                                           \
+        if (lane == 0) __hip_atomic_store(prog + wave, (unsigned)sCur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        --left;                                                                           \
+    } while (0)
+        PIPE_FILL(R0);
+        PIPE_FILL(R1);
+        while (left > 0)
+        {
+            PIPE_STEP(R0, R2);
+            if (left == 0) break;
+            PIPE_STEP(R1, R0);
+            if (left == 0) break;
+            PIPE_STEP(R2, R1);
+        }
+#undef PIPE_STEP
+#undef PIPE_FILL
+    }
+    __syncthreads();
+    for (int i = tid; i < nCells; i += LDU_WAVE * NW) psi[i] = x[i];
+}
+
+// need[s]: slices of the previous sweep that must be complete before slice s (all levels up to the highest level that
+// holds an upper neighbour of any row in the levels up to s's own: a running maximum, so it is monotone)
+static int small_need_build(ldu_addr* a)
+{
+    if (a->d_smallNeed) return 0;
+    const int nLev = a->nLevels;
+    std::vector<int> M(nLev, 0);
+    for (int f = 0; f < a->nFaces; f++)
+    {
+        const int Ll = a->level[a->l[f]], Lu = a->level[a->u[f]];
+        if (Lu > M[Ll]) M[Ll] = Lu;
+    }
+    for (int L = 0; L < nLev; L++)
+    {
+        if (M[L] < L) M[L] = L;
+        if (L && M[L] < M[L - 1]) M[L] = M[L - 1];
+    }
+    std::vector<int> need(a->nSlices > 0 ? a->nSlices : 1, 0);
+    double lag = 0;
+    for (int L = 0; L < nLev; L++)
+        for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++)
+        {
+            need[sl] = a->levelSliceStart[M[L] + 1];
+            lag += need[sl] - sl;
+        }
+    a->smallLag = a->nSlices ? lag / a->nSlices : 0;
+    LDU_CHECK_HIP(hipMalloc((void**)&a->d_smallNeed, sizeof(int) * need.size()));
+    LDU_CHECK_HIP(hipMemcpy(a->d_smallNeed, need.data(), sizeof(int) * need.size(), hipMemcpyHostToDevice));
+    if (getenv("LDU_VERBOSE"))
+        fprintf(stderr, "[ldugpu] small pipelined sweeps: %d cells, %d slices, %d levels, a sweep trails the previous one by "
+                        "%.1f slices on average\n", a->nCells, a->nSlices, nLev, a->smallLag);
+    return 0;
+}
+
+template <int W, int NW>
+static int launch_gs_small_pipe(ldu_addr* a, const SliceTab& T, size_t lds, double* psi, const double* rhs,
+                                const double* diag, const double* val)
+{
+    static bool attrSet = false;
+    if (!attrSet)
+    {
+        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_small_pipe_kernel<W, NW>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_MAX_LDS));
+        attrSet = true;
+    }
+    gs_small_pipe_kernel<W, NW><<<1, LDU_WAVE * NW, lds, a->ctx->stream>>>(T, a->nSlices, a->nCells, a->d_smallNeed, psi,
+                                                                         rhs, diag, val);
+    return 0;
+}
+
+template <int W>
+static int launch_gs_small_pipe_k(ldu_addr* a, const SliceTab& T, size_t lds, int k, double* psi, const double* rhs,
+                                  const double* diag, const double* val)
+{
+    switch (k)
+    {
+    case 2: return launch_gs_small_pipe<W, 2>(a, T, lds, psi, rhs, diag, val);
+    case 3: return launch_gs_small_pipe<W, 3>(a, T, lds, psi, rhs, diag, val);
+    case 4: return launch_gs_small_pipe<W, 4>(a, T, lds, psi, rhs, diag, val);
+    }
+    return -1;
+}
+
 template <int W>
 static int launch_gs_small(ldu_addr* a, const SliceTab& T, size_t lds, int k, double* psi, const double* rhs,
                            const double* diag, const double* val)
@@ -1408,14 +1552,36 @@ int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const d
     ldu_ctx* ctx = a->ctx;
     if (!ctx->smallKernels || a->nCells > ctx->smallMaxCells || a->nCells == 0 || k <= 0 || a->maxRowWidth > 16)
         return 1;
-    const size_t lds = sizeof(double) * (size_t)a->nCells + sizeof(int) * (2 * ((size_t)a->nSlices + 1));
+    const size_t lds = sizeof(double) * (size_t)a->nCells + sizeof(int) * (3 * ((size_t)a->nSlices + 1)) + 64;
     if (lds > SMALL_MAX_LDS) return 1;
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    const bool pipe = ctx->smallPipe && k >= 2;
+    // one wavefront walking every slice of every sweep: only worth it below ~3000 cells; the pipelined form
+    // (k wavefronts) carries the larger small levels too
+    if (!pipe && a->nCells > 3000) return 1;
+    if (pipe && small_need_build(a)) return -1;
     ctx->profStart(a, 4);
-    int rc;
-    if (a->maxRowWidth <= 8) rc = launch_gs_small<8>(a, T, lds, k, psi, rhs, diag, val);
-    else if (a->maxRowWidth <= 12) rc = launch_gs_small<12>(a, T, lds, k, psi, rhs, diag, val);
-    else rc = launch_gs_small<16>(a, T, lds, k, psi, rhs, diag, val);
+    int rc = 0;
+    if (pipe)
+    {
+        int left = k;
+        while (left > 0 && !rc)
+        {
+            const int kk = left > 4 ? (left == 5 ? 3 : 4) : left;    // never leave a single sweep over
+            if (kk == 1) break;
+            if (a->maxRowWidth <= 8) rc = launch_gs_small_pipe_k<8>(a, T, lds, kk, psi, rhs, diag, val);
+            else if (a->maxRowWidth <= 12) rc = launch_gs_small_pipe_k<12>(a, T, lds, kk, psi, rhs, diag, val);
+            else rc = launch_gs_small_pipe_k<16>(a, T, lds, kk, psi, rhs, diag, val);
+            left -= kk;
+        }
+        k = left;
+    }
+    if (!rc && k > 0)
+    {
+        if (a->maxRowWidth <= 8) rc = launch_gs_small<8>(a, T, lds, k, psi, rhs, diag, val);
+        else if (a->maxRowWidth <= 12) rc = launch_gs_small<12>(a, T, lds, k, psi, rhs, diag, val);
+        else rc = launch_gs_small<16>(a, T, lds, k, psi, rhs, diag, val);
+    }
     ctx->profStop(a, 4);
     if (rc) return -1;
     LDU_CHECK_HIP(hipGetLastError());
@@ -1684,6 +1850,7 @@ __global__ void apply_patches_kernel(int nBRows, const int* __restrict__ bRow,
 int k_apply_patches(ldu_addr* a, double* result, const double* coeffs, double sign, hipStream_t s)
 {
     if (!a->nPatchFaces) return 0;
+    if (comm_wait_halo(a->ctx, s)) return -1;   // updateMatrixInterfaces: the received values are needed from here on
     apply_patches_kernel<<<ewGrid(a->nBRows), BLK, 0, s>>>(a->nBRows, a->d_bRow, a->d_bStart, a->d_bFace,
                                                           coeffs, a->d_recvAll, sign, result);
     LDU_CHECK_HIP(hipGetLastError());

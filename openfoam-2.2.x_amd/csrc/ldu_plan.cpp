@@ -473,6 +473,7 @@ void plan_free(ldu_addr* a)
     cluster_free(a);
     for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
     a->graphs.clear();
+    if (a->d_smallNeed) { (void)hipFree(a->d_smallNeed); a->d_smallNeed = nullptr; }
     for (auto& kv : a->gsTasks)
     {
         if (kv.second.d_tasks) (void)hipFree(kv.second.d_tasks);

@@ -72,10 +72,43 @@ for u in fvMesh/fvPatches/constraint/cyclic/cyclicFvPatch.C \
          finiteVolume/gradSchemes/gaussGrad/gaussGrads.C \
          interpolation/surfaceInterpolation/schemes/linear/linear.C \
          fvMatrices/solvers/GAMGSymSolver/GAMGAgglomerations/faceAreaPairGAMGAgglomeration/faceAreaPairGAMGAgglomeration.C \
-         fields/fvsPatchFields/constraint/cyclic/cyclicFvsPatchFields.C; do
+         fields/fvsPatchFields/constraint/cyclic/cyclicFvsPatchFields.C \
+         fvMesh/fvPatches/derived/wall/wallFvPatch.C \
+         fvMesh/fvPatches/constraint/empty/emptyFvPatch.C \
+         fields/fvPatchFields/constraint/empty/emptyFvPatchFields.C \
+         fields/fvsPatchFields/constraint/empty/emptyFvsPatchFields.C; do
     i=$(grep -n "/$u\$" "$W/fvsources.txt" | head -1 | cut -d: -f1)
     [ -n "$i" ] && FORCE="$FORCE $W/fvobj/f$i.o"
 done
+# the reference's blockMesh library (18 units, src/mesh/blockMesh/Make/files): SURVEY.md 8c tier 2, what turns
+# tutorials/incompressible/simpleFoam/pitzDaily/constant/polyMesh/blockMeshDict into config C2's mesh
+if [ -f "$HERE/blockmesh_driver.C" ]; then
+    mkdir -p "$W/bmobj" "$W/inc_blockMesh"
+    if [ ! -f "$W/inc_blockMesh/.done" ]; then
+        find "$REF/src/mesh/blockMesh" \( -name '*.[CH]' -o -name '*.h' \) -exec ln -sf {} "$W/inc_blockMesh/" \;
+        touch "$W/inc_blockMesh/.done"
+    fi
+    BMFLAGS="$CXXFLAGS -I$W/inc_blockMesh"
+    i=0
+    for u in $(grep '\.C$' "$REF/src/mesh/blockMesh/Make/files"); do
+        i=$((i+1))
+        [ -f "$W/bmobj/b$i.o" ] || g++ $BMFLAGS -c "$REF/src/mesh/blockMesh/$u" -o "$W/bmobj/b$i.o" &
+        [ $((i % JOBS)) -eq 0 ] && wait
+    done
+    # arcEdge holds a cylindricalCS: the coordinate-system units of libmeshTools (the reference's own sources,
+    # src/meshTools/coordinateSystems; nothing else of meshTools is reached)
+    for u in coordinateSystem.C coordinateSystemNew.C coordinateSystems.C cylindricalCS.C sphericalCS.C toroidalCS.C \
+             parabolicCylindricalCS.C coordinateRotation/coordinateRotation.C coordinateRotation/EulerCoordinateRotation.C \
+             coordinateRotation/STARCDCoordinateRotation.C; do
+        i=$((i+1))
+        [ -f "$W/bmobj/b$i.o" ] || g++ $BMFLAGS -c "$REF/src/meshTools/coordinateSystems/$u" -o "$W/bmobj/b$i.o" &
+        [ $((i % JOBS)) -eq 0 ] && wait
+    done
+    wait
+    g++ $BMFLAGS -o "$OUT/blockmesh_driver" "$HERE/blockmesh_driver.C" "$W"/bmobj/*.o -L"$OUT" -lOpenFOAM -ldl -lm \
+        -Wl,-rpath,'$ORIGIN'
+    echo "build_ref_fv.sh: OK -> $OUT/blockmesh_driver ($i units: blockMesh + meshTools/coordinateSystems)"
+fi
 if [ -f "$HERE/fv_driver.C" ]; then
     g++ $CXXFLAGS -o "$OUT/fv_driver" "$HERE/fv_driver.C" $FORCE "$W/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm \
         -Wl,-rpath,'$ORIGIN'

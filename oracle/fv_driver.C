@@ -678,6 +678,116 @@ static int nonorth(fvMesh& mesh, Time& runTime, const std::vector<double>& in)
     return 0;
 }
 
+// Config C2: the pressure equation of simpleFoam's pEqn.H on the pitzDaily mesh the reference's own
+// blockMesh produced - fvm::laplacian(rAU, p) == fvc::div(phiHbyA) with the tutorial's schemes (Gauss linear
+// corrected, snGrad corrected: system/fvSchemes of the case) and boundary conditions (0/p: outlet fixedValue 0,
+// everything else zeroGradient, frontAndBack empty), solved by the reference's own fvScalarMatrix::solve with the
+// dictionary passed on the command line (the motorBike GAMG block).  rAU and HbyA are analytic fields of the cell
+// centres (simpleFoam itself - turbulence libraries - is not built here).
+static int pitz(fvMesh& mesh, Time& runTime, const char* solverDict)
+{
+    const label nC = mesh.nCells();
+    dimensionSet::debug = 0;
+    wordList types(mesh.boundary().size());
+    forAll(types, p)
+    {
+        const fvPatch& fp = mesh.boundary()[p];
+        types[p] = fp.type() == "empty" ? word("empty") : (fp.name() == "outlet" ? word("fixedValue") : word("zeroGradient"));
+    }
+    volScalarField p(IOobject("p", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0), types);
+    wordList calcTypes(mesh.boundary().size());
+    forAll(calcTypes, pi) calcTypes[pi] = mesh.boundary()[pi].type() == "empty" ? word("empty") : word("calculated");
+    volScalarField rAU(IOobject("rAU", runTime.timeName(), mesh), mesh, dimensionedScalar("0", dimless, 0.0), calcTypes);
+    volVectorField HbyA(IOobject("HbyA", runTime.timeName(), mesh), mesh, dimensionedVector("0", dimless, vector::zero), calcTypes);
+    const vectorField& C = mesh.C().internalField();
+    for (label c = 0; c < nC; c++)
+    {
+        const scalar x = 40.0 * C[c].x(), y = 40.0 * C[c].y();
+        rAU.internalField()[c] = 1.0 + 0.3 * Foam::sin(1.7 * x) * Foam::cos(2.3 * y);
+        HbyA.internalField()[c] = vector(10.0 * (1.0 - 0.6 * y * y), 0.8 * Foam::sin(2.0 * x + y), 0.0);
+        // the pressure of the previous SIMPLE iteration: a non-trivial field, so that the explicit non-orthogonal
+        // correction (correctedSnGrad of grad(p)) is at work and the solver starts from a non-zero guess
+        p.internalField()[c] = 3.0 * Foam::cos(0.13 * x) - 0.4 * y + 0.02 * x * y;
+    }
+    p.correctBoundaryConditions();
+    put("p0", p.internalField());
+    forAll(mesh.boundary(), pi)
+    {
+        if (mesh.boundary()[pi].type() == "empty") continue;
+        const vectorField& Cf = mesh.Cf().boundaryField()[pi];
+        const bool wall = mesh.boundary()[pi].type() == "wall";
+        forAll(Cf, i)
+        {
+            const scalar x = 40.0 * Cf[i].x(), y = 40.0 * Cf[i].y();
+            rAU.boundaryField()[pi][i] = 1.0 + 0.3 * Foam::sin(1.7 * x) * Foam::cos(2.3 * y);
+            HbyA.boundaryField()[pi][i] = wall ? vector::zero : vector(10.0 * (1.0 - 0.6 * y * y), 0.8 * Foam::sin(2.0 * x + y), 0.0);
+        }
+    }
+    surfaceScalarField rAUf("rAUf", linear<scalar>(mesh).interpolate(rAU));
+    surfaceScalarField phiHbyA("phiHbyA", linear<vector>(mesh).interpolate(HbyA) & mesh.Sf());
+    fv::gaussLaplacianScheme<scalar, scalar> ls
+    (
+        mesh, tmp<surfaceInterpolationScheme<scalar> >(new linear<scalar>(mesh)),
+        tmp<fv::snGradScheme<scalar> >(new fv::correctedSnGrad<scalar>(mesh))
+    );
+    tmp<fvScalarMatrix> tLap = ls.fvmLaplacian(rAUf, p);
+    fvScalarMatrix pEqn(tLap() == fvc::surfaceIntegrate(phiHbyA));
+
+    put("rAUf", rAUf.internalField());
+    put("phiHbyA", phiHbyA.internalField());
+    put("upper", pEqn.upper());
+    put("diag", pEqn.diag());
+    put("source", pEqn.source());
+    put("V", mesh.V().field());
+    put("Sf", mesh.Sf().internalField());
+    put("magSf", mesh.magSf().internalField());
+    put("C", C);
+    put("weights", mesh.weights().internalField());
+    put("nonOrthDeltaCoeffs", mesh.nonOrthDeltaCoeffs().internalField());
+    put("nonOrthCorrectionVectors", mesh.nonOrthCorrectionVectors().internalField());
+    {
+        scalarField np(1, scalar(mesh.boundary().size()));
+        put("nPatches", np);
+    }
+    forAll(mesh.boundary(), pi)
+    {
+        const labelUList& fc = mesh.boundary()[pi].faceCells();
+        scalarField fcd(fc.size());
+        forAll(fc, i) fcd[i] = fc[i];
+        put(pname(pi, "faceCells").c_str(), fcd);
+        put(pname(pi, "internalCoeffs").c_str(), pEqn.internalCoeffs()[pi]);
+        put(pname(pi, "boundaryCoeffs").c_str(), pEqn.boundaryCoeffs()[pi]);
+        put(pname(pi, "phiHbyA").c_str(), phiHbyA.boundaryField()[pi]);
+        put(pname(pi, "rAUf").c_str(), rAUf.boundaryField()[pi]);
+        put(pname(pi, "magSf").c_str(), mesh.magSf().boundaryField()[pi]);
+        put(pname(pi, "deltaCoeffs").c_str(), mesh.deltaCoeffs().boundaryField()[pi]);
+        put(pname(pi, "p0").c_str(), p.boundaryField()[pi]);
+        put(pname(pi, "Sf").c_str(), mesh.Sf().boundaryField()[pi]);
+    }
+    if (pEqn.faceFluxCorrectionPtr()) put("faceFluxCorrection", pEqn.faceFluxCorrectionPtr()->internalField());
+    {
+        scalarField w(mag(cmptMultiply(mesh.Sf().internalField() / sqrt(mesh.magSf().internalField()),
+                                       vector(1, 1.01, 1.02))));
+        put("faceAreaPairWeights", w);
+    }
+    solverPerformance::debug = 2;   // per-iteration residual lines (SolverPerformance.C:65-71)
+    IStringStream dictStream(solverDict);
+    dictionary d(dictStream);
+    solverPerformance perf = pEqn.solve(d);
+    scalarField pf(5);
+    pf[0] = perf.initialResidual(); pf[1] = perf.finalResidual(); pf[2] = perf.nIterations(); pf[3] = perf.converged();
+    pf[4] = perf.singular();
+    put("ref_perf", pf);
+    put("ref_psi", p.internalField());
+    // the flux the application takes from the solved equation (pEqn.H: phi = phiHbyA - pEqn.flux())
+    {
+        tmp<surfaceScalarField> fl = pEqn.flux();
+        put("ref_flux", fl().internalField());
+    }
+    fclose(out);
+    return 0;
+}
+
 int main(int argc, char* argv[])
 {
     if (argc < 4 || argc > 6) { fprintf(stderr, "usage: fv_driver caseDir in.bin out.bin [stencils|glue|glueV|solve|solve2] [extra GAMG controls for solve]\n"); return 2; }
@@ -687,6 +797,11 @@ int main(int argc, char* argv[])
     const label nC = mesh.nCells();
     const label nF = mesh.nInternalFaces();
 
+    if (argc == 6 && std::string(argv[4]) == "pitz")
+    {
+        out = fopen(argv[3], "wb");
+        return pitz(mesh, runTime, argv[5]);
+    }
     std::vector<double> in((size_t)nC * 4 + (size_t)nF * 2);
     {
         FILE* f = fopen(argv[2], "rb");

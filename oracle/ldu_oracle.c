@@ -150,6 +150,7 @@ static void update_interfaces(const orc_sys* s, int d, double* result /* domain-
 /* lduMatrix/lduMatrixATmul.C:34-92 */
 void orc_Amul(const orc_sys* s, double* ApsiAll, const double* psiAll)
 {
+    ORC_PAR
     for (int d = 0; d < s->nDom; d++)
     {
         const orc_dom* D = &s->dom[d];
@@ -168,6 +169,7 @@ void orc_Amul(const orc_sys* s, double* ApsiAll, const double* psiAll)
 /* lduMatrixATmul.C:95-151 */
 void orc_Tmul(const orc_sys* s, double* TpsiAll, const double* psiAll)
 {
+    ORC_PAR
     for (int d = 0; d < s->nDom; d++)
     {
         const orc_dom* D = &s->dom[d];
@@ -186,6 +188,7 @@ void orc_Tmul(const orc_sys* s, double* TpsiAll, const double* psiAll)
 /* lduMatrixATmul.C:154-200 */
 void orc_sumA(const orc_sys* s, double* sumAAll)
 {
+    ORC_PAR
     for (int d = 0; d < s->nDom; d++)
     {
         const orc_dom* D = &s->dom[d];
@@ -207,6 +210,7 @@ void orc_sumA(const orc_sys* s, double* sumAAll)
 /* lduMatrixATmul.C:203-280 */
 void orc_residual(const orc_sys* s, double* rAAll, const double* psiAll, const double* sourceAll)
 {
+    ORC_PAR
     for (int d = 0; d < s->nDom; d++)
     {
         const orc_dom* D = &s->dom[d];
@@ -252,9 +256,18 @@ void orc_faceH(const orc_dom* D, double* faceH, const double* psi)
 /* ------------------------------------------------------------------ reductions
  * src/OpenFOAM/fields/Fields/scalarField/scalarField.C:91-104 (sumProd),
  * Fields/Field/FieldFunctions.C:421-434 (sumMag), :477-503 (g* = local + reduce) */
-double orc_gSumProd(const orc_sys* s, const double* a, const double* b)
+/* the local sums of the ranks (one thread each in the OpenMP build), then the reduce in rank order */
+static double sum_in_rank_order(const double* part, int n)
 {
     double g = 0;
+    for (int d = 0; d < n; d++) g = (d == 0) ? part[d] : g + part[d];
+    return g;
+}
+
+double orc_gSumProd(const orc_sys* s, const double* a, const double* b)
+{
+    double part[ORC_MAXDOM];
+    ORC_PAR
     for (int d = 0; d < s->nDom; d++)
     {
         const orc_dom* D = &s->dom[d];
@@ -262,23 +275,24 @@ double orc_gSumProd(const orc_sys* s, const double* a, const double* b)
         const double* y = b + D->cellOffset;
         double sum = 0.0;
         for (int i = 0; i < D->nCells; i++) sum += x[i] * y[i];
-        g = (d == 0) ? sum : g + sum;
+        part[d] = sum;
     }
-    return g;
+    return sum_in_rank_order(part, s->nDom);
 }
 
 double orc_gSumMag(const orc_sys* s, const double* a)
 {
-    double g = 0;
+    double part[ORC_MAXDOM];
+    ORC_PAR
     for (int d = 0; d < s->nDom; d++)
     {
         const orc_dom* D = &s->dom[d];
         const double* x = a + D->cellOffset;
         double sum = 0.0;
         for (int i = 0; i < D->nCells; i++) sum += fabs(x[i]);
-        g = (d == 0) ? sum : g + sum;
+        part[d] = sum;
     }
-    return g;
+    return sum_in_rank_order(part, s->nDom);
 }
 
 /* lduMatrix/lduMatrixSolver.C:179-197; gAverage FieldFunctions.C:514-533 */
@@ -450,6 +464,7 @@ static void precond_free(const orc_sys* s, precond_t* P)
 static void precond_apply(const orc_sys* s, const precond_t* P, double* wAll, const double* rAll,
                           int transpose)
 {
+    ORC_PAR
     for (int d = 0; d < s->nDom; d++)
     {
         const orc_dom* D = &s->dom[d];
@@ -536,6 +551,7 @@ static void smooth_gs_nonblocking(const orc_sys* s, double* psiAll, const double
     }
     for (int sweep = 0; sweep < nSweeps; sweep++)
     {
+        ORC_PAR
         for (int d = 0; d < s->nDom; d++)
         {
             const orc_dom* D = &s->dom[d];
@@ -543,8 +559,10 @@ static void smooth_gs_nonblocking(const orc_sys* s, double* psiAll, const double
             for (int c = 0; c < D->nCells; c++) bPrime[c] = sourceAll[D->cellOffset + c];
             gs_forward_range(D, psiAll + D->cellOffset, bPrime, 0, blockStart[d]);
         }
+        ORC_PAR
         for (int d = 0; d < s->nDom; d++)
             update_interfaces(s, d, bPrimeAll + s->dom[d].cellOffset, psiAll, 0, -1.0);
+        ORC_PAR
         for (int d = 0; d < s->nDom; d++)
         {
             const orc_dom* D = &s->dom[d];
@@ -582,6 +600,7 @@ static void smooth_gs(const orc_sys* s, double* psiAll, const double* sourceAll,
         /* phase 1 (all ranks, before any rank sweeps): bPrime = source, then the
          * coupled boundary added Jacobi-style with negated coefficients
          * (GaussSeidelSmoother.C:98-145) */
+        ORC_PAR
         for (int d = 0; d < s->nDom; d++)
         {
             const orc_dom* D = &s->dom[d];
@@ -590,6 +609,7 @@ static void smooth_gs(const orc_sys* s, double* psiAll, const double* sourceAll,
             update_interfaces(s, d, bPrime, psiAll, 0, -1.0);
         }
         /* phase 2: rank-local sweeps */
+        ORC_PAR
         for (int d = 0; d < s->nDom; d++)
         {
             const orc_dom* D = &s->dom[d];
@@ -610,6 +630,7 @@ static void smooth_dic(const orc_sys* s, int kind, double* psiAll, const double*
     for (int sweep = 0; sweep < nSweeps; sweep++)
     {
         orc_residual(s, rAAll, psiAll, sourceAll);
+        ORC_PAR
         for (int d = 0; d < s->nDom; d++)
         {
             const orc_dom* D = &s->dom[d];

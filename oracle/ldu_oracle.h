@@ -52,6 +52,17 @@ typedef struct orc_dom {
     int* losortStart;
 } orc_dom;
 
+/* CPU baseline on all host cores (SURVEY.md 8d "CPU reference timing"): the sub-domains of a decomposed system are
+ * the reference's MPI ranks; in the build with -fopenmp -DORC_OMP (libldu_oracle_omp.so) every loop over domains whose
+ * iterations touch only their own domain's data runs one domain per thread.  Per-domain arithmetic and the rank-ordered
+ * sums are untouched, so the results are bit-identical to the serial build (tests/test_multidomain_oracle.py). */
+#ifdef ORC_OMP
+#define ORC_PAR _Pragma("omp parallel for schedule(static, 1)")
+#else
+#define ORC_PAR
+#endif
+#define ORC_MAXDOM 256
+
 typedef struct orc_sys {
     int nDom;
     orc_dom* dom;

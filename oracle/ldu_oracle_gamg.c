@@ -574,6 +574,7 @@ static void restrict_field(const orc_gamg* g, double* cf, const double* ff, int 
 {
     const orc_sys* cs = &g->lev[fineLevelIndex].sys;
     const orc_sys* fs = level_sys(g, fineLevelIndex);
+    ORC_PAR
     for (int d = 0; d < g->nDom; d++)
     {
         const dom_level* L = &g->lev[fineLevelIndex].dl[d];
@@ -589,6 +590,7 @@ static void prolong_field(const orc_gamg* g, double* ff, const double* cf, int c
 {
     const orc_sys* cs = &g->lev[coarseLevelIndex].sys;
     const orc_sys* fs = level_sys(g, coarseLevelIndex);
+    ORC_PAR
     for (int d = 0; d < g->nDom; d++)
     {
         const dom_level* L = &g->lev[coarseLevelIndex].dl[d];
@@ -603,6 +605,8 @@ static void gamg_scale(const orc_sys* A, double* field, double* Acf, const doubl
 {
     orc_Amul(A, Acf, field);
     double num = 0, den = 0;
+    double pn[ORC_MAXDOM], pd[ORC_MAXDOM];
+    ORC_PAR
     for (int d = 0; d < A->nDom; d++)
     {
         const orc_dom* D = &A->dom[d];
@@ -612,12 +616,18 @@ static void gamg_scale(const orc_sys* A, double* field, double* Acf, const doubl
             scalingFactorNum += source[i] * field[i];
             scalingFactorDenom += Acf[i] * field[i];
         }
-        num = d == 0 ? scalingFactorNum : num + scalingFactorNum;
-        den = d == 0 ? scalingFactorDenom : den + scalingFactorDenom;
+        pn[d] = scalingFactorNum;
+        pd[d] = scalingFactorDenom;
+    }
+    for (int d = 0; d < A->nDom; d++)
+    {
+        num = d == 0 ? pn[d] : num + pn[d];
+        den = d == 0 ? pd[d] : den + pd[d];
     }
     /* stabilise(y, VSMALL): src/OpenFOAM/primitives/Scalar/Scalar.H: y<0 ? y-small : y+small */
     const double stab = den < 0 ? den - ORC_VSMALL : den + ORC_VSMALL;
     const double sf = num / stab;
+    ORC_PAR
     for (int d = 0; d < A->nDom; d++)
     {
         const orc_dom* D = &A->dom[d];

@@ -70,13 +70,16 @@ class Perf(C.Structure):
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", HERE, "libldu_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", HERE, "libldu_oracle.so", "libldu_oracle_omp.so"])
 
 
 def lib():
+    """LDU_ORACLE_OMP=1 (set before the first call) selects the OpenMP build: one thread per sub-domain = per
+    emulated rank, bit-identical results (oracle/ldu_oracle.h ORC_PAR); OMP_NUM_THREADS sets the cores used."""
     global _LIB
     if _LIB is None:
-        path = os.path.join(HERE, "libldu_oracle.so")
+        omp = os.environ.get("LDU_ORACLE_OMP") == "1"
+        path = os.path.join(HERE, "libldu_oracle_omp.so" if omp else "libldu_oracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -1,9 +1,14 @@
 """world_size-2 gloo test on CPU of the N>1 host path: the decomposition bench.py hands to the
-ranks (decompose.decompose(only_rank=...)), the processor-patch pairing and the communication
-schedule of one PCG iteration (pack -> exchange -> apply, one all-reduce per global sum) - the
-same schedule libldugpu issues on RCCL.  Each rank runs a small numpy PCG (diagonal
-preconditioner, decomposition-invariant) over torch.distributed/gloo; rank 0 compares with the
-oracle's serial emulation of the 2-rank run and with the undecomposed solve."""
+ranks (decompose.decompose(only_rank=...)), the processor-patch list the library consumes (`patches_dev`, in
+patch order) and the communication schedule libldugpu issues on RCCL for one operator application
+(csrc/ldu_solvers.cpp dev_amul + csrc/ldu_comm.cpp comm_exchange): pack all patches into one send buffer ->
+start send/recv per patch in patch order (k-th send to a rank pairs with its k-th receive) -> interior rows while
+the exchange is in flight -> wait -> apply the received values to the boundary rows; one all-reduce per global sum.
+The RCCL calls themselves need GPUs (tests/test_gpu_multidomain.py: test_rccl_halo_exchange_on_one_rank,
+test_rccl_two_processes).  Each rank runs a numpy PCG over torch.distributed/gloo, once with the diagonal
+preconditioner (decomposition-invariant: must equal the undecomposed solve) and once with the RANK-LOCAL DIC
+preconditioner of the reference's parallel runs (decomposition-dependent: must equal the oracle's serial emulation
+of the 2-rank algorithm); rank 0 compares."""
 import os
 import sys
 
@@ -16,27 +21,46 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _amul(sp, x, recv):
+def _amul(sp, x):
+    """dev_amul: pack -> exchange started -> interior rows -> wait -> apply (lduMatrixATmul.C:34-92)"""
+    dev = sp["patches_dev"]                       # what capi.Addressing(patches=...) receives
+    offs = np.concatenate([[0], np.cumsum([len(q["faceCells"]) for q in dev])]).astype(int)
+    send_all = np.concatenate([x[q["faceCells"]] for q in dev]) if dev else np.zeros(0)   # pack_kernel
+    recv_all = torch.zeros(send_all.size, dtype=torch.float64)
+    reqs = []
+    for i, q in enumerate(dev):                   # comm_exchange: grouped send/recv in patch order
+        reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(send_all[offs[i]:offs[i + 1]])), q["nbrRank"]))
+        reqs.append(dist.irecv(recv_all[offs[i]:offs[i + 1]], q["nbrRank"]))
     l, u = sp["lowerAddr"], sp["upperAddr"]
-    y = sp["diag"] * x
+    y = sp["diag"] * x                            # interior rows, overlapped with the exchange
     np.add.at(y, u, sp["upper"] * x[l])
     np.add.at(y, l, sp["upper"] * x[u])
-    for q, r in zip(sp["patches"], recv):
-        np.subtract.at(y, q["faceCells"], q["bouCoeffs"] * r)   # result[faceCells] -= bouCoeffs*psiNbr
+    for rq in reqs:                               # comm_wait_halo
+        rq.wait()
+    recv = recv_all.numpy()
+    for i, q in enumerate(sp["patches"]):         # apply_patches: result[faceCells] -= bouCoeffs*psiNbr
+        np.subtract.at(y, q["faceCells"], q["bouCoeffs"] * recv[offs[i]:offs[i + 1]])
     return y
 
 
-def _exchange(sp, x):
-    reqs, recv = [], []
-    for q in sp["patches"]:
-        send = torch.from_numpy(np.ascontiguousarray(x[q["faceCells"]]))
-        r = torch.zeros(len(q["faceCells"]), dtype=torch.float64)
-        reqs.append(dist.isend(send, q["nbrRank"]))
-        reqs.append(dist.irecv(r, q["nbrRank"]))
-        recv.append(r)
-    for rq in reqs:
-        rq.wait()
-    return [r.numpy() for r in recv]
+def _dic_factor(sp):
+    """DICPreconditioner::calcReciprocalD (DICPreconditioner.C:57-84), rank-local: the interfaces do not enter"""
+    rD = sp["diag"].copy()
+    l, u, up = sp["lowerAddr"], sp["upperAddr"], sp["upper"]
+    for f in range(l.size):
+        rD[u[f]] -= up[f] * up[f] / rD[l[f]]
+    return 1.0 / rD
+
+
+def _dic_apply(sp, rD, r):
+    """DICPreconditioner::precondition (DICPreconditioner.C:87-123)"""
+    l, u, up = sp["lowerAddr"], sp["upperAddr"], sp["upper"]
+    w = rD * r
+    for f in range(l.size):
+        w[u[f]] -= rD[u[f]] * up[f] * w[l[f]]
+    for f in range(l.size - 1, -1, -1):
+        w[l[f]] -= rD[l[f]] * up[f] * w[u[f]]
+    return w
 
 
 def _gsum(v):
@@ -55,26 +79,30 @@ def _worker(rank, world, port, out):
     cr = decompose.block_ranks(8, 8, 8, 1, 1, world)
     subs, maps = decompose.decompose(p, cr, world, only_rank=rank)
     sp = subs[rank]
-    x = np.zeros(sp["nCells"]); b = sp["source"]
-    rD = 1.0 / sp["diag"]
-    r = b - _amul(sp, x, _exchange(sp, x))
-    norm = _gsum(np.sum(np.abs(b)))
-    hist = [_gsum(np.sum(np.abs(r))) / norm]
-    pvec = None
-    rho_old = 1.0
-    for it in range(200):
-        w = rD * r
-        rho = _gsum(float(w @ r))
-        pvec = w if pvec is None else w + (rho / rho_old) * pvec
-        Ap = _amul(sp, pvec, _exchange(sp, pvec))
-        alpha = rho / _gsum(float(Ap @ pvec))
-        x += alpha * pvec
-        r -= alpha * Ap
-        rho_old = rho
-        hist.append(_gsum(np.sum(np.abs(r))) / norm)
-        if hist[-1] < 1e-8:
-            break
-    out[rank] = (x, hist, maps[rank])
+    assert [q["nbrRank"] for q in sp["patches_dev"]] == [1 - rank]       # one processor patch towards the other rank
+    res = {}
+    for pre in ("diagonal", "DIC"):
+        x = np.zeros(sp["nCells"]); b = sp["source"]
+        rD = 1.0 / sp["diag"] if pre == "diagonal" else _dic_factor(sp)
+        r = b - _amul(sp, x)
+        norm = _gsum(np.sum(np.abs(b)))
+        hist = [_gsum(np.sum(np.abs(r))) / norm]
+        pvec = None
+        rho_old = 1.0
+        for it in range(200):
+            w = rD * r if pre == "diagonal" else _dic_apply(sp, rD, r)
+            rho = _gsum(float(w @ r))
+            pvec = w if pvec is None else w + (rho / rho_old) * pvec
+            Ap = _amul(sp, pvec)
+            alpha = rho / _gsum(float(Ap @ pvec))
+            x += alpha * pvec
+            r -= alpha * Ap
+            rho_old = rho
+            hist.append(_gsum(np.sum(np.abs(r))) / norm)
+            if hist[-1] < 1e-8:
+                break
+        res[pre] = (x, hist)
+    out[rank] = (res["diagonal"][0], res["diagonal"][1], maps[rank], res["DIC"][0], res["DIC"][1])
     dist.destroy_process_group()
 
 
@@ -103,3 +131,12 @@ def test_two_rank_gloo_pcg(oracle):
     for r in range(world):
         full[out[r][2]] = out[r][0]
     np.testing.assert_allclose(full, x1, rtol=1e-6, atol=1e-8)
+    # rank-local DIC (the reference's parallel semantics): equals the oracle's serial emulation of the
+    # 2-rank algorithm - and differs from the undecomposed DIC-PCG, whose preconditioner sees the cut faces
+    xd, pd = oracle.System(subs).solve(X0, B, solver="PCG", precond="DIC", tolerance=1e-8, relTol=0)
+    histd = np.array(out[0][4])
+    assert len(histd) - 1 == pd["nIterations"]
+    np.testing.assert_allclose(histd, pd["history"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([out[r][3] for r in range(world)]), xd, rtol=1e-7, atol=1e-9)
+    x2, p2 = oracle.System(p).solve(p["psi"], p["source"], solver="PCG", precond="DIC", tolerance=1e-8, relTol=0)
+    assert not np.allclose(histd[:len(p2["history"])][1:4], p2["history"][1:4], rtol=1e-6)

@@ -203,3 +203,82 @@ def test_cluster_engine_with_processor_patches(oracle, monkeypatch):
     perf = res[0]["solve"][1]
     assert perf["nIterations"] == po["nIterations"]
     np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+
+
+def _self_coupled_problem(asym=False):
+    """one sub-domain whose two processor patches talk to rank 0 itself: over RCCL send k of a rank pairs with its
+    k-th receive, so each patch receives what it sent - the oracle's patch with nbrPatch = itself"""
+    n = 12
+    p = cases.box3d(n, asym=asym)
+    rng = np.random.RandomState(3)
+    planes = [np.arange(n * n, dtype=np.int32), (n * n * (n - 1) + np.arange(n * n)).astype(np.int32)]
+    p["patches"], p["patches_dev"] = [], []
+    for i, fc in enumerate(planes):
+        bou = -(0.3 + 0.4 * rng.rand(fc.size))
+        intc = bou - (0.1 * (2 * rng.rand(fc.size) - 1) if asym else 0.0)
+        p["patches"].append(dict(faceCells=fc, bouCoeffs=bou, intCoeffs=intc, nbrDom=0, nbrPatch=i))
+        p["patches_dev"].append(dict(faceCells=fc, nbrRank=0))
+    p["diag"] = p["diag"] + 2.0          # keep the system diagonally dominant with the extra coupling
+    return p
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_rccl_halo_exchange_on_one_rank(oracle, monkeypatch, overlap):
+    """The REAL RCCL halo path on a 1-GPU box: ncclSend / ncclRecv of the packed patch values to rank 0 itself,
+    on the communication stream overlapped with the interior rows (LDU_HALO_OVERLAP=1, the default) and on the
+    compute stream (=0): pack -> exchange -> rows -> wait -> apply.  Bit-exact operator results, solver histories
+    against the oracle's emulation of the same coupling."""
+    monkeypatch.setenv("LDU_FORCE_COMM", "1")
+    monkeypatch.setenv("LDU_HALO_OVERLAP", overlap)
+    for asym in (False, True):
+        p = _self_coupled_problem(asym)
+        S = oracle.System([p])
+        ctx = capi.Context(0)
+        ctx.comm_init(0, 1, capi.Context.unique_id())
+        a = capi.Addressing(ctx, p["nCells"], p["lowerAddr"], p["upperAddr"], p.get("faceWeights"), patches=p["patches_dev"])
+        m = capi.Matrix(a)
+        m.set_coeffs(p["diag"], p["upper"], p.get("lower"))
+        for i, q in enumerate(p["patches"]):
+            m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+        rng = np.random.RandomState(8)
+        x, b = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+        before = ctx.overlapped_halo_count()
+        for rep in range(3):
+            assert np.array_equal(m.Amul(x), S.Amul(x))
+            assert np.array_equal(m.Tmul(x), S.Tmul(x))
+            assert np.array_equal(m.residual(x, b), S.residual(x, b))
+            assert np.array_equal(m.smooth("GaussSeidel", x, b, 2), S.smooth("GaussSeidel", x, b, 2))
+        assert (ctx.overlapped_halo_count() > before) == (overlap == "1")
+        kw = dict(tolerance=1e-9, relTol=0)
+        if asym:
+            xs, perf = m.solve(p["psi"], p["source"], solver="PBiCG", preconditioner="DILU", **kw)
+            xo, po = S.solve(p["psi"], p["source"], solver="PBiCG", precond="DILU", **kw)
+        else:
+            xs, perf = m.solve(p["psi"], p["source"], solver="PCG", preconditioner="DIC", **kw)
+            xo, po = S.solve(p["psi"], p["source"], solver="PCG", precond="DIC", **kw)
+        assert perf["nIterations"] == po["nIterations"]
+        np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+        assert np.max(np.abs(xs - xo)) <= 1e-8 * np.max(np.abs(xo))
+        m.close(); a.close(); ctx.close()
+
+
+def test_rccl_two_processes():
+    """Two processes, one GPU each, real RCCL over xGMI (ldu_ctx_comm_init, csrc/ldu_comm.cpp): operators, smoother,
+    PCG/DIC and GAMG of a 2-way decomposed box against the oracle's emulation of the 2-rank algorithm.
+    Needs two visible GPUs: skipped on the 1-GPU boxes of this pool (RCCL refuses two ranks on one device,
+    tools/rccl_2proc_probe.py)."""
+    import subprocess
+    import sys
+    import os
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (found %d)" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + (os.getpid() % 200)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tools", "rccl_2rank_check.py")],
+                       capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rccl_2rank_check (2 ranks)" in r.stdout

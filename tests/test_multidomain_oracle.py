@@ -64,3 +64,50 @@ def test_decomposed_solvers_converge_to_same_solution(oracle, kw):
     np.testing.assert_allclose(xN, x1[np.concatenate(maps)], rtol=2e-5, atol=2e-6)
     # block-local preconditioning costs iterations, never fewer than ~the serial count / 2
     assert pN["nIterations"] >= 1
+
+
+def test_openmp_build_is_bit_identical(tmp_path):
+    """oracle/libldu_oracle_omp.so (one thread per sub-domain = per emulated rank; the all-host-cores CPU baseline of
+    bench.py) must reproduce the serial emulation bit for bit: per-domain loops are untouched, sums stay in rank order."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    from openfoam_amd import cases, decompose
+    import oracle_py
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = tmp_path / "run.py"
+    script.write_text('''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import conftest
+from openfoam_amd import cases, decompose
+import oracle_py
+p = cases.box3d(12, asym=(sys.argv[1] == "asym"))
+subs, _ = decompose.decompose(p, decompose.block_ranks(12, 12, 12, 2, 2, 1), 4)
+S = oracle_py.System(subs)
+X0 = np.concatenate([s["psi"] for s in subs]); B = np.concatenate([s["source"] for s in subs])
+out = {}
+kw = dict(tolerance=1e-9, relTol=0)
+if sys.argv[1] == "asym":
+    x, pf = S.solve(X0, B, solver="PBiCG", precond="DILU", **kw)
+else:
+    x, pf = S.solve(X0, B, solver="PCG", precond="DIC", **kw)
+out["k_x"], out["k_h"] = x, pf["history"]
+x, pf = S.solve(X0, B, solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
+                mergeLevels=1, **kw)
+out["g_x"], out["g_h"] = x, pf["history"]
+out["gs"] = S.smooth("GaussSeidel", X0 + 1.0, B, 3)
+out["amul"] = S.Amul(B)
+np.savez(sys.argv[2], **out)
+''' % (here, os.path.join(here, "..", "oracle")))
+    for kind in ("sym", "asym"):
+        res = {}
+        for omp in ("0", "1"):
+            f = str(tmp_path / ("out_%s_%s.npz" % (kind, omp)))
+            env = dict(os.environ, LDU_ORACLE_OMP=omp, OMP_NUM_THREADS="4")
+            subprocess.run([sys.executable, str(script), kind, f], check=True, env=env)
+            res[omp] = dict(np.load(f))
+        for k in res["0"]:
+            assert np.array_equal(res["0"][k], res["1"][k]), (kind, k)
