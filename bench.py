@@ -44,10 +44,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
-    ap.add_argument("--mesh", choices=["box", "renumbered", "random"], default="box",
+    ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random"], default="box",
                     help="box: the SURVEY 8d C3 stand-in in blockMesh's natural ordering (the metric's workload); "
                          "renumbered: the same matrix under Foam::bandCompression (what renumberMesh applies); "
-                         "random: an irregular 5-9-neighbour graph of the same size (unstructured stand-in)")
+                         "irregular: the box plus random diagonal faces (6-12 neighbours per cell, 3-D locality), "
+                         "renumbered by Foam::bandCompression - the unstructured stand-in; "
+                         "random: a band-limited random graph (quasi 1-D: ~nC/100 dependency levels, pathological)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCG / asymmetric / host-path legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=0, help="box edge of the CPU sample (0 = same)")
@@ -77,8 +79,8 @@ def main():
     if args.mesh == "random":
         p = cases.random_graph_fast(n ** 3, 7.0, 600)
     else:
-        p = cases.box3d(n)
-        if args.mesh == "renumbered":
+        p = cases.irregular_box(n) if args.mesh == "irregular" else cases.box3d(n)
+        if args.mesh in ("renumbered", "irregular"):
             order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
             nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
             p = cases.renumbered(p, order, fmap, flip, nl, nu)
@@ -359,7 +361,9 @@ def main():
                                     "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
                                     "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total))
                                    + ({"box": "", "renumbered": "; cells renumbered by Foam::bandCompression",
-                                       "random": "; NOT the box: irregular random graph, 5-9 neighbours per cell"}[args.mesh]),
+                                       "irregular": "; NOT the plain box: random diagonal faces added (6-12 neighbours per cell), "
+                                                    "renumbered by Foam::bandCompression",
+                                       "random": "; NOT the box: band-limited random graph, 5-9 neighbours per cell"}[args.mesh]),
                        "mesh": args.mesh,
                        "parallelism": "domain decomposition x%d" % world,
                        "vcycles_per_solve": perf["nIterations"],

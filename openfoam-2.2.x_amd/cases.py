@@ -184,6 +184,37 @@ def random_graph_fast(nC, avg_deg=7.0, band=600, seed=11):
     return p
 
 
+def irregular_box(n, extra=0.6, seed=21):
+    """Unstructured-like 3-D addressing with the locality of a real mesh: the n^3 hex box plus, per cell and with
+    probability `extra` each, a face to one of its diagonal neighbours (+x+y), (+y+z), (+x+z) - what split-hex /
+    polyhedral cells of a snappyHexMesh refinement region look like to the matrix: 6 ... 12 neighbours per cell
+    (8 on average for extra = 0.6... ), ragged rows, no i+j+k wavefront structure for the sweeps to lean on.
+    Symmetric M-matrix, b = A x*.  bench.py --mesh irregular renumbers it with Foam::bandCompression first."""
+    nC = n ** 3
+    c = np.arange(nC, dtype=np.int64)
+    i, j, k = c % n, (c // n) % n, c // (n * n)
+    rng = np.random.RandomState(seed)
+    own, nbr = [], []
+    for (di, dj, dk), prob in (((1, 0, 0), 1.0), ((0, 1, 0), 1.0), ((0, 0, 1), 1.0),
+                               ((1, 1, 0), extra), ((0, 1, 1), extra), ((1, 0, 1), extra)):
+        ok = (i + di < n) & (j + dj < n) & (k + dk < n)
+        if prob < 1.0:
+            ok &= rng.rand(nC) < prob
+        own.append(c[ok])
+        nbr.append(c[ok] + di + dj * n + dk * n * n)
+    own, nbr = np.concatenate(own), np.concatenate(nbr)
+    key = np.sort(own * np.int64(nC) + nbr)
+    l, u = (key // nC).astype(np.int32), (key % nC).astype(np.int32)
+    nF = l.size
+    upper = -(0.5 + u01(seed, nF))
+    diag = _neg_sum_diag(nC, l, u, upper, upper)
+    diag[0] *= 2.0
+    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, upper=upper, diag=diag, faceWeights=0.5 + u01(seed + 1, nF))
+    p["source"] = amul(p, np.sin(1e-3 * np.arange(nC)))
+    p["psi"] = np.zeros(nC)
+    return p
+
+
 def renumbered(p, order, faceMap, flip, newLower, newUpper):
     """the same matrix after a cell renumbering (capi.renumber_addressing): cell order[i] becomes cell i"""
     q = dict(nCells=p["nCells"], lowerAddr=newLower, upperAddr=newUpper, diag=p["diag"][order],

@@ -58,6 +58,7 @@ static inline void cl_advance(ClBase& B, int nChunks, int grid)
         B.b[q] += (unsigned)(nCh + nBl);   // every workgroup overshoots its counter exactly once
     }
 }
+#define CL_MAXSEG 1536  // runs of the pipelined task list kept in LDS (12 KB)
 #define CL_MAXD 12     // dependencies (lower resp. upper neighbours) per row held in registers (variants 3 / 6 / 12)
 #define CL_SPIN_LIMIT_DEFAULT (1u << 22)
 
@@ -79,6 +80,9 @@ struct ClusterPlan {
     double avgDepth = 0;
     bool eligible = false;
     int maxDep = CL_MAXD;             // max over rows of max(nL, nU): picks the kernel instantiation
+    // entries of cluster s start at s * fixedW * 64 when every cluster is (nearly) equally wide: a task then needs no
+    // sliceEnt load before it can fetch its columns and coefficients (one dependent round trip less); 0 = variable
+    int fixedW = 0;
     // cluster s owns the cluster-rows [64 s, 64 s + 64): fixed stride, so a wave finds its rows from the
     // ticket alone (one dependent load round trip less than with a row table); unused lanes carry intra = 255
     int* d_sliceEnt = nullptr;        // [nSlices]
@@ -108,7 +112,7 @@ struct ClusterPlan {
     int genV[2] = {0, 0};
     std::vector<int> levelStart;      // [nClusterLevels+1] clusters of one cluster level are contiguous
     std::vector<int> upLevel;         // [nClusterLevels] running max of the cluster level holding an upper neighbour
-    struct Tasks { int* d = nullptr; int n = 0; };
+    struct Tasks { int* d = nullptr; int n = 0; int* d_segStart = nullptr; int* d_segInfo = nullptr; int nSeg = 0; };
     std::map<int, Tasks> tasks;       // k -> topological (sweep, cluster) list of k pipelined GaussSeidel sweeps
     struct Conv { double* d = nullptr; unsigned long long stamp = 0; };
     std::map<const double*, Conv> conv;   // level-layout value array -> cluster-layout copy
@@ -132,7 +136,12 @@ void cluster_free(ldu_addr* a)
                     P->d_granuleV[0], P->d_ticketV[0], P->d_granuleV[1], P->d_ticketV[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : P->conv) if (kv.second.d) (void)hipFree(kv.second.d);
-    for (auto& kv : P->tasks) if (kv.second.d) (void)hipFree(kv.second.d);
+    for (auto& kv : P->tasks)
+    {
+        if (kv.second.d) (void)hipFree(kv.second.d);
+        if (kv.second.d_segStart) (void)hipFree(kv.second.d_segStart);
+        if (kv.second.d_segInfo) (void)hipFree(kv.second.d_segInfo);
+    }
     delete P;
     a->cluster = nullptr;
 }
@@ -244,23 +253,35 @@ static int cluster_build(ldu_addr* a)
     std::vector<int2> rowMeta((size_t)nCl * LDU_WAVE, make_int2(0, 255 << 16));
     long ent = 0;
     std::vector<int> sliceW(nCl);
+    int Wmax = 0;
     for (int s = 0; s < nCl; s++)
     {
         const int id = order[s];
         sliceDepth[s] = (unsigned char)cDepth[id];
         int W = 0;
         int row = s * LDU_WAVE;
+        // every lane of the cluster carries its depth (bits 24..31): the wave needs no sliceDepth load
+        for (int i = 0; i < LDU_WAVE; i++) rowMeta[(size_t)row + i].y = (255 << 16) | (cDepth[id] << 24);
         for (int c : members[id])
         {
             crowOf[c] = row;
             const int cl_ = a->losortStart[c + 1] - a->losortStart[c], cu = a->ownerStart[c + 1] - a->ownerStart[c];
-            rowMeta[row] = make_int2(a->iperm[c], cl_ | (cu << 8) | (intra[c] << 16));
+            rowMeta[row] = make_int2(a->iperm[c], cl_ | (cu << 8) | (intra[c] << 16) | (cDepth[id] << 24));
             W = std::max(W, cl_ + cu);
             row++;
         }
         sliceW[s] = W;
-        sliceEnt[s] = (int)ent;
+        Wmax = std::max(Wmax, W);
         ent += (long)W * LDU_WAVE;
+    }
+    // fixed stride when the padding it costs is small (a hex mesh tiled by cubes: none)
+    if (nCl && (double)Wmax * LDU_WAVE * nCl <= 1.15 * (double)ent && !getenv("LDU_CLUSTER_VARW")) P->fixedW = Wmax;
+    ent = 0;
+    for (int s = 0; s < nCl; s++)
+    {
+        if (P->fixedW) sliceW[s] = P->fixedW;
+        sliceEnt[s] = (int)ent;
+        ent += (long)sliceW[s] * LDU_WAVE;
         if (ent > 2000000000L) return 0;
     }
     P->nRows = (long)nCl * LDU_WAVE;
@@ -447,7 +468,12 @@ __device__ __forceinline__ double cl_value(const cl_u32x4& g)
 struct ClTab {
     const int* sliceEnt; const unsigned char* sliceDepth; const int2* rowMeta;
     const int* colDep;      // dependency part in cluster rows, the other part in level rows
+    int fixedW;             // > 0: entries of cluster s start at s * fixedW * 64 (no sliceEnt load)
 };
+__device__ __forceinline__ long cl_ent0(const ClTab& T, int s)
+{
+    return T.fixedW ? (long)s * (long)(T.fixedW * LDU_WAVE) : (long)T.sliceEnt[s];
+}
 
 // MODE as SweepMode.  FWD modes: dependencies = lower part (entries 0..nl-1, ascending); BWD modes:
 // dependencies = upper part, DEscending (TRI_BWD) resp. ascending (GS_BWD, symGaussSeidelSmoother.C:178-205).
@@ -463,14 +489,14 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
     constexpr bool FWD = (B == SW_TRI_FWD || B == SW_RD || B == SW_GS_FWD);
     const int row0 = s * LDU_WAVE;
     const int cnt = LDU_WAVE;
-    const int depth = T.sliceDepth[s];
     const int r = row0 + lane;
     const int2 rm = T.rowMeta[r];
+    const int depth = __builtin_amdgcn_readfirstlane(rm.y >> 24) & 255;
     const int myLv = (rm.y >> 16) & 255;
     const bool on = myLv != 255;
     const int lr = rm.x;
     const int nl = on ? (rm.y & 255) : 0, nu = on ? ((rm.y >> 8) & 255) : 0;
-    const long ent = (long)T.sliceEnt[s] + lane;
+    const long ent = cl_ent0(T, s) + lane;
     const int nd = FWD ? nl : nu;            // dependencies
     const int d0 = FWD ? 0 : nl;             // first dependency entry
     // everything that does not depend on this sweep
@@ -676,7 +702,7 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     const double* val2 = cluster_values(a, g.val2, s);
     if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
     constexpr bool FWD = (sw_base(MODE) == SW_TRI_FWD || sw_base(MODE) == SW_RD || sw_base(MODE) == SW_GS_FWD);
-    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB};
+    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB, P.fixedW};
     const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
     // one workgroup per CU while a cluster level holds few clusters (fewer waiting waves: faster hand-offs),
     // two when it is wide (tools/det_probe.py: 64^3 .104 / .114 ms, 216^3 .763 / .603 ms at 1 / 2 per CU)
@@ -743,14 +769,14 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
     constexpr bool FWD = (B == SW_TRI_FWD || B == SW_GS_FWD);
     constexpr int LSZ = LDU_WAVE * (1 + ND);   // LDS doubles per plane
     const int row0 = s * LDU_WAVE;
-    const int depth = T.sliceDepth[s];
     const int r = row0 + lane;
     const int2 rm = T.rowMeta[r];
+    const int depth = __builtin_amdgcn_readfirstlane(rm.y >> 24) & 255;
     const int myLv = (rm.y >> 16) & 255;
     const bool on = myLv != 255;
     const int lr = rm.x;
     const int nl = on ? (rm.y & 255) : 0, nu = on ? ((rm.y >> 8) & 255) : 0;
-    const long ent = (long)T.sliceEnt[s] + lane;
+    const long ent = cl_ent0(T, s) + lane;
     const int nd = FWD ? nl : nu;
     const int d0 = FWD ? 0 : nl;
     int c[ND];
@@ -941,7 +967,7 @@ static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t 
     const double* val = cluster_values(a, levelVal, s);
     if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
     constexpr bool FWD = (B == SW_TRI_FWD || B == SW_GS_FWD);
-    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB};
+    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, FWD ? P.d_colF : P.d_colB, P.fixedW};
     const int nChunks = (P.nSlices + CL_WPB - 1) / CL_WPB;
     int bpc = ctx->clusterBlocksPerCU;
     if (!ctx->clusterBpcForced && ctx->dualActive && bpc > 2) bpc = 2;   // two sweeps at once (PBiCG): 2 + 2 per CU
@@ -1087,14 +1113,14 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
 {
     const int row0 = s * LDU_WAVE;
     const int cnt = LDU_WAVE;
-    const int depth = T.sliceDepth[s];
     const int r = row0 + lane;
     const int2 rm = T.rowMeta[r];
+    const int depth = __builtin_amdgcn_readfirstlane(rm.y >> 24) & 255;
     const int myLv = (rm.y >> 16) & 255;
     const bool on = myLv != 255;
     const int lr = rm.x;
     const int nl = on ? (rm.y & 255) : 0, nu = on ? ((rm.y >> 8) & 255) : 0;
-    const long ent = (long)T.sliceEnt[s] + lane;
+    const long ent = cl_ent0(T, s) + lane;
     const unsigned tagNew = tag0 + (unsigned)j;
     int c[ND], cu[ND];
     double v[ND], vu[ND];
@@ -1215,13 +1241,23 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
 template <int ND>
 __global__ void __launch_bounds__(CL_BLK)
 sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int* __restrict__ tasks, int nTasks,
+                              const int* __restrict__ segStart, const int* __restrict__ segInfo, int nSeg,
                               int nChunks, int k, unsigned* ticket, ClBase ticketBase, uint4* G, unsigned tag0,
                               int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
 {
     __shared__ int s_chunk[2];
     __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + ND)];   // slots 0..63: the cluster's rows, then ND x 64 outside values
+    // The task list is runs of consecutive clusters: (sweep j, cluster level L) = clusters levelStart[L] ... of sweep j.
+    // With the run table in LDS a wave turns its ticket into a task with a few LDS reads instead of a global load of
+    // tasks[ti] - one dependent memory round trip less between the ticket and the task's first poll.  (Tables with
+    // more than CL_MAXSEG runs - very deep, irregular cluster DAGs - keep the global task list: nSeg = 0.)
+    __shared__ int s_segStart[CL_MAXSEG + 1];
+    __shared__ int s_segInfo[CL_MAXSEG];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < nSeg; i += CL_BLK) { s_segStart[i] = segStart[i]; s_segInfo[i] = segInfo[i]; }
+    if (threadIdx.x == 0) s_segStart[nSeg] = nTasks;
+    int cur = 0;
     int nextT = 0;
     const int nq = gridDim.x >= 8 * CL_NQ ? CL_NQ : 1;
     const int tq = blockIdx.x % nq;
@@ -1242,7 +1278,14 @@ sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int*
         const int ti = chunk * CL_WPB + wave;
         if (ti < nTasks)
         {
-            const int task = tasks[ti];
+            int task;
+            if (nSeg)
+            {
+                while (ti >= s_segStart[cur + 1]) cur++;      // tickets of a workgroup ascend: the cursor only moves forward
+                const int info = s_segInfo[cur];
+                task = info + (ti - s_segStart[cur]);         // (j << 28 | first cluster of the run) + offset in the run
+            }
+            else task = tasks[ti];
             cl_gs_task<ND>(T, colUp, task & 0x0fffffff, task >> 28, k, lane, s_x[wave], G, tag0, abortFlag, psi, rhs, diag,
                        val);
         }
@@ -1260,7 +1303,7 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     if (it == P.tasks.end())
     {
         const int nLev = P.nClusterLevels;
-        std::vector<int> tasks;
+        std::vector<int> tasks, segStart, segInfo;
         tasks.reserve((size_t)k * P.nSlices);
         std::vector<int> next(k, 0);
         bool progress = true;
@@ -1278,6 +1321,11 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
                 const int L = next[j];
                 if (L >= nLev) continue;
                 if (j > 0 && next[j - 1] <= P.upLevel[L]) continue;
+                if (P.levelStart[L + 1] > P.levelStart[L])
+                {
+                    segStart.push_back((int)tasks.size());
+                    segInfo.push_back((j << 28) | P.levelStart[L]);
+                }
                 for (int sl = P.levelStart[L]; sl < P.levelStart[L + 1]; sl++) tasks.push_back((j << 28) | sl);
                 next[j]++;
                 progress = true;
@@ -1304,11 +1352,16 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
         T.n = (int)tasks.size();
         LDU_CHECK_HIP(hipMalloc((void**)&T.d, sizeof(int) * (tasks.size() + 1)));
         LDU_CHECK_HIP(hipMemcpy(T.d, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice));
+        if (!segStart.empty() && (int)segStart.size() <= CL_MAXSEG && !getenv("LDU_CLUSTER_NOSEG"))
+        {
+            T.nSeg = (int)segStart.size();
+            if (cl_upload(&T.d_segStart, segStart) || cl_upload(&T.d_segInfo, segInfo)) return -1;
+        }
         it = P.tasks.emplace(k, T).first;
     }
     const double* val = cluster_values(a, valA, s);
     if (!val) { ldu_set_error("cluster engine: value conversion failed"); return -1; }
-    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, P.d_colF};
+    ClTab T{P.d_sliceEnt, P.d_sliceDepth, P.d_rowMeta, P.d_colF, P.fixedW};
     const int nTasks = it->second.n;
     const int nChunks = (nTasks + CL_WPB - 1) / CL_WPB;
     int bpc = ctx->clusterBlocksPerCUMulti;
@@ -1330,13 +1383,16 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     P.epoch += (unsigned)k;
     ctx->profStart(a, 4);
     if (P.maxDep <= 3)
-        sweep_cluster_gs_multi_kernel<3><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
+        sweep_cluster_gs_multi_kernel<3><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
+            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     else if (P.maxDep <= 6)
-        sweep_cluster_gs_multi_kernel<6><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
+        sweep_cluster_gs_multi_kernel<6><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
+            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     else
-        sweep_cluster_gs_multi_kernel<CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks, nChunks, k,
+        sweep_cluster_gs_multi_kernel<CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
+            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     ctx->profStop(a, 4);
     cl_advance(P.ticketBase, nChunks, grid);

@@ -385,6 +385,8 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
     {
         if (g) { gamg_free(g); m->gamg = nullptr; }
         g = new GamgHierarchy();
+        // whatever goes wrong below: the half-built hierarchy is released (every error path just returns)
+        struct Guard { GamgHierarchy* g; ~Guard() { if (g) gamg_free(g); } } guard{g};
         g->nCellsInCoarsestLevel = c->nCellsInCoarsestLevel;
         g->mergeLevels = c->mergeLevels;
         g->agglomerator = c->agglomerator;
@@ -401,7 +403,6 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             if ((int)a->faceWeights.size() != a->nFaces)
             {
                 ldu_set_error("faceAreaPair agglomeration needs ldu_addr_set_face_weights()");
-                delete g;
                 return -7;
             }
             w = a->faceWeights;
@@ -409,7 +410,6 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
         std::vector<HostLevel> hl;
         if (agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl))
         {
-            delete g;
             return -1;
         }
         if (hl.empty())
@@ -417,7 +417,6 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             // GAMGSolver.C:108-126
             ldu_set_error("No coarse levels created, either matrix too small for GAMG or "
                           "nCellsInCoarsestLevel too large.");
-            delete g;
             return -8;
         }
         g->levels.resize(hl.size());
@@ -494,6 +493,7 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
         LDU_CHECK_HIP(hipMalloc((void**)&g->d_Apsi, sizeof(double) * n));
         LDU_CHECK_HIP(hipMalloc((void**)&g->d_finestCorr, sizeof(double) * n));
         LDU_CHECK_HIP(hipMalloc((void**)&g->d_finestRes, sizeof(double) * n));
+        guard.g = nullptr;
         m->gamg = g;
     }
     // level coefficients: rebuilt from the fine matrix whenever the coefficients changed

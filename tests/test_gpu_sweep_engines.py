@@ -25,9 +25,11 @@ ENGINES = {
     "cluster_bpc1": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1", "LDU_CLUSTER_BPC": "1"},
     "nocluster": {"LDU_CLUSTER": "0"},
     "small8192": {"LDU_SMALL_MAX": "8192"},
+    "small16384": {"LDU_SMALL_MAX": "16384"},
+    "small_nopipe": {"LDU_SMALL_PIPE": "0"},
 }
 KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
-        "LDU_CLUSTER_BPC")
+        "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE")
 
 
 def _problems():
@@ -101,6 +103,39 @@ def test_sweeps_bitexact_on_every_engine(engine, expected):
                     assert np.array_equal(m.precondition("DILU", src), e["dilu"]), (engine, name, "dilu")
                     assert np.array_equal(m.precondition("DILU", src, transpose=True), e["diluT"]), (engine, name)
                     assert np.array_equal(m.smooth("DILUGaussSeidel", psi, src, 2), e["dilugs"]), (engine, name)
+            m.close(); a.close()
+        ctx.close()
+    finally:
+        for k in KEYS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("pipe", ["1", "0"])
+def test_small_pipelined_sweeps_bitexact(oracle, pipe):
+    """gs_small_pipe_kernel: k GaussSeidel sweeps of a small matrix pipelined over k wavefronts of ONE workgroup
+    (sweep j trails sweep j-1 by the upper-neighbour lag, one solution vector in LDS) - every k the GAMG V-cycle can
+    ask for (2 ... 8: chunks of 4 / 3 / 2), tiny to 6000 cells, narrow and wide rows, hex, random and chain graphs;
+    bit-exact against the sequential sweeps; LDU_SMALL_PIPE=0 = the single-wavefront kernel."""
+    saved = {k: os.environ.pop(k, None) for k in KEYS}
+    os.environ["LDU_SMALL_PIPE"] = pipe
+    try:
+        ctx = capi.Context(0)
+        rng = np.random.RandomState(4)
+        probs = [cases.box3d(3, 4, 3), cases.box3d(11, 12, 13), cases.box3d(18, 18, 18), cases.random_graph(2999, 9, 200),
+                 cases.random_graph(5900, 5, 150, asym=True), cases.random_graph(700, 13, 60), cases.laplacian2d(1, 50),
+                 cases.laplacian2d(64, 64), cases.irregular_box(17)]
+        for p in probs:
+            a, m = capi.from_problem(ctx, p)
+            # (rows wider than 16 entries stay on the chip-wide engines: the comparison below still holds)
+            if p["nCells"] in (36, 1716) or (pipe == "1" and p["nCells"] == 5832):
+                assert a.sweep_engine(2) == "single wavefront", p["nCells"]
+            S = oracle.System(p)
+            psi, src = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+            for k in (2, 3, 4, 5, 6, 7, 8):
+                for rep in range(2):
+                    assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k)
             m.close(); a.close()
         ctx.close()
     finally:
