@@ -158,6 +158,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->smallPipe = atoi(e);
     e = getenv("LDU_P2P_SLABS");
     if (e) c->p2pSlabs = atoi(e);
+    e = getenv("LDU_P2P_WINDOW");
+    if (e) c->p2pWindowLevels = atof(e);
     e = getenv("LDU_HALO_OVERLAP");
     if (e) c->haloOverlap = atoi(e);
     e = getenv("LDU_SPIN_LIMIT");

@@ -73,8 +73,9 @@ struct ldu_ctx {
     int dualStream = 1;              // PBiCG: A system and transposed system on two streams
     int dualActive = 0;              // two cluster sweeps share the chip right now: two workgroups per CU each
     int gsPipeline = 1;
-    int gsPipelineMaxSkew = 4;       // pipeline sweeps only if upper neighbours are <= this many levels ahead              // pipeline consecutive GaussSeidel sweeps in one launch
+    int gsPipelineMaxSkew = 1 << 30; // (round 1: 4) with the run-ahead window pipelined sweeps no longer starve at large skew; LDU_GS_MAXSKEW              // pipeline consecutive GaussSeidel sweeps in one launch
     int p2pBlocksPerCU = 2;          // measured best on MI355X (fewer pollers): tools/sweep_probe.py
+    double p2pWindowLevels = 8.0;    // run-ahead window of the level engines in dependency levels (LDU_P2P_WINDOW; 0 = off)
     // cluster (row-blocking) sweep engine, ldu_cluster.hip
     int clusterEngine = 1;           // LDU_CLUSTER=0: off
     int clusterMinCells = 50000;     // LDU_CLUSTER_MIN
@@ -187,8 +188,9 @@ struct ldu_addr {
         unsigned* d_ctl = nullptr;         // [2][8] per-slab chunk tickets, double-buffered by launch parity
         unsigned par = 0;
         uint4* d_granule = nullptr;        // [nCells]
-        unsigned* d_ticket = nullptr;      // [1]
+        unsigned* d_ticket = nullptr;      // [64]: [0] tickets, [32] chunks reported complete
         unsigned ticketBase = 0;
+        unsigned doneBase = 0;             // advanced by the chunks of every launch that reports (window > 0)
         unsigned epoch = 0;
         int gen = 0;
     };

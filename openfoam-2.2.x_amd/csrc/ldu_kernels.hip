@@ -560,6 +560,47 @@ int k_read_p2p_dbg(int* out)
     return 0;
 }
 
+// an expired wait leaves a record (only then: nothing on the fast path): which row waited for which column, which tag it
+// expected and which it saw - ldu_debug_p2p_records
+__device__ __forceinline__ void p2p_dbg_record(int kind, int row, unsigned expected, int col, unsigned seenY, unsigned seenW, int aux)
+{
+    // lower-neighbour waits (kind 1) in records 0..31, upper-neighbour waits (kind 2) in 32..63
+    static __device__ int nKind[2] = {0, 0};
+    atomicAdd(&g_p2p_dbgN, 1);
+    const int q = atomicAdd(&nKind[kind == 1 ? 0 : 1], 1);
+    const int i = (kind == 1 ? 0 : 32) + q;
+    if (q < 32)
+    {
+        int* rec = g_p2p_dbgRec + 8 * i;
+        rec[0] = kind; rec[1] = row; rec[2] = (int)expected; rec[3] = col; rec[4] = (int)seenY; rec[5] = (int)seenW; rec[6] = aux; rec[7] = 1;
+    }
+}
+
+// (A nap that grows with the time a wave has been waiting - 24 / 96 / 512 polls -> 8 / 32 / 127 x 64 clocks - was measured:
+//  it ends the polling storm of waves that ran far ahead on deep irregular graphs, but such waves then sleep through the
+//  arrival of their data: +90 % on a single sweep of the irregular 100^3 graph, -7 % on the 216^3 box benchmark.  What
+//  bounds the storm instead is the run-ahead window below.)
+
+// Run-ahead window.  Tickets are drawn in dependency order, so every resident wave beyond the front holds a task and
+// polls for data that will not arrive for a long time.  On wide levels that is a few hundred waves for a few
+// microseconds; on DEEP graphs (thousands of narrow levels: unstructured numberings) all ~5000 resident waves sit up to
+// hundreds of levels ahead and their 16-byte re-reads slow the front itself down by orders of magnitude (irregular 60^3
+// graph, two pipelined sweeps, chip-wide engine: > 1 s instead of ~3 ms - the round-1 "spin-bound aborts" at large skew).
+// A workgroup therefore starts chunk t only once `done` (chunks reported complete) has reached t - window: the waves
+// inside the window are the ones that can do useful prefetching (~8 dependency levels), the others nap on ONE counter.
+// Progress: a chunk never waits for a later chunk; the lowest unfinished chunks are inside every window.
+__device__ __forceinline__ void p2p_window_wait(const unsigned* done, unsigned doneBase, int t, int window,
+                                                volatile int* abortFlag)
+{
+    if (t < window) return;
+    const int need = t - window;
+    while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - doneBase) < need)
+    {
+        if (*abortFlag) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 // poll back-off between two granule polls, in units of s_sleep(1) (64 clocks); tunable (LDU_P2P_SLEEP)
 __device__ int g_p2p_sleep = 2;
 __device__ unsigned g_p2p_backoff = 4096u;   // polls before a waiting wave backs off (0 = never)
@@ -687,6 +728,13 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             if (ok) break;
             if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag))
             {
+                if (spins > spinLimit)
+                {
+                    if (i0 + 0 < n && !((g0.y == tag) & (g0.w == tag))) p2p_dbg_record(1, selfRow, tag, c[0], g0.y, g0.w, i0);
+                    else if (i0 + 1 < n && !((g1.y == tag) & (g1.w == tag))) p2p_dbg_record(1, selfRow, tag, c[1], g1.y, g1.w, i0 + 1);
+                    else if (i0 + 2 < n && !((g2.y == tag) & (g2.w == tag))) p2p_dbg_record(1, selfRow, tag, c[2], g2.y, g2.w, i0 + 2);
+                    else if (i0 + 3 < n) p2p_dbg_record(1, selfRow, tag, c[3], g3.y, g3.w, i0 + 3);
+                }
                 *abortFlag = 1;
                 return false;
             }
@@ -822,6 +870,9 @@ struct SlabCtl {
     const int* list;                 // slices (or GaussSeidel tasks) of every slab in schedule order
     unsigned* tick;                  // [8] this launch's chunk tickets, one per slab (zero at launch)
     unsigned* tickNext;              // [8] the next launch's: zeroed by this one
+    unsigned* done;                  // [8] chunks reported complete, per slab (run-ahead window), zero at launch
+    unsigned* doneNext;              // [8] the next launch's
+    int window[8];                   // run-ahead window per slab in chunks (0 = none)
     uint4* X;                        // write-through granule copies of exported rows
     const unsigned char* xflag;      // per row: exported
 };
@@ -853,16 +904,21 @@ sweep_slab_kernel(SliceTab T, SlabCtl C, uint4* G, unsigned tag, int* abortFlag,
     unsigned* ticket = C.tick + slab;
     P2PStat waitEst = {0, 0, 0, -1, nullptr};
     int nextT = 0;
+    const int window = C.window[slab];
+    unsigned* const done = C.done + slab;
     if (threadIdx.x == 0)
     {
         __hip_atomic_store(C.tickNext + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(C.doneNext + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nextT = (int)atomicAdd(ticket, 1u);
     }
     for (int it = 0;; it++)
     {
         if (threadIdx.x == 0)
         {
+            if (window && it) atomicAdd(done, 1u);   // the previous chunk is complete (barrier at the end of the loop body)
             const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            if (window && t < nChunks) p2p_window_wait(done, 0u, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)atomicAdd(ticket, 1u);
         }
@@ -876,15 +932,18 @@ sweep_slab_kernel(SliceTab T, SlabCtl C, uint4* G, unsigned tag, int* abortFlag,
             p2p_slice<MODE, false, true>(T, s, lane, G, C.X, C.xflag, tag, abortFlag, w, rhs, scale, val, val2,
                                          aux, waitEst);
         }
+        if (window) __syncthreads();
     }
 }
 
 template <int MODE, bool DESC, bool DIAG>
 __global__ void __launch_bounds__(P2P_BLK)
-sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, uint4* G,
+sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, int window,
+                 unsigned doneBase, uint4* G,
                  unsigned tag, int* abortFlag, double* w, const double* rhs, const double* scale,
                  const double* val, const double* val2, double* aux)
 {
+    unsigned* const done = ticket + 32;   // chunks reported complete (own cache line)
     __shared__ int s_chunk[2];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -896,8 +955,10 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
     {
         if (threadIdx.x == 0)
         {
+            if (window && it) atomicAdd(done, 1u);
             // an expired spin anywhere drains the whole grid (uniform per workgroup)
             const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            if (window && t < nChunks) p2p_window_wait(done, doneBase, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
         }
@@ -929,6 +990,7 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
                 rec[4] = waitEst.polls; rec[5] = xcc & 0xf; rec[6] = (unsigned long long)blockIdx.x; rec[7] = chunk;
             }
         }
+        if (window) __syncthreads();
     }
 }
 
@@ -1016,9 +1078,24 @@ static void slab_ctl(ldu_addr* a, ldu_addr::P2PLane& P, SlabCtl& C)
     C.nSlabs = a->nSlabs;
     C.tick = P.d_ctl + 8 * P.par;
     C.tickNext = P.d_ctl + 8 * (P.par ^ 1u);
+    C.done = P.d_ctl + 16 + 8 * P.par;
+    C.doneNext = P.d_ctl + 16 + 8 * (P.par ^ 1u);
+    for (int i = 0; i < 8; i++) C.window[i] = 0;
     P.par ^= 1u;
     C.X = P.d_X;
     C.xflag = a->d_xflag;
+}
+
+// run-ahead window in chunks: `levels` dependency levels' worth of chunks of k sweeps; 0 (off) when the grid could not
+// run further ahead than that anyway
+static int p2p_window(const ldu_addr* a, long nChunks, int k, int grid)
+{
+    const double lv = a->ctx->p2pWindowLevels;
+    if (lv <= 0 || a->nLevels <= 0) return 0;
+    const double perLevel = (double)nChunks / (double)a->nLevels;    // chunks per level, all k sweeps together
+    long w = (long)(lv * perLevel + 0.5);
+    if (w < 8 * k) w = 8 * k;
+    return w >= 2L * grid ? 0 : (int)w;
 }
 
 template <int MODE, bool DESC>
@@ -1038,6 +1115,9 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
         P.epoch++;
         if (P.epoch == 0) P.epoch = 1;
         const int grid = ctx->numCUs * slab_bpc(a, 1);
+        for (int i = 0; i < a->nSlabs; i++)
+            C.window[i] = p2p_window(a, cdiv(a->slabStart[i + 1] - a->slabStart[i], P2P_CHUNK), 1,
+                                     grid / std::max(1, a->nSlabs));
         sweep_slab_kernel<MODE, DESC><<<grid, P2P_BLK, 0, s>>>(TS, C, P.d_granule, P.epoch, ctx->d_abort, g.w,
             g.rhs, g.scale, g.val, g.val2, g.aux);
         LDU_CHECK_HIP(hipGetLastError());
@@ -1056,20 +1136,23 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     if (P.gen != ctx->p2pGen)
     {
         // a previous sweep aborted somewhere: ticket counters are no longer in step
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned) * 64, s));
         P.ticketBase = 0;
+        P.doneBase = 0;
         P.gen = ctx->p2pGen;
     }
     P.epoch++;
     if (P.epoch == 0) P.epoch = 1;   // tag 0 = never published
+    const int window = p2p_window(a, nChunks, 1, grid);
     if (ctx->p2pGate || ctx->p2pTrace)
         sweep_p2p_kernel<MODE, DESC, true><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, P.d_ticket,
-            P.ticketBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+            P.ticketBase, window, P.doneBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
     else
         sweep_p2p_kernel<MODE, DESC, false><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, P.d_ticket,
-            P.ticketBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
-    // every workgroup overshoots the ticket exactly once
+            P.ticketBase, window, P.doneBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+    // every workgroup overshoots the ticket exactly once; with a window every chunk is reported complete once
     P.ticketBase += (unsigned)(nChunks + grid);
+    if (window) P.doneBase += (unsigned)nChunks;
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1109,6 +1192,13 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
         if (ok) break;
         if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag))
         {
+            if (spins > spinLimit)
+            {
+                if (BASE + 0 < nu && !((g0.y == t) & (g0.w == t))) p2p_dbg_record(2, selfRow, t, c[0], g0.y, g0.w, BASE);
+                else if (BASE + 1 < nu && !((g1.y == t) & (g1.w == t))) p2p_dbg_record(2, selfRow, t, c[1], g1.y, g1.w, BASE + 1);
+                else if (BASE + 2 < nu && !((g2.y == t) & (g2.w == t))) p2p_dbg_record(2, selfRow, t, c[2], g2.y, g2.w, BASE + 2);
+                else if (BASE + 3 < nu) p2p_dbg_record(2, selfRow, t, c[3], g3.y, g3.w, BASE + 3);
+            }
             *abortFlag = 1;
             return false;
         }
@@ -1203,10 +1293,11 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
 
 __global__ void __launch_bounds__(P2P_BLK)
 sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
-                          unsigned* ticket, unsigned ticketBase, uint4* G, unsigned tag0, int* abortFlag,
-                          double* psi, const double* rhs, const double* diag, const double* val)
+                          unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
+                          int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
 {
     __shared__ int s_chunk[2];
+    unsigned* const done = ticket + 32;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     P2PStat waitEst = {0, 0, 0, -1, nullptr};
@@ -1216,7 +1307,9 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
     {
         if (threadIdx.x == 0)
         {
+            if (window && it) atomicAdd(done, 1u);
             const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            if (window && t < nChunks) p2p_window_wait(done, doneBase, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
         }
@@ -1233,6 +1326,7 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
                 p2p_gs_task<false>(T, sl, task >> 28, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst);
             }
         }
+        if (window) __syncthreads();
     }
 }
 
@@ -1253,16 +1347,21 @@ sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0
     unsigned* ticket = C.tick + slab;
     P2PStat waitEst = {0, 0, 0, -1, nullptr};
     int nextT = 0;
+    const int window = C.window[slab];
+    unsigned* const done = C.done + slab;
     if (threadIdx.x == 0)
     {
         __hip_atomic_store(C.tickNext + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(C.doneNext + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nextT = (int)atomicAdd(ticket, 1u);
     }
     for (int it = 0;; it++)
     {
         if (threadIdx.x == 0)
         {
+            if (window && it) atomicAdd(done, 1u);
             const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            if (window && t < nChunks) p2p_window_wait(done, 0u, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)atomicAdd(ticket, 1u);
         }
@@ -1276,6 +1375,7 @@ sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0
             p2p_gs_task<true>(T, task & 0x0fffffff, task >> 28, k, lane, G, C.X, C.xflag, tag0, abortFlag, psi,
                               rhs, diag, val, waitEst);
         }
+        if (window) __syncthreads();
     }
 }
 
@@ -1618,11 +1718,11 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         if (getenv("LDU_VERBOSE"))
             fprintf(stderr, "[ldugpu] GS pipeline plan: %d cells, %d levels, max upper-neighbour skew %d levels\n",
                     a->nCells, nLev, maxSkew);
-        // Pipelining pays when sweep j+1 can follow sweep j closely.  On irregular DAGs the upper
-        // neighbours can sit dozens of levels ahead: the trailing sweep's waves would then wait (and
-        // poll) for a long time and starve the leading sweep (measured: spin-bound aborts on a random
-        // graph with skew ~70).  Such addressings run their sweeps one after the other.
-        // (small addressings cannot starve anything: few waiting waves)
+        // On irregular DAGs the upper neighbours can sit dozens or hundreds of levels ahead.  Round 1 ran such
+        // addressings sweep by sweep (spin-bound aborts at skew ~70: thousands of waves far ahead of the front polled
+        // so hard that the front itself crawled); with the run-ahead window (p2p_window_wait) they pipeline like the
+        // others: irregular 100^3 graph, 1463 levels, skew 262: 4 sweeps 7.2 ms instead of 14.8.  The limit remains as
+        // a knob (LDU_GS_MAXSKEW).
         if (maxSkew > ctx->gsPipelineMaxSkew && a->nSlices > 512)
         {
             ldu_addr::GsTasks none;
@@ -1701,8 +1801,9 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     if (grid < 1) grid = 1;
     if (P.gen != ctx->p2pGen)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned), s));
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned) * 64, s));
         P.ticketBase = 0;
+        P.doneBase = 0;
         P.gen = ctx->p2pGen;
     }
     // tags tag0 .. tag0+k-1; keep them away from 0 and from wrapping inside one launch
@@ -1723,16 +1824,22 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         slab_ctl(a, P, C);
         C.list = it->second.d_slabTasks;
         for (int i = 0; i <= 8; i++) C.start[i] = it->second.slabStart[i];
-        sweep_slab_gs_multi_kernel<<<ctx->numCUs * slab_bpc(a, k), P2P_BLK, 0, s>>>(TS, C, k, P.d_granule, tag0,
+        const int sgrid = ctx->numCUs * slab_bpc(a, k);
+        for (int i = 0; i < a->nSlabs; i++)
+            C.window[i] = p2p_window(a, cdiv(it->second.slabStart[i + 1] - it->second.slabStart[i], P2P_CHUNK), k,
+                                     sgrid / std::max(1, a->nSlabs));
+        sweep_slab_gs_multi_kernel<<<sgrid, P2P_BLK, 0, s>>>(TS, C, k, P.d_granule, tag0,
             ctx->d_abort, psi, rhs, diag, val);
         ctx->profStop(a, 4);
         LDU_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    const int window = p2p_window(a, nChunks, k, grid);
     sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
-            P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+            P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     ctx->profStop(a, 4);
     P.ticketBase += (unsigned)(nChunks + grid);
+    if (window) P.doneBase += (unsigned)nChunks;
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }

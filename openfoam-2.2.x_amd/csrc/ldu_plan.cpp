@@ -25,20 +25,23 @@ ldu_addr::P2PLane* ldu_addr::lane(int i)
         // tags start at 0 = never published
         if (hipMalloc((void**)&P.d_granule, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
         if (hipMemset(P.d_granule, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
-        if (hipMalloc((void**)&P.d_ticket, sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(P.d_ticket, 0, sizeof(unsigned)) != hipSuccess) return nullptr;
+        // [0] chunk tickets, [32] chunks reported complete (run-ahead window), each on its own cache line
+        if (hipMalloc((void**)&P.d_ticket, sizeof(unsigned) * 64) != hipSuccess) return nullptr;
+        if (hipMemset(P.d_ticket, 0, sizeof(unsigned) * 64) != hipSuccess) return nullptr;
         if (nSlabs > 0)
         {
             if (hipMalloc((void**)&P.d_X, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
             if (hipMemset(P.d_X, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
-            if (hipMalloc((void**)&P.d_ctl, sizeof(unsigned) * 16) != hipSuccess) return nullptr;
-            if (hipMemset(P.d_ctl, 0, sizeof(unsigned) * 16) != hipSuccess) return nullptr;
+            // [2][8] per-slab tickets, [2][8] per-slab completed chunks, double-buffered by launch parity
+            if (hipMalloc((void**)&P.d_ctl, sizeof(unsigned) * 32) != hipSuccess) return nullptr;
+            if (hipMemset(P.d_ctl, 0, sizeof(unsigned) * 32) != hipSuccess) return nullptr;
             P.par = 0;
         }
         // hipMemset on device memory may return before the fill ran and the compute streams do not wait for
         // the null stream: the fills must be complete before the first sweep publishes its tags
         if (hipDeviceSynchronize() != hipSuccess) return nullptr;
         P.ticketBase = 0;
+        P.doneBase = 0;
         P.epoch = 0;
         P.gen = ctx->p2pGen;
     }

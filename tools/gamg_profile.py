@@ -23,22 +23,15 @@ def step():
     d_psi.zero_(); torch.cuda.synchronize()
     mat.set_coeffs(d_diag, d_upper)
     return mat.solve(d_psi, d_source, history=True, **kw)[1]
-# rocprofv3 --selected-regions: only the steady-state solves are traced (set-up uploads its tables once, through
-# hundreds of staged copyBuffer blits that belong to no solve)
-import ctypes
-try:
-    roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
-    roctx.roctxProfilerPause.argtypes = roctx.roctxProfilerResume.argtypes = [ctypes.c_uint64]
-except OSError:
-    roctx = None
-if roctx: roctx.roctxProfilerPause(0)
+# steady-state marker for tools/trace_steady.py: a second context runs the placement census kernel once; nothing
+# after it belongs to set-up (which uploads its tables through hundreds of staged copyBuffer blits)
 step(); torch.cuda.synchronize()
+marker_ctx = capi.Context(0)
+torch.cuda.synchronize()
 print("MARK warm-up done", flush=True)
-if roctx: roctx.roctxProfilerResume(0)
 t0 = time.perf_counter(); its = 0
 for _ in range(solves):
     its += step()["nIterations"]
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-if roctx: roctx.roctxProfilerPause(0)
 print("GAMG only: %d solves, %d V-cycles, %.3f ms per solve, %.1f V-cycles/s" % (solves, its, 1e3 * dt / solves, its / dt))

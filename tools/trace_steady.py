@@ -1,0 +1,25 @@
+"""Per-kernel statistics of the STEADY-STATE part of a rocprofv3 kernel trace.
+python tools/trace_steady.py <..._kernel_trace.csv> [marker=xcc_census_kernel] > stats.csv
+
+tools/gamg_profile.py creates a second library context after its warm-up solve; the context's placement census
+(`xcc_census_kernel`) is the only launch of that kernel outside set-up, so everything after its LAST occurrence is
+steady state (no agglomeration, no plan uploads).  Output: the columns of rocprofv3's own kernel_stats.csv."""
+import csv, sys, collections, math
+path = sys.argv[1]
+marker = sys.argv[2] if len(sys.argv) > 2 else "xcc_census_kernel"
+rows = list(csv.DictReader(open(path)))
+kn = "Kernel_Name"; ts = "Start_Timestamp"; te = "End_Timestamp"
+t0 = max((int(r[ts]) for r in rows if marker in r[kn]), default=None)
+if t0 is None:
+    sys.exit("marker kernel %s not in the trace" % marker)
+agg = collections.defaultdict(list)
+for r in rows:
+    if int(r[ts]) > t0 and marker not in r[kn]:
+        agg[r[kn]].append(int(r[te]) - int(r[ts]))
+tot = sum(sum(v) for v in agg.values())
+w = csv.writer(sys.stdout, quoting=csv.QUOTE_NONNUMERIC)
+w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    m = sum(v) / len(v)
+    sd = math.sqrt(sum((x - m) ** 2 for x in v) / len(v))
+    w.writerow([k, len(v), sum(v), round(m, 1), round(100.0 * sum(v) / tot, 3), min(v), max(v), round(sd, 1)])
