@@ -193,6 +193,11 @@ int ldu_profile_end(ldu_matrix* m, double ms[8], int64_t counts[8]);
 int ldu_debug_p2p_trace(ldu_matrix* m, void* buf);
 /* Debug: the first dependency wait that expired in an aborted sweep (row, tag, columns, seen tags). */
 int ldu_debug_p2p_stuck(ldu_matrix* m, int32_t out[16]);
+/* Debug: the GaussSeidel rows end in `curPsi /= diagPtr[cellI]` (GaussSeidelSmoother.C:154); the sweep kernels do the
+ * denominator's half of that IEEE division ahead of the dependency wait.  This runs n operand pairs (random bit
+ * patterns, exponents at the edges of the fast range, zeros, denormals, huge values) through that path and through
+ * the compiler's division and returns the number of quotients that differ in any bit (must be 0). */
+int ldu_debug_div_check(ldu_ctx* ctx, uint64_t seed, int64_t n, uint64_t* mismatches);
 
 /* ---- finite-volume stencils feeding the matrix ------------- */
 typedef struct ldu_mesh_geom {

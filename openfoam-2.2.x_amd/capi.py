@@ -20,7 +20,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
-    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count",
+    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
@@ -173,6 +173,14 @@ class Context:
         f = lib().ldu_ctx_overlapped_halo_count
         f.restype = C.c_int64
         return int(f(self.h))
+
+    def div_check(self, n, seed=1):
+        """ldu_debug_div_check: mismatches between the sweep kernels' split division and the compiler's (must be 0)."""
+        bad = C.c_uint64(0)
+        f = lib().ldu_debug_div_check
+        f.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
+        _chk(f(self.h, seed, n, C.byref(bad)))
+        return int(bad.value)
 
     def fallback_count(self):
         f = lib().ldu_ctx_fallback_count

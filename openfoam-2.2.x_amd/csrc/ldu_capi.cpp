@@ -156,6 +156,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->smallMaxCells = std::min(atoi(e), 16384);
     e = getenv("LDU_SMALL_PIPE");
     if (e) c->smallPipe = atoi(e);
+    e = getenv("LDU_CLUSTER_PREFETCH");
+    if (e) c->clusterPrefetch = atoi(e);
     e = getenv("LDU_P2P_SLABS");
     if (e) c->p2pSlabs = atoi(e);
     e = getenv("LDU_P2P_WINDOW");
@@ -683,6 +685,15 @@ int ldu_debug_p2p_records(ldu_matrix* m, int32_t* out /* 1 + 512 */)
 {
     LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
     return k_read_p2p_dbg_records(out);
+}
+
+int ldu_debug_div_check(ldu_ctx* ctx, uint64_t seed, int64_t n, uint64_t* mismatches)
+{
+    if (!ctx || !mismatches) { ldu_set_error("ldu_debug_div_check: null argument"); return -1; }
+    unsigned long long bad = 0;
+    const int rc = k_div_check(ctx, (unsigned long long)seed, (long)n, &bad);
+    *mismatches = bad;
+    return rc;
 }
 
 int ldu_debug_p2p_stuck(ldu_matrix* m, int32_t out[16])

@@ -86,6 +86,7 @@ struct ldu_ctx {
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
+    int clusterPrefetch = 1;   // software-pipelined cluster GaussSeidel sweeps (LDU_CLUSTER_PREFETCH=0: off)
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
@@ -443,6 +444,7 @@ static inline int run_with_fallback(ldu_matrix* m, F&& op)
     ctx->sweepP2P = p2p;
     return rc;
 }
+int k_div_check(ldu_ctx* ctx, unsigned long long seed, long n, unsigned long long* mismatches);
 int k_set_spin_limit(unsigned polls);          // ldu_kernels.hip (0 = default)
 int k_cluster_set_spin_limit(unsigned polls);  // ldu_cluster.hip
 void gamg_invalidate_factors(GamgHierarchy* g);
@@ -465,3 +467,60 @@ int matrix_alloc(ldu_addr* a, ldu_matrix** out);
 int matrix_refresh_layout(ldu_matrix* m);   // LDU-space device coefficients -> compute layout
 void matrix_free(ldu_matrix* m);
 int addr_create_internal(ldu_ctx* ctx, ldu_addr** out, int nCells, int nFaces, const int* l, const int* u);
+
+#if defined(__HIPCC__)
+// ---- IEEE double division with the denominator's half done ahead of time.
+// `acc / d` is the last operation of every GaussSeidel row (GaussSeidelSmoother.C:154: `curPsi /= diagPtr[cellI]`) and
+// sits on the dependency chain of the sweep.  The compiler's f64 division (gfx950 ISA of `a / b`) is
+//     s = div_scale(d, d, t); r = rcp(s); e = fma(-s, r, 1); r = fma(r, e, r); e = fma(-s, r, 1); r = fma(r, e, r);
+//     n = div_scale(t, d, t); q = n * r; f = fma(-s, q, n); q = div_fmas(f, r, q); div_fixup(q, d, t)
+// eleven dependent instructions after t arrives (v_div_scale makes even the reciprocal depend on t).  div_scale only
+// rescales - and div_fmas / div_fixup only act - when an exponent is extreme: with both biased exponents in
+// [700, 1300] (2^-323 .. 2^277: no zero, denormal, infinity, NaN; |exp(t) - exp(d)| <= 600 < 768) they are the
+// identity, and the quotient is `q = t * r; f = fma(-d, q, t); fma(f, r, q)` with r from the SAME five instructions -
+// which depend on d alone and are issued before the wait.  Three dependent instructions after t; the same bits
+// (tests: every bit-exact sweep test and tools/fuzz_gpu.py run through it; ldu_debug_div_check compares it with
+// the compiler's division on random and boundary operands).  Anything outside the range takes the compiler's division.
+__device__ __forceinline__ bool ldu_div_exp_safe(double x)
+{
+    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+    return e - 700u <= 600u;
+}
+// refined reciprocal of d, or 0 when d is outside the safe range (marks "use the plain division")
+__device__ __forceinline__ double ldu_div_prepare(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return ldu_div_exp_safe(d) ? r : 0.0;
+}
+// t / d for the lanes that are active here (the choice is made per wave: no divergence)
+__device__ __forceinline__ double ldu_div(double t, double d, double r)
+{
+    // the quotient is computed unconditionally (three dependent instructions); the range test runs beside it and
+    // only a wave that holds an operand outside the range goes through the compiler's division as well
+    const double q = t * r;
+    const double f = __builtin_fma(-d, q, t);
+    double out = __builtin_fma(f, r, q);
+    asm volatile("" : "+v"(out));   // ... before the branch below, not inside it
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!((r != 0.0) & ldu_div_exp_safe(t))) != 0ull, 0))
+    {
+        // (the volatile statement keeps the compiler from turning the branch into compute-both-and-select)
+        asm volatile("; operand outside the range: the compiler's division");
+        out = t / d;
+    }
+    return out;
+}
+
+// Between two steps of a recurrence that a wavefront runs through LDS (write this step's values, read them in the
+// next): LDS instructions of one wave execute in issue order, so the next step's ds_read sees this step's ds_write
+// without waiting for the write to retire - only the compiler must not reorder them.  -DLDU_LDS_WAIT=1 restores the
+// explicit `s_waitcnt lgkmcnt(0)` (costs a write round trip per step).
+#if defined(LDU_LDS_WAIT) && LDU_LDS_WAIT
+#define LDU_STEP_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define LDU_STEP_FENCE() asm volatile("" ::: "memory")
+#endif
+#endif

@@ -820,6 +820,7 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
         // old values of the upper neighbours: plain loads, issued before the wait
         double acc = rhs[r];
         const double d = scale[r];
+        const double rd = TF ? 0.0 : ldu_div_prepare(d);
         double xu[8];
         double vu[8];
         const int nuFast = nu <= 8 ? nu : 0;
@@ -849,13 +850,15 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
                 acc -= val[e] * w[T.col[e] & 0x7fffffff];
             }
         }
-        out = TF ? d * acc : acc / d;
+        out = TF ? d * acc : ldu_div(acc, d, rd);
     }
     else   // SW_GS_BWD
     {
         double acc = rhs[r];
+        const double d = scale[r];
+        const double rd = ldu_div_prepare(d);
         if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, nl, 1, nu, r, abortFlag, waitEst)) return false;
-        out = acc / scale[r];
+        out = ldu_div(acc, d, rd);
     }
     w[r] = out;
     if (SLAB) granule_store_slab(G, X, r, out, tag, exported);
@@ -992,6 +995,65 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
         }
         if (window) __syncthreads();
     }
+}
+
+// ---- self-check of ldu_div (ldu_internal.hpp) against the compiler's division: ldu_debug_div_check
+__device__ __forceinline__ unsigned long long dc_mix(unsigned long long z)
+{
+    z += 0x9e3779b97f4a7c15ull; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double dc_make(unsigned long long bits, int mode, int which)
+{
+    // mode (uniform per wave, so that the wave-level choice in ldu_div is exercised both ways):
+    // 0 any bit pattern; 1 exponents around the edges of the fast range; 2 moderate exponents (always fast);
+    // 3 moderate denominator, numerator zero / -0 / denormal / tiny / huge
+    unsigned long long m = bits & 0x800fffffffffffffull;
+    unsigned long long e;
+    if (mode == 0) return __longlong_as_double((long long)bits);
+    if (mode == 1) { const int edge[4] = {697, 700, 1300, 1303}; e = (unsigned long long)(edge[(bits >> 52) & 3] + (int)((bits >> 54) & 3) - 1); }
+    else if (mode == 2 || which == 1) e = 1023ull - 60ull + ((bits >> 52) % 121ull);
+    else
+    {
+        const int sel = (int)((bits >> 52) & 7);
+        if (sel == 0) return 0.0;
+        if (sel == 1) return -0.0;
+        if (sel == 2) { e = 0; }                       // denormal
+        else if (sel == 3) e = 1ull + ((bits >> 55) & 63);
+        else if (sel == 4) e = 2046ull - ((bits >> 55) & 63);
+        else e = 1023ull - 400ull + ((bits >> 55) % 801ull);
+    }
+    return __longlong_as_double((long long)(m | (e << 52)));
+}
+__global__ void __launch_bounds__(256) div_check_kernel(unsigned long long seed, long n, unsigned long long* out)
+{
+    unsigned long long bad = 0;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    {
+        const int mode = (int)((i >> 6) & 3);
+        const double t = dc_make(dc_mix(seed + 2ull * (unsigned long long)i), mode, 0);
+        const double d = dc_make(dc_mix(seed + 2ull * (unsigned long long)i + 1ull), mode, 1);
+        const double r = ldu_div_prepare(d);
+        const double q = ldu_div(t, d, r);
+        double tt = t, ddv = d;
+        asm volatile("" : "+v"(tt), "+v"(ddv));       // an independent division, not a copy of the one inside ldu_div
+        const double ref = tt / ddv;
+        const bool same = __double_as_longlong(q) == __double_as_longlong(ref) || (q != q && ref != ref);
+        if (!same) bad++;
+    }
+    if (bad) atomicAdd(out, bad);
+}
+int k_div_check(ldu_ctx* ctx, unsigned long long seed, long n, unsigned long long* mismatches)
+{
+    unsigned long long* d = nullptr;
+    LDU_CHECK_HIP(hipMalloc((void**)&d, sizeof(unsigned long long)));
+    LDU_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+    div_check_kernel<<<ctx->numCUs * 8, 256, 0, ctx->stream>>>(seed, n, d);
+    LDU_CHECK_HIP(hipMemcpyAsync(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    return 0;
 }
 
 // Placement census: the slab engine needs workgroups of one launch on every XCD it assigns a slab to
@@ -1239,6 +1301,7 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
     const bool exported = SLAB ? xflag[r] != 0 : false;
     double acc = rhs[r];
     const double d = diag[r];
+    const double rd = ldu_div_prepare(d);
     const unsigned tagNew = tag0 + (unsigned)j;
     // 1. "old" values of the upper neighbours: before the kernel (sweep 0) or sweep j-1's granules,
     //    which are long published (that sweep runs ahead of this one)
@@ -1285,7 +1348,7 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
     {
         if (!p2p_accumulate<0, false, SLAB>(acc, G, X, tagNew - 1u, T.col, val, nullptr, ent, nl, 1, nu, r, abortFlag, waitEst)) return;
     }
-    const double out = acc / d;
+    const double out = ldu_div(acc, d, rd);
     if (j == k - 1) psi[r] = out;
     if (SLAB) granule_store_slab(G, X, r, out, tagNew, exported);
     else granule_store(G, r, out, tagNew);
@@ -1457,6 +1520,8 @@ gs_small_kernel(SliceTab T, int nSlices, int nCells, int k, double* __restrict__
         {                                                                                 \
             double acc = (CUR).b;                                                         \
             const int nn = (int)(CUR).nl + (int)(CUR).nu;                                 \
+            /* the denominator's half of the division runs under the LDS reads */         \
+            const double rd_ = ldu_div_prepare((CUR).d);                                  \
             /* all W LDS reads in flight, then the products, then ONE dependent subtraction per entry;  \
                entries beyond the row subtract +0.0 (identity for every acc, also -0.0).  Written as   \
                `if (q < nn) acc -= v*x[c]` the compiler sinks each read into its branch: W serial      \
@@ -1468,10 +1533,10 @@ gs_small_kernel(SliceTab T, int nSlices, int nCells, int k, double* __restrict__
             _Pragma("unroll") for (int q = 0; q < W; q++)                                 \
                 pr[q] = q < nn ? (CUR).v[q] * xv[q] : 0.0;                                \
             _Pragma("unroll") for (int q = 0; q < W; q++) acc -= pr[q];                   \
-            if ((CUR).r >= 0) x[(CUR).r] = acc / (CUR).d;                                 \
+            if ((CUR).r >= 0) x[(CUR).r] = ldu_div(acc, (CUR).d, rd_);                                 \
         }                                                                                 \
         /* the next slice may read what this one wrote: LDS is in order within a wave */  \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+        LDU_STEP_FENCE();                                \
         --left;                                                                           \
     } while (0)
     SMALL_FILL(R0);
@@ -1528,6 +1593,8 @@ gs_small_pipe_kernel(SliceTab T, int nSlices, int nCells, const int* __restrict_
 #define PIPE_STEP(CUR, FILL)                                                              \
     do {                                                                                  \
         PIPE_FILL(FILL);                                                                  \
+        /* the denominator's half of the division: before the wait for the previous sweep */ \
+        const double rd_ = ldu_div_prepare((CUR).d);                                      \
         if (wave > 0)                                                                     \
         {                                                                                 \
             const unsigned want = (unsigned)sNeed[sCur];                                  \
@@ -1544,9 +1611,9 @@ gs_small_pipe_kernel(SliceTab T, int nSlices, int nCells, const int* __restrict_
             _Pragma("unroll") for (int q = 0; q < W; q++)                                 \
                 pr[q] = q < nn ? (CUR).v[q] * xv[q] : 0.0;                                \
             _Pragma("unroll") for (int q = 0; q < W; q++) acc -= pr[q];                   \
-            if ((CUR).r >= 0) x[(CUR).r] = acc / (CUR).d;                                 \
+            if ((CUR).r >= 0) x[(CUR).r] = ldu_div(acc, (CUR).d, rd_);                                 \
         }                                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+        LDU_STEP_FENCE();                                \
         ++sCur;                                                                           \
         if (lane == 0) __hip_atomic_store(prog + wave, (unsigned)sCur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         --left;                                                                           \

@@ -143,3 +143,14 @@ def test_small_pipelined_sweeps_bitexact(oracle, pipe):
             os.environ.pop(k, None)
             if saved[k] is not None:
                 os.environ[k] = saved[k]
+
+
+@pytest.mark.gpu
+def test_split_division_is_the_compilers_division():
+    """GaussSeidelSmoother.C:154 `curPsi /= diagPtr[cellI]`: the sweep kernels do the denominator's half of the IEEE
+    division before the dependency wait (ldu_div, csrc/ldu_internal.hpp).  2^28 operand pairs per seed - random bit
+    patterns, exponents at the edges of the fast range, zeros / denormals / huge numerators - must give the bits of the
+    compiler's division."""
+    ctx = capi.Context(0)
+    for seed in (1, 20260928, 0xdeadbeef):
+        assert ctx.div_check(1 << 28, seed) == 0
