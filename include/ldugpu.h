@@ -193,6 +193,12 @@ int ldu_profile_end(ldu_matrix* m, double ms[8], int64_t counts[8]);
 int ldu_debug_p2p_trace(ldu_matrix* m, void* buf);
 /* Debug: the first dependency wait that expired in an aborted sweep (row, tag, columns, seen tags). */
 int ldu_debug_p2p_stuck(ldu_matrix* m, int32_t out[16]);
+/* Debug: per-task timeline of the pipelined GaussSeidel sweeps of the cluster engine.  buf = device memory of
+ * nSweeps * nClusters * 64 bytes (8 x u64 per (sweep, cluster): start, upper values there, lower values there,
+ * steps done, stores acknowledged [100 MHz wall clock], polls, XCC id, workgroup), or NULL to switch tracing off.
+ * ldu_debug_cluster_levels: out[0] = clusters, out[1] = cluster levels, out[2..] = first cluster of every level. */
+int ldu_debug_cluster_trace(ldu_matrix* m, void* buf);
+int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap);
 /* Debug: the GaussSeidel rows end in `curPsi /= diagPtr[cellI]` (GaussSeidelSmoother.C:154); the sweep kernels do the
  * denominator's half of that IEEE division ahead of the dependency wait.  This runs n operand pairs (random bit
  * patterns, exponents at the edges of the fast range, zeros, denormals, huge values) through that path and through

@@ -156,8 +156,6 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->smallMaxCells = std::min(atoi(e), 16384);
     e = getenv("LDU_SMALL_PIPE");
     if (e) c->smallPipe = atoi(e);
-    e = getenv("LDU_CLUSTER_PREFETCH");
-    if (e) c->clusterPrefetch = atoi(e);
     e = getenv("LDU_P2P_SLABS");
     if (e) c->p2pSlabs = atoi(e);
     e = getenv("LDU_P2P_WINDOW");
@@ -685,6 +683,17 @@ int ldu_debug_p2p_records(ldu_matrix* m, int32_t* out /* 1 + 512 */)
 {
     LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
     return k_read_p2p_dbg_records(out);
+}
+
+int ldu_debug_cluster_trace(ldu_matrix* m, void* buf)
+{
+    LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+    return k_cluster_set_trace((unsigned long long*)buf);
+}
+
+int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap)
+{
+    return k_cluster_levels(m->a, out, cap);
 }
 
 int ldu_debug_div_check(ldu_ctx* ctx, uint64_t seed, int64_t n, uint64_t* mismatches)

@@ -73,6 +73,15 @@ int k_cluster_set_spin_limit(unsigned polls)
     return 0;
 }
 
+// Debug: per-task timeline of the pipelined GaussSeidel cluster sweeps (ldu_debug_cluster_trace): 8 x u64 per (sweep,
+// cluster): tStart, tUpperDone, tLowerDone (poll success), tStepsDone, tStored [100 MHz wall clock], polls, XCC id, spare.
+__device__ unsigned long long* g_cl_trace = nullptr;
+int k_cluster_set_trace(unsigned long long* buf)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_cl_trace), &buf, sizeof(buf)));
+    return 0;
+}
+
 struct ClusterPlan {
     int nSlices = 0;
     long nEntries = 0;
@@ -555,7 +564,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
                 if (e1) ok &= (g1.y == tag) & (g1.w == tag);
                 if (e2) ok &= (g2.y == tag) & (g2.w == tag);
                 if (ok) break;
-                if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);
@@ -653,17 +662,17 @@ sweep_cluster_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, ClBase
     __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + ND)];   // slots 0..63: the cluster's rows, then ND x 64 outside values
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    int nextT = 0;
     const int nq = gridDim.x >= 8 * CL_NQ ? CL_NQ : 1;
     const int tq = blockIdx.x % nq;
     unsigned* const tk = ticket + tq * CL_QSTRIDE;
     const unsigned tb = ticketBase.b[tq];
+    int nextT = 0;
     if (threadIdx.x == 0) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
     for (int it = 0;; it++)
     {
         if (threadIdx.x == 0)
         {
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            const int t = ldu_abort_seen(abortFlag, it) ? 0x7fffffff : nextT;
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
         }
@@ -852,7 +861,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
                     if (e2) ok &= (g[j][2].y == tag) & (g[j][2].w == tag);
                 }
                 if (ok) break;
-                if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
 #pragma unroll
@@ -943,7 +952,7 @@ sweep_cluster_vec_kernel(ClTab T, int nSlices, int nChunks, unsigned* ticket, Cl
     {
         if (threadIdx.x == 0)
         {
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            const int t = ldu_abort_seen(abortFlag, it) ? 0x7fffffff : nextT;
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
         }
@@ -1107,7 +1116,7 @@ bool k_cluster_active(ldu_addr* a)
 // itself cannot run sweep j+1 before those lower neighbours have published theirs.
 template <int ND>
 __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict__ colUp, int s, int j, int k,
-                                           int lane, double* __restrict__ lds, uint4* __restrict__ G, unsigned tag0,
+                                           int traceStride, int lane, double* __restrict__ lds, uint4* __restrict__ G, unsigned tag0,
                                            volatile int* abortFlag, double* __restrict__ psi,
                                            const double* __restrict__ rhs, const double* __restrict__ diag,
                                            const double* __restrict__ val)
@@ -1123,6 +1132,9 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
     const int nl = on ? (rm.y & 255) : 0, nu = on ? ((rm.y >> 8) & 255) : 0;
     const long ent = cl_ent0(T, s) + lane;
     const unsigned tagNew = tag0 + (unsigned)j;
+    unsigned long long* const trc = g_cl_trace ? g_cl_trace + ((size_t)j * (size_t)traceStride + (size_t)s) * 8 : nullptr;
+    unsigned nPolls = 0;
+    if (trc && lane == 0) trc[0] = (unsigned long long)wall_clock64();
     int c[ND], cu[ND];
     double v[ND], vu[ND];
 #pragma unroll
@@ -1166,7 +1178,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                     if (e1) ok &= (g1.y == t) & (g1.w == t);
                     if (e2) ok &= (g2.y == t) & (g2.w == t);
                     if (ok) break;
-                    if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                    if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
                     __builtin_amdgcn_s_sleep(CL_NAP_UP);
                 }
                 if (e0) xu[k0] = cl_value(g0);
@@ -1175,6 +1187,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
             }
         }
     }
+    if (trc && lane == 0) trc[1] = (unsigned long long)wall_clock64();
     double xe[ND];
     bool internal[ND];
 #pragma unroll
@@ -1193,12 +1206,13 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
             for (;;)
             {
                 cl_load3(G + c[k0], G + c[k0 + 1], G + c[k0 + 2], e0, e1, e2, g0, g1, g2);
+                nPolls++;
                 bool ok = true;
                 if (e0) ok &= (g0.y == tagNew) & (g0.w == tagNew);
                 if (e1) ok &= (g1.y == tagNew) & (g1.w == tagNew);
                 if (e2) ok &= (g2.y == tagNew) & (g2.w == tagNew);
                 if (ok) break;
-                if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return; }
+                if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);
@@ -1216,6 +1230,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
         pu[q] = q < nu ? vu[q] * xu[q] : 0.0;   // exactly +0.0 when unused (the step loop subtracts it unconditionally)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (trc && lane == 0) trc[2] = (unsigned long long)wall_clock64();
     double res = 0.0;
     for (int st = 0; st < depth; st++)
     {
@@ -1233,10 +1248,21 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
         }
         LDU_STEP_FENCE();
     }
+    if (trc && lane == 0) trc[3] = (unsigned long long)wall_clock64();
     if (on)
     {
         if (j == k - 1) psi[lr] = res;
         cl_store(G, r, res, tagNew);
+    }
+    if (trc)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores are acknowledged
+        if (lane == 0)
+        {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            trc[4] = (unsigned long long)wall_clock64(); trc[5] = nPolls; trc[6] = xcc & 0xf; trc[7] = blockIdx.x;
+        }
     }
 }
 
@@ -1244,8 +1270,9 @@ template <int ND>
 __global__ void __launch_bounds__(CL_BLK)
 sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int* __restrict__ tasks, int nTasks,
                               const int* __restrict__ segStart, const int* __restrict__ segInfo, int nSeg,
-                              int nChunks, int k, unsigned* ticket, ClBase ticketBase, uint4* G, unsigned tag0,
-                              int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
+                              int nChunks, int k, int nSlicesTrace, unsigned* ticket, ClBase ticketBase, uint4* G,
+                              unsigned tag0, int* abortFlag, double* psi, const double* rhs, const double* diag,
+                              const double* val)
 {
     __shared__ int s_chunk[2];
     __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + ND)];   // slots 0..63: the cluster's rows, then ND x 64 outside values
@@ -1270,7 +1297,7 @@ sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int*
     {
         if (threadIdx.x == 0)
         {
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            const int t = ldu_abort_seen(abortFlag, it) ? 0x7fffffff : nextT;
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
         }
@@ -1288,319 +1315,9 @@ sweep_cluster_gs_multi_kernel(ClTab T, const int* __restrict__ colUp, const int*
                 task = info + (ti - s_segStart[cur]);         // (j << 28 | first cluster of the run) + offset in the run
             }
             else task = tasks[ti];
-            cl_gs_task<ND>(T, colUp, task & 0x0fffffff, task >> 28, k, lane, s_x[wave], G, tag0, abortFlag, psi, rhs, diag,
+            cl_gs_task<ND>(T, colUp, task & 0x0fffffff, task >> 28, k, nSlicesTrace, lane, s_x[wave], G, tag0, abortFlag, psi, rhs, diag,
                        val);
         }
-    }
-}
-
-// ---- the same k pipelined sweeps, software-pipelined across tasks
-// A task's inputs hang on a chain of dependent memory round trips: ticket -> row metadata -> columns / coefficients /
-// rhs / diag -> old psi of the upper neighbours (or the previous sweep's granules) -> this sweep's granules of the
-// lower neighbours -> steps.  Under load a round trip is 1-1.5 us and the ~3000 resident waves each spend 5-6 us of a
-// 9 us task in them: the finest level of the 216^3 benchmark is bound by waves x task time, not by its dependencies
-// (5.9 us per cluster level against 3.4 us on the coarse levels, where the same chain is latency).  Here a wave
-// holds TWO tasks: while task n waits and steps, the loads of task n+1 that depend on nothing but the task list are
-// already in flight (metadata issued before n's polls, columns / coefficients behind them - the polls' vmcnt(0)
-// is what delivers the metadata), and the upper- and lower-neighbour polls of a task share one loop (six granule
-// loads in flight).  What is left on a task's own time: one poll round trip, the steps, the stores.
-// Tickets: thread 0 keeps two chunks ahead; a workgroup's chunks ascend and it finishes the lower before it touches
-// the higher, so the lowest unfinished chunk of a counter is still either some workgroup's CURRENT chunk or the
-// next ticket (the deadlock argument of CL_NQ above is unchanged).
-template <int ND> struct ClPre {
-    int s, j;              // cluster, sweep; s < 0: no task
-    int2 rm;
-    int c[ND], cu[ND];
-    double v[ND], vu[ND];
-    double acc0, dd;
-};
-
-__device__ __forceinline__ void cl_load6(const uint4* p0, const uint4* p1, const uint4* p2, const uint4* p3,
-                                         const uint4* p4, const uint4* p5, bool e0, bool e1, bool e2, bool e3, bool e4,
-                                         bool e5, cl_u32x4& g0, cl_u32x4& g1, cl_u32x4& g2, cl_u32x4& g3, cl_u32x4& g4,
-                                         cl_u32x4& g5)
-{
-    const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1), m2 = __ballot(e2), m3 = __ballot(e3),
-                             m4 = __ballot(e4), m5 = __ballot(e5);
-    unsigned long long sv;
-    asm volatile(
-        "s_mov_b64 %6, exec\n\t"
-        "s_and_b64 exec, %6, %13\n\t"
-        "global_load_dwordx4 %0, %7, off sc1\n\t"
-        "s_and_b64 exec, %6, %14\n\t"
-        "global_load_dwordx4 %1, %8, off sc1\n\t"
-        "s_and_b64 exec, %6, %15\n\t"
-        "global_load_dwordx4 %2, %9, off sc1\n\t"
-        "s_and_b64 exec, %6, %16\n\t"
-        "global_load_dwordx4 %3, %10, off sc1\n\t"
-        "s_and_b64 exec, %6, %17\n\t"
-        "global_load_dwordx4 %4, %11, off sc1\n\t"
-        "s_and_b64 exec, %6, %18\n\t"
-        "global_load_dwordx4 %5, %12, off sc1\n\t"
-        "s_mov_b64 exec, %6\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&s"(sv)
-        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5)
-        : "memory", "scc");
-}
-
-// stage A: the row metadata of a task (one load, nothing depends on anything but the task id)
-template <int ND>
-__device__ __forceinline__ void cl_pre_meta(const ClTab& T, int task, int lane, ClPre<ND>& P)
-{
-    P.s = task < 0 ? -1 : (task & 0x0fffffff);
-    P.j = task < 0 ? 0 : (task >> 28);
-    P.rm = T.rowMeta[(P.s < 0 ? 0 : P.s) * LDU_WAVE + lane];
-}
-// stage B: columns, coefficients, rhs and diagonal (needs the metadata)
-template <int ND>
-__device__ __forceinline__ void cl_pre_entries(const ClTab& T, const int* __restrict__ colUp, int lane,
-                                               const double* __restrict__ rhs, const double* __restrict__ diag,
-                                               const double* __restrict__ val, ClPre<ND>& P)
-{
-    const int s = P.s < 0 ? 0 : P.s;
-    const int r = s * LDU_WAVE + lane;
-    const bool on = ((P.rm.y >> 16) & 255) != 255;
-    const int lr = P.rm.x;
-    const int nl = on ? (P.rm.y & 255) : 0, nu = on ? ((P.rm.y >> 8) & 255) : 0;
-    const long ent = cl_ent0(T, s) + lane;
-#pragma unroll
-    for (int q = 0; q < ND; q++)
-    {
-        const long e = ent + (long)q * LDU_WAVE;
-        const long eu = ent + (long)(nl + q) * LDU_WAVE;
-        P.c[q] = q < nl ? T.colDep[e] : r;
-        P.v[q] = q < nl ? val[e] : 0.0;
-        P.cu[q] = q < nu ? (P.j == 0 ? T.colDep[eu] : colUp[eu]) : (P.j == 0 ? lr : r);
-        P.vu[q] = q < nu ? val[eu] : 0.0;
-    }
-    P.acc0 = rhs[lr];
-    P.dd = diag[lr];
-}
-
-// stages C-E of one task: old values of the upper neighbours, the wait, the steps, the stores.  `between` runs after
-// the polls and before the steps (the next task's stage B).  Returns false after an abort.
-template <int ND, class F>
-__device__ __forceinline__ bool cl_gs_run(const ClPre<ND>& P, int k, int lane, double* __restrict__ lds,
-                                          uint4* __restrict__ G, unsigned tag0, volatile int* abortFlag,
-                                          double* __restrict__ psi, F between)
-{
-    const int row0 = P.s * LDU_WAVE;
-    const int r = row0 + lane;
-    const int depth = __builtin_amdgcn_readfirstlane(P.rm.y >> 24) & 255;
-    const int myLv = (P.rm.y >> 16) & 255;
-    const bool on = myLv != 255;
-    const int lr = P.rm.x;
-    const int nl = on ? (P.rm.y & 255) : 0, nu = on ? ((P.rm.y >> 8) & 255) : 0;
-    const unsigned tagNew = tag0 + (unsigned)P.j;
-    const unsigned tagOld = tagNew - 1u;
-    const double rdd = ldu_div_prepare(P.dd);
-    double xu[ND], xe[ND];
-    bool internal[ND];
-#pragma unroll
-    for (int q = 0; q < ND; q++)
-    {
-        internal[q] = (q < nl) && (P.c[q] >= row0 && P.c[q] < row0 + LDU_WAVE);
-        xe[q] = 1.0;          // unused slots: finite, non-zero (their coefficient is 0)
-        xu[q] = 0.0;
-    }
-    const bool first = __builtin_amdgcn_readfirstlane(P.j) == 0;
-    if (first)
-    {
-        // sweep 0: old psi of the upper neighbours (level rows): plain gathers, in flight with the first poll
-#pragma unroll
-        for (int q = 0; q < ND; q++) xu[q] = psi[P.cu[q]];
-    }
-#pragma unroll
-    for (int k0 = 0; k0 < ND; k0 += 3)
-    {
-        const bool l0 = (k0 < nl) && !internal[k0], l1 = (k0 + 1 < nl) && !internal[k0 + 1],
-                   l2 = (k0 + 2 < nl) && !internal[k0 + 2];
-        const bool u0 = !first && k0 < nu, u1 = !first && k0 + 1 < nu, u2 = !first && k0 + 2 < nu;
-        if (__any(l0 | l1 | l2 | u0 | u1 | u2))
-        {
-            cl_u32x4 g0, g1, g2, h0, h1, h2;
-            unsigned spins = 0;
-            const unsigned spinLimit = g_cl_spin_limit;
-            for (;;)
-            {
-                bool ok = true;
-                if (first)
-                    cl_load3(G + P.c[k0], G + P.c[k0 + 1], G + P.c[k0 + 2], l0, l1, l2, g0, g1, g2);
-                else
-                {
-                    cl_load6(G + P.c[k0], G + P.c[k0 + 1], G + P.c[k0 + 2], G + P.cu[k0], G + P.cu[k0 + 1],
-                             G + P.cu[k0 + 2], l0, l1, l2, u0, u1, u2, g0, g1, g2, h0, h1, h2);
-                    if (u0) ok &= (h0.y == tagOld) & (h0.w == tagOld);
-                    if (u1) ok &= (h1.y == tagOld) & (h1.w == tagOld);
-                    if (u2) ok &= (h2.y == tagOld) & (h2.w == tagOld);
-                }
-                if (l0) ok &= (g0.y == tagNew) & (g0.w == tagNew);
-                if (l1) ok &= (g1.y == tagNew) & (g1.w == tagNew);
-                if (l2) ok &= (g2.y == tagNew) & (g2.w == tagNew);
-                if (ok) break;
-                if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag)) { *abortFlag = 1; return false; }
-                __builtin_amdgcn_s_sleep(CL_NAP);
-            }
-            if (l0) xe[k0] = cl_value(g0);
-            if (l1) xe[k0 + 1] = cl_value(g1);
-            if (l2) xe[k0 + 2] = cl_value(g2);
-            if (u0) xu[k0] = cl_value(h0);
-            if (u1) xu[k0 + 1] = cl_value(h1);
-            if (u2) xu[k0 + 2] = cl_value(h2);
-        }
-    }
-    between();
-    int slot[ND];
-    double pu[ND];
-#pragma unroll
-    for (int q = 0; q < ND; q++)
-    {
-        slot[q] = internal[q] ? P.c[q] - row0 : LDU_WAVE + q * LDU_WAVE + lane;
-        lds[LDU_WAVE + q * LDU_WAVE + lane] = xe[q];
-        pu[q] = q < nu ? P.vu[q] * xu[q] : 0.0;   // exactly +0.0 when unused (subtracted unconditionally below)
-    }
-    double res = 0.0;
-    for (int st = 0; st < depth; st++)
-    {
-        double t = P.acc0;
-#pragma unroll
-        for (int q = 0; q < ND; q++) t -= P.v[q] * lds[slot[q]];
-        if (myLv == st)
-        {
-#pragma unroll
-            for (int q = 0; q < ND; q++) t -= pu[q];
-            const double out = ldu_div(t, P.dd, rdd);
-            lds[lane] = out;
-            res = out;
-        }
-        LDU_STEP_FENCE();
-    }
-    if (on)
-    {
-        if (P.j == k - 1) psi[lr] = res;
-        cl_store(G, r, res, tagNew);
-    }
-    return true;
-}
-
-// Ticket ring: the ticket counter is a device-scope atomic (1-2 us round trip under load), the abort flag another
-// round trip.  Drawn by the working waves themselves - even "one iteration ahead" - both end up in front of a
-// workgroup barrier (the compiler turns thread 0's atomicAdd into a wave reduction + readfirstlane and waits for it on
-// the spot: ISA checked), so every task of every wave paid ~2.5 us for its ticket, and the four waves of a workgroup
-// moved in lockstep.  Here a fifth wavefront per workgroup does nothing but draw tickets into a small LDS ring, a few
-// ahead of the slowest worker; the workers take them from LDS at their own pace - no barrier in the task loop.
-#define CL_RING 4
-struct ClRing { int t[CL_RING]; unsigned head; unsigned tail[CL_WPB]; };
-
-__device__ __forceinline__ unsigned cl_lds_ld(const unsigned* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void cl_lds_st(unsigned* p, unsigned v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// the fetcher wave (lane 0 does the work)
-__device__ __forceinline__ void cl_ring_fetch(ClRing* R, unsigned* tk, unsigned tb, int nq, int tq, int nChunks,
-                                              volatile int* abortFlag)
-{
-    unsigned n = 0;
-    for (;;)
-    {
-        // flow control: at most CL_RING tickets ahead of the slowest worker
-        for (;;)
-        {
-            unsigned lo = cl_lds_ld(&R->tail[0]);
-#pragma unroll
-            for (int w = 1; w < CL_WPB; w++) { const unsigned x = cl_lds_ld(&R->tail[w]); lo = x < lo ? x : lo; }
-            if (n - lo < CL_RING) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        int t = 0x7fffffff;
-        if (!*abortFlag) t = (int)(atomicAdd(tk, 1u) - tb) * nq + tq;
-        cl_lds_st((unsigned*)&R->t[n % CL_RING], (unsigned)t);
-        n++;
-        cl_lds_st(&R->head, n);          // LDS stores of one wave are performed in order: the ticket is there first
-        if (t >= nChunks) return;        // every workgroup overshoots its counter exactly once (cl_advance)
-    }
-}
-// ticket number i of this workgroup (blocks until the fetcher has published it)
-__device__ __forceinline__ int cl_ring_get(ClRing* R, unsigned i)
-{
-    for (;;)
-    {
-        const unsigned h = cl_lds_ld(&R->head);
-        const int t = (int)cl_lds_ld((const unsigned*)&R->t[i % CL_RING]);
-        if (h > i) return t;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// PRE: the next task's columns / coefficients are prefetched too (two register sets: fits 4 waves per SIMD for ND = 3
-// only); without it the next task's metadata is still loaded ahead and the polls are still merged.
-template <int ND, bool PRE>
-__global__ void __launch_bounds__(CL_BLK + LDU_WAVE)
-sweep_cluster_gs_pipe_kernel(ClTab T, const int* __restrict__ colUp, const int* __restrict__ tasks, int nTasks,
-                             const int* __restrict__ segStart, const int* __restrict__ segInfo, int nSeg,
-                             int nChunks, int k, unsigned* ticket, ClBase ticketBase, uint4* G, unsigned tag0,
-                             int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
-{
-    __shared__ ClRing s_ring;
-    __shared__ double s_x[CL_WPB][LDU_WAVE * (1 + ND)];
-    __shared__ int s_segStart[CL_MAXSEG + 1];
-    __shared__ int s_segInfo[CL_MAXSEG];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < nSeg; i += CL_BLK + LDU_WAVE) { s_segStart[i] = segStart[i]; s_segInfo[i] = segInfo[i]; }
-    if (threadIdx.x == 0)
-    {
-        s_segStart[nSeg] = nTasks;
-        s_ring.head = 0;
-        for (int w = 0; w < CL_WPB; w++) s_ring.tail[w] = 0;
-    }
-    __syncthreads();
-    const int nq = gridDim.x >= 8 * CL_NQ ? CL_NQ : 1;
-    const int tq = blockIdx.x % nq;
-    if (wave == CL_WPB)
-    {
-        if (lane == 0) cl_ring_fetch(&s_ring, ticket + tq * CL_QSTRIDE, ticketBase.b[tq], nq, tq, nChunks, abortFlag);
-        return;
-    }
-    int cur = 0;
-    auto task_of = [&](int ch) -> int {
-        if (ch >= nChunks) return -1;
-        const int ti = ch * CL_WPB + wave;
-        if (ti >= nTasks) return -1;
-        if (!nSeg) return tasks[ti];
-        while (ti >= s_segStart[cur + 1]) cur++;      // a workgroup's tickets ascend: the cursor only moves forward
-        return s_segInfo[cur] + (ti - s_segStart[cur]);
-    };
-    unsigned cnt = 0;                                  // tickets this wave has taken
-    int chunk = __builtin_amdgcn_readfirstlane(cl_ring_get(&s_ring, 0));
-    ClPre<ND> A, B;
-    cl_pre_meta<ND>(T, task_of(chunk), lane, A);
-    if (PRE) cl_pre_entries<ND>(T, colUp, lane, rhs, diag, val, A);
-    for (;;)
-    {
-        if (chunk >= nChunks) return;
-        if (!PRE) cl_pre_entries<ND>(T, colUp, lane, rhs, diag, val, A);
-        const int nextChunk = __builtin_amdgcn_readfirstlane(cl_ring_get(&s_ring, cnt + 1));
-        cnt++;
-        if (lane == 0) cl_lds_st(&s_ring.tail[wave], cnt);   // slot (cnt - 1) % CL_RING may be reused
-        cl_pre_meta<ND>(T, task_of(nextChunk), lane, B);
-        if (A.s >= 0)
-        {
-            if (!cl_gs_run<ND>(A, k, lane, s_x[wave], G, tag0, abortFlag, psi,
-                               [&]() { if (PRE) cl_pre_entries<ND>(T, colUp, lane, rhs, diag, val, B); }))
-                return;
-        }
-        else if (PRE)
-            cl_pre_entries<ND>(T, colUp, lane, rhs, diag, val, B);
-        if (PRE) A = B;
-        else { A.s = B.s; A.j = B.j; A.rm = B.rm; }
-        chunk = nextChunk;
     }
 }
 
@@ -1694,29 +1411,32 @@ int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs,
     const unsigned tag0 = P.epoch + 1;
     P.epoch += (unsigned)k;
     ctx->profStart(a, 4);
-    if (ctx->clusterPrefetch && P.maxDep <= 3)
-        sweep_cluster_gs_pipe_kernel<3, true><<<grid, CL_BLK + LDU_WAVE, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
-            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
-            P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
-    else if (ctx->clusterPrefetch && P.maxDep <= 6)
-        sweep_cluster_gs_pipe_kernel<6, false><<<grid, CL_BLK + LDU_WAVE, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
-            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
-            P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
-    else if (P.maxDep <= 3)
+    if (P.maxDep <= 3)
         sweep_cluster_gs_multi_kernel<3><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
-            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
+            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k, P.nSlices,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     else if (P.maxDep <= 6)
         sweep_cluster_gs_multi_kernel<6><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
-            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
+            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k, P.nSlices,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     else
         sweep_cluster_gs_multi_kernel<CL_MAXD><<<grid, CL_BLK, 0, s>>>(T, P.d_colB, it->second.d, nTasks,
-            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k,
+            it->second.d_segStart, it->second.d_segInfo, it->second.nSeg, nChunks, k, P.nSlices,
             P.d_ticket, P.ticketBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
     ctx->profStop(a, 4);
     cl_advance(P.ticketBase, nChunks, grid);
     LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Debug: cluster levels of the plan (out[0] = clusters, out[1] = cluster levels, then levelStart[0..levels])
+int k_cluster_levels(ldu_addr* a, int* out, int cap)
+{
+    if (!a->cluster || !a->cluster->eligible) { ldu_set_error("no cluster plan for this addressing"); return -1; }
+    const ClusterPlan& P = *a->cluster;
+    if (cap < 3 + P.nClusterLevels) { ldu_set_error("k_cluster_levels: buffer too small"); return -1; }
+    out[0] = P.nSlices; out[1] = P.nClusterLevels;
+    for (int L = 0; L <= P.nClusterLevels; L++) out[2 + L] = P.levelStart[L];
     return 0;
 }
 

@@ -86,7 +86,6 @@ struct ldu_ctx {
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
-    int clusterPrefetch = 1;   // software-pipelined cluster GaussSeidel sweeps (LDU_CLUSTER_PREFETCH=0: off)
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
@@ -447,6 +446,8 @@ static inline int run_with_fallback(ldu_matrix* m, F&& op)
 int k_div_check(ldu_ctx* ctx, unsigned long long seed, long n, unsigned long long* mismatches);
 int k_set_spin_limit(unsigned polls);          // ldu_kernels.hip (0 = default)
 int k_cluster_set_spin_limit(unsigned polls);  // ldu_cluster.hip
+int k_cluster_set_trace(unsigned long long* buf);
+int k_cluster_levels(ldu_addr* a, int* out, int cap);
 void gamg_invalidate_factors(GamgHierarchy* g);
 void coupled_invalidate(ldu_matrix* m);
 
@@ -512,6 +513,18 @@ __device__ __forceinline__ double ldu_div(double t, double d, double r)
         out = t / d;
     }
     return out;
+}
+
+// The abort flag is ONE address.  Read by thread 0 of every workgroup before every task (as in round 1) that is
+// ~80 M system-scope loads per second on one memory channel at 216^3 - the same order as the ~70 M/s one address
+// takes for atomics (why the ticket counter was split in eight) - and it throttled every ticketed kernel: the finest
+// GaussSeidel launch ran at 9.9 us per task and wave, 4 us of it outside the task (tools/cluster_trace.py), whatever was
+// done to the ticket path.  Now thread 0 looks every 32nd task, a waiting wave at its 8th poll and then every 256th:
+// a sweep that aborted still drains (every wait is bounded and looks at the flag), just not within one task.
+#define LDU_ABORT_POLL 8u
+__device__ __forceinline__ bool ldu_abort_seen(volatile int* abortFlag, int it)
+{
+    return (it & 31) == 31 && *abortFlag != 0;
 }
 
 // Between two steps of a recurrence that a wavefront runs through LDS (write this step's values, read them in the

@@ -594,9 +594,10 @@ __device__ __forceinline__ void p2p_window_wait(const unsigned* done, unsigned d
 {
     if (t < window) return;
     const int need = t - window;
+    unsigned naps = 0;
     while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - doneBase) < need)
     {
-        if (*abortFlag) return;
+        if ((++naps & 63u) == 0 && *abortFlag) return;   // (one address for the whole chip: look rarely)
         __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -707,7 +708,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             {
                 const unsigned gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(gv - tag) >= 0) break;
-                if (++gspins > spinLimit || ((gspins & 255u) == 0 && *abortFlag)) break;
+                if (++gspins > spinLimit || ((gspins & 255u) == LDU_ABORT_POLL && *abortFlag)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
             waitEst.gateSlice = -1;
@@ -726,7 +727,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             if (i0 + 2 < n) ok &= (g2.y == tag) & (g2.w == tag);
             if (i0 + 3 < n) ok &= (g3.y == tag) & (g3.w == tag);
             if (ok) break;
-            if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag))
+            if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
             {
                 if (spins > spinLimit)
                 {
@@ -920,7 +921,7 @@ sweep_slab_kernel(SliceTab T, SlabCtl C, uint4* G, unsigned tag, int* abortFlag,
         if (threadIdx.x == 0)
         {
             if (window && it) atomicAdd(done, 1u);   // the previous chunk is complete (barrier at the end of the loop body)
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            const int t = ldu_abort_seen(abortFlag, it) ? 0x7fffffff : nextT;
             if (window && t < nChunks) p2p_window_wait(done, 0u, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)atomicAdd(ticket, 1u);
@@ -960,7 +961,7 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
         {
             if (window && it) atomicAdd(done, 1u);
             // an expired spin anywhere drains the whole grid (uniform per workgroup)
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            const int t = ldu_abort_seen(abortFlag, it) ? 0x7fffffff : nextT;
             if (window && t < nChunks) p2p_window_wait(done, doneBase, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
@@ -1252,7 +1253,7 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
         if (BASE + 2 < nu) ok &= (g2.y == t) & (g2.w == t);
         if (BASE + 3 < nu) ok &= (g3.y == t) & (g3.w == t);
         if (ok) break;
-        if (++spins > spinLimit || ((spins & 255u) == 0 && *abortFlag))
+        if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
         {
             if (spins > spinLimit)
             {
@@ -1371,7 +1372,7 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
         if (threadIdx.x == 0)
         {
             if (window && it) atomicAdd(done, 1u);
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            const int t = ldu_abort_seen(abortFlag, it) ? 0x7fffffff : nextT;
             if (window && t < nChunks) p2p_window_wait(done, doneBase, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)(atomicAdd(ticket, 1u) - ticketBase);
@@ -1423,7 +1424,7 @@ sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0
         if (threadIdx.x == 0)
         {
             if (window && it) atomicAdd(done, 1u);
-            const int t = (*(volatile int*)abortFlag) ? 0x7fffffff : nextT;
+            const int t = ldu_abort_seen(abortFlag, it) ? 0x7fffffff : nextT;
             if (window && t < nChunks) p2p_window_wait(done, 0u, t, window, abortFlag);
             s_chunk[it & 1] = t;
             if (t < nChunks) nextT = (int)atomicAdd(ticket, 1u);
