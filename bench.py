@@ -367,7 +367,10 @@ def main():
                        "mesh": args.mesh,
                        "parallelism": "domain decomposition x%d" % world,
                        "vcycles_per_solve": perf["nIterations"],
-                       "dependency_levels_finest": info["nLevels"]},
+                       "dependency_levels_finest": info["nLevels"],
+                       # sweeps that expired a dependency wait and were re-run on the level-kernel engine (0 = the fast
+                       # engines carried every sweep of the timed region)
+                       "engine_fallbacks": ctx.fallback_count()},
             "roofline": roof,
             "roofline_vcycle": roof_v,
             "cpu_baseline": cpu,

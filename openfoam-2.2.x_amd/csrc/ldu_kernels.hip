@@ -603,6 +603,12 @@ __device__ __forceinline__ void p2p_window_wait(const unsigned* done, unsigned d
 }
 
 // poll back-off between two granule polls, in units of s_sleep(1) (64 clocks); tunable (LDU_P2P_SLEEP)
+__device__ int g_p2p_wide = 1;    // 8-wide polls for rows with more than four dependencies (LDU_P2P_WIDE=0: groups of four)
+int k_set_p2p_wide(int on)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_wide), &on, sizeof(int)));
+    return 0;
+}
 __device__ int g_p2p_sleep = 2;
 __device__ unsigned g_p2p_backoff = 4096u;   // polls before a waiting wave backs off (0 = never)
 int k_set_p2p_backoff(unsigned n)
@@ -659,6 +665,24 @@ __device__ __forceinline__ void granule_load4(const uint4* p0, const uint4* p1, 
         : "memory");
 }
 
+// eight in flight (rows with 5..8 dependencies: one round trip instead of two)
+__device__ __forceinline__ void granule_load8(const uint4* const (&p)[8], u32x4 (&g)[8])
+{
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %9, off sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc1\n\t"
+        "global_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\t"
+        "global_load_dwordx4 %7, %15, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+        : "memory");
+}
+
 __device__ __forceinline__ double granule_value(const u32x4& g)
 {
     return __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
@@ -679,7 +703,72 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
     // (An adaptive pre-sleep before the first poll was tried and measured 2-6x SLOWER: the wait
     //  shrinks quickly while the levels grow, so any history-based nap oversleeps at the front.)
     if (DIAG && g_p2p_trace) waitEst.tWait = wall_clock64();
-    for (int i0 = 0; i0 < n; i0 += 4)
+    int iStart = 0;
+    if (!DIAG && g_p2p_wide && __any(n > 4))
+    {
+        // Wide rows (agglomerated levels, polyhedral / irregular meshes).  Group by group, every group of four costs
+        // two DEPENDENT round trips (its columns and coefficients, then its granules) that start only after the
+        // previous group has arrived: rows with 5-8 dependencies spent 2-3 us per dependency level after their last
+        // neighbour had published.  Here the first eight columns / coefficients are loaded before the first poll and
+        // the eight granules are polled together: one round trip after the last neighbour, as for narrow rows.
+        int c8[8];
+        double v8[8], w8[8];
+        const uint4* gp8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+            const bool need = j < n;
+            const long e = ent + (long)(first + j * step) * LDU_WAVE;
+            c8[j] = need ? col[e] : selfRow;
+            v8[j] = need ? val[e] : 0.0;
+            w8[j] = ((OP == 1 || OP == 3) && need) ? val2[e] : 0.0;
+            gp8[j] = SLAB ? (c8[j] < 0 ? X : G) + (c8[j] & 0x7fffffff) : G + c8[j];
+        }
+        u32x4 g8[8];
+        unsigned spins = 0;
+        const int sleepN = g_p2p_sleep;
+        const unsigned spinLimit = g_p2p_spin_limit;
+        for (;;)
+        {
+            granule_load8(gp8, g8);
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j < n) ok &= (g8[j].y == tag) & (g8[j].w == tag);
+            if (ok) break;
+            if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+            {
+                if (spins > spinLimit)
+                {
+                    bool rec = false;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (!rec && j < n && !((g8[j].y == tag) & (g8[j].w == tag)))
+                        {
+                            p2p_dbg_record(1, selfRow, tag, c8[j], g8[j].y, g8[j].w, j);
+                            rec = true;
+                        }
+                }
+                *abortFlag = 1;
+                return false;
+            }
+            for (int q = 0; q < sleepN; q++) __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+            if (j < n)
+            {
+                const double x = granule_value(g8[j]);
+                if (OP == 0) acc -= v8[j] * x;
+                else if (OP == 1) acc -= (w8[j] * v8[j]) / x;
+                else if (OP == 2) acc -= sc * (v8[j] * x);
+                else acc -= (w8[j] * v8[j]) * (1.0 / x);
+            }
+        }
+        iStart = 8;
+    }
+    for (int i0 = iStart; i0 < n; i0 += 4)
     {
         int c[4];
         double v[4], v2[4];
@@ -1276,6 +1365,59 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
     return true;
 }
 
+// the same for rows with 5..8 upper neighbours: eight columns, then eight granules, each in ONE round trip
+template <bool SLAB = false>
+__device__ __forceinline__ bool gs_gather_old8(const SliceTab& T, const uint4* __restrict__ G,
+                                               const uint4* __restrict__ X, unsigned t,
+                                               const double* __restrict__ val, long ent, int nl, int nu,
+                                               int selfRow, volatile int* abortFlag, double (&xu)[8],
+                                               double (&vu)[8])
+{
+    int c[8];
+    const uint4* gp[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+    {
+        const bool need = q < nu;
+        const long e = ent + (long)(nl + q) * LDU_WAVE;
+        c[q] = need ? T.col[e] : selfRow;
+        vu[q] = need ? val[e] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
+    u32x4 g[8];
+    unsigned spins = 0;
+    const unsigned spinLimit = g_p2p_spin_limit;
+    for (;;)
+    {
+        granule_load8(gp, g);
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (q < nu) ok &= (g[q].y == t) & (g[q].w == t);
+        if (ok) break;
+        if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+        {
+            if (spins > spinLimit)
+            {
+                bool rec = false;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (!rec && q < nu && !((g[q].y == t) & (g[q].w == t)))
+                    {
+                        p2p_dbg_record(2, selfRow, t, c[q], g[q].y, g[q].w, q);
+                        rec = true;
+                    }
+            }
+            *abortFlag = 1;
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) xu[q] = granule_value(g[q]);
+    return true;
+}
 
 // k consecutive GaussSeidel sweeps of the SAME matrix in ONE launch.  Sweep j+1 of a row only needs
 // sweep j's values of its UPPER neighbours (its "old" values) and sweep j+1's values of its LOWER
@@ -1323,9 +1465,16 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
         }
         else
         {
-            if (!gs_gather_old4<0, SLAB>(T, G, X, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
-            if (nuFast > 4)
-                if (!gs_gather_old4<4, SLAB>(T, G, X, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+            if (g_p2p_wide && __any(nuFast > 4))
+            {
+                if (!gs_gather_old8<SLAB>(T, G, X, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+            }
+            else
+            {
+                if (!gs_gather_old4<0, SLAB>(T, G, X, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+                if (nuFast > 4)
+                    if (!gs_gather_old4<4, SLAB>(T, G, X, tagNew - 1u, val, ent, nl, nuFast, r, abortFlag, xu, vu)) return;
+            }
         }
     }
     // 2. new values of the lower neighbours (the critical path)
