@@ -146,6 +146,11 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         step(GAMG_CONTROLS)
 
+    if os.environ.get("LDU_TRACE_MARKER"):
+        # for rocprofv3 summaries of the TIMED region only: a second context runs the placement-census kernel, the
+        # marker tools/trace_steady.py cuts the kernel trace at (set-up and warm-up, with their one-time table
+        # uploads, lie before it)
+        marker_ctx = capi.Context(local_rank)
     barrier()
     mat.profile_begin()
     t0 = time.perf_counter()

@@ -646,9 +646,9 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
     // cluster waits for ALL its external rows, and the last of them finishes in the last step anyway.
     if (on)
     {
+        cl_store(G, r, res, tag);   // first what the neighbours wait for, then the scattered stores
         if (B == SW_GS_FWD && aux) aux[lr] = auxv;
         w[lr] = res;
-        cl_store(G, r, res, tag);
     }
 }
 
@@ -926,8 +926,8 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
 #pragma unroll
         for (int j = 0; j < NC; j++)
         {
-            w[j * stride + lr] = res[j];
             cl_store(G + j * gStride, r, res[j], tag);
+            w[j * stride + lr] = res[j];
         }
     }
 }
@@ -1251,8 +1251,9 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
     if (trc && lane == 0) trc[3] = (unsigned long long)wall_clock64();
     if (on)
     {
-        if (j == k - 1) psi[lr] = res;
+        // the granules are what the neighbours wait for: publish them before the (scattered) psi store
         cl_store(G, r, res, tagNew);
+        if (j == k - 1) psi[lr] = res;
     }
     if (trc)
     {

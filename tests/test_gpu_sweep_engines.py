@@ -161,15 +161,12 @@ def test_cluster_trace_timeline():
     """ldu_debug_cluster_trace: every (sweep, cluster) of the pipelined cluster sweeps leaves an ordered timeline
     (start <= upper values <= lower values <= steps done <= stores acknowledged) and the traced result is unchanged."""
     import ctypes as C
-    import torch
     p = cases.box3d(64)
     ctx = capi.Context(0)
     a, m = capi.from_problem(ctx, p)
     if a.sweep_engine(2) != "clusters":
         pytest.skip("cluster engine not selected for this size")
     L = capi.lib()
-    dev = torch.device("cuda", 0)
-    d_src = torch.from_numpy(p["source"]).to(dev)
     ref = m.smooth("GaussSeidel", np.zeros(p["nCells"]), p["source"], 2)
     lev = np.zeros(4096, dtype=np.int32)
     L.ldu_debug_cluster_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -177,17 +174,30 @@ def test_cluster_trace_timeline():
     nCl, nLev = int(lev[0]), int(lev[1])
     assert nCl >= p["nCells"] // 64 and 1 <= nLev < a.info()["nLevels"]
     assert lev[2] == 0 and lev[2 + nLev] == nCl and np.all(np.diff(lev[2:3 + nLev]) > 0)
-    buf = torch.zeros(2 * nCl * 8, dtype=torch.int64, device=dev)
-    L.ldu_debug_cluster_trace.argtypes = [C.c_void_p, C.c_void_p]
-    capi._chk(L.ldu_debug_cluster_trace(m.h, C.c_void_p(buf.data_ptr())))
+    # device buffer from the HIP runtime the library itself uses (no torch here: INTEGRATION.md section 8)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    nbytes = 2 * nCl * 64
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), nbytes) == 0
     try:
-        d_psi = torch.zeros(p["nCells"], dtype=torch.float64, device=dev)
-        capi._chk(L.ldu_smooth(m.h, capi.SMOOTHERS["GaussSeidel"], capi._ptr(d_psi), capi._ptr(d_src), 2))
-        torch.cuda.synchronize()
+        assert hip.hipMemset(buf, 0, nbytes) == 0
+        assert hip.hipDeviceSynchronize() == 0
+        L.ldu_debug_cluster_trace.argtypes = [C.c_void_p, C.c_void_p]
+        capi._chk(L.ldu_debug_cluster_trace(m.h, buf))
+        try:
+            got = m.smooth("GaussSeidel", np.zeros(p["nCells"]), p["source"], 2)
+        finally:
+            capi._chk(L.ldu_debug_cluster_trace(m.h, None))
+        T = np.zeros(2 * nCl * 8, dtype=np.int64)
+        assert hip.hipMemcpy(T.ctypes.data, buf, nbytes, 2) == 0   # hipMemcpyDeviceToHost
     finally:
-        capi._chk(L.ldu_debug_cluster_trace(m.h, None))
-    assert np.array_equal(d_psi.cpu().numpy(), ref)
-    T = buf.cpu().numpy().reshape(2, nCl, 8)
+        hip.hipFree(buf)
+    assert np.array_equal(got, ref)
+    T = T.reshape(2, nCl, 8)
     assert np.all(T[:, :, 0] > 0)
     for q in range(4):
         assert np.all(T[:, :, q] <= T[:, :, q + 1])
