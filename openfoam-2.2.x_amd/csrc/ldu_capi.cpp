@@ -134,6 +134,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e) > 0) { c->p2pBlocksPerCU = atoi(e); c->p2pBpcForced = 1; }
     e = getenv("LDU_P2P_BACKOFF");
     if (e) k_set_p2p_backoff((unsigned)atoi(e));
+    e = getenv("LDU_P2P_BACKOFF_CAP");
+    if (e) k_set_p2p_backoff_cap((unsigned)atoi(e));
     e = getenv("LDU_P2P_SLEEP");
     if (e) k_set_p2p_sleep(atoi(e));
     e = getenv("LDU_NO_GRAPH");

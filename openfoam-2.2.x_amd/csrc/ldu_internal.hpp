@@ -206,6 +206,7 @@ struct ldu_addr {
     int nSlabs = 0;                        // 0 = chip-wide engine
     double slabWidth = 0;                  // average slices per level per slab (sizes the grid)
     int slabStart[9] = {0};                // offsets into slabList
+    int slabLevelSpan[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // dependency levels a slab's slices span
     int* d_slabList = nullptr;             // [nSlices]
     int* d_colX = nullptr;                 // [nEntries]
     unsigned char* d_xflag = nullptr;      // [nCells] 1 = has a neighbour in another slab
@@ -328,6 +329,7 @@ int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const
 int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_set_p2p_backoff(unsigned n);
+int k_set_p2p_backoff_cap(unsigned n);
 int k_read_p2p_dbg(int* out);
 int k_read_p2p_dbg_records(int* out);
 int k_set_p2p_trace(unsigned long long* buf);

@@ -610,10 +610,33 @@ int k_set_p2p_wide(int on)
     return 0;
 }
 __device__ int g_p2p_sleep = 2;
-__device__ unsigned g_p2p_backoff = 4096u;   // polls before a waiting wave backs off (0 = never)
+// Optional back-off of a waiting wave (LDU_P2P_BACKOFF=<polls>, LDU_P2P_BACKOFF_CAP): after that many failed polls
+// the nap doubles every 8 polls up to 2^cap x 64 clocks.  Meant for waves far from the front (the first tasks of a
+// slab whose predecessors lie in another slab, the trailing sweeps of a pipelined launch).  Measured on the irregular
+// 216^3 graph (seven of eight XCDs waiting for the eighth): no gain (4 sweeps 43.3 ms with it, 40.1 without; one
+// sweep 21.7 / 21.2) - the run-ahead window already keeps the pollers few.  Off by default.
+__device__ unsigned g_p2p_backoff = 0u;    // polls before a waiting wave backs off (0 = never: the default)
+__device__ unsigned g_p2p_backoff_cap = 7u;
+__device__ __forceinline__ void p2p_nap(unsigned spins, int sleepN)
+{
+    const unsigned th = g_p2p_backoff;
+    if (th == 0u || spins < th) { for (int q = 0; q < sleepN; q++) __builtin_amdgcn_s_sleep(1); return; }
+    unsigned sh = 1u + ((spins - th) >> 3);
+    const unsigned cap = g_p2p_backoff_cap;
+    if (sh > cap) sh = cap;
+    const unsigned units = 1u << sh;
+    for (unsigned q = 0; q < units; q += 2u) __builtin_amdgcn_s_sleep(2);
+}
 int k_set_p2p_backoff(unsigned n)
 {
     LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_backoff), &n, sizeof(unsigned)));
+    return 0;
+}
+int k_set_p2p_backoff_cap(unsigned n)
+{
+    if (n < 1u) n = 1u;
+    if (n > 12u) n = 12u;
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_backoff_cap), &n, sizeof(unsigned)));
     return 0;
 }
 int k_set_p2p_sleep(int n)
@@ -752,7 +775,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
                 *abortFlag = 1;
                 return false;
             }
-            for (int q = 0; q < sleepN; q++) __builtin_amdgcn_s_sleep(1);
+            p2p_nap(spins, sleepN);
         }
 #pragma unroll
         for (int j = 0; j < 8; j++)
@@ -828,7 +851,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
                 *abortFlag = 1;
                 return false;
             }
-            for (int q = 0; q < sleepN; q++) __builtin_amdgcn_s_sleep(1);
+            p2p_nap(spins, sleepN);
         }
         const double x0 = granule_value(g0), x1 = granule_value(g1), x2 = granule_value(g2),
                      x3 = granule_value(g3);
@@ -1185,6 +1208,10 @@ int k_xcd_census(ldu_ctx* ctx)
 static int slab_bpc(const ldu_addr* a, int k)
 {
     const ldu_ctx* ctx = a->ctx;
+    {
+        static const char* e = getenv("LDU_SLAB_BPC");   // experiment knob: workgroups per CU of every slab launch
+        if (e && atoi(e) > 0) return std::min(atoi(e), ctx->p2pMaxBlocksPerCU);
+    }
     if (ctx->p2pBpcForced) return std::min(ctx->p2pBlocksPerCU * k, ctx->p2pMaxBlocksPerCU);
     const double wavesPerXcdPerBpc = std::max(1, ctx->numCUs / std::max(1, ctx->nXcd)) * 4.0;
     int bpc = (int)std::ceil(8.0 * k * a->slabWidth / wavesPerXcdPerBpc);
@@ -1240,11 +1267,14 @@ static void slab_ctl(ldu_addr* a, ldu_addr::P2PLane& P, SlabCtl& C)
 
 // run-ahead window in chunks: `levels` dependency levels' worth of chunks of k sweeps; 0 (off) when the grid could not
 // run further ahead than that anyway
-static int p2p_window(const ldu_addr* a, long nChunks, int k, int grid)
+static int p2p_window(const ldu_addr* a, long nChunks, int k, int grid, int nLevelsOfQueue = 0)
 {
     const double lv = a->ctx->p2pWindowLevels;
-    if (lv <= 0 || a->nLevels <= 0) return 0;
-    const double perLevel = (double)nChunks / (double)a->nLevels;    // chunks per level, all k sweeps together
+    if (nLevelsOfQueue <= 0) nLevelsOfQueue = a->nLevels;
+    if (lv <= 0 || nLevelsOfQueue <= 0) return 0;
+    // (a slab's queue only spans the slab's levels: measured against ALL levels of the addressing the window of a
+    //  bandCompression-numbered mesh was one level instead of eight - irregular 216^3: one sweep 21.7 instead of 13.8 ms)
+    const double perLevel = (double)nChunks / (double)nLevelsOfQueue;    // chunks per level, all k sweeps together
     long w = (long)(lv * perLevel + 0.5);
     if (w < 8 * k) w = 8 * k;
     return w >= 2L * grid ? 0 : (int)w;
@@ -1269,7 +1299,7 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
         const int grid = ctx->numCUs * slab_bpc(a, 1);
         for (int i = 0; i < a->nSlabs; i++)
             C.window[i] = p2p_window(a, cdiv(a->slabStart[i + 1] - a->slabStart[i], P2P_CHUNK), 1,
-                                     grid / std::max(1, a->nSlabs));
+                                     grid / std::max(1, a->nSlabs), a->slabLevelSpan[i]);
         sweep_slab_kernel<MODE, DESC><<<grid, P2P_BLK, 0, s>>>(TS, C, P.d_granule, P.epoch, ctx->d_abort, g.w,
             g.rhs, g.scale, g.val, g.val2, g.aux);
         LDU_CHECK_HIP(hipGetLastError());
@@ -1356,7 +1386,7 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
         }
         // never on the critical path (the previous sweep runs ahead): back off quickly so that
         // thousands of waiting waves do not starve the waves of the sweep they wait for
-        __builtin_amdgcn_s_sleep(1);
+        p2p_nap(spins, 1);
     }
     xu[BASE + 0] = granule_value(g0);
     xu[BASE + 1] = granule_value(g1);
@@ -1412,7 +1442,7 @@ __device__ __forceinline__ bool gs_gather_old8(const SliceTab& T, const uint4* _
             *abortFlag = 1;
             return false;
         }
-        __builtin_amdgcn_s_sleep(1);
+        p2p_nap(spins, 1);
     }
 #pragma unroll
     for (int q = 0; q < 8; q++) xu[q] = granule_value(g[q]);
@@ -2044,7 +2074,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         const int sgrid = ctx->numCUs * slab_bpc(a, k);
         for (int i = 0; i < a->nSlabs; i++)
             C.window[i] = p2p_window(a, cdiv(it->second.slabStart[i + 1] - it->second.slabStart[i], P2P_CHUNK), k,
-                                     sgrid / std::max(1, a->nSlabs));
+                                     sgrid / std::max(1, a->nSlabs), a->slabLevelSpan[i]);
         sweep_slab_gs_multi_kernel<<<sgrid, P2P_BLK, 0, s>>>(TS, C, k, P.d_granule, tag0,
             ctx->d_abort, psi, rhs, diag, val);
         ctx->profStop(a, 4);

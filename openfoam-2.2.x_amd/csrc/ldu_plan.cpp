@@ -277,6 +277,19 @@ int plan_build(ldu_addr* a)
                 if (sliceSlab[s] == sl) slabList.push_back(s);
         }
         for (int sl = S; sl <= 8; sl++) a->slabStart[sl] = (int)slabList.size();
+        // dependency levels each slab spans: all of them on a natural numbering (slabs = slices across the level
+        // planes), one eighth when the numbering follows the levels (bandCompression) - what the run-ahead window
+        // of a slab's queue is measured in
+        {
+            std::vector<int> lo(S, nLevels), hi(S, -1);
+            for (int L = 0; L < nLevels; L++)
+                for (int s = a->levelSliceStart[L]; s < a->levelSliceStart[L + 1]; s++)
+                {
+                    lo[sliceSlab[s]] = std::min(lo[sliceSlab[s]], L);
+                    hi[sliceSlab[s]] = std::max(hi[sliceSlab[s]], L);
+                }
+            for (int sl = 0; sl < 8; sl++) a->slabLevelSpan[sl] = sl < S && hi[sl] >= lo[sl] ? hi[sl] - lo[sl] + 1 : 1;
+        }
         colX = col;
         xflag.assign(nC, 0);
         if (S > 1)
