@@ -1,10 +1,11 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-run() { n=$1; shift; echo "== $n"; env "$@" PROBE_KS=1,3,4 timeout 300 python tools/irregular_probe.py 216 2>&1 | grep -E "^GS|^DIC" | tr '\n' ' '; echo; }
-run auto X=1
-run bpc1 LDU_SLAB_BPC=1
-run bpc2 LDU_SLAB_BPC=2
-run bpc3 LDU_SLAB_BPC=3
-run bpc4 LDU_SLAB_BPC=4
-run bpc1_win16 LDU_SLAB_BPC=1 LDU_P2P_WINDOW=16
+run() { n=$1; shift; echo "== $n"; env "$@" PROBE_KS=1,2,3,4 timeout 300 python tools/irregular_probe.py 216 2>&1 | grep -E "^GS|^DIC" | tr '\n' ' '; echo; }
+run pairs X=1
+timeout 900 python tools/irregular_gamg_probe.py 216 2>&1 | grep "^irregular"
+LDU_GS_PAIRSKEW=1000000 timeout 900 python tools/irregular_gamg_probe.py 216 2>&1 | grep "^irregular"
+timeout 900 python tools/irregular_gamg_probe.py 100 2>&1 | grep "^irregular"
+timeout 600 python bench.py --no-cpu --no-extras --steps 10 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('box',d['value'],d['roofline']['avg_launch_ms'])"
+timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -1
