@@ -237,16 +237,20 @@ def main():
         # what the OpenFOAM shim pays today: diag/upper/source/psi handed over as pageable HOST arrays every solve
         # (PCIe-inclusive; never `value`)
         if world == 1:
+            # (only the library calls are timed: the caller's own array handling - zeroing psi - is not the boundary's)
             h_psi = np.zeros(lp["nCells"])
-            t0 = time.perf_counter()
+            tH = 0.0
             itsH = 0
-            for _ in range(2):
+            for _ in range(3):
                 h_psi[:] = 0.0
+                barrier()
+                t0 = time.perf_counter()
                 mat.set_coeffs(lp["diag"], lp["upper"])
-                _, ph = mat.solve(h_psi, lp["source"], history=False, **GAMG_CONTROLS)
+                _, ph = mat.solve(h_psi, lp["source"], history=False, inplace=True, **GAMG_CONTROLS)
+                barrier()
+                tH += time.perf_counter() - t0
                 itsH += ph["nIterations"]
-            barrier()
-            extra["host_pointer_path_vcycles_per_s"] = round(itsH / (time.perf_counter() - t0), 2)
+            extra["host_pointer_path_vcycles_per_s"] = round(itsH / tH, 2)
             mat.set_coeffs(d_diag, d_upper)
       except Exception as e:  # pragma: no cover
         extra["host_path_error"] = str(e)

@@ -402,15 +402,21 @@ class Matrix:
         _chk(lib().ldu_smooth(self.h, SMOOTHERS[smoother], _ptr(x), _ptr(_f64(source)), int(nSweeps)))
         return x
 
-    def solve(self, psi, source, history=True, **controls):
-        """psi, source: numpy arrays (psi is copied) or device tensors (psi updated in place)."""
+    def solve(self, psi, source, history=True, inplace=False, **controls):
+        """psi, source: numpy arrays (psi is copied unless inplace=True: then the C-contiguous float64 array is handed
+        to the library as it is, like the OpenFOAM shim hands over psi.begin()) or device tensors (psi updated in place)."""
         c = make_controls(**controls)
         cap = c.maxIter + 3
         hist = np.zeros(cap)
         c.historyCapacity = cap if history else 0
         perf = Perf()
         if isinstance(psi, np.ndarray):
-            x = np.array(psi, dtype=np.float64, copy=True)
+            if inplace:
+                if psi.dtype != np.float64 or not psi.flags["C_CONTIGUOUS"]:
+                    raise ValueError("inplace solve needs a C-contiguous float64 array")
+                x = psi
+            else:
+                x = np.array(psi, dtype=np.float64, copy=True)
         else:
             x = psi
         _chk(lib().ldu_solve(self.h, C.byref(c), _ptr(x), _ptr(_f64(source)), C.byref(perf), _ptr(hist)))
