@@ -360,6 +360,19 @@ static int dev_normFactor(ldu_matrix* m, const double* psi, const double* source
 
 // ---------------------------------------------------------------- PCG / PBiCG
 
+// An error return out of the Krylov loop may leave work forked onto the second stream (PBiCG's transposed system):
+// join it before the caller sees the error, so that nothing of this solve is still running behind its back.
+static int krylov_joined(ldu_matrix* m, int rc)
+{
+    if (rc < 0)
+    {
+        ldu_ctx* ctx = m->a->ctx;
+        (void)hipStreamSynchronize(ctx->stream2);
+        ctx->dualActive = 0;
+    }
+    return rc;
+}
+
 static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source,
                         ldu_perf* perf, double* hist, bool bi)
 {
@@ -538,9 +551,9 @@ int dev_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
             ldu_set_error("Unknown asymmetric matrix solver PCG (lduMatrixSolver.C:96-110)");
             return -16;
         }
-        return solve_krylov(m, c, psi, source, perf, hist, false);
+        return krylov_joined(m, solve_krylov(m, c, psi, source, perf, hist, false));
     case LDU_SOLVER_PBICG:
-        return solve_krylov(m, c, psi, source, perf, hist, true);
+        return krylov_joined(m, solve_krylov(m, c, psi, source, perf, hist, true));
     case LDU_SOLVER_SMOOTH:
         return solve_smooth(m, c, psi, source, perf, hist);
     case LDU_SOLVER_GAMG:
