@@ -198,6 +198,11 @@ int ldu_debug_p2p_stuck(ldu_matrix* m, int32_t out[16]);
  * steps done, stores acknowledged [100 MHz wall clock], polls, XCC id, workgroup), or NULL to switch tracing off.
  * ldu_debug_cluster_levels: out[0] = clusters, out[1] = cluster levels, out[2..] = first cluster of every level. */
 int ldu_debug_cluster_trace(ldu_matrix* m, void* buf);
+/* The same for the pipelined sweeps of the level engines: 8 x u64 per (sweep, slice) - start, upper values there,
+ * lower values there, stored [100 MHz wall clock], XCC id, workgroup; buf = nSweeps * nSlices * 64 bytes of device
+ * memory or NULL.  ldu_debug_slice_levels: out[0] = dependency levels, out[1..] = first slice of every level. */
+int ldu_debug_gs_multi_trace(ldu_matrix* m, void* buf);
+int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap);
 int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap);
 /* Debug: the GaussSeidel rows end in `curPsi /= diagPtr[cellI]` (GaussSeidelSmoother.C:154); the sweep kernels do the
  * denominator's half of that IEEE division ahead of the dependency wait.  This runs n operand pairs (random bit

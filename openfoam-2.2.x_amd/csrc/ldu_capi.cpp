@@ -695,6 +695,21 @@ int ldu_debug_cluster_trace(ldu_matrix* m, void* buf)
     return k_cluster_set_trace((unsigned long long*)buf);
 }
 
+int ldu_debug_gs_multi_trace(ldu_matrix* m, void* buf)
+{
+    LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+    return k_set_gs_multi_trace((unsigned long long*)buf, m->a->nSlices);
+}
+
+int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap)
+{
+    const ldu_addr* a = m->a;
+    if (cap < a->nLevels + 2) { ldu_set_error("ldu_debug_slice_levels: buffer too small"); return -1; }
+    out[0] = a->nLevels;
+    for (int L = 0; L <= a->nLevels; L++) out[1 + L] = a->levelSliceStart[L];
+    return 0;
+}
+
 int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap)
 {
     return k_cluster_levels(m->a, out, cap);

@@ -447,6 +447,7 @@ static inline int run_with_fallback(ldu_matrix* m, F&& op)
 }
 int k_div_check(ldu_ctx* ctx, unsigned long long seed, long n, unsigned long long* mismatches);
 int k_set_p2p_wide(int on);
+int k_set_gs_multi_trace(unsigned long long* buf, int nSlices);
 int k_set_spin_limit(unsigned polls);          // ldu_kernels.hip (0 = default)
 int k_cluster_set_spin_limit(unsigned polls);  // ldu_cluster.hip
 int k_cluster_set_trace(unsigned long long* buf);

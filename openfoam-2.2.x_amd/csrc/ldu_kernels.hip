@@ -1201,6 +1201,15 @@ int k_xcd_census(ldu_ctx* ctx)
     return 0;
 }
 
+// the slabs' level ranges do not overlap much: sum of the spans < 2 x the number of levels
+static bool slabs_sequential(const ldu_addr* a)
+{
+    if (a->nSlabs < 2) return false;
+    long sum = 0;
+    for (int i = 0; i < a->nSlabs; i++) sum += a->slabLevelSpan[i];
+    return sum < 2L * a->nLevels;
+}
+
 // Workgroups per CU of a slab-engine launch with k sweeps in flight.  Every waiting wave slows the
 // hand-offs of its CU (measured: 0.86 us per level at 1 workgroup per CU, 1.0 at 2, 1.1 at 3), but
 // too few waves cannot cover the several dependent loads a slice needs before it can wait: about
@@ -1214,6 +1223,15 @@ static int slab_bpc(const ldu_addr* a, int k)
     }
     if (ctx->p2pBpcForced) return std::min(ctx->p2pBlocksPerCU * k, ctx->p2pMaxBlocksPerCU);
     const double wavesPerXcdPerBpc = std::max(1, ctx->numCUs / std::max(1, ctx->nXcd)) * 4.0;
+    if (slabs_sequential(a))
+    {
+        // one slab (one XCD) carries a whole dependency level, and the k sweeps sit in different slabs: two levels
+        // of look-ahead per XCD; more waiting waves only slow the hand-offs (irregular 216^3 graph, 44 slices per
+        // level: 4 sweeps 15.9 / 22.0 / 32.5 ms at 1 / 2 / 3 workgroups per CU)
+        const double levelWidth = (double)a->nCells / LDU_WAVE / std::max(1, a->nLevels);
+        const int b = (int)std::ceil(2.0 * levelWidth / wavesPerXcdPerBpc);
+        return std::max(1, std::min(b, std::min(4, ctx->p2pMaxBlocksPerCU)));
+    }
     int bpc = (int)std::ceil(8.0 * k * a->slabWidth / wavesPerXcdPerBpc);
     return std::max(1, std::min(bpc, std::min(4, ctx->p2pMaxBlocksPerCU)));
 }
@@ -1234,6 +1252,11 @@ static bool use_slab(const ldu_addr* a, int kind, int k = 1)
     if (kind == 0) return a->slabWidth <= 24.0;
     if (kind == 1) return a->slabWidth <= 16.0;
     if (k <= 2) return k * a->slabWidth <= 14.0;
+    // Slabs that follow one another along the dependency levels (numberings whose index ranges follow the levels:
+    // bandCompression): every level lies in ONE slab, the k sweeps of a launch sit in k different slabs most of the
+    // time, each front on its own XCD with same-XCD hand-offs.  The chip-wide engine, with all k fronts polled for
+    // by the whole chip, took 9-11 us per level there (irregular 216^3 graph, tools/gsm_trace.py: 4 sweeps 40.8 ms).
+    if (slabs_sequential(a)) return (double)a->nCells / LDU_WAVE / std::max(1, a->nLevels) <= 96.0;
     return a->nSlabs == 1 && k * a->slabWidth <= 10.0;
 }
 
@@ -1336,6 +1359,17 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     P.ticketBase += (unsigned)(nChunks + grid);
     if (window) P.doneBase += (unsigned)nChunks;
     LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Debug: per-task timeline of the pipelined GaussSeidel sweeps of the level engines (ldu_debug_gs_multi_trace):
+// 8 x u64 per (sweep, slice): tStart, tUpperDone, tLowerDone, tStored [100 MHz wall clock], XCC id, workgroup, 0, 0
+__device__ unsigned long long* g_gsm_trace = nullptr;
+__device__ int g_gsm_trace_stride = 0;
+int k_set_gs_multi_trace(unsigned long long* buf, int nSlices)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gsm_trace), &buf, sizeof(buf)));
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gsm_trace_stride), &nSlices, sizeof(int)));
     return 0;
 }
 
@@ -1467,6 +1501,8 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
 {
     const int cnt = T.sliceCnt[s];
     if (lane >= cnt) return;
+    unsigned long long* const trc = g_gsm_trace ? g_gsm_trace + ((size_t)j * (size_t)g_gsm_trace_stride + (size_t)s) * 8 : nullptr;
+    if (trc && lane == 0) trc[0] = (unsigned long long)wall_clock64();
     const int r = T.sliceRow[s] + lane;
     const int nl = T.nL[r];
     const int nu = T.nU[r];
@@ -1507,8 +1543,10 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
             }
         }
     }
+    if (trc && lane == 0) trc[1] = (unsigned long long)wall_clock64();
     // 2. new values of the lower neighbours (the critical path)
     if (!p2p_accumulate<0, false, SLAB>(acc, G, X, tagNew, T.col, val, nullptr, ent, 0, 1, nl, r, abortFlag, waitEst)) return;
+    if (trc && lane == 0) trc[2] = (unsigned long long)wall_clock64();
     // 3. upper part, in face order
     if (nuFast >= 0)
     {
@@ -1532,6 +1570,12 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
     if (j == k - 1) psi[r] = out;
     if (SLAB) granule_store_slab(G, X, r, out, tagNew, exported);
     else granule_store(G, r, out, tagNew);
+    if (trc && lane == 0)
+    {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trc[3] = (unsigned long long)wall_clock64(); trc[4] = xcc & 0xf; trc[5] = blockIdx.x;
+    }
 }
 
 __global__ void __launch_bounds__(P2P_BLK)

@@ -202,3 +202,64 @@ def test_cluster_trace_timeline():
     for q in range(4):
         assert np.all(T[:, :, q] <= T[:, :, q + 1])
     assert np.all(T[:, :, 5] >= 0) and np.all(T[:, :, 6] < 8)
+
+
+def test_pipelined_sweeps_on_level_following_numbering_bitexact(oracle):
+    """An irregular graph renumbered by Foam::bandCompression: cell indices follow the dependency levels, the XCD slabs
+    lie one behind the other along the levels and every level sits in ONE slab.  1 ... 4 pipelined GaussSeidel sweeps
+    (the slab engine takes all of them there), DIC and two repeats must reproduce the oracle bit for bit; the timeline
+    of the level engines (ldu_debug_gs_multi_trace) must be complete and ordered."""
+    import ctypes as C
+    p = cases.irregular_box(56)
+    order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+    nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+    p = cases.renumbered(p, order, fmap, flip, nl, nu)
+    rng = np.random.RandomState(5)
+    psi, src = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+    S = oracle.System(p)
+    exp = {k: S.smooth("GaussSeidel", psi, src, k) for k in (1, 2, 3, 4)}
+    dic = S.precondition("DIC", src)[0]
+    for env in ({}, {"LDU_P2P_SLABS": "0"}):
+        saved = {k: os.environ.pop(k, None) for k in KEYS}
+        os.environ.update(env)
+        try:
+            ctx = capi.Context(0)
+            a, m = capi.from_problem(ctx, p)
+            for rep in range(2):
+                for k in (1, 2, 3, 4):
+                    assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), exp[k]), (env, k, rep)
+                assert np.array_equal(m.precondition("DIC", src), dic), (env, "dic", rep)
+            assert ctx.fallback_count() == 0
+            if not env:
+                # timeline of 3 pipelined sweeps
+                L = capi.lib()
+                nS = a.info()["nSlices"]
+                hip = C.CDLL("libamdhip64.so")
+                hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+                hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+                hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                hip.hipFree.argtypes = [C.c_void_p]
+                nbytes = 3 * nS * 64
+                buf = C.c_void_p()
+                assert hip.hipMalloc(C.byref(buf), nbytes) == 0
+                try:
+                    assert hip.hipMemset(buf, 0, nbytes) == 0 and hip.hipDeviceSynchronize() == 0
+                    L.ldu_debug_gs_multi_trace.argtypes = [C.c_void_p, C.c_void_p]
+                    capi._chk(L.ldu_debug_gs_multi_trace(m.h, buf))
+                    try:
+                        got = m.smooth("GaussSeidel", psi, src, 3)
+                    finally:
+                        capi._chk(L.ldu_debug_gs_multi_trace(m.h, None))
+                    T = np.zeros(3 * nS * 8, dtype=np.int64)
+                    assert hip.hipMemcpy(T.ctypes.data, buf, nbytes, 2) == 0
+                finally:
+                    hip.hipFree(buf)
+                assert np.array_equal(got, exp[3])
+                T = T.reshape(3, nS, 8)
+                assert np.all(T[:, :, 0] > 0)
+                for q in range(3):
+                    assert np.all(T[:, :, q] <= T[:, :, q + 1])
+        finally:
+            for k in KEYS:
+                os.environ.pop(k, None)
+            os.environ.update({k: v for k, v in saved.items() if v is not None})
