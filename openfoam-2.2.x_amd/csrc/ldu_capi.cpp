@@ -158,6 +158,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->smallMaxCells = std::min(atoi(e), 16384);
     e = getenv("LDU_P2P_WIDE");
     if (e) k_set_p2p_wide(atoi(e));
+    e = getenv("LDU_GS_WIDE_UPPER");
+    if (e) c->gsWideUpper = atoi(e);
     e = getenv("LDU_SMALL_PIPE");
     if (e) c->smallPipe = atoi(e);
     e = getenv("LDU_P2P_SLABS");

@@ -86,6 +86,7 @@ struct ldu_ctx {
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
+    int gsWideUpper = 1;             // LDU_GS_WIDE_UPPER=0: upper parts of more than 8 entries after the lower part (round-1 order)
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
@@ -207,6 +208,7 @@ struct ldu_addr {
     double slabWidth = 0;                  // average slices per level per slab (sizes the grid)
     int slabStart[9] = {0};                // offsets into slabList
     int slabLevelSpan[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // dependency levels a slab's slices span
+    int maxUpper = 0;                      // most upper neighbours of a row
     int* d_slabList = nullptr;             // [nSlices]
     int* d_colX = nullptr;                 // [nEntries]
     unsigned char* d_xflag = nullptr;      // [nCells] 1 = has a neighbour in another slab

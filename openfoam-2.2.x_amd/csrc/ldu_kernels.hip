@@ -1483,6 +1483,72 @@ __device__ __forceinline__ bool gs_gather_old8(const SliceTab& T, const uint4* _
     return true;
 }
 
+// Rows with more than eight upper neighbours (agglomerated levels of an irregular mesh: 10-15 of them): the products
+// coefficient x old value of entries base .. base+7 of the upper part, for the lanes with `active`.  Sweep 0 reads the
+// old psi, a later sweep the previous sweep's granules (tag t).
+template <bool SLAB>
+__device__ __forceinline__ bool gs_upper_block(const SliceTab& T, const uint4* __restrict__ G,
+                                               const uint4* __restrict__ X, bool first, unsigned t,
+                                               const double* __restrict__ psi, const double* __restrict__ val,
+                                               long ent, int nl, int nu, int base, bool active, int selfRow,
+                                               volatile int* abortFlag, double (&pu)[8])
+{
+    int c[8];
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+    {
+        const bool need = active && base + q < nu;
+        const long e = ent + (long)(nl + base + q) * LDU_WAVE;
+        c[q] = need ? T.col[e] : selfRow;
+        v[q] = need ? val[e] : 0.0;
+    }
+    if (first)
+    {
+        double x[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = psi[c[q] & 0x7fffffff];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pu[q] = v[q] * x[q];
+        return true;
+    }
+    const uint4* gp[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
+    u32x4 g[8];
+    unsigned spins = 0;
+    const unsigned spinLimit = g_p2p_spin_limit;
+    for (;;)
+    {
+        granule_load8(gp, g);
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (active && base + q < nu) ok &= (g[q].y == t) & (g[q].w == t);
+        if (ok) break;
+        if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+        {
+            if (spins > spinLimit)
+            {
+                bool rec = false;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (!rec && active && base + q < nu && !((g[q].y == t) & (g[q].w == t)))
+                    {
+                        p2p_dbg_record(2, selfRow, t, c[q], g[q].y, g[q].w, base + q);
+                        rec = true;
+                    }
+            }
+            *abortFlag = 1;
+            return false;
+        }
+        p2p_nap(spins, 1);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) pu[q] = v[q] * granule_value(g[q]);
+    return true;
+}
+
 // k consecutive GaussSeidel sweeps of the SAME matrix in ONE launch.  Sweep j+1 of a row only needs
 // sweep j's values of its UPPER neighbours (its "old" values) and sweep j+1's values of its LOWER
 // neighbours, so sweep j+1 can trail sweep j by the level distance to the upper neighbours: the
@@ -1497,7 +1563,8 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
                                             volatile int* abortFlag, double* __restrict__ psi,
                                             const double* __restrict__ rhs,
                                             const double* __restrict__ diag,
-                                            const double* __restrict__ val, P2PStat& waitEst)
+                                            const double* __restrict__ val, P2PStat& waitEst,
+                                            double* __restrict__ puLds = nullptr, int puSlots = 0)
 {
     const int cnt = T.sliceCnt[s];
     if (lane >= cnt) return;
@@ -1516,6 +1583,22 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
     //    which are long published (that sweep runs ahead of this one)
     double xu[8], vu[8];
     const int nuFast = nu <= 8 ? nu : -1;
+    // Wider upper parts: their products are formed HERE, before the wait for the lower neighbours, and parked in this
+    // lane's LDS slots (subtracted in face order after the lower part, as the reference does).  Left to the end - one
+    // dependent column / value round trip per entry after the lower neighbours had arrived - they were most of a
+    // dependency level's time on agglomerated levels (20-29 neighbours per row: 8-20 us per level).
+    const bool puWide = nuFast < 0 && nu <= puSlots;
+    if (__any(puWide))
+    {
+        for (int b = 0; b < puSlots && __any(puWide && nu > b); b += 8)
+        {
+            double pb[8];
+            if (!gs_upper_block<SLAB>(T, G, X, j == 0, tagNew - 1u, psi, val, ent, nl, nu, b, puWide, r, abortFlag, pb)) return;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (puWide && b + q < nu) puLds[(b + q) * LDU_WAVE + lane] = pb[q];
+        }
+    }
     if (nuFast >= 0)
     {
         if (j == 0)
@@ -1554,6 +1637,10 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
         for (int q = 0; q < 8; q++)
             if (q < nuFast) acc -= vu[q] * xu[q];
     }
+    else if (puWide)
+    {
+        for (int q = 0; q < nu; q++) acc -= puLds[q * LDU_WAVE + lane];
+    }
     else if (j == 0)
     {
         for (int q = nl; q < nl + nu; q++)
@@ -1581,9 +1668,11 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
 __global__ void __launch_bounds__(P2P_BLK)
 sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
                           unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
-                          int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val)
+                          int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val,
+                          int puSlots)
 {
     __shared__ int s_chunk[2];
+    extern __shared__ double s_pu[];   // [wave][puSlots][64]: parked products of wide upper parts
     unsigned* const done = ticket + 32;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -1610,7 +1699,8 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
             if (task >= 0)
             {
                 const int sl = task & 0x0fffffff;
-                p2p_gs_task<false>(T, sl, task >> 28, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst);
+                p2p_gs_task<false>(T, sl, task >> 28, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst,
+                                   s_pu + (size_t)wave * puSlots * LDU_WAVE, puSlots);
             }
         }
         if (window) __syncthreads();
@@ -1621,9 +1711,10 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
 // (slab engine twin of sweep_p2p_gs_multi_kernel: per-slab task queues)
 __global__ void __launch_bounds__(P2P_BLK)
 sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0, int* abortFlag, double* psi,
-                           const double* rhs, const double* diag, const double* val)
+                           const double* rhs, const double* diag, const double* val, int puSlots)
 {
     __shared__ int s_chunk[2];
+    extern __shared__ double s_pu[];   // [wave][puSlots][64]
     const int slab = xcc_id();
     if (slab >= C.nSlabs) return;
     const int wave = threadIdx.x >> 6;
@@ -1660,7 +1751,7 @@ sweep_slab_gs_multi_kernel(SliceTab T, SlabCtl C, int k, uint4* G, unsigned tag0
         {
             const int task = C.list[first + ti];
             p2p_gs_task<true>(T, task & 0x0fffffff, task >> 28, k, lane, G, C.X, C.xflag, tag0, abortFlag, psi,
-                              rhs, diag, val, waitEst);
+                              rhs, diag, val, waitEst, s_pu + (size_t)wave * puSlots * LDU_WAVE, puSlots);
         }
         if (window) __syncthreads();
     }
@@ -1979,6 +2070,13 @@ int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const d
     return 0;
 }
 
+// LDS slots per lane for the parked upper-part products of rows with more than eight upper neighbours (0: none)
+static int gs_pu_slots(const ldu_addr* a)
+{
+    if (a->maxUpper <= 8 || !a->ctx->gsWideUpper) return 0;
+    return std::min(24, (a->maxUpper + 7) / 8 * 8);
+}
+
 // Host side: topological task order for k pipelined sweeps (cached per k in the addressing).
 int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
                      const double* val)
@@ -2087,6 +2185,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     // k sweeps are in flight at once: keep the same look-ahead (in levels) as a single sweep
     int bpc = ctx->p2pBlocksPerCU * k;
     if (bpc > ctx->p2pMaxBlocksPerCU) bpc = ctx->p2pMaxBlocksPerCU;
+    if (gs_pu_slots(a) && bpc > 3) bpc = 3;   // 48 KB of LDS per workgroup
     int grid = ctx->numCUs * bpc * 256 / P2P_BLK;
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
@@ -2115,19 +2214,25 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         slab_ctl(a, P, C);
         C.list = it->second.d_slabTasks;
         for (int i = 0; i <= 8; i++) C.start[i] = it->second.slabStart[i];
-        const int sgrid = ctx->numCUs * slab_bpc(a, k);
+        const int puSlots = gs_pu_slots(a);
+        const size_t puBytes = sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE;
+        int sbpc = slab_bpc(a, k);
+        if (puBytes) sbpc = std::min(sbpc, 3);   // 48 KB of LDS per workgroup
+        const int sgrid = ctx->numCUs * sbpc;
         for (int i = 0; i < a->nSlabs; i++)
             C.window[i] = p2p_window(a, cdiv(it->second.slabStart[i + 1] - it->second.slabStart[i], P2P_CHUNK), k,
                                      sgrid / std::max(1, a->nSlabs), a->slabLevelSpan[i]);
-        sweep_slab_gs_multi_kernel<<<sgrid, P2P_BLK, 0, s>>>(TS, C, k, P.d_granule, tag0,
-            ctx->d_abort, psi, rhs, diag, val);
+        sweep_slab_gs_multi_kernel<<<sgrid, P2P_BLK, puBytes, s>>>(TS, C, k, P.d_granule, tag0,
+            ctx->d_abort, psi, rhs, diag, val, puSlots);
         ctx->profStop(a, 4);
         LDU_CHECK_HIP(hipGetLastError());
         return 0;
     }
     const int window = p2p_window(a, nChunks, k, grid);
-    sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, 0, s>>>(T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
-            P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val);
+    const int puSlots = gs_pu_slots(a);
+    sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE, s>>>(
+            T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
+            P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val, puSlots);
     ctx->profStop(a, 4);
     P.ticketBase += (unsigned)(nChunks + grid);
     if (window) P.doneBase += (unsigned)nChunks;

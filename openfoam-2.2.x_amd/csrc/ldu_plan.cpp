@@ -204,6 +204,7 @@ int plan_build(ldu_addr* a)
         }
         nL[r] = (unsigned char)cl;
         nU[r] = (unsigned char)cu;
+        a->maxUpper = std::max(a->maxUpper, cu);
     }
     long ent = 0;
     for (int L = 0; L < nLevels; L++)
