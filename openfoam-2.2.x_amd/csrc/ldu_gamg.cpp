@@ -655,8 +655,11 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
             (void)hipEventRecord(e1, s);
             (void)hipEventSynchronize(e1);
             (void)hipEventElapsedTime(&ms, e0, e1);
-            fprintf(stderr, "[ldugpu] level %2d: %9d cells %5d dag-levels %d slabs width %.1f maxrow %d: %d sweeps %.3f ms\n",
-                    leveli + 1, n, L.addr->nLevels, L.addr->nSlabs, L.addr->slabWidth, L.addr->maxRowWidth, nPost, ms);
+            long span = 0;
+            for (int i = 0; i < L.addr->nSlabs; i++) span += L.addr->slabLevelSpan[i];
+            fprintf(stderr, "[ldugpu] level %2d: %9d cells %5d dag-levels %d slabs (spans %.2f x levels) width %.1f maxrow %d: %d sweeps %.3f ms\n",
+                    leveli + 1, n, L.addr->nLevels, L.addr->nSlabs, (double)span / std::max(1, L.addr->nLevels),
+                    L.addr->slabWidth, L.addr->maxRowWidth, nPost, ms);
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
     }

@@ -1201,13 +1201,15 @@ int k_xcd_census(ldu_ctx* ctx)
     return 0;
 }
 
-// the slabs' level ranges do not overlap much: sum of the spans < 2 x the number of levels
+// the slabs' level ranges overlap little: sum of the spans < 3 x the number of levels (a natural numbering, where the
+// slabs cut across the level planes: ~ nSlabs x; bandCompression-numbered graph and its agglomerated levels: 1.3 - 2.4 x)
 static bool slabs_sequential(const ldu_addr* a)
 {
     if (a->nSlabs < 2) return false;
     long sum = 0;
     for (int i = 0; i < a->nSlabs; i++) sum += a->slabLevelSpan[i];
-    return sum < 2L * a->nLevels;
+    static const double factor = getenv("LDU_SLAB_SEQ_FACTOR") ? atof(getenv("LDU_SLAB_SEQ_FACTOR")) : 3.0;
+    return (double)sum < factor * a->nLevels;
 }
 
 // Workgroups per CU of a slab-engine launch with k sweeps in flight.  Every waiting wave slows the
