@@ -1,9 +1,12 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-LDU_GAMG_TIME=1 timeout 900 python tools/irregular_gamg_probe.py 216 2>&1 | grep "level " | sed -n 33,38p | cut -c1-170
-for f in 2 3 4 9; do echo "factor $f"; LDU_SLAB_SEQ_FACTOR=$f timeout 900 python tools/irregular_gamg_probe.py 216 2>&1 | grep "^irregular"; done
-LDU_SLAB_SEQ_FACTOR=4 timeout 600 python bench.py --no-cpu --no-extras --steps 10 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('box f4',d['value'],d['roofline']['avg_launch_ms'])"
-LDU_SLAB_SEQ_FACTOR=9 timeout 600 python bench.py --no-cpu --no-extras --steps 10 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('box f9',d['value'],d['roofline']['avg_launch_ms'])"
+mkdir -p gpurun_out/r2final4
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed" | tail -1
+timeout 900 python bench.py --mesh irregular --no-cpu --no-extras > gpurun_out/r2final4/bench_irregular.json 2>/dev/null; python -c "
+import json;d=json.load(open('gpurun_out/r2final4/bench_irregular.json'));print('irregular bench',d['value'],d['roofline']['avg_launch_ms'],d['config']['engine_fallbacks'])"
+timeout 900 python bench.py --mesh renumbered --no-cpu --no-extras > gpurun_out/r2final4/bench_renumbered.json 2>/dev/null; python -c "
+import json;d=json.load(open('gpurun_out/r2final4/bench_renumbered.json'));print('renumbered bench',d['value'],d['roofline']['avg_launch_ms'],d['config']['engine_fallbacks'])"
+timeout 900 python bench.py > gpurun_out/r2final4/bench_default.json 2>/dev/null; python -c "
+import json;d=json.load(open('gpurun_out/r2final4/bench_default.json'));print('default bench',d['value'],d['roofline']['avg_launch_ms'],d['roofline']['frac'],d['roofline_vcycle']['frac'],d['extra'])"
+timeout 400 python tools/fuzz_gpu.py 300 8086 2>&1 | tail -1
