@@ -888,6 +888,13 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
     return true;
 }
 
+template <bool SLAB>
+__device__ __forceinline__ bool gs_upper_block(const SliceTab& T, const uint4* __restrict__ G,
+                                               const uint4* __restrict__ X, bool first, unsigned t,
+                                               const double* __restrict__ psi, const double* __restrict__ val,
+                                               long ent, int nl, int nu, int base, bool active, int selfRow,
+                                               volatile int* abortFlag, double (&pu)[8]);
+
 template <int MODE, bool DIAG = false, bool SLAB = false>
 __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, uint4* __restrict__ G,
                                           uint4* __restrict__ X, const unsigned char* __restrict__ xflag,
@@ -896,7 +903,7 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
                                           const double* __restrict__ scale,
                                           const double* __restrict__ val,
                                           const double* __restrict__ val2, double* __restrict__ aux,
-                                          P2PStat& waitEst)
+                                          P2PStat& waitEst, double* __restrict__ puLds = nullptr, int puSlots = 0)
 {
     const int cnt = T.sliceCnt[s];
     if (lane >= cnt) return true;
@@ -947,6 +954,19 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
                 xu[j] = w[T.col[e] & 0x7fffffff];
             }
         }
+        // wider upper parts: products formed before the wait, parked in this lane's LDS slots (see p2p_gs_task)
+        const bool puWide = nu > 8 && nu <= puSlots;
+        if (__any(puWide))
+        {
+            for (int b = 0; b < puSlots && __any(puWide && nu > b); b += 8)
+            {
+                double pb[8];
+                if (!gs_upper_block<SLAB>(T, G, X, true, 0u, w, val, ent, nl, nu, b, puWide, r, abortFlag, pb)) return false;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (puWide && b + q < nu) puLds[(b + q) * LDU_WAVE + lane] = pb[q];
+            }
+        }
         if (!p2p_accumulate<0, DIAG, SLAB>(acc, G, X, tag, T.col, val, val2, ent, 0, 1, nl, r, abortFlag, waitEst)) return false;
         if (aux) aux[r] = acc;
         if (nuFast)
@@ -954,6 +974,10 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 if (j < nuFast) acc -= vu[j] * xu[j];
+        }
+        else if (puWide)
+        {
+            for (int q = 0; q < nu; q++) acc -= puLds[q * LDU_WAVE + lane];
         }
         else
         {
@@ -1007,9 +1031,11 @@ __device__ __forceinline__ int xcc_id()
 template <int MODE, bool DESC>
 __global__ void __launch_bounds__(P2P_BLK)
 sweep_slab_kernel(SliceTab T, SlabCtl C, uint4* G, unsigned tag, int* abortFlag, double* w,
-                  const double* rhs, const double* scale, const double* val, const double* val2, double* aux)
+                  const double* rhs, const double* scale, const double* val, const double* val2, double* aux,
+                  int puSlots)
 {
     __shared__ int s_chunk[2];
+    extern __shared__ double s_pu[];   // [wave][puSlots][64] (GaussSeidel rows with wide upper parts)
     const int slab = xcc_id();
     if (slab >= C.nSlabs) return;
     const int wave = threadIdx.x >> 6;
@@ -1046,7 +1072,7 @@ sweep_slab_kernel(SliceTab T, SlabCtl C, uint4* G, unsigned tag, int* abortFlag,
         {
             const int s = C.list[first + (DESC ? nSl - 1 - si : si)];
             p2p_slice<MODE, false, true>(T, s, lane, G, C.X, C.xflag, tag, abortFlag, w, rhs, scale, val, val2,
-                                         aux, waitEst);
+                                         aux, waitEst, s_pu + (size_t)wave * puSlots * LDU_WAVE, puSlots);
         }
         if (window) __syncthreads();
     }
@@ -1057,10 +1083,11 @@ __global__ void __launch_bounds__(P2P_BLK)
 sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigned ticketBase, int window,
                  unsigned doneBase, uint4* G,
                  unsigned tag, int* abortFlag, double* w, const double* rhs, const double* scale,
-                 const double* val, const double* val2, double* aux)
+                 const double* val, const double* val2, double* aux, int puSlots)
 {
     unsigned* const done = ticket + 32;   // chunks reported complete (own cache line)
     __shared__ int s_chunk[2];
+    extern __shared__ double s_pu[];   // [wave][puSlots][64] (GaussSeidel rows with wide upper parts)
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     P2PStat waitEst = {0, 0, 0, -1, nullptr};   // gate + timestamps / poll count of the current slice
@@ -1093,7 +1120,7 @@ sweep_p2p_kernel(SliceTab T, int nSlices, int nChunks, unsigned* ticket, unsigne
                 waitEst.sliceDone = T.sliceDone;
             }
             p2p_slice<MODE, DIAG, false>(T, s, lane, G, nullptr, nullptr, tag, abortFlag, w, rhs, scale, val, val2,
-                                         aux, waitEst);
+                                         aux, waitEst, s_pu + (size_t)wave * puSlots * LDU_WAVE, puSlots);
             if (DIAG && T.sliceDone && lane == 0)
                 __hip_atomic_store(T.sliceDone + s, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (DIAG && g_p2p_trace && lane == 0)
@@ -1305,6 +1332,13 @@ static int p2p_window(const ldu_addr* a, long nChunks, int k, int grid, int nLev
     return w >= 2L * grid ? 0 : (int)w;
 }
 
+// LDS slots per lane for the parked upper-part products of rows with more than eight upper neighbours (0: none)
+static int gs_pu_slots(const ldu_addr* a)
+{
+    if (a->maxUpper <= 8 || !a->ctx->gsWideUpper) return 0;
+    return std::min(24, (a->maxUpper + 7) / 8 * 8);
+}
+
 template <int MODE, bool DESC>
 static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 {
@@ -1312,6 +1346,9 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     ldu_addr::P2PLane* Pp = a->lane(g.lane);
     if (!Pp) { ldu_set_error("p2p lane allocation failed"); return -1; }
     ldu_addr::P2PLane& P = *Pp;
+    // forward GaussSeidel sweeps park the products of wide upper parts in LDS (see p2p_gs_task)
+    const int puSlots = sw_base(MODE) == SW_GS_FWD ? gs_pu_slots(a) : 0;
+    const size_t puBytes = sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE;
     if (use_slab(a, (sw_base(MODE) == SW_GS_FWD || sw_base(MODE) == SW_GS_BWD) ? 1 : 0))
     {
         SliceTab TS{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_colX};
@@ -1321,12 +1358,12 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
         for (int i = 0; i <= 8; i++) C.start[i] = a->slabStart[i];
         P.epoch++;
         if (P.epoch == 0) P.epoch = 1;
-        const int grid = ctx->numCUs * slab_bpc(a, 1);
+        const int grid = ctx->numCUs * (puBytes ? std::min(slab_bpc(a, 1), 3) : slab_bpc(a, 1));
         for (int i = 0; i < a->nSlabs; i++)
             C.window[i] = p2p_window(a, cdiv(a->slabStart[i + 1] - a->slabStart[i], P2P_CHUNK), 1,
                                      grid / std::max(1, a->nSlabs), a->slabLevelSpan[i]);
-        sweep_slab_kernel<MODE, DESC><<<grid, P2P_BLK, 0, s>>>(TS, C, P.d_granule, P.epoch, ctx->d_abort, g.w,
-            g.rhs, g.scale, g.val, g.val2, g.aux);
+        sweep_slab_kernel<MODE, DESC><<<grid, P2P_BLK, puBytes, s>>>(TS, C, P.d_granule, P.epoch, ctx->d_abort, g.w,
+            g.rhs, g.scale, g.val, g.val2, g.aux, puSlots);
         LDU_CHECK_HIP(hipGetLastError());
         return 0;
     }
@@ -1352,11 +1389,11 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     if (P.epoch == 0) P.epoch = 1;   // tag 0 = never published
     const int window = p2p_window(a, nChunks, 1, grid);
     if (ctx->p2pGate || ctx->p2pTrace)
-        sweep_p2p_kernel<MODE, DESC, true><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, P.d_ticket,
-            P.ticketBase, window, P.doneBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+        sweep_p2p_kernel<MODE, DESC, true><<<grid, P2P_BLK, puBytes, s>>>(T, a->nSlices, nChunks, P.d_ticket,
+            P.ticketBase, window, P.doneBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux, puSlots);
     else
-        sweep_p2p_kernel<MODE, DESC, false><<<grid, P2P_BLK, 0, s>>>(T, a->nSlices, nChunks, P.d_ticket,
-            P.ticketBase, window, P.doneBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux);
+        sweep_p2p_kernel<MODE, DESC, false><<<grid, P2P_BLK, puBytes, s>>>(T, a->nSlices, nChunks, P.d_ticket,
+            P.ticketBase, window, P.doneBase, P.d_granule, P.epoch, ctx->d_abort, g.w, g.rhs, g.scale, g.val, g.val2, g.aux, puSlots);
     // every workgroup overshoots the ticket exactly once; with a window every chunk is reported complete once
     P.ticketBase += (unsigned)(nChunks + grid);
     if (window) P.doneBase += (unsigned)nChunks;
@@ -2070,13 +2107,6 @@ int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const d
     if (rc) return -1;
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
-}
-
-// LDS slots per lane for the parked upper-part products of rows with more than eight upper neighbours (0: none)
-static int gs_pu_slots(const ldu_addr* a)
-{
-    if (a->maxUpper <= 8 || !a->ctx->gsWideUpper) return 0;
-    return std::min(24, (a->maxUpper + 7) / 8 * 8);
 }
 
 // Host side: topological task order for k pipelined sweeps (cached per k in the addressing).

@@ -1,12 +1,8 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r2final4
-timeout 1200 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed" | tail -1
-timeout 900 python bench.py --mesh irregular --no-cpu --no-extras > gpurun_out/r2final4/bench_irregular.json 2>/dev/null; python -c "
-import json;d=json.load(open('gpurun_out/r2final4/bench_irregular.json'));print('irregular bench',d['value'],d['roofline']['avg_launch_ms'],d['config']['engine_fallbacks'])"
-timeout 900 python bench.py --mesh renumbered --no-cpu --no-extras > gpurun_out/r2final4/bench_renumbered.json 2>/dev/null; python -c "
-import json;d=json.load(open('gpurun_out/r2final4/bench_renumbered.json'));print('renumbered bench',d['value'],d['roofline']['avg_launch_ms'],d['config']['engine_fallbacks'])"
-timeout 900 python bench.py > gpurun_out/r2final4/bench_default.json 2>/dev/null; python -c "
-import json;d=json.load(open('gpurun_out/r2final4/bench_default.json'));print('default bench',d['value'],d['roofline']['avg_launch_ms'],d['roofline']['frac'],d['roofline_vcycle']['frac'],d['extra'])"
-timeout 400 python tools/fuzz_gpu.py 300 8086 2>&1 | tail -1
+timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed" | tail -1
+for w in 1 0; do echo "LDU_GS_WIDE_UPPER=$w"; LDU_GS_WIDE_UPPER=$w PROBE_KS=1,2,4 timeout 300 python tools/irregular_probe.py 216 2>&1 | grep -E "^GS|^DIC" | tr '\n' ' '; echo; done
+timeout 600 python bench.py --no-cpu --steps 10 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('box',d['value'],d['roofline']['avg_launch_ms'],d['extra'].get('smoothsolver_gs_iterations_per_s'))"
+timeout 400 python tools/fuzz_gpu.py 240 2718 2>&1 | tail -1
