@@ -173,8 +173,10 @@ row_kernel(int nSlices, const int* __restrict__ sliceRow, const int* __restrict_
             if (k < W)
             {
                 const long e = ent + (long)k * LDU_WAVE;
-                c[k] = col[e];       // padding entries point at the row itself
-                v[k] = val[e];
+                // columns and coefficients are streamed once: nontemporal, so that L2 keeps the x values the gathers
+                // come back for (216^3 Amul 0.1838 -> 0.1784 ms); padding entries point at the row itself
+                c[k] = __builtin_nontemporal_load(col + e);
+                v[k] = __builtin_nontemporal_load(val + e);
             }
 #pragma unroll
         for (int k = 0; k < 8; k++)

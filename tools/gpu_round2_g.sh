@@ -1,11 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-run() { n=$1; shift; echo "== $n"; env "$@" PROBE_KS=1,2,4 timeout 300 python tools/irregular_probe.py 216 2>&1 | grep -E "^GS|^DIC" | tr '\n' ' '; echo; }
-run base X=1
-run sleep4 LDU_P2P_SLEEP=4
-run sleep8 LDU_P2P_SLEEP=8
-run bpc2_sleep4 LDU_SLAB_BPC=2 LDU_P2P_SLEEP=4
-run bpc2_sleep8 LDU_SLAB_BPC=2 LDU_P2P_SLEEP=8
-run bpc2_sleep16 LDU_SLAB_BPC=2 LDU_P2P_SLEEP=16
-run sleep1 LDU_P2P_SLEEP=1
+timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed" | tail -1
+timeout 600 python bench.py --no-cpu --steps 10 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('box',d['value'],d['roofline']['avg_launch_ms'],d['amul']['avg_launch_ms'],d['amul']['frac'],d['extra'].get('pcg_dic_iterations_per_s'),d['extra'].get('pbicg_dilu_iterations_per_s'))"
+timeout 300 python tools/pcg_probe.py 2>&1 | tail -1
