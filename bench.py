@@ -44,12 +44,18 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
-    ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random"], default="box",
+    ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random", "octree", "octree_hexref"],
+                    default="box",
                     help="box: the SURVEY 8d C3 stand-in in blockMesh's natural ordering (the metric's workload); "
                          "renumbered: the same matrix under Foam::bandCompression (what renumberMesh applies); "
                          "irregular: the box plus random diagonal faces (6-12 neighbours per cell, 3-D locality), "
                          "renumbered by Foam::bandCompression - the unstructured stand-in; "
-                         "random: a band-limited random graph (quasi 1-D: ~nC/100 dependency levels, pathological)")
+                         "random: a band-limited random graph (quasi 1-D: ~nC/100 dependency levels, pathological); "
+                         "octree: snappyHexMesh-like castellated octree around a motorBike-sized body (hanging faces, "
+                         "hexRef8 numbering), renumbered by Foam::bandCompression (openfoam-2.2.x_amd/octree.py); "
+                         "octree_hexref: the same in hexRef8's own numbering (what the tutorial's Allrun solves on)")
+    ap.add_argument("--octree-q", type=int, default=14, help="octree background mesh 5q x 2q x 2q (14 -> ~10 M cells)")
+    ap.add_argument("--octree-levels", type=int, nargs=2, default=[6, 7], help="octree surface refinement levels")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCG / asymmetric / host-path legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=0, help="box edge of the CPU sample (0 = same)")
@@ -78,6 +84,15 @@ def main():
     t_gen = time.perf_counter()
     if args.mesh == "random":
         p = cases.random_graph_fast(n ** 3, 7.0, 600)
+    elif args.mesh in ("octree", "octree_hexref"):
+        from openfoam_amd import octree
+        q = args.octree_q
+        p = octree.problem(base=(5 * q, 2 * q, 2 * q), surface_levels=tuple(args.octree_levels))
+        cell_level_hist = np.bincount(p.pop("cellLevel")).tolist()
+        if args.mesh == "octree":
+            order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+            nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+            p = cases.renumbered(p, order, fmap, flip, nl, nu)
     else:
         p = cases.irregular_box(n) if args.mesh == "irregular" else cases.box3d(n)
         if args.mesh in ("renumbered", "irregular"):
@@ -86,6 +101,7 @@ def main():
             p = cases.renumbered(p, order, fmap, flip, nl, nu)
     t_gen = time.perf_counter() - t_gen
     nC_total, nF_total = p["nCells"], int(p["lowerAddr"].size)
+    is_octree = args.mesh.startswith("octree")
     if world > 1 and args.mesh != "box":
         raise SystemExit("bench.py: --mesh %s is a single-GPU measurement" % args.mesh)
 
@@ -305,9 +321,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py
         cn = args.cpu_n or n
-        cp = p if cn == n else cases.box3d(cn)
-        scale = (cn ** 3) / float(n ** 3)
-        note = "" if cn == n else "; scaled by cell count to %d^3" % n
+        cp = p if (cn == n or is_octree) else cases.box3d(cn)
+        scale = 1.0 if is_octree else (cn ** 3) / float(n ** 3)
+        note = "" if (cn == n or is_octree) else "; scaled by cell count to %d^3" % n
         if oracle_py.ref_available():
             # the reference's own libOpenFOAM (oracle/_ref, built from /root/reference by oracle/build_ref.sh)
             # on this host: the same GAMG p-solve, second of two solves (agglomeration cached like the
@@ -336,7 +352,7 @@ def main():
     # core, one thread per sub-domain emulating the reference's MPI ranks (oracle/time_allcores.py); a port, never
     # the reference itself (no MPI in this image)
     cpu_all = None
-    if cpu is not None and not args.no_extras:
+    if cpu is not None and not args.no_extras and not is_octree:
         import subprocess
         cores = max(1, min(os.cpu_count() or 1, 64))
         try:
@@ -366,13 +382,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": ("simpleFoam motorBike ~10M-cell p-solve stand-in: %d^3 hex box "
-                                    "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
-                                    "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total))
+            "config": {"workload": (("simpleFoam motorBike ~10M-cell p-solve twin: castellated octree (background %dx%dx%d, "
+                                     "refinementBox level 4, surface levels %d-%d, hanging faces, cells per refinement level %s; "
+                                     "%d cells, %d faces), laplacian coefficients |Sf|/|d| x (1 + 0.5 u01), GAMG "
+                                     "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)"
+                                     % (5 * args.octree_q, 2 * args.octree_q, 2 * args.octree_q, args.octree_levels[0],
+                                        args.octree_levels[1], cell_level_hist, nC_total, nF_total)) if is_octree else
+                                    ("simpleFoam motorBike ~10M-cell p-solve stand-in: %d^3 hex box "
+                                     "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
+                                     "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total)))
                                    + ({"box": "", "renumbered": "; cells renumbered by Foam::bandCompression",
                                        "irregular": "; NOT the plain box: random diagonal faces added (6-12 neighbours per cell), "
                                                     "renumbered by Foam::bandCompression",
-                                       "random": "; NOT the box: band-limited random graph, 5-9 neighbours per cell"}[args.mesh]),
+                                       "random": "; NOT the box: band-limited random graph, 5-9 neighbours per cell",
+                                       "octree": "; hexRef8 cell numbering renumbered by Foam::bandCompression",
+                                       "octree_hexref": "; hexRef8 cell numbering (parent keeps its label, 7 children appended)"}[args.mesh]),
                        "mesh": args.mesh,
                        "parallelism": "domain decomposition x%d" % world,
                        "vcycles_per_solve": perf["nIterations"],

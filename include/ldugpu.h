@@ -204,11 +204,18 @@ int ldu_debug_cluster_trace(ldu_matrix* m, void* buf);
 int ldu_debug_gs_multi_trace(ldu_matrix* m, void* buf);
 int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap);
 int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap);
+/* ldu_debug_slices: per slice of the level-ordered layout {first row, rows, entries per row, most lower, most upper
+ * neighbours of a row}; out holds 5 * cap values, cap >= slices */
+int ldu_debug_slices(ldu_matrix* m, int32_t* out, int32_t cap);
 /* Debug: the GaussSeidel rows end in `curPsi /= diagPtr[cellI]` (GaussSeidelSmoother.C:154); the sweep kernels do the
  * denominator's half of that IEEE division ahead of the dependency wait.  This runs n operand pairs (random bit
  * patterns, exponents at the edges of the fast range, zeros, denormals, huge values) through that path and through
  * the compiler's division and returns the number of quotients that differ in any bit (must be 0). */
 int ldu_debug_div_check(ldu_ctx* ctx, uint64_t seed, int64_t n, uint64_t* mismatches);
+/* Achievable HBM bandwidth of this device with the library's own stream kernels (McCalpin STREAM, f64): mode 0 copy
+ * a = b (16 B per element), mode 1 triad a = b + s*c (24 B per element); n doubles per array; *seconds = average
+ * launch time over `reps` launches (HIP events on the library's stream).  bench.py: roofline.peak_measured. */
+int ldu_debug_stream(ldu_ctx* ctx, int32_t mode, int64_t n, int32_t reps, double* seconds);
 
 /* ---- finite-volume stencils feeding the matrix ------------- */
 typedef struct ldu_mesh_geom {
@@ -453,6 +460,16 @@ int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAdd
 int ldu_renumber_addressing(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
                             const int32_t* newOrder, int32_t* newLower, int32_t* newUpper, int32_t* faceMap,
                             uint8_t* flip);
+
+/* Host-only plan statistics of an addressing (no device needed): dependency levels of the lower-triangular DAG
+ * (what bounds every sequential sweep of the reference: GaussSeidelSmoother.C:147-176, DICPreconditioner.C:71-122)
+ * and the cluster partition of the cluster sweep engine.  out[0] dependency levels, [1] clusters, [2] cluster levels,
+ * [3] sum and [4] maximum of the clusters' internal steps, [5]/[6] most lower/upper neighbours of a row, [7]/[8] rows
+ * with more than 6/12 lower or upper neighbours, [9] faces between clusters, [10]/[11] widest dependency / cluster
+ * level.  cellLevel[nCells], cellCluster[nCells], clusterLevel[>= clusters] may be NULL. */
+int ldu_debug_dag_stats(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
+                        int32_t maxCellsPerCluster, int64_t out[16], int32_t* cellLevel, int32_t* cellCluster,
+                        int32_t* clusterLevel);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,7 @@ EXPORTS = [
     "ldu_fv_faceScale", "ldu_fvc_correctedSnGrad", "ldu_fv_interpolateBoundary", "ldu_fvc_gaussGradBoundary",
     "ldu_fvc_surfaceIntegrateFull", "ldu_fvm_sourceMinusVDiv", "ldu_fv_tensorGammaFactors",
     "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
+    "ldu_debug_dag_stats", "ldu_debug_stream", "ldu_debug_slices",
 ]
 
 # LduMatrix<Type, scalar, scalar> run-time selection names (Solvers/*/*.H TypeName)
@@ -181,6 +182,14 @@ class Context:
         f.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
         _chk(f(self.h, seed, n, C.byref(bad)))
         return int(bad.value)
+
+    def stream(self, mode, n, reps=10):
+        """ldu_debug_stream: GB/s of the copy (mode 0, 16 B/element) or triad (mode 1, 24 B/element) kernel on n doubles"""
+        sec = C.c_double()
+        f = lib().ldu_debug_stream
+        f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
+        _chk(f(self.h, int(mode), int(n), int(reps), C.byref(sec)))
+        return (16.0 if mode == 0 else 24.0) * (int(n) // 2 * 2) / sec.value / 1e9
 
     def fallback_count(self):
         f = lib().ldu_ctx_fallback_count
@@ -784,3 +793,22 @@ def renumber_addressing(nCells, lowerAddr, upperAddr, newOrder):
     _chk(lib().ldu_renumber_addressing(int(nCells), l.size, _ptr(l), _ptr(u), _ptr(o), _ptr(nl), _ptr(nu), _ptr(fm),
                                        _ptr(fl)))
     return nl, nu, fm, fl
+
+
+def dag_stats(nCells, lowerAddr, upperAddr, maxCells=64, arrays=False):
+    """ldu_debug_dag_stats (host only): dependency levels and cluster partition of an addressing"""
+    l, u = _i32(lowerAddr), _i32(upperAddr)
+    out = np.zeros(16, dtype=np.int64)
+    lev = np.zeros(int(nCells), dtype=np.int32) if arrays else None
+    clu = np.zeros(int(nCells), dtype=np.int32) if arrays else None
+    cl = np.zeros(int(nCells), dtype=np.int32) if arrays else None
+    f = lib().ldu_debug_dag_stats
+    f.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _chk(f(int(nCells), l.size, _ptr(l), _ptr(u), int(maxCells), _ptr(out), _ptr(lev) if arrays else None,
+           _ptr(clu) if arrays else None, _ptr(cl) if arrays else None))
+    keys = ("levels", "clusters", "clusterLevels", "sumDepth", "maxDepth", "maxLower", "maxUpper", "rowsOver6",
+            "rowsOver12", "interClusterFaces", "widestLevel", "widestClusterLevel")
+    d = {k: int(out[i]) for i, k in enumerate(keys)}
+    if arrays:
+        d.update(cellLevel=lev, cellCluster=clu, clusterLevel=cl[:d["clusters"]])
+    return d

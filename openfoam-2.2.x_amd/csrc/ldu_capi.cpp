@@ -168,6 +168,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->p2pWindowLevels = atof(e);
     e = getenv("LDU_HALO_OVERLAP");
     if (e) c->haloOverlap = atoi(e);
+    e = getenv("LDU_SORT_ROWS");
+    if (e) c->sortRowsByWidth = atoi(e);
     e = getenv("LDU_SPIN_LIMIT");
     if (e && (k_set_spin_limit((unsigned)strtoul(e, nullptr, 10)) || k_cluster_set_spin_limit((unsigned)strtoul(e, nullptr, 10))))
         return -1;
@@ -712,6 +714,27 @@ int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap)
     return 0;
 }
 
+// per slice: first row, row count, entries per row (padded width), most lower / upper neighbours of its rows
+int ldu_debug_slices(ldu_matrix* m, int32_t* out /* [nSlices][5] */, int32_t cap)
+{
+    const ldu_addr* a = m->a;
+    if (cap < a->nSlices) { ldu_set_error("ldu_debug_slices: buffer too small"); return -1; }
+    std::vector<int> row(a->nSlices + 1), cnt(a->nSlices), w(a->nSlices);
+    std::vector<unsigned char> nl(a->nCells), nu(a->nCells);
+    LDU_CHECK_HIP(hipMemcpy(row.data(), a->d_sliceRow, sizeof(int) * (a->nSlices + 1), hipMemcpyDeviceToHost));
+    LDU_CHECK_HIP(hipMemcpy(cnt.data(), a->d_sliceCnt, sizeof(int) * a->nSlices, hipMemcpyDeviceToHost));
+    LDU_CHECK_HIP(hipMemcpy(w.data(), a->d_sliceW, sizeof(int) * a->nSlices, hipMemcpyDeviceToHost));
+    LDU_CHECK_HIP(hipMemcpy(nl.data(), a->d_nL, a->nCells, hipMemcpyDeviceToHost));
+    LDU_CHECK_HIP(hipMemcpy(nu.data(), a->d_nU, a->nCells, hipMemcpyDeviceToHost));
+    for (int s = 0; s < a->nSlices; s++)
+    {
+        int ml = 0, mu = 0;
+        for (int i = 0; i < cnt[s]; i++) { ml = std::max(ml, (int)nl[row[s] + i]); mu = std::max(mu, (int)nu[row[s] + i]); }
+        out[5 * s] = row[s]; out[5 * s + 1] = cnt[s]; out[5 * s + 2] = w[s]; out[5 * s + 3] = ml; out[5 * s + 4] = mu;
+    }
+    return 0;
+}
+
 int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap)
 {
     return k_cluster_levels(m->a, out, cap);
@@ -724,6 +747,13 @@ int ldu_debug_div_check(ldu_ctx* ctx, uint64_t seed, int64_t n, uint64_t* mismat
     const int rc = k_div_check(ctx, (unsigned long long)seed, (long)n, &bad);
     *mismatches = bad;
     return rc;
+}
+
+int ldu_debug_stream(ldu_ctx* ctx, int32_t mode, int64_t n, int32_t reps, double* seconds)
+{
+    if (!ctx || !seconds) { ldu_set_error("ldu_debug_stream: null argument"); return -1; }
+    LDU_CHECK_HIP(hipSetDevice(ctx->device));
+    return k_stream(ctx, mode, (long)n, reps, seconds);
 }
 
 int ldu_debug_p2p_stuck(ldu_matrix* m, int32_t out[16])

@@ -25,6 +25,7 @@
 #include <thread>
 
 #include "ldu_internal.hpp"
+#include "ldu_cluster_greedy.hpp"
 
 #ifndef CL_BLK
 #define CL_BLK 256
@@ -186,65 +187,15 @@ static int cluster_build(ldu_addr* a)
     P->maxDep = maxDep;
     if (nC < 64) return 0;
 
-    // ---- greedy clustering in a topological order
-    std::vector<int> indeg(nC, 0), cluster(nC, -1), intra(nC, 0);
-    for (int f = 0; f < nF; f++) indeg[u[f]]++;
-    // seeds in (dependency level, index) order: the clusters are created along the wavefront, so the
-    // fragments left over where blobs do not tile (mesh dimensions that are no multiple of the blob size)
-    // depend on their neighbours in parallel instead of forming one serial chain (54^3 box: 51 cluster
-    // levels instead of 95 with index-ordered seeds; 40 would be ideal)
-    typedef std::pair<int, int> Seed;
-    std::priority_queue<Seed, std::vector<Seed>, std::greater<Seed>> ready;
-    for (int c = 0; c < nC; c++) if (!indeg[c]) ready.push(Seed(a->level[c], c));
-    std::vector<std::vector<int>> members;
-    std::vector<int> cLevel, cDepth;
-    std::vector<int> cand;
-    // lower neighbours of a cell already inside the cluster being grown, kept incrementally (valid while
-    // cntId[c] == id): the candidate scores without rescanning every candidate's neighbours at every pick
-    std::vector<int> cnt(nC, 0), cntId(nC, -1);
-    while (!ready.empty())
-    {
-        const int seed = ready.top().second; ready.pop();
-        if (cluster[seed] >= 0) continue;
-        const int id = (int)members.size();
-        members.emplace_back();
-        cand.clear(); cand.push_back(seed);
-        int lev = 0, depth = 0;
-        while (!cand.empty() && (int)members[id].size() < LDU_WAVE)
-        {
-            // most neighbours already inside; the earliest candidate wins ties
-            int bi = 0, bscore = -1;
-            for (size_t t = 0; t < cand.size(); t++)
-            {
-                const int c = cand[t];
-                const int sc = cntId[c] == id ? cnt[c] : 0;
-                if (sc > bscore) { bscore = sc; bi = (int)t; }
-            }
-            const int c = cand[bi];
-            cand.erase(cand.begin() + bi);
-            cluster[c] = id;
-            members[id].push_back(c);
-            int il = 0;
-            for (int j = a->losortStart[c]; j < a->losortStart[c + 1]; j++)
-            {
-                const int p = l[a->losort[j]];
-                if (cluster[p] == id) il = std::max(il, intra[p] + 1);
-                else lev = std::max(lev, cLevel[cluster[p]] + 1);
-            }
-            intra[c] = il;
-            depth = std::max(depth, il + 1);
-            for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++)
-            {
-                const int v = u[f];
-                if (cntId[v] != id) { cntId[v] = id; cnt[v] = 0; }
-                cnt[v]++;
-                if (--indeg[v] == 0) cand.push_back(v);
-            }
-        }
-        for (int c : cand) ready.push(Seed(a->level[c], c));
-        cLevel.push_back(lev);
-        cDepth.push_back(depth);
-    }
+    // ---- greedy clustering in a topological order (ldu_cluster_greedy.hpp)
+    ClGreedy GR;
+    cluster_greedy(nC, nF, l.data(), u.data(), a->losort.data(), a->losortStart.data(), a->ownerStart.data(),
+                   a->level.data(), LDU_WAVE, GR);
+    const std::vector<int>& cluster = GR.cluster;
+    const std::vector<int>& intra = GR.intra;
+    const std::vector<std::vector<int>>& members = GR.members;
+    const std::vector<int>& cLevel = GR.cLevel;
+    const std::vector<int>& cDepth = GR.cDepth;
     const int nCl = (int)members.size();
     const auto tGreedy = std::chrono::steady_clock::now();
     // ---- schedule order: by cluster level (ties: creation order) = a topological order of the quotient

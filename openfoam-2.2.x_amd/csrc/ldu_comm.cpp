@@ -140,6 +140,32 @@ int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s)
     return 0;
 }
 
+// The abort flag of the bounded dependency waits, made collective: max over the ranks, on the stream, right before
+// a rank reads it.  Every rank issues the same sequence of exchanges and reductions between two reads whether or not
+// one of its sweeps gave up (an aborted sweep drains, the operation carries on), so with this every rank takes the
+// engine fallback at the same point of the same operation, or none does (run_with_fallback).
+int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s)
+{
+    static const bool force = getenv("LDU_FORCE_COMM") && atoi(getenv("LDU_FORCE_COMM"));
+    if (!ctx->comm || (ctx->nRanks <= 1 && !force)) return 0;
+    if (ctx->comm->local)
+    {
+        LocalGroup* G = ctx->comm->local;
+        int mine = 0;
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+        LDU_CHECK_HIP(hipMemcpy(&mine, ctx->d_abort, sizeof(int), hipMemcpyDeviceToHost));
+        G->dbuf[ctx->rank][0] = (double)mine;
+        G->barrier();
+        int any = 0;
+        for (int r = 0; r < G->n; r++) any |= G->dbuf[r][0] != 0.0;
+        G->barrier();
+        if (any && !mine) LDU_CHECK_HIP(hipMemcpy(ctx->d_abort, &any, sizeof(int), hipMemcpyHostToDevice));
+        return 0;
+    }
+    LDU_CHECK_NCCL(ncclAllReduce(ctx->d_abort, ctx->d_abort, 1, ncclInt, ncclMax, ctx->comm->comm, s));
+    return 0;
+}
+
 // index of the patch on rank `nbr` that pairs with my patch `p`: the k-th patch of nbr towards me,
 // k = ordinal of p among my patches towards nbr
 static int paired_patch(const std::vector<Patch>& mine, int p, const std::vector<Patch>& theirs, int me)

@@ -31,25 +31,31 @@ static bool fs_dev_ptr(const void* p)
 struct FsBuf {
     hipStream_t s;
     std::vector<void*> owned;
+    bool bad = false;   // an allocation or upload failed: nothing may be launched on these pointers
     explicit FsBuf(hipStream_t ss) : s(ss) {}
+    int failed() const
+    {
+        if (bad) ldu_set_error("fv schemes: device allocation or upload of an argument failed");
+        return bad ? -1 : 0;
+    }
     ~FsBuf() { for (void* p : owned) (void)hipFree(p); }
     template <class T>
     const T* in(const T* user, size_t n)
     {
         if (!user || fs_dev_ptr(user)) return user;
         T* d = nullptr;
-        if (hipMalloc((void**)&d, sizeof(T) * (n ? n : 1)) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&d, sizeof(T) * (n ? n : 1)) != hipSuccess) { bad = true; return nullptr; }
         owned.push_back(d);
-        (void)hipMemcpyAsync(d, user, sizeof(T) * n, hipMemcpyHostToDevice, s);
+        if (hipMemcpyAsync(d, user, sizeof(T) * n, hipMemcpyHostToDevice, s) != hipSuccess) bad = true;
         return d;
     }
     double* inout(double* user, size_t n, bool copyIn)
     {
         if (!user || fs_dev_ptr(user)) return user;
         double* d = nullptr;
-        if (hipMalloc((void**)&d, sizeof(double) * (n ? n : 1)) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&d, sizeof(double) * (n ? n : 1)) != hipSuccess) { bad = true; return nullptr; }
         owned.push_back(d);
-        if (copyIn) (void)hipMemcpyAsync(d, user, sizeof(double) * n, hipMemcpyHostToDevice, s);
+        if (copyIn && hipMemcpyAsync(d, user, sizeof(double) * n, hipMemcpyHostToDevice, s) != hipSuccess) bad = true;
         return d;
     }
     int finish(double* user, double* dev, size_t n)
@@ -275,8 +281,8 @@ fs_surfaceIntegrate_kernel(int nCells, const int* __restrict__ cs, const int* __
                            const int* __restrict__ ownerStart, const double* __restrict__ ssf,
                            const double* __restrict__ bssf, const double* __restrict__ V, double* __restrict__ out)
 {
-    const long c = (long)blockIdx.x * FS_BLK + threadIdx.x;
-    if (c >= nCells) return;
+  for (long c = (long)blockIdx.x * FS_BLK + threadIdx.x; c < nCells; c += (long)gridDim.x * FS_BLK)
+  {
     double acc[NC];
 #pragma unroll
     for (int q = 0; q < NC; q++) acc[q] = 0.0;
@@ -305,6 +311,7 @@ fs_surfaceIntegrate_kernel(int nCells, const int* __restrict__ cs, const int* __
         if (MODE == 0) out[NC * c + q] = acc[q] / v;
         else out[NC * c + q] -= v * (acc[q] / v);
     }
+  }
 }
 
 // ---------------------------------------------------------------- C ABI
@@ -325,6 +332,7 @@ int ldu_mesh_nonorth_factors(ldu_ctx* ctx, int32_t nCells, int32_t nInternalFace
     const double* c = B.in(cellCentres, 3 * (size_t)nCells);
     double* d = B.inout(nonOrthDeltaCoeffs, nF, false);
     double* cv = B.inout(nonOrthCorrectionVectors, 3 * nF, false);
+    if (B.failed()) return -1;
     if (nF)
         fs_nonorth_kernel<<<fs_grid(nInternalFaces), FS_BLK, 0, B.s>>>(nInternalFaces, o, n, sf, ms, c, d, cv);
     LDU_CHECK_HIP(hipGetLastError());
@@ -345,6 +353,7 @@ int ldu_mesh_patch_nonorth_factors(ldu_ctx* ctx, int32_t nPatchFaces, const doub
     const double* dl = B.in(patchDelta, 3 * n);
     double* d = B.inout(nonOrthDeltaCoeffs, n, false);
     double* cv = B.inout(nonOrthCorrectionVectors, 3 * n, false);
+    if (B.failed()) return -1;
     if (n) fs_nonorth_patch_kernel<<<fs_grid(nPatchFaces), FS_BLK, 0, B.s>>>(nPatchFaces, sf, ms, dl, coupled, d, cv);
     LDU_CHECK_HIP(hipGetLastError());
     if (B.finish(nonOrthDeltaCoeffs, d, n) || B.finish(nonOrthCorrectionVectors, cv, 3 * n)) return -1;
@@ -367,6 +376,7 @@ int ldu_fv_tensorGammaFactors(ldu_ctx* ctx, int32_t nFaces, int32_t nGammaCmpt, 
     const double* g = B.in(gamma, (size_t)nGammaCmpt * n);
     double* a = B.inout(SfGammaSn, n, false);
     double* c = B.inout(SfGammaCorr, 3 * n, false);
+    if (B.failed()) return -1;
     if (n)
     {
         if (nGammaCmpt == 6) fs_tensorGamma_kernel<6><<<fs_grid(nFaces), FS_BLK, 0, B.s>>>(nFaces, sf, ms, g, a, c);
@@ -386,6 +396,7 @@ int ldu_fv_faceDot(ldu_ctx* ctx, int32_t nFaces, int32_t nComp, const double* ve
     const double* v = B.in(vec, 3 * n);
     const double* f = B.in(field, (size_t)nComp * n);
     double* o = B.inout(out, nOut, false);
+    if (B.failed()) return -1;
     if (n)
     {
         if (nComp == 3) fs_faceDot_kernel<3><<<fs_grid(nFaces), FS_BLK, 0, B.s>>>(nFaces, v, f, o);
@@ -406,6 +417,7 @@ int ldu_fv_faceScale(ldu_ctx* ctx, int32_t nFaces, int32_t nComp, const double* 
     const double* s = B.in(scale, (size_t)nFaces);
     const double* f = B.in(field, n);
     double* o = B.inout(out, n, accumulate != 0);
+    if (B.failed()) return -1;
     if (n) fs_faceScale_kernel<<<fs_grid((long)n), FS_BLK, 0, B.s>>>(nFaces, nComp, s, f, accumulate, o);
     LDU_CHECK_HIP(hipGetLastError());
     if (B.finish(out, o, n)) return -1;
@@ -423,6 +435,7 @@ int ldu_fv_interpolateDot(ldu_addr* a, int32_t nComp, const double* vec, const d
     const double* w = B.in(weights, nF);
     const double* f = B.in(field, (size_t)nComp * a->nCells);
     double* o = B.inout(out, nOut, false);
+    if (B.failed()) return -1;
     if (nF)
     {
         if (nComp == 3) fs_interpolateDot_kernel<3><<<fs_grid(a->nFaces), FS_BLK, 0, B.s>>>(a->nFaces, a->d_l, a->d_u, v, w, f, o);
@@ -444,6 +457,7 @@ int ldu_fvc_correctedSnGrad(ldu_addr* a, int32_t nComp, const double* nonOrthDel
     const double* v = B.in(vf, (size_t)a->nCells * nComp);
     const double* c = B.in(correction, n);
     double* o = B.inout(ssf, n, false);
+    if (B.failed()) return -1;
     if (n) fs_correctedSnGrad_kernel<<<fs_grid((long)n), FS_BLK, 0, B.s>>>(a->nFaces, nComp, a->d_l, a->d_u, d, v, c, o);
     LDU_CHECK_HIP(hipGetLastError());
     if (B.finish(ssf, o, n)) return -1;
@@ -463,6 +477,7 @@ int ldu_fv_interpolateBoundary(ldu_fv_boundary* b, int32_t nComp, const double* 
     const double* pn = B.in(patchNeighbourField, n);
     const double* pv = B.in(patchValues, n);
     double* o = B.inout(out, n, patchValues == nullptr);
+    if (B.failed()) return -1;
     if (n)
         fs_interpolateBoundary_kernel<<<fs_grid((long)n), FS_BLK, 0, B.s>>>(b->nFacesTotal, nComp, b->d_faceCells, b->d_coupled,
                                                                           w, v, pn, pv, o);
@@ -483,6 +498,7 @@ int ldu_fvc_gaussGradBoundary(ldu_fv_boundary* b, int32_t nComp, const double* p
     const double* g = B.in(grad, 3 * (size_t)nComp * a->nCells);
     const double* sg = B.in(patchSnGrad, (size_t)nComp * nB);
     double* o = B.inout(boundaryGrad, 3 * (size_t)nComp * nB, true);   // coupled faces keep what the caller put there
+    if (B.failed()) return -1;
     if (nB)
     {
         if (nComp == 1)
@@ -507,6 +523,7 @@ static int fs_integrate(ldu_addr* a, ldu_fv_boundary* b, int nComp, const double
     const double* bf = B.in(boundarySsf, (size_t)nComp * nB);
     const double* v = B.in(V, (size_t)a->nCells);
     double* o = B.inout(out, (size_t)nComp * a->nCells, mode == 1);
+    if (B.failed()) return -1;
     const int* cs = (b && boundarySsf) ? b->d_cellStart : nullptr;
     const int* cf = (b && boundarySsf) ? b->d_cellFace : nullptr;
     const int grid = fs_grid(a->nCells);

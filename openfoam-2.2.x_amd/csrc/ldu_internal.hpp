@@ -85,6 +85,7 @@ struct ldu_ctx {
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
+    int sortRowsByWidth = 1;         // LDU_SORT_ROWS: rows of a level ordered by width class (narrow slices stay narrow)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
     int gsWideUpper = 1;             // LDU_GS_WIDE_UPPER=0: upper parts of more than 8 entries after the lower part (round-1 order)
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
@@ -411,6 +412,7 @@ int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s);   
 int comm_exchange(ldu_addr* a, hipStream_t s);                                   // halo send/recv (may return before it ran)
 int comm_wait_halo(ldu_ctx* ctx, hipStream_t s);                                 // s waits for the exchange started last
 int comm_allreduce_min_int(ldu_ctx* ctx, int* v);
+int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s);                             // abort flag := max over the ranks
 int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
                        const std::vector<std::vector<int>>& send, std::vector<std::vector<int>>& recv);
 int k_patch_agglomerate(int nCoarse, const int* start, const int* fine, const double* fBou,
@@ -432,6 +434,8 @@ int dev_check_abort(ldu_ctx* ctx);
 // expires drains and flags the context (the reference's sweeps simply always complete,
 // DICPreconditioner.C:87-123, GaussSeidelSmoother.C:66-187).  An operation that saw such an abort is run
 // again from its (untouched) inputs on the level-kernel engine, whose results are bit-identical.
+// Multi-rank: the flag is max-reduced over the ranks before it is read (comm_allreduce_abort), so the re-run is
+// taken by every rank or by none and the sequence of collectives stays in step.
 int fallback_prepare(ldu_matrix* m);           // drain, clear the flag, drop sweep-built caches; 0 = ok
 template <class F>
 static inline int run_with_fallback(ldu_matrix* m, F&& op)
@@ -448,6 +452,7 @@ static inline int run_with_fallback(ldu_matrix* m, F&& op)
     return rc;
 }
 int k_div_check(ldu_ctx* ctx, unsigned long long seed, long n, unsigned long long* mismatches);
+int k_stream(ldu_ctx* ctx, int mode, long n, int reps, double* seconds);
 int k_set_p2p_wide(int on);
 int k_set_gs_multi_trace(unsigned long long* buf, int nSlices);
 int k_set_spin_limit(unsigned polls);          // ldu_kernels.hip (0 = default)

@@ -1198,6 +1198,61 @@ int k_div_check(ldu_ctx* ctx, unsigned long long seed, long n, unsigned long lon
     return 0;
 }
 
+// ---- achievable HBM bandwidth of this chip, measured with the library's own stream kernels (ldu_debug_stream):
+// copy a[i] = b[i] (16 B per element) and triad a[i] = b[i] + s*c[i] (24 B per element, McCalpin's STREAM), f64,
+// grid-stride over numCUs x 8 workgroups of 256 threads, two elements per thread and trip (dwordx4 accesses).
+// bench.py prints the triad figure as roofline.peak_measured next to the 8 TB/s spec (SURVEY.md 8d "bound").
+typedef double stream_d2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ void __launch_bounds__(256) stream_kernel(long n2, stream_d2* __restrict__ a, const stream_d2* __restrict__ b,
+                                                     const stream_d2* __restrict__ c, double s)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
+    {
+        const stream_d2 x = __builtin_nontemporal_load(b + i);
+        stream_d2 y;
+        if (MODE == 0) y = x;
+        else
+        {
+            const stream_d2 z = __builtin_nontemporal_load(c + i);
+            y.x = x.x + s * z.x; y.y = x.y + s * z.y;
+        }
+        __builtin_nontemporal_store(y, a + i);
+    }
+}
+
+// mode 0 copy, 1 triad; n doubles per array (rounded down to even); returns the average seconds of `reps` launches
+// (HIP events on the library's stream, after one untimed launch)
+int k_stream(ldu_ctx* ctx, int mode, long n, int reps, double* seconds)
+{
+    const long n2 = n / 2;
+    if (n2 < 1 || reps < 1 || mode < 0 || mode > 1) { ldu_set_error("ldu_debug_stream: bad argument"); return -1; }
+    stream_d2 *a = nullptr, *b = nullptr, *c = nullptr;
+    LDU_CHECK_HIP(hipMalloc((void**)&a, sizeof(stream_d2) * n2));
+    LDU_CHECK_HIP(hipMalloc((void**)&b, sizeof(stream_d2) * n2));
+    LDU_CHECK_HIP(hipMalloc((void**)&c, sizeof(stream_d2) * n2));
+    LDU_CHECK_HIP(hipMemsetAsync(b, 0, sizeof(stream_d2) * n2, ctx->stream));
+    LDU_CHECK_HIP(hipMemsetAsync(c, 0, sizeof(stream_d2) * n2, ctx->stream));
+    hipEvent_t e0, e1;
+    LDU_CHECK_HIP(hipEventCreate(&e0));
+    LDU_CHECK_HIP(hipEventCreate(&e1));
+    const int grid = (int)std::min<long>((n2 + 255) / 256, (long)ctx->numCUs * 8);
+    for (int r = -1; r < reps; r++)
+    {
+        if (r == 0) LDU_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+        if (mode == 0) stream_kernel<0><<<grid, 256, 0, ctx->stream>>>(n2, a, b, c, 3.0);
+        else stream_kernel<1><<<grid, 256, 0, ctx->stream>>>(n2, a, b, c, 3.0);
+    }
+    LDU_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+    LDU_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    LDU_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *seconds = (double)ms * 1e-3 / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+    return 0;
+}
+
 // Placement census: the slab engine needs workgroups of one launch on every XCD it assigns a slab to
 // and HW_REG_XCC_ID values 0..n-1.  HIP promises neither, so it is checked once per context with the
 // sweep kernels' own geometry; a failed census leaves the chip-wide engine in charge.
@@ -1954,7 +2009,7 @@ gs_small_pipe_kernel(SliceTab T, int nSlices, int nCells, const int* __restrict_
         if (wave > 0)                                                                     \
         {                                                                                 \
             const unsigned want = (unsigned)sNeed[sCur];                                  \
-            while (__hip_atomic_load(prog + wave - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) \
+            while (__hip_atomic_load(prog + wave - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) \
                 __builtin_amdgcn_s_sleep(1);                                              \
         }                                                                                 \
         {                                                                                 \
@@ -1971,7 +2026,8 @@ gs_small_pipe_kernel(SliceTab T, int nSlices, int nCells, const int* __restrict_
         }                                                                                 \
         LDU_STEP_FENCE();                                \
         ++sCur;                                                                           \
-        if (lane == 0) __hip_atomic_store(prog + wave, (unsigned)sCur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        /* release: the slice's x[] stores are ordered before the progress word (acquire on the consumer's load) */ \
+        if (lane == 0) __hip_atomic_store(prog + wave, (unsigned)sCur, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
         --left;                                                                           \
     } while (0)
         PIPE_FILL(R0);
@@ -2038,6 +2094,7 @@ static int launch_gs_small_pipe(ldu_addr* a, const SliceTab& T, size_t lds, doub
     }
     gs_small_pipe_kernel<W, NW><<<1, LDU_WAVE * NW, lds, a->ctx->stream>>>(T, a->nSlices, a->nCells, a->d_smallNeed, psi,
                                                                          rhs, diag, val);
+    LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "ldu_internal.hpp"
+#include "ldu_cluster_greedy.hpp"
 
 template <class T>
 static int upload(T** dst, const std::vector<T>& src)
@@ -169,10 +170,31 @@ int plan_build(ldu_addr* a)
     a->perm.assign(nC, 0);
     a->iperm.assign(nC, 0);
     {
-        std::vector<int> pos(a->levelStart.begin(), a->levelStart.end() - 1);
-        for (int c = 0; c < nC; c++)   // stable: original order inside a level
+        // Inside a level the rows are independent, so their order is free.  Narrow rows first in their original
+        // order, then the wider ones class by class (stable): a slice is padded to its widest row, and on meshes
+        // with hanging faces / agglomerated levels ~1 % wide rows scattered over the level would sit in half of its
+        // slices (octree twin of the motorBike mesh: 50 % of the slices padded from 6 to 9..25 entries per row).
+        // Class = entries per row (lower + upper): <= 6 | <= 8 | <= 12 | <= 16 | more, or more than 8 on one side.
+        const bool sortRows = a->ctx->sortRowsByWidth;
+        auto widthClass = [&](int c) -> int {
+            if (!sortRows) return 0;
+            const int cl = a->losortStart[c + 1] - a->losortStart[c], cu = a->ownerStart[c + 1] - a->ownerStart[c];
+            if (cl > 8 || cu > 8) return 4;
+            const int t = cl + cu;
+            return t <= 6 ? 0 : (t <= 8 ? 1 : (t <= 12 ? 2 : 3));
+        };
+        constexpr int NCLS = 5;
+        std::vector<long> cnt((size_t)nLevels * NCLS + 1, 0);
+        std::vector<unsigned char> cls(nC);
+        for (int c = 0; c < nC; c++)
         {
-            int r = pos[a->level[c]]++;
+            cls[c] = (unsigned char)widthClass(c);
+            cnt[(size_t)a->level[c] * NCLS + cls[c] + 1]++;
+        }
+        for (size_t i = 0; i + 1 < cnt.size(); i++) cnt[i + 1] += cnt[i];
+        for (int c = 0; c < nC; c++)   // stable: original order inside a (level, class)
+        {
+            const int r = (int)cnt[(size_t)a->level[c] * NCLS + cls[c]]++;
             a->perm[r] = c;
             a->iperm[c] = r;
         }
@@ -206,6 +228,12 @@ int plan_build(ldu_addr* a)
         nU[r] = (unsigned char)cu;
         a->maxUpper = std::max(a->maxUpper, cu);
     }
+    std::vector<unsigned char> rowClass(nC, 0);
+    for (int r = 0; r < nC; r++)
+    {
+        const int t = (int)nL[r] + (int)nU[r];
+        rowClass[r] = (nL[r] > 8 || nU[r] > 8) ? 4 : (t <= 6 ? 0 : (t <= 8 ? 1 : (t <= 12 ? 2 : 3)));
+    }
     long ent = 0;
     for (int L = 0; L < nLevels; L++)
     {
@@ -213,7 +241,11 @@ int plan_build(ldu_addr* a)
         for (int r0 = a->levelStart[L], cnt = 0; r0 < a->levelStart[L + 1]; r0 += cnt)
         {
             cnt = 1;
-            while (cnt < LDU_WAVE && r0 + cnt < a->levelStart[L + 1] && rowSlab[r0 + cnt] == rowSlab[r0]) cnt++;
+            // (a slice also ends where the width class changes, on levels wide enough not to care about one more
+            //  slice: the single-wavefront kernels of the small levels walk the slices one after the other)
+            const bool cutAtClass = a->ctx->sortRowsByWidth && a->levelStart[L + 1] - a->levelStart[L] >= 256;
+            while (cnt < LDU_WAVE && r0 + cnt < a->levelStart[L + 1] && rowSlab[r0 + cnt] == rowSlab[r0]
+                   && !(cutAtClass && rowClass[r0 + cnt] != rowClass[r0])) cnt++;
             sliceSlab.push_back(rowSlab[r0]);
             int W = 0;
             for (int i = 0; i < cnt; i++) W = std::max(W, (int)nL[r0 + i] + (int)nU[r0 + i]);
@@ -507,4 +539,70 @@ void plan_free(ldu_addr* a)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (double* p : a->scratch) if (p) (void)hipFree(p);
     a->scratch.clear();
+}
+
+// Host-only plan statistics of an addressing (no device, no context): dependency levels of the lower-triangular
+// DAG and the greedy cluster partition the cluster sweep engine would use.  For studying numberings and meshes on
+// the build host.  out[0] dependency levels, [1] clusters, [2] cluster levels, [3] sum of the clusters' internal
+// steps, [4] most internal steps, [5] most lower, [6] most upper neighbours of a row, [7] rows with more than 6
+// lower or upper neighbours, [8] ... more than 12, [9] faces between different clusters, [10] widest dependency
+// level (cells), [11] widest cluster level (clusters).
+extern "C" int ldu_debug_dag_stats(int32_t nCells, int32_t nFaces, const int32_t* l, const int32_t* u, int32_t maxCells,
+                                   int64_t out[16], int32_t* cellLevel, int32_t* cellCluster, int32_t* clusterLevel)
+{
+    if (nCells < 0 || nFaces < 0 || (nFaces && (!l || !u)) || !out) { ldu_set_error("ldu_debug_dag_stats: bad argument"); return -1; }
+    const int nC = nCells, nF = nFaces;
+    for (int f = 0; f < nF; f++)
+        if (l[f] < 0 || u[f] >= nC || l[f] >= u[f] || (f && l[f] < l[f - 1]))
+        {
+            ldu_set_error("ldu_debug_dag_stats: faces must be in upper-triangular order");
+            return -2;
+        }
+    std::vector<int> losort(nF), ownerStart(nC + 1, 0), losortStart(nC + 1, 0), level(nC, 0);
+    {
+        std::vector<int> cnt(nC + 1, 0);
+        for (int f = 0; f < nF; f++) cnt[u[f] + 1]++;
+        for (int c = 0; c < nC; c++) cnt[c + 1] += cnt[c];
+        losortStart = cnt;
+        for (int f = 0; f < nF; f++) losort[cnt[u[f]]++] = f;
+        for (int f = 0; f < nF; f++) ownerStart[l[f] + 1]++;
+        for (int c = 0; c < nC; c++) ownerStart[c + 1] += ownerStart[c];
+    }
+    for (int f = 0; f < nF; f++) level[u[f]] = std::max(level[u[f]], level[l[f]] + 1);
+    int nLevels = 0;
+    for (int c = 0; c < nC; c++) nLevels = std::max(nLevels, level[c] + 1);
+    ClGreedy G;
+    cluster_greedy(nC, nF, l, u, losort.data(), losortStart.data(), ownerStart.data(), level.data(),
+                   maxCells > 0 ? maxCells : LDU_WAVE, G);
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    out[0] = nLevels;
+    out[1] = (int64_t)G.members.size();
+    int maxCl = 0;
+    for (size_t i = 0; i < G.members.size(); i++)
+    {
+        maxCl = std::max(maxCl, G.cLevel[i]);
+        out[3] += G.cDepth[i];
+        out[4] = std::max<int64_t>(out[4], G.cDepth[i]);
+    }
+    out[2] = G.members.empty() ? 0 : maxCl + 1;
+    for (int c = 0; c < nC; c++)
+    {
+        const int nl = losortStart[c + 1] - losortStart[c], nu = ownerStart[c + 1] - ownerStart[c];
+        out[5] = std::max<int64_t>(out[5], nl);
+        out[6] = std::max<int64_t>(out[6], nu);
+        if (nl > 6 || nu > 6) out[7]++;
+        if (nl > 12 || nu > 12) out[8]++;
+    }
+    for (int f = 0; f < nF; f++) if (G.cluster[l[f]] != G.cluster[u[f]]) out[9]++;
+    {
+        std::vector<int> w(nLevels + 1, 0), wc(out[2] + 1, 0);
+        for (int c = 0; c < nC; c++) w[level[c]]++;
+        for (size_t i = 0; i < G.members.size(); i++) wc[G.cLevel[i]]++;
+        for (int x : w) out[10] = std::max<int64_t>(out[10], x);
+        for (int x : wc) out[11] = std::max<int64_t>(out[11], x);
+    }
+    if (cellLevel) for (int c = 0; c < nC; c++) cellLevel[c] = level[c];
+    if (cellCluster) for (int c = 0; c < nC; c++) cellCluster[c] = G.cluster[c];
+    if (clusterLevel) for (size_t i = 0; i < G.members.size(); i++) clusterLevel[i] = G.cLevel[i];
+    return 0;
 }

@@ -24,6 +24,7 @@ double* ldu_matrix::workVec(int i)
 
 int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
 {
+    if (comm_allreduce_abort(ctx, ctx->stream)) return -1;
     // scalars and the abort flag (stored behind them) in one copy: a second small copy costs ~20 us of latency
     LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * (S_NSLOTS + 1), hipMemcpyDeviceToHost,
                                  ctx->stream));
@@ -44,6 +45,7 @@ int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
 // Surface an aborted point-to-point sweep to callers that do not read scalars (ldu_smooth, ...).
 int dev_check_abort(ldu_ctx* ctx)
 {
+    if (comm_allreduce_abort(ctx, ctx->stream)) return -1;
     LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_abort, ctx->d_abort, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     if (*ctx->h_abort)
@@ -62,7 +64,9 @@ int fallback_prepare(ldu_matrix* m)
     ldu_ctx* ctx = m->a->ctx;
     // whatever the failed attempt left in flight (the second stream of PBiCG included) has to end first
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream2));
+    if (ctx->streamComm) LDU_CHECK_HIP(hipStreamSynchronize(ctx->streamComm));   // a halo exchange of the failed attempt
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->haloInFlight = false;
     LDU_CHECK_HIP(hipMemset(ctx->d_abort, 0, sizeof(int)));
     *ctx->h_abort = 0;
     ctx->dualActive = 0;

@@ -116,11 +116,15 @@ static void hipEvictOldest()
     hipEntries_.erase(old);
 }
 
-// device memory is returned when the library is unloaded (dlclose / exit)
+// device memory is returned when the library is unloaded (dlclose / exit).  Not in a parallel run: static destructors
+// run after Pstream::exit() / MPI_Finalize and possibly during the HIP / RCCL runtime's own teardown, where
+// ncclCommDestroy and stream synchronisation can hang or crash - the process is ending, the driver reclaims the memory.
+static bool hipParallelRun_ = false;
 struct hipLduRegistryCleaner
 {
     ~hipLduRegistryCleaner()
     {
+        if (hipParallelRun_) return;
         for (std::map<const lduAddressing*, hipLduEntry>::iterator i = hipEntries_.begin(); i != hipEntries_.end(); ++i)
         {
             hipFreeEntry(i->second);
@@ -160,6 +164,7 @@ static ldu_ctx* hipContext()
         hipCheck(ldu_ctx_create(&hipCtx_, dev), "hipContext()");
         if (Pstream::parRun())
         {
+            hipParallelRun_ = true;
             // RCCL communicator bootstrapped over the existing Pstream (replaces MPI on the hot path)
             labelList id(128/sizeof(label), 0);      // 128-byte ncclUniqueId as labels
             uint8_t raw[128];

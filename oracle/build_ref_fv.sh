@@ -114,3 +114,37 @@ if [ -f "$HERE/fv_driver.C" ]; then
         -Wl,-rpath,'$ORIGIN'
     echo "build_ref_fv.sh: OK -> $OUT/fv_driver"
 fi
+# The reference's own icoFoam (BASELINE config C1): applications/solvers/incompressible/icoFoam/icoFoam.C
+# compiled where it lies and linked against the archive above + libOpenFOAM.so - an UNCHANGED reference application.
+# Units that are only reachable through their run-time selection tables (the schemes and patch fields the cavity's
+# dictionaries name) are listed explicitly; nothing stands in for anything.
+ICO="$REF/applications/solvers/incompressible/icoFoam"
+if [ -f "$ICO/icoFoam.C" ]; then
+    FORCE_ICO=""
+    for u in fvMesh/fvPatches/derived/wall/wallFvPatch.C \
+             fvMesh/fvPatches/constraint/empty/emptyFvPatch.C \
+             fields/fvPatchFields/constraint/empty/emptyFvPatchFields.C \
+             fields/fvsPatchFields/constraint/empty/emptyFvsPatchFields.C \
+             fields/fvPatchFields/basic/fixedValue/fixedValueFvPatchFields.C \
+             fields/fvPatchFields/basic/zeroGradient/zeroGradientFvPatchFields.C \
+             fields/fvPatchFields/basic/calculated/calculatedFvPatchFields.C \
+             fields/fvsPatchFields/basic/calculated/calculatedFvsPatchFields.C \
+             finiteVolume/gradSchemes/gaussGrad/gaussGrads.C \
+             interpolation/surfaceInterpolation/schemes/linear/linear.C \
+             finiteVolume/ddtSchemes/EulerDdtScheme/EulerDdtSchemes.C \
+             finiteVolume/convectionSchemes/gaussConvectionScheme/gaussConvectionSchemes.C \
+             finiteVolume/laplacianSchemes/gaussLaplacianScheme/gaussLaplacianSchemes.C \
+             finiteVolume/snGradSchemes/orthogonalSnGrad/orthogonalSnGrads.C \
+             finiteVolume/snGradSchemes/correctedSnGrad/correctedSnGrads.C \
+             finiteVolume/divSchemes/gaussDivScheme/gaussDivSchemes.C \
+             fvMatrices/solvers/GAMGSymSolver/GAMGAgglomerations/faceAreaPairGAMGAgglomeration/faceAreaPairGAMGAgglomeration.C; do
+        i=$(grep -n "/$u\$" "$W/fvsources.txt" | head -1 | cut -d: -f1)
+        if [ -n "$i" ] && [ -f "$W/fvobj/f$i.o" ]; then FORCE_ICO="$FORCE_ICO $W/fvobj/f$i.o"
+        else echo "build_ref_fv.sh: unit $u is not built - icoFoam cannot be linked (no stand-ins)" >&2; FORCE_ICO="MISSING"; break; fi
+    done
+    if [ "$FORCE_ICO" != "MISSING" ]; then
+        g++ $CXXFLAGS -I"$ICO" -c "$ICO/icoFoam.C" -o "$W/icoFoam.o"
+        g++ -o "$OUT/icoFoam" "$W/icoFoam.o" $FORCE_ICO "$W/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm -Wl,-rpath,'$ORIGIN'
+        echo "build_ref_fv.sh: OK -> $OUT/icoFoam (the reference's icoFoam.C, unchanged)"
+    fi
+fi

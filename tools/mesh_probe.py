@@ -1,0 +1,119 @@
+"""Probe: GaussSeidel (1 and k pipelined sweeps), DIC half sweep and Amul on one mesh for several engine settings,
+with an optional per-level timeline of the pipelined sweeps on the level engines.
+usage: python tools/mesh_probe.py MESH [cfg ...]
+  MESH = box:N | octree:Q:Lmin:Lmax[:hexref] | irregular:N
+  cfg  = name:ENV=VAL,ENV=VAL        (PROBE_SWEEPS=k, PROBE_TRACE=1 are read per configuration)"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+
+entry.load_package()
+from openfoam_amd import capi, cases, octree
+import torch
+
+
+def make(spec):
+    f = spec.split(":")
+    if f[0] == "box":
+        return cases.box3d(int(f[1]))
+    if f[0] == "irregular":
+        p = cases.irregular_box(int(f[1]))
+    elif f[0] == "octree":
+        q = int(f[1])
+        p = octree.problem(base=(5 * q, 2 * q, 2 * q), surface_levels=(int(f[2]), int(f[3])))
+        p.pop("cellLevel")
+        if len(f) > 4 and f[4] == "hexref":
+            return p
+    else:
+        raise SystemExit("unknown mesh " + spec)
+    order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+    nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+    return cases.renumbered(p, order, fmap, flip, nl, nu)
+
+
+spec = sys.argv[1]
+cfgs = sys.argv[2:] or ["default:"]
+t0 = time.perf_counter()
+p = make(spec)
+nC, nF = p["nCells"], p["lowerAddr"].size
+print("mesh %s: %d cells %d faces (%.1f s)" % (spec, nC, nF, time.perf_counter() - t0), flush=True)
+dev = torch.device("cuda", 0)
+d_src = torch.from_numpy(p["source"]).to(dev)
+L = capi.lib()
+set_before = set()
+for cfg in cfgs:
+    name, _, envs = cfg.partition(":")
+    for k in set_before:
+        os.environ.pop(k, None)
+    set_before = set()
+    for kv in filter(None, envs.split(",")):
+        k, v = kv.split("=")
+        os.environ[k] = v
+        set_before.add(k)
+    ctx = capi.Context(0)
+    ts = time.perf_counter()
+    a, m = capi.from_problem(ctx, p)
+    info = a.info()
+    NS = int(os.environ.get("PROBE_SWEEPS", "2"))
+    d_psi = torch.zeros(nC, dtype=torch.float64, device=dev)
+    d_w = torch.zeros(nC, dtype=torch.float64, device=dev)
+    res = {}
+    for label, fn in (("gs1", lambda: L.ldu_smooth(m.h, 0, capi._ptr(d_psi), capi._ptr(d_src), 1)),
+                      ("gs%d" % NS, lambda: L.ldu_smooth(m.h, 0, capi._ptr(d_psi), capi._ptr(d_src), NS)),
+                      ("dic", lambda: L.ldu_precondition(m.h, 2, capi._ptr(d_w), capi._ptr(d_src), 0)),
+                      ("amul", lambda: L.ldu_amul(m.h, capi._ptr(d_w), capi._ptr(d_src)))):
+        capi._chk(fn()); ctx.sync()
+        if label == "gs1":
+            setup = time.perf_counter() - ts
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            capi._chk(fn())
+        ctx.sync()
+        res[label] = (time.perf_counter() - t1) / reps * 1e3
+    eng = (a.sweep_engine(0), a.sweep_engine(1), a.sweep_engine(2))
+    print("%-14s levels=%d padded=%s engines tri/gs/gsk=%s | GS1 %.3f ms (%.2f us/lvl)  GS%d %.3f ms  DIC(2 half sweeps) %.3f ms  "
+          "Amul %.3f ms  fallbacks %d  setup %.1f s"
+          % (name, info["nLevels"], "%.2fM entries" % (info["nEntriesPadded"] / 1e6), "/".join(e.split()[0] for e in eng), res["gs1"],
+             res["gs1"] * 1e3 / info["nLevels"], NS, res["gs%d" % NS], res["dic"], res["amul"], ctx.fallback_count(), setup),
+          flush=True)
+    if os.environ.get("PROBE_TRACE") and "clusters" not in eng[2]:
+        lev = np.zeros(info["nLevels"] + 8, dtype=np.int32)
+        L.ldu_debug_slice_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        capi._chk(L.ldu_debug_slice_levels(m.h, lev.ctypes.data, lev.size))
+        nLev = int(lev[0]); start = lev[1:2 + nLev]; nS = int(start[-1])
+        buf = torch.zeros(NS * nS * 8, dtype=torch.int64, device="cuda")
+        L.ldu_debug_gs_multi_trace.argtypes = [C.c_void_p, C.c_void_p]
+        capi._chk(L.ldu_debug_gs_multi_trace(m.h, C.c_void_p(buf.data_ptr())))
+        capi._chk(L.ldu_smooth(m.h, 0, capi._ptr(d_psi), capi._ptr(d_src), NS)); ctx.sync()
+        capi._chk(L.ldu_debug_gs_multi_trace(m.h, None))
+        T = buf.cpu().numpy().reshape(NS, nS, 8).astype(np.float64)
+        if os.environ.get("PROBE_DUMP"):
+            sl = np.zeros((nS, 5), dtype=np.int32)
+            L.ldu_debug_slices.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+            capi._chk(L.ldu_debug_slices(m.h, sl.ctypes.data, nS))
+            np.savez_compressed(os.environ["PROBE_DUMP"] + "_" + name + ".npz", T=buf.cpu().numpy().reshape(NS, nS, 8)[:, :, :6],
+                                start=start, slices=sl)
+        tmin = T[:, :, 0][T[:, :, 0] > 0].min()
+        T[:, :, :4] = (T[:, :, :4] - tmin) * 0.01
+        for j in range(NS):
+            X = T[j]
+            done = np.array([X[start[l]:start[l + 1], 3].max() for l in range(nLev)])
+            d = np.diff(done)
+            print("   sweep %d: level 0 done at %.0f us, last at %.0f us; per level mean %.2f p50 %.2f p90 %.2f p99 %.2f max %.1f us"
+                  % (j, done[0], done[-1], d.mean(), *np.percentile(d, [50, 90, 99]), d.max()))
+            print("      per task medians: start->upper %.2f  upper->ready %.2f  ready->stored %.2f us; p99: %.2f %.2f %.2f"
+                  % (np.median(X[:, 1] - X[:, 0]), np.median(X[:, 2] - X[:, 1]), np.median(X[:, 3] - X[:, 2]),
+                     np.percentile(X[:, 1] - X[:, 0], 99), np.percentile(X[:, 2] - X[:, 1], 99),
+                     np.percentile(X[:, 3] - X[:, 2], 99)))
+            # which slice finishes a level last, and how wide is it
+            q = max(1, nLev // 10)
+            print("      level: slices, done [us]:", "  ".join("%d: %d, %.0f" % (l, start[l + 1] - start[l], done[l]) for l in range(0, nLev, q)))
+    m.close(); a.close(); ctx.close()
