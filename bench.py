@@ -38,13 +38,95 @@ GAMG_CONTROLS = dict(solver="GAMG", tolerance=1e-7, relTol=0.01, smoother="Gauss
                      agglomerator="faceAreaPair", nCellsInCoarsestLevel=10, mergeLevels=1)
 
 
+def resident_pipeline(torch, capi, cases, ctx, addr, mat, n, dev, reps=3):
+    """SURVEY 8(f)-1 / VERDICT r2 item 9: simpleFoam's pEqn.H on the box with every field resident in HBM - nothing crosses
+    PCIe between assembly, solve and flux (what the fvMatrix glue and the fv kernels exist for):
+        rAUf = interpolate(rAU); pEqn = fvm::laplacian(rAUf, p) == fvc::div(phiHbyA), phiHbyA = interpolate(HbyA) & Sf;
+        boundary glue (fixedValue outlet, zeroGradient elsewhere); GAMG solve; phi = phiHbyA - pEqn.flux()
+    through the C ABI on device pointers only.  Unit-cube hex cells (Sf = unit vectors, weights 1/2, delta 1, V 1).
+    Returns V-cycles/s of the whole chain and the share of the time spent outside ldu_solve."""
+    import ctypes as C
+    L = capi.lib()
+    P = capi._ptr
+    chk = capi._chk
+    l, u, d = cases.box_addressing(n, n, n)
+    nC, nF = n ** 3, l.size
+    f64 = dict(dtype=torch.float64, device=dev)
+    Sf = torch.zeros(nF, 3, **f64)
+    Sf[torch.arange(nF, device=dev), torch.from_numpy(d.astype(np.int64)).to(dev)] = 1.0
+    negSf = -Sf
+    magSf, w, delta, V = (torch.ones(nF, **f64), torch.full((nF,), 0.5, **f64), torch.ones(nF, **f64), torch.ones(nC, **f64))
+    c = torch.arange(nC, device=dev, dtype=torch.float64)
+    rAU = 1.0 + 0.25 * torch.sin(1e-3 * c)
+    HbyA = torch.stack([torch.sin(2e-3 * c), 0.3 * torch.cos(1e-3 * c), 0.1 * torch.sin(3e-3 * c)], dim=1).contiguous()
+    # patches: x-min, x-max (outlet: fixedValue 0), y-min, y-max, z-min, z-max
+    cc = np.arange(nC, dtype=np.int64)
+    i, j, k = cc % n, (cc // n) % n, cc // (n * n)
+    fcs = [cc[i == 0], cc[i == n - 1], cc[j == 0], cc[j == n - 1], cc[k == 0], cc[k == n - 1]]
+    b = capi.FvBoundary(addr, [x.astype(np.int32) for x in fcs])
+    nB = b.n
+    iC = torch.zeros(nB, **f64)
+    o0, o1 = fcs[0].size, fcs[0].size + fcs[1].size
+    iC[o0:o1] = 2.0 * rAU[torch.from_numpy(fcs[1]).to(dev)]      # gamma*magSf*deltaCoeffs of the outlet faces (delta = 1/(h/2))
+    bC = torch.zeros(nB, **f64)                                   # fixedValue 0
+    mphiB = torch.zeros(nB, **f64)                                # no flux through the walls / outlet of this test field
+    rAUf, gms, diag, upper, mphi, source, psi, fluxI, fluxB, phi = (torch.empty(nF, **f64), torch.empty(nF, **f64),
+        torch.empty(nC, **f64), torch.empty(nF, **f64), torch.empty(nF, **f64), torch.empty(nC, **f64), torch.zeros(nC, **f64),
+        torch.empty(nF, **f64), torch.empty(nB, **f64), torch.empty(nF, **f64))
+    minus1 = torch.full((nF,), -1.0, **f64)
+    ctl = capi.make_controls(**GAMG_CONTROLS)
+    perf = capi.Perf()
+
+    def assemble():
+        chk(L.ldu_fv_interpolate(addr.h, 1, P(w), P(rAU), P(rAUf)))
+        chk(L.ldu_fv_faceScale(ctx.h, nF, 1, P(magSf), P(rAUf), 0, P(gms)))
+        chk(L.ldu_fvm_laplacian(addr.h, P(delta), P(gms), P(diag), P(upper)))
+        chk(L.ldu_fv_interpolateDot(addr.h, 3, P(negSf), P(w), P(HbyA), P(mphi)))          # -phiHbyA
+        source.zero_()
+        chk(L.ldu_fvm_sourceMinusVDiv(addr.h, b.h, 1, P(mphi), P(mphiB), P(V), P(source)))   # source += V*div(phiHbyA)
+        chk(L.ldu_fvm_addBoundaryDiag(b.h, P(iC), P(diag)))
+        chk(L.ldu_fvm_addBoundarySource(b.h, P(bC), None, 0, P(source)))
+
+    def solve():
+        psi.zero_()
+        torch.cuda.synchronize()
+        chk(L.ldu_matrix_set_coeffs(mat.h, P(diag), P(upper), None))
+        chk(L.ldu_solve(mat.h, C.byref(ctl), P(psi), P(source), C.byref(perf), None))
+        return perf.nIterations
+
+    def flux():
+        chk(L.ldu_fvm_flux(b.h, P(iC), P(bC), None, P(upper), None, P(psi), P(fluxI), P(fluxB)))
+        chk(L.ldu_fv_faceScale(ctx.h, nF, 1, P(minus1), P(mphi), 0, P(phi)))                 # phi = phiHbyA
+        chk(L.ldu_fv_faceScale(ctx.h, nF, 1, P(minus1), P(fluxI), 1, P(phi)))                # phi -= flux
+
+    def sync():
+        torch.cuda.synchronize(); ctx.sync(); torch.cuda.synchronize()
+    assemble(); solve(); flux(); sync()          # warm-up (agglomeration of these face weights is cached on the addressing)
+    t_all = t_solve = 0.0
+    its = 0
+    for _ in range(reps):
+        sync(); t0 = time.perf_counter()
+        assemble(); sync(); t1 = time.perf_counter()
+        its += solve(); sync(); t2 = time.perf_counter()
+        flux(); sync(); t3 = time.perf_counter()
+        t_all += t3 - t0
+        t_solve += t2 - t1
+    out = dict(resident_pipeline_vcycles_per_s=round(its / t_all, 2),
+               resident_pipeline_assembly_and_flux_share=round(1.0 - t_solve / t_all, 4),
+               resident_pipeline_ms=dict(total=round(t_all / reps * 1e3, 3), solve=round(t_solve / reps * 1e3, 3)),
+               resident_pipeline_vcycles_per_solve=its // reps,
+               resident_pipeline_final_flux_sum=float(phi.sum().item()))
+    b.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
-    ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random", "octree", "octree_hexref"],
+    ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random", "octree", "octree_hexref", "jump2d"],
                     default="box",
                     help="box: the SURVEY 8d C3 stand-in in blockMesh's natural ordering (the metric's workload); "
                          "renumbered: the same matrix under Foam::bandCompression (what renumberMesh applies); "
@@ -53,14 +135,26 @@ def main():
                          "random: a band-limited random graph (quasi 1-D: ~nC/100 dependency levels, pathological); "
                          "octree: snappyHexMesh-like castellated octree around a motorBike-sized body (hanging faces, "
                          "hexRef8 numbering), renumbered by Foam::bandCompression (openfoam-2.2.x_amd/octree.py); "
-                         "octree_hexref: the same in hexRef8's own numbering (what the tutorial's Allrun solves on)")
+                         "octree_hexref: the same in hexRef8's own numbering (what the tutorial's Allrun solves on); "
+                         "jump2d: BASELINE config C5's twin at its size - n x n 2-D 5-point matrix with the coefficient "
+                         "jumping 1 <-> 1000 across the diagonal (damBreak p_rgh, --n 2000 = 4.0 M cells)")
     ap.add_argument("--octree-q", type=int, default=14, help="octree background mesh 5q x 2q x 2q (14 -> ~10 M cells)")
     ap.add_argument("--octree-levels", type=int, nargs=2, default=[6, 7], help="octree surface refinement levels")
+    ap.add_argument("--rank-of", type=int, default=0, metavar="N",
+                    help="single-rank PROJECTION of an N-rank run (N = 2, 4, 8) on ONE GPU: rank 0's sub-domain of the N-way "
+                         "block decomposition, its processor patches wired to itself over a size-1 RCCL communicator "
+                         "(real ncclSend/ncclRecv halo exchanges on the comm stream, real ncclAllReduce for every global "
+                         "sum: LDU_FORCE_COMM=1).  Prints the per-rank V-cycle time and the exchanges / all-reduces / "
+                         "host read-backs per V-cycle.  Never the headline value: the coupling is to itself, the "
+                         "inter-GPU latency is not in it.")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCG / asymmetric / host-path legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=0, help="box edge of the CPU sample (0 = same)")
     args = ap.parse_args()
 
+    if args.rank_of > 1:
+        os.environ["LDU_FORCE_COMM"] = "1"   # read once by the library: every reduction goes through RCCL
+        args.no_extras = args.no_cpu = True
     import torch
     import torch.distributed as dist
 
@@ -84,6 +178,8 @@ def main():
     t_gen = time.perf_counter()
     if args.mesh == "random":
         p = cases.random_graph_fast(n ** 3, 7.0, 600)
+    elif args.mesh == "jump2d":
+        p = cases.jump2d(n, n)
     elif args.mesh in ("octree", "octree_hexref"):
         from openfoam_amd import octree
         q = args.octree_q
@@ -105,13 +201,21 @@ def main():
     if world > 1 and args.mesh != "box":
         raise SystemExit("bench.py: --mesh %s is a single-GPU measurement" % args.mesh)
 
-    if world > 1:
+    if world > 1 or args.rank_of > 1:
         # 2x2x2 blocks at 8 ranks, slabs/blocks otherwise
-        shape = {2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(world, (1, 1, world))
+        nr = world if world > 1 else args.rank_of
+        if args.mesh != "box":
+            raise SystemExit("bench.py: the block decomposition is defined on the box")
+        shape = {2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(nr, (1, 1, nr))
         cell_rank = decompose.block_ranks(n, n, n, *shape)
-        subs, cell_maps = decompose.decompose(p, cell_rank, world, only_rank=rank)
+        subs, cell_maps = decompose.decompose(p, cell_rank, nr, only_rank=rank)
         lp = subs[rank]
         del subs
+        if args.rank_of > 1:
+            # every processor patch exchanges with this rank itself (the k-th patch towards rank 0 pairs with the
+            # k-th patch of rank 0 towards it: each patch receives its own send buffer through ncclSend/ncclRecv)
+            for q in lp["patches_dev"]:
+                q["nbrRank"] = 0
     else:
         lp = p
 
@@ -120,6 +224,8 @@ def main():
         uid = [capi.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(rank, world, uid[0])
+    elif args.rank_of > 1:
+        ctx.comm_init(0, 1, capi.Context.unique_id())
 
     t0 = time.perf_counter()
     addr = capi.Addressing(ctx, lp["nCells"], lp["lowerAddr"], lp["upperAddr"], lp.get("faceWeights"),
@@ -168,6 +274,7 @@ def main():
         # uploads, lie before it)
         marker_ctx = capi.Context(local_rank)
     barrier()
+    comm0 = ctx.comm_counters()
     mat.profile_begin()
     t0 = time.perf_counter()
     iters = 0
@@ -177,6 +284,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = mat.profile_end()
+    comm1 = ctx.comm_counters()
+    comm_per_vcycle = {k: round((comm1[k] - comm0[k]) / float(max(1, iters)), 2) for k in comm1}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -316,13 +425,20 @@ def main():
         except Exception as e:  # pragma: no cover
             extra["asym_error"] = str(e)
 
+    if world == 1 and args.mesh == "box" and not args.no_extras and args.rank_of <= 1:
+        try:
+            extra.update(resident_pipeline(torch, capi, cases, ctx, addr, mat, n, dev))
+            mat.set_coeffs(d_diag, d_upper)
+        except Exception as e:  # pragma: no cover
+            extra["resident_pipeline_error"] = str(e)[:300]
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:   # the CPU leg is timed at N=1 only
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py
         cn = args.cpu_n or n
-        cp = p if (cn == n or is_octree) else cases.box3d(cn)
-        scale = 1.0 if is_octree else (cn ** 3) / float(n ** 3)
+        cp = p if (cn == n or is_octree or args.mesh == "jump2d") else cases.box3d(cn)
+        scale = 1.0 if (is_octree or args.mesh == "jump2d") else (cn ** 3) / float(n ** 3)
         note = "" if (cn == n or is_octree) else "; scaled by cell count to %d^3" % n
         if oracle_py.ref_available():
             # the reference's own libOpenFOAM (oracle/_ref, built from /root/reference by oracle/build_ref.sh)
@@ -352,7 +468,7 @@ def main():
     # core, one thread per sub-domain emulating the reference's MPI ranks (oracle/time_allcores.py); a port, never
     # the reference itself (no MPI in this image)
     cpu_all = None
-    if cpu is not None and not args.no_extras and not is_octree:
+    if cpu is not None and not args.no_extras and not is_octree and args.mesh != "jump2d":
         import subprocess
         cores = max(1, min(os.cpu_count() or 1, 64))
         try:
@@ -368,7 +484,22 @@ def main():
         except Exception as e:  # pragma: no cover
             cpu_all = dict(error=str(e)[:300], cores=cores)
 
-    if rank == 0:
+    if rank == 0 and args.rank_of > 1:
+        # a projection, not a measurement of N GPUs: its own line shape so that nobody mistakes it for the metric
+        print(json.dumps({
+            "projection": "ONE rank of a %d-rank run on one GPU (bench.py --rank-of %d): rank 0's %d-cell sub-domain of the "
+                          "%d^3 box, %d processor patches (%d faces) exchanging with itself through RCCL (size-1 communicator, "
+                          "LDU_FORCE_COMM=1); inter-GPU latency and load imbalance are NOT in it"
+                          % (args.rank_of, args.rank_of, lp["nCells"], n, len(lp["patches_dev"]),
+                             sum(len(q["faceCells"]) for q in lp["patches_dev"])),
+            "per_rank_vcycles_per_s": round(iters / elapsed, 3), "ms_per_vcycle": round(elapsed / max(1, iters) * 1e3, 3),
+            "vcycles_per_solve": perf["nIterations"], "steps": args.steps,
+            "per_vcycle": comm_per_vcycle,
+            "engine_fallbacks": ctx.fallback_count(),
+            "levels": [[L["nCells"], L["nFaces"], L["nLevels"], L["engine_gs_multi"]] for L in (levels or [])],
+            "finest": [nC, nF, info["nLevels"], addr.sweep_engine(1)],
+            "residual_history": [float("%.6e" % h) for h in perf["history"]]}))
+    elif rank == 0:
         out = {
             "metric": "GAMG p-solve iterations/sec (V-cycles/s) + achieved HBM GB/s, 10M-cell motorBike stand-in",
             "value": round(iters / elapsed, 3),
@@ -388,6 +519,9 @@ def main():
                                      "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)"
                                      % (5 * args.octree_q, 2 * args.octree_q, 2 * args.octree_q, args.octree_levels[0],
                                         args.octree_levels[1], cell_level_hist, nC_total, nF_total)) if is_octree else
+                                    ("interFoam damBreak p_rgh twin (BASELINE config C5): %d x %d cells 2-D (%d cells, %d faces), "
+                                     "GAMG (GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, n, nC_total, nF_total))
+                                    if args.mesh == "jump2d" else
                                     ("simpleFoam motorBike ~10M-cell p-solve stand-in: %d^3 hex box "
                                      "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
                                      "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total)))
@@ -395,6 +529,7 @@ def main():
                                        "irregular": "; NOT the plain box: random diagonal faces added (6-12 neighbours per cell), "
                                                     "renumbered by Foam::bandCompression",
                                        "random": "; NOT the box: band-limited random graph, 5-9 neighbours per cell",
+                                       "jump2d": "; 5-point matrix, face coefficient jumping 1 <-> 1000 across the diagonal (two-phase density ratio)",
                                        "octree": "; hexRef8 cell numbering renumbered by Foam::bandCompression",
                                        "octree_hexref": "; hexRef8 cell numbering (parent keeps its label, 7 children appended)"}[args.mesh]),
                        "mesh": args.mesh,

@@ -82,6 +82,16 @@ int ldu_ctx_sync(ldu_ctx* ctx);
  * the level-kernel engine (bit-identical results) instead of failing.  ldu_ctx_fallback_count = how many
  * operations of this context took that path.  polls = 0 restores the default. */
 int ldu_ctx_set_spin_limit(ldu_ctx* ctx, uint32_t polls);
+/* Time bound of the dependency waits of the sweep engines (besides the poll bound of ldu_ctx_set_spin_limit): a wave
+ * that has waited longer than budgetMs (wall clock; default 200, 0 = no time bound) gives up, the sweep drains and the
+ * operation is re-run on the level-kernel engine (ldu_ctx_fallback_count counts) - a launch that crawls cannot stall a
+ * solve.  debugStallMs > 0 (tests only) makes the wave that runs the first task of every sweep launch sit still for
+ * that long.  Process-wide like the spin limit (one device variable per kernel file). */
+int ldu_ctx_set_watchdog(ldu_ctx* ctx, double budgetMs, double debugStallMs);
+/* communication counters of a context since its creation: out[0] halo exchanges with other ranks (initMatrixInterfaces),
+ * [1] scalar all-reduces (reduce(..., sumOp)), [2] device-to-host read-backs of solver scalars (one per convergence
+ * check), [3] halo exchanges that ran on the communication stream overlapped with the interior rows */
+int ldu_ctx_comm_counters(const ldu_ctx* ctx, int64_t out[4]);
 int64_t ldu_ctx_fallback_count(const ldu_ctx* ctx);
 /* RCCL halo exchanges that ran on the communication stream, overlapped with the interior rows of the operator
  * (between initMatrixInterfaces and updateMatrixInterfaces, lduMatrixUpdateMatrixInterfaces.C:30-93, 127-160);
@@ -460,6 +470,16 @@ int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAdd
 int ldu_renumber_addressing(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
                             const int32_t* newOrder, int32_t* newLower, int32_t* newUpper, int32_t* faceMap,
                             uint8_t* flip);
+
+/* Host-only views of the halo wire protocol (no device, no communicator; tests/test_gloo_2rank.py):
+ * ldu_comm_paired_patch: index, on the neighbour rank, of the patch that pairs with my patch p - the k-th patch of the
+ *   neighbour towards me, k = ordinal of p among my patches towards that neighbour (processorFvPatch pairs by
+ *   myProcNo / neighbProcNo the same way); -1 = none.
+ * ldu_comm_exchange_order: the patches for which one operator application issues an ncclSend + ncclRecv, in issue
+ *   order (patches with faces that are not cyclic: nbrPatch < 0); returns their number. */
+int ldu_comm_paired_patch(int32_t nMine, const int32_t* mineNbrRank, int32_t p, int32_t nTheirs,
+                          const int32_t* theirsNbrRank, int32_t me);
+int ldu_comm_exchange_order(int32_t nPatches, const int32_t* nFaces, const int32_t* nbrPatch, int32_t* order);
 
 /* Host-only plan statistics of an addressing (no device needed): dependency levels of the lower-triangular DAG
  * (what bounds every sequential sweep of the reference: GaussSeidelSmoother.C:147-176, DICPreconditioner.C:71-122)

@@ -40,7 +40,7 @@ EXPORTS = [
     "ldu_fv_faceScale", "ldu_fvc_correctedSnGrad", "ldu_fv_interpolateBoundary", "ldu_fvc_gaussGradBoundary",
     "ldu_fvc_surfaceIntegrateFull", "ldu_fvm_sourceMinusVDiv", "ldu_fv_tensorGammaFactors",
     "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
-    "ldu_debug_dag_stats", "ldu_debug_stream", "ldu_debug_slices",
+    "ldu_debug_dag_stats", "ldu_debug_stream", "ldu_debug_slices", "ldu_ctx_set_watchdog", "ldu_ctx_comm_counters", "ldu_comm_paired_patch", "ldu_comm_exchange_order",
 ]
 
 # LduMatrix<Type, scalar, scalar> run-time selection names (Solvers/*/*.H TypeName)
@@ -190,6 +190,18 @@ class Context:
         f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
         _chk(f(self.h, int(mode), int(n), int(reps), C.byref(sec)))
         return (16.0 if mode == 0 else 24.0) * (int(n) // 2 * 2) / sec.value / 1e9
+
+    def set_watchdog(self, budget_ms=200.0, debug_stall_ms=0.0):
+        f = lib().ldu_ctx_set_watchdog
+        f.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        _chk(f(self.h, float(budget_ms), float(debug_stall_ms)))
+
+    def comm_counters(self):
+        out = (C.c_int64 * 4)()
+        f = lib().ldu_ctx_comm_counters
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(f(self.h, out))
+        return dict(halo_exchanges=out[0], all_reduces=out[1], scalar_readbacks=out[2], halo_overlapped=out[3])
 
     def fallback_count(self):
         f = lib().ldu_ctx_fallback_count
@@ -812,3 +824,23 @@ def dag_stats(nCells, lowerAddr, upperAddr, maxCells=64, arrays=False):
     if arrays:
         d.update(cellLevel=lev, cellCluster=clu, clusterLevel=cl[:d["clusters"]])
     return d
+
+
+def comm_paired_patch(mine_nbr_ranks, p, their_nbr_ranks, me):
+    """ldu_comm_paired_patch (host only): the neighbour's patch that pairs with my patch p (-1: none)"""
+    a, b = _i32(mine_nbr_ranks), _i32(their_nbr_ranks)
+    f = lib().ldu_comm_paired_patch
+    f.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+    return int(f(a.size, _ptr(a), int(p), b.size, _ptr(b), int(me)))
+
+
+def comm_exchange_order(n_faces, nbr_patch):
+    """ldu_comm_exchange_order (host only): patch indices in the order one operator application sends / receives"""
+    n, q = _i32(n_faces), _i32(nbr_patch)
+    out = np.zeros(n.size, dtype=np.int32)
+    f = lib().ldu_comm_exchange_order
+    f.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    k = int(f(n.size, _ptr(n), _ptr(q), _ptr(out)))
+    if k < 0:
+        raise LduError("ldu_comm_exchange_order failed")
+    return out[:k]

@@ -168,6 +168,11 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e) c->p2pWindowLevels = atof(e);
     e = getenv("LDU_HALO_OVERLAP");
     if (e) c->haloOverlap = atoi(e);
+    e = getenv("LDU_WATCHDOG_MS");
+    if (e && (k_set_watchdog((unsigned long long)(atof(e) * 1e5), 0) || k_cluster_set_watchdog((unsigned long long)(atof(e) * 1e5), 0)))
+        return -1;
+    e = getenv("LDU_COOP_ROWS");
+    if (e) c->coopRows = atoi(e);
     e = getenv("LDU_SORT_ROWS");
     if (e) c->sortRowsByWidth = atoi(e);
     e = getenv("LDU_SPIN_LIMIT");
@@ -204,6 +209,25 @@ int ldu_ctx_set_spin_limit(ldu_ctx* c, uint32_t polls)
     LDU_CHECK_HIP(hipSetDevice(c->device));
     LDU_CHECK_HIP(hipStreamSynchronize(c->stream));
     if (k_set_spin_limit(polls) || k_cluster_set_spin_limit(polls)) return -1;
+    return 0;
+}
+
+int ldu_ctx_set_watchdog(ldu_ctx* c, double budgetMs, double debugStallMs)
+{
+    if (!c || budgetMs < 0 || debugStallMs < 0) { ldu_set_error("ldu_ctx_set_watchdog: bad argument"); return -1; }
+    LDU_CHECK_HIP(hipSetDevice(c->device));
+    LDU_CHECK_HIP(hipStreamSynchronize(c->stream));
+    LDU_CHECK_HIP(hipStreamSynchronize(c->stream2));
+    // wall_clock64() ticks at 100 MHz on gfx950 (s_memrealtime)
+    const unsigned long long b = (unsigned long long)(budgetMs * 1e5), st = (unsigned long long)(debugStallMs * 1e5);
+    if (k_set_watchdog(b, st) || k_cluster_set_watchdog(b, st)) return -1;
+    return 0;
+}
+
+int ldu_ctx_comm_counters(const ldu_ctx* c, int64_t out[4])
+{
+    if (!c || !out) { ldu_set_error("ldu_ctx_comm_counters: null argument"); return -1; }
+    out[0] = c->nHaloExchanges; out[1] = c->nAllReduces; out[2] = c->nScalarReadbacks; out[3] = c->nHaloOverlapped;
     return 0;
 }
 

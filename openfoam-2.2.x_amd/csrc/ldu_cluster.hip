@@ -447,6 +447,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
     constexpr int B = sw_base(MODE);
     constexpr bool TF = sw_tform(MODE);
     constexpr bool FWD = (B == SW_TRI_FWD || B == SW_RD || B == SW_GS_FWD);
+    ldu_debug_stall(s == 0);
     const int row0 = s * LDU_WAVE;
     const int cnt = LDU_WAVE;
     const int r = row0 + lane;
@@ -506,6 +507,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
         {
             cl_u32x4 g0, g1, g2;
             unsigned spins = 0;
+            unsigned long long tw0 = 0;
             const unsigned spinLimit = g_cl_spin_limit;
             for (;;)
             {
@@ -515,7 +517,7 @@ __device__ __forceinline__ void cl_cluster(const ClTab& T, int s, int lane, doub
                 if (e1) ok &= (g1.y == tag) & (g1.w == tag);
                 if (e2) ok &= (g2.y == tag) & (g2.w == tag);
                 if (ok) break;
-                if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
+                if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);
@@ -799,6 +801,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
         {
             cl_u32x4 g[3][3];
             unsigned spins = 0;
+            unsigned long long tw0 = 0;
             const unsigned spinLimit = g_cl_spin_limit;
             for (;;)
             {
@@ -812,7 +815,7 @@ __device__ __forceinline__ void cl_cluster_vec(const ClTab& T, int s, int lane, 
                     if (e2) ok &= (g[j][2].y == tag) & (g[j][2].w == tag);
                 }
                 if (ok) break;
-                if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
+                if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
 #pragma unroll
@@ -1072,6 +1075,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                                            const double* __restrict__ rhs, const double* __restrict__ diag,
                                            const double* __restrict__ val)
 {
+    ldu_debug_stall(s == 0 && j == 0);
     const int row0 = s * LDU_WAVE;
     const int cnt = LDU_WAVE;
     const int r = row0 + lane;
@@ -1120,6 +1124,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
             {
                 cl_u32x4 g0, g1, g2;
                 unsigned spins = 0;
+            unsigned long long tw0 = 0;
                 const unsigned spinLimit = g_cl_spin_limit;
                 for (;;)
                 {
@@ -1129,7 +1134,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                     if (e1) ok &= (g1.y == t) & (g1.w == t);
                     if (e2) ok &= (g2.y == t) & (g2.w == t);
                     if (ok) break;
-                    if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
+                    if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0)) { *abortFlag = 1; return; }
                     __builtin_amdgcn_s_sleep(CL_NAP_UP);
                 }
                 if (e0) xu[k0] = cl_value(g0);
@@ -1153,6 +1158,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
         {
             cl_u32x4 g0, g1, g2;
             unsigned spins = 0;
+            unsigned long long tw0 = 0;
             const unsigned spinLimit = g_cl_spin_limit;
             for (;;)
             {
@@ -1163,7 +1169,7 @@ __device__ __forceinline__ void cl_gs_task(const ClTab& T, const int* __restrict
                 if (e1) ok &= (g1.y == tagNew) & (g1.w == tagNew);
                 if (e2) ok &= (g2.y == tagNew) & (g2.w == tagNew);
                 if (ok) break;
-                if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag)) { *abortFlag = 1; return; }
+                if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0)) { *abortFlag = 1; return; }
                 __builtin_amdgcn_s_sleep(CL_NAP);
             }
             if (e0) xe[k0] = cl_value(g0);
@@ -1398,4 +1404,11 @@ bool k_cluster_kind_active(ldu_addr* a, int kind)
     if (!ctx->clusterEngine || !ctx->sweepP2P || a->nCells < ctx->clusterMinCells) return false;
     if (cluster_build(a) < 0) return false;
     return a->cluster->eligible && cluster_pays(a, kind == 0 ? 0 : 1);
+}
+
+int k_cluster_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks)
+{
+    const unsigned long long v[2] = {budgetTicks, stallTicks};
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wait_budget), v, sizeof(v)));
+    return 0;
 }

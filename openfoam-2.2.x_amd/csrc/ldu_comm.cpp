@@ -117,6 +117,7 @@ int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s)
     // LDU_FORCE_COMM=1 sends even a 1-rank reduction through RCCL (exercises the backend on 1 GPU)
     static const bool force = getenv("LDU_FORCE_COMM") && atoi(getenv("LDU_FORCE_COMM"));
     if (!ctx->comm || (ctx->nRanks <= 1 && !force)) return 0;
+    ctx->nAllReduces++;
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;
@@ -177,6 +178,39 @@ static int paired_patch(const std::vector<Patch>& mine, int p, const std::vector
     return -1;
 }
 
+// the patches comm_exchange sends / receives for, in the order it issues the ncclSend / ncclRecv pairs (processor patches
+// with faces; cyclic patches are local copies).  RCCL matches the k-th send to a peer with the k-th receive posted for
+// it there, so this order together with paired_patch IS the wire protocol.
+static std::vector<int> comm_remote_order(const std::vector<Patch>& patches)
+{
+    std::vector<int> order;
+    for (int p = 0; p < (int)patches.size(); p++)
+        if (patches[p].n != 0 && patches[p].nbrPatch < 0) order.push_back(p);
+    return order;
+}
+
+// Host-only views of the two rules above (no device, no communicator): the CPU tests drive them over gloo
+// (tests/test_gloo_2rank.py) so that a change of the pairing or of the issue order fails there.
+extern "C" int ldu_comm_paired_patch(int32_t nMine, const int32_t* mineNbrRank, int32_t p, int32_t nTheirs,
+                                     const int32_t* theirsNbrRank, int32_t me)
+{
+    if (nMine < 0 || nTheirs < 0 || p < 0 || p >= nMine || !mineNbrRank || (nTheirs && !theirsNbrRank)) return -2;
+    std::vector<Patch> mine(nMine), theirs(nTheirs);
+    for (int i = 0; i < nMine; i++) mine[i].nbrRank = mineNbrRank[i];
+    for (int i = 0; i < nTheirs; i++) theirs[i].nbrRank = theirsNbrRank[i];
+    return paired_patch(mine, p, theirs, me);
+}
+
+extern "C" int ldu_comm_exchange_order(int32_t nPatches, const int32_t* nFaces, const int32_t* nbrPatch, int32_t* order)
+{
+    if (nPatches < 0 || (nPatches && (!nFaces || !nbrPatch || !order))) return -2;
+    std::vector<Patch> patches(nPatches);
+    for (int i = 0; i < nPatches; i++) { patches[i].n = nFaces[i]; patches[i].nbrPatch = nbrPatch[i]; }
+    const std::vector<int> o = comm_remote_order(patches);
+    for (size_t i = 0; i < o.size(); i++) order[i] = o[i];
+    return (int)o.size();
+}
+
 int comm_exchange(ldu_addr* a, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
@@ -197,6 +231,7 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
         ldu_set_error("processor patches present but no communicator (ldu_ctx_comm_init)");
         return -4;
     }
+    ctx->nHaloExchanges++;
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;
@@ -228,9 +263,9 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
         cs = ctx->streamComm;
     }
     LDU_CHECK_NCCL(ncclGroupStart());
-    for (auto& p : a->patches)
+    for (int pi : comm_remote_order(a->patches))
     {
-        if (p.n == 0 || p.nbrPatch >= 0) continue;
+        Patch& p = a->patches[pi];
         LDU_CHECK_NCCL(ncclSend(p.d_send, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, cs));
         LDU_CHECK_NCCL(ncclRecv(p.d_recv, (size_t)p.n, ncclDouble, p.nbrRank, ctx->comm->comm, cs));
     }

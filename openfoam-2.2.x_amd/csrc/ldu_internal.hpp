@@ -85,6 +85,8 @@ struct ldu_ctx {
     int clusterMulti = 1;            // pipelined GaussSeidel sweeps on the cluster engine (LDU_CLUSTER_MULTI=0: off)
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
+    long nHaloExchanges = 0, nAllReduces = 0, nScalarReadbacks = 0;   // communication counters (ldu_ctx_comm_counters)
+    int coopRows = 1;                // LDU_COOP_ROWS: several lanes per row for rows with more than 8 lower / upper neighbours
     int sortRowsByWidth = 1;         // LDU_SORT_ROWS: rows of a level ordered by width class (narrow slices stay narrow)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
     int gsWideUpper = 1;             // LDU_GS_WIDE_UPPER=0: upper parts of more than 8 entries after the lower part (round-1 order)
@@ -153,6 +155,8 @@ struct ldu_addr {
     int* d_sliceCnt = nullptr;             // [nSlices] rows in slice (<= 64)
     int* d_sliceEnt = nullptr;             // [nSlices] first entry
     int* d_sliceW = nullptr;               // [nSlices] width (max nL+nU)
+    unsigned char* d_sliceT = nullptr;     // [nSlices] lanes per row: 1, or 2 / 4 / 8 in a cooperative slice (ldu_plan.cpp)
+    int nCoopSlices = 0;
     int* d_levelSliceStart = nullptr;      // [nLevels+1]
     unsigned char* d_nL = nullptr;         // [nCells] lower-part entries per row (new numbering)
     unsigned char* d_nU = nullptr;         // [nCells]
@@ -353,6 +357,7 @@ int k_faceH(ldu_matrix* m, double* faceH, const double* xOld, hipStream_t s);
 // interfaces: pack psi[faceCells] -> send buffers; apply result[row] -= sign*coeff*recv
 int k_pack_patches(ldu_addr* a, const double* x, hipStream_t s);
 int k_apply_patches(ldu_addr* a, double* result, const double* coeffs, double sign, hipStream_t s);
+int k_apply_patches_from(ldu_addr* a, double* out, const double* in, const double* coeffs, double sign, hipStream_t s);
 int k_sumA_patches(ldu_addr* a, double* sumA, const double* bou, hipStream_t s);
 
 // elementwise
@@ -455,6 +460,8 @@ int k_div_check(ldu_ctx* ctx, unsigned long long seed, long n, unsigned long lon
 int k_stream(ldu_ctx* ctx, int mode, long n, int reps, double* seconds);
 int k_set_p2p_wide(int on);
 int k_set_gs_multi_trace(unsigned long long* buf, int nSlices);
+int k_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks);           // ldu_kernels.hip
+int k_cluster_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks);   // ldu_cluster.hip
 int k_set_spin_limit(unsigned polls);          // ldu_kernels.hip (0 = default)
 int k_cluster_set_spin_limit(unsigned polls);  // ldu_cluster.hip
 int k_cluster_set_trace(unsigned long long* buf);
@@ -533,6 +540,36 @@ __device__ __forceinline__ double ldu_div(double t, double d, double r)
 // done to the ticket path.  Now thread 0 looks every 32nd task, a waiting wave at its 8th poll and then every 256th:
 // a sweep that aborted still drains (every wait is bounded and looks at the flag), just not within one task.
 #define LDU_ABORT_POLL 8u
+// Time bound of a dependency wait (the poll bound above counts polls, and a launch that merely CRAWLS - one gpurun box in
+// ten ran the 4-sweep launches of an irregular graph 20-1000x slower, DESIGN.md - never reaches it): a wave that has been
+// waiting longer than the budget (wall clock, 100 MHz s_memrealtime; default 200 ms, no healthy launch lasts that long)
+// gives up like a wave whose polls ran out - abort flag, the grid drains, run_with_fallback re-runs the operation on
+// the level kernels.  The clock is read at the 8th poll of a wait and then every 256th: nothing on the fast path.
+// One copy per translation unit (set together by ldu_ctx_set_watchdog): [0] budget in ticks (0 = off), [1] debug stall
+// in ticks injected into the first task of every sweep launch (tests).
+static __device__ unsigned long long g_wait_budget[2] = {20000000ull, 0ull};
+__device__ __forceinline__ bool ldu_wait_expired(unsigned& spins, unsigned spinLimit, volatile int* abortFlag,
+                                                 unsigned long long& tw0)
+{
+    if (++spins > spinLimit) return true;
+    if ((spins & 255u) != LDU_ABORT_POLL) return false;
+    if (*abortFlag) return true;
+    const unsigned long long budget = g_wait_budget[0];
+    if (!budget) return false;
+    const unsigned long long now = wall_clock64();
+    if (!tw0) { tw0 = now; return false; }
+    return now - tw0 > budget;
+}
+// tests: the wave that runs the first task of a launch sits still for g_wait_budget[1] ticks
+__device__ __forceinline__ void ldu_debug_stall(bool first)
+{
+    const unsigned long long st = g_wait_budget[1];
+    if (first && st)
+    {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < st) __builtin_amdgcn_s_sleep(64);
+    }
+}
 __device__ __forceinline__ bool ldu_abort_seen(volatile int* abortFlag, int it)
 {
     return (it & 31) == 31 && *abortFlag != 0;

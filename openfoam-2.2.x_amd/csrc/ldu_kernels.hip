@@ -264,6 +264,7 @@ struct SliceTab {
     const int* sliceRow; const int* sliceCnt; const int* sliceEnt;
     const unsigned char* nL; const unsigned char* nU; const int* col;
     const int* sliceW = nullptr;      // per slice: entries per row (max nL+nU)
+    const unsigned char* sliceT = nullptr;   // per slice: lanes per row (cooperative slices: 2 / 4 / 8), or no table
     const int* gate = nullptr;        // per slice: slice whose completion opens the polling gate (-1: none)
     unsigned* sliceDone = nullptr;    // per slice: tag of the last sweep that completed it (hint only)
 };
@@ -597,9 +598,16 @@ __device__ __forceinline__ void p2p_window_wait(const unsigned* done, unsigned d
     if (t < window) return;
     const int need = t - window;
     unsigned naps = 0;
+    unsigned long long tw0 = 0;
     while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - doneBase) < need)
     {
-        if ((++naps & 63u) == 0 && *abortFlag) return;   // (one address for the whole chip: look rarely)
+        if ((++naps & 63u) == 0)   // (one address for the whole chip: look rarely)
+        {
+            if (*abortFlag) return;
+            const unsigned long long budget = g_wait_budget[0], now = wall_clock64();
+            if (!tw0) tw0 = now;
+            else if (budget && now - tw0 > budget) { *abortFlag = 1; return; }
+        }
         __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -751,6 +759,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
         }
         u32x4 g8[8];
         unsigned spins = 0;
+            unsigned long long tw0 = 0;
         const int sleepN = g_p2p_sleep;
         const unsigned spinLimit = g_p2p_spin_limit;
         for (;;)
@@ -761,7 +770,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             for (int j = 0; j < 8; j++)
                 if (j < n) ok &= (g8[j].y == tag) & (g8[j].w == tag);
             if (ok) break;
-            if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+            if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0))
             {
                 if (spins > spinLimit)
                 {
@@ -817,18 +826,20 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             // fine-grained polling below runs for ~1 hand-off instead of the whole look-ahead.
             const unsigned* gp = waitEst.sliceDone + waitEst.gateSlice;
             unsigned gspins = 0;
+            unsigned long long tw0g = 0;
             const unsigned spinLimit = g_p2p_spin_limit;
             for (;;)
             {
                 const unsigned gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(gv - tag) >= 0) break;
-                if (++gspins > spinLimit || ((gspins & 255u) == LDU_ABORT_POLL && *abortFlag)) break;
+                if (ldu_wait_expired(gspins, spinLimit, abortFlag, tw0g)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
             waitEst.gateSlice = -1;
         }
         u32x4 g0, g1, g2, g3;
         unsigned spins = 0;
+            unsigned long long tw0 = 0;
         const int sleepN = g_p2p_sleep;
         const unsigned spinLimit = g_p2p_spin_limit;
         for (;; waitEst.polls += DIAG ? 1u : 0u)
@@ -841,7 +852,7 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
             if (i0 + 2 < n) ok &= (g2.y == tag) & (g2.w == tag);
             if (i0 + 3 < n) ok &= (g3.y == tag) & (g3.w == tag);
             if (ok) break;
-            if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+            if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0))
             {
                 if (spins > spinLimit)
                 {
@@ -890,6 +901,157 @@ __device__ __forceinline__ bool p2p_accumulate(double& acc, const uint4* __restr
     return true;
 }
 
+
+// ---------------------------------------------------------------- cooperative rows
+// Rows with more than eight lower or upper neighbours (hanging faces of an octree mesh: up to 24; agglomerated GAMG
+// levels of such a mesh: 25 ... 66 entries per row) were the critical path of every dependency level they sit in: one
+// lane walked the row in groups of four or eight entries, every group two DEPENDENT round trips (columns /
+// coefficients, then the granules): 8 - 13 us per level on the octree twin of the motorBike mesh, where a narrow row
+// takes 1.5.  Here Tl = 2 / 4 / 8 lanes share a row (the plan puts such rows into slices of 64 / Tl rows of one width
+// class): every lane loads, polls and multiplies EIGHT entries of the row's sequence - one round trip for the whole
+// row - and parks the products in LDS; the row's first lane then subtracts them in the reference's order (lower part
+// ascending, then the upper part; descending for the backward triangular sweep), which is the only part that has to be
+// sequential: ~11 ns per entry.  Same products, same order of subtraction: bit-identical.
+// Sequence of a row: positions 0 .. nd-1 = the entries whose values THIS sweep produces (polled with `tag`), then, for
+// the forward GaussSeidel sweep, nOld = nU positions of "old" upper values (plain loads of w, or the previous
+// pipelined sweep's granules, tag - 1).  lds: 512 doubles of this wave.
+template <int MODE, bool SLAB, bool MULTI>
+__device__ __forceinline__ bool coop_rows(const SliceTab& T, int s, int Tl, int lane, uint4* __restrict__ G,
+                                          uint4* __restrict__ X, const unsigned char* __restrict__ xflag, unsigned tag,
+                                          bool oldFromGranules, bool writeW, volatile int* abortFlag,
+                                          double* __restrict__ w, const double* __restrict__ rhs,
+                                          const double* __restrict__ scale, const double* __restrict__ val,
+                                          const double* __restrict__ val2, double* __restrict__ aux,
+                                          double* __restrict__ lds, unsigned long long* trc = nullptr)
+{
+    constexpr int B = sw_base(MODE);
+    constexpr bool TF = sw_tform(MODE);
+    if (trc && lane == 0) trc[0] = (unsigned long long)wall_clock64();
+    const int R = LDU_WAVE / Tl;                 // rows of this wave (power of two)
+    const int i = lane & (R - 1), t = lane / R;  // row, part: lanes of one part read consecutive rows (coalesced)
+    const int cnt = T.sliceCnt[s];
+    const bool act = i < cnt;
+    const int r = T.sliceRow[s] + (act ? i : 0);
+    const int nl = act ? T.nL[r] : 0, nu = act ? T.nU[r] : 0;
+    const long ent0 = (long)T.sliceEnt[s] + i;
+    int first, step, nd, nOld;
+    if (B == SW_TRI_FWD || B == SW_RD) { first = 0; step = 1; nd = nl; nOld = 0; }
+    else if (B == SW_TRI_BWD) { first = nl + nu - 1; step = -1; nd = nu; nOld = 0; }
+    else if (B == SW_GS_FWD) { first = 0; step = 1; nd = nl; nOld = nu; }
+    else { first = nl; step = 1; nd = nu; nOld = 0; }   // SW_GS_BWD
+    const int M = nd + nOld;
+    // what the leader needs, before any wait
+    const bool leader = act && t == 0;
+    double acc = 0.0, d = 1.0, rd = 0.0, sc = 0.0;
+    if (act)
+    {
+        if (B == SW_TRI_FWD) { sc = scale[r]; acc = sc * rhs[r]; }
+        else if (B == SW_TRI_BWD) { acc = w[r]; if (TF) sc = scale[r]; }
+        else if (B == SW_RD) acc = scale[r];
+        else { acc = rhs[r]; d = scale[r]; if (!(B == SW_GS_FWD && TF)) rd = ldu_div_prepare(d); }
+    }
+    int c[8];
+    double v[8], v2[8], x[8];
+    bool poll[8], use[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+    {
+        const int m = 8 * t + q;
+        const bool dep = act && m < nd, old = act && m >= nd && m < M;
+        const int k = dep ? first + m * step : nl + (m - nd);
+        use[q] = dep || old;
+        const long e = ent0 + (long)(use[q] ? k : 0) * LDU_WAVE;
+        c[q] = use[q] ? T.col[e] : r;
+        v[q] = use[q] ? val[e] : 0.0;
+        v2[q] = (B == SW_RD && use[q]) ? val2[e] : 0.0;
+        poll[q] = dep || (old && oldFromGranules);
+        x[q] = (B == SW_RD) ? 1.0 : 0.0;
+        if (old && !oldFromGranules) x[q] = w[c[q] & 0x7fffffff];
+    }
+    bool anyPoll = false;
+#pragma unroll
+    for (int q = 0; q < 8; q++) anyPoll |= poll[q];
+    if (trc && lane == 0) trc[1] = (unsigned long long)wall_clock64();
+    if (anyPoll)
+    {
+        const uint4* gp[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
+        u32x4 g[8];
+        unsigned spins = 0;
+        unsigned long long tw0 = 0;
+        const int sleepN = g_p2p_sleep;
+        const unsigned spinLimit = g_p2p_spin_limit;
+        for (;;)
+        {
+            granule_load8(gp, g);
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+            {
+                const unsigned want = (8 * t + q < nd) ? tag : tag - 1u;
+                if (poll[q]) ok &= (g[q].y == want) & (g[q].w == want);
+            }
+            if (ok) break;
+            if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0))
+            {
+                if (spins > spinLimit) p2p_dbg_record(3, r, tag, c[0], g[0].y, g[0].w, t);
+                *abortFlag = 1;
+                return false;
+            }
+            p2p_nap(spins, sleepN);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (poll[q]) x[q] = granule_value(g[q]);
+    }
+    // the terms, in the family's association (p2p_accumulate OP 0..3)
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+    {
+        double term;
+        if (B == SW_RD) term = TF ? (v2[q] * v[q]) * (1.0 / x[q]) : (v2[q] * v[q]) / x[q];
+        else if (TF && (B == SW_TRI_FWD || B == SW_TRI_BWD)) term = sc * (v[q] * x[q]);
+        else term = v[q] * x[q];
+        lds[(8 * t + q) * R + i] = term;
+    }
+    LDU_STEP_FENCE();   // LDS is in order within a wave: the leader's reads below see the helpers' writes
+    if (trc && lane == 0) trc[2] = (unsigned long long)wall_clock64();
+    if (leader)
+    {
+        double auxv = acc;
+        for (int m0 = 0; m0 < 8 * Tl; m0 += 8)
+        {
+            double pr[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) pr[q] = lds[(m0 + q) * R + i];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+            {
+                if (m0 + q < M) acc -= pr[q];
+                if (m0 + q < nd) auxv = acc;
+            }
+        }
+        double out = acc;
+        if (B == SW_GS_FWD)
+        {
+            if (aux) aux[r] = auxv;
+            out = TF ? d * acc : ldu_div(acc, d, rd);
+        }
+        else if (B == SW_GS_BWD) out = ldu_div(acc, d, rd);
+        if (writeW) w[r] = out;
+        if (SLAB) granule_store_slab(G, X, r, out, tag, xflag[r] != 0);
+        else granule_store(G, r, out, tag);
+    }
+    if (trc && lane == 0)
+    {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trc[3] = (unsigned long long)wall_clock64(); trc[4] = xcc & 0xf; trc[5] = blockIdx.x;
+    }
+    return true;
+}
+
 template <bool SLAB>
 __device__ __forceinline__ bool gs_upper_block(const SliceTab& T, const uint4* __restrict__ G,
                                                const uint4* __restrict__ X, bool first, unsigned t,
@@ -907,8 +1069,19 @@ __device__ __forceinline__ bool p2p_slice(const SliceTab& T, int s, int lane, ui
                                           const double* __restrict__ val2, double* __restrict__ aux,
                                           P2PStat& waitEst, double* __restrict__ puLds = nullptr, int puSlots = 0)
 {
+    if (T.sliceT)
+    {
+        const int Tl = T.sliceT[s];   // wave-uniform
+        if (Tl > 1)
+        {
+            ldu_debug_stall(s == 0);
+            return coop_rows<MODE, SLAB, false>(T, s, Tl, lane, G, X, xflag, tag, false, true, abortFlag, w, rhs, scale, val,
+                                                val2, aux, puLds);
+        }
+    }
     const int cnt = T.sliceCnt[s];
     if (lane >= cnt) return true;
+    ldu_debug_stall(s == 0);
     const int r = T.sliceRow[s] + lane;
     const int nl = T.nL[r];
     const int nu = T.nU[r];
@@ -1386,14 +1559,23 @@ static int p2p_window(const ldu_addr* a, long nChunks, int k, int grid, int nLev
     const double perLevel = (double)nChunks / (double)nLevelsOfQueue;    // chunks per level, all k sweeps together
     long w = (long)(lv * perLevel + 0.5);
     if (w < 8 * k) w = 8 * k;
-    return w >= 2L * grid ? 0 : (int)w;
+    // The window only pays when the grid would otherwise run dozens of levels ahead of the front (deep, narrow DAGs:
+    // every resident wave polls for data that is far away).  On levels a quarter of the grid wide or wider the
+    // bookkeeping (one atomic and a workgroup barrier per chunk, workgroups idling at the window's edge) costs more
+    // than the polls it saves: octree twin of the motorBike mesh, finest level (660 levels, 59 chunks each, grid 512):
+    // one GaussSeidel sweep 4.9 ms with the window, 1.9 ms without; two pipelined 9.3 / 3.5 ms; DIC 9.8 / 3.1 ms.
+    // (round 2's rule was w >= 2 grid; measured per GAMG level of that mesh: off wins at >= 2.5 chunks per level and
+    //  slab (64 workgroups per slab), on wins below 1.2)
+    if ((double)grid <= 2.0 * lv * perLevel) return 0;   // the grid cannot run more than 2 windows (16 levels) ahead
+    return (int)w;
 }
 
 // LDS slots per lane for the parked upper-part products of rows with more than eight upper neighbours (0: none)
 static int gs_pu_slots(const ldu_addr* a)
 {
-    if (a->maxUpper <= 8 || !a->ctx->gsWideUpper) return 0;
-    return std::min(24, (a->maxUpper + 7) / 8 * 8);
+    const int coop = a->nCoopSlices ? 8 : 0;   // cooperative rows: 512 doubles per wave
+    if (a->maxUpper <= 8 || !a->ctx->gsWideUpper) return coop;
+    return std::max(coop, std::min(24, (a->maxUpper + 7) / 8 * 8));
 }
 
 template <int MODE, bool DESC>
@@ -1404,18 +1586,19 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
     if (!Pp) { ldu_set_error("p2p lane allocation failed"); return -1; }
     ldu_addr::P2PLane& P = *Pp;
     // forward GaussSeidel sweeps park the products of wide upper parts in LDS (see p2p_gs_task)
-    const int puSlots = sw_base(MODE) == SW_GS_FWD ? gs_pu_slots(a) : 0;
+    const int puSlots = sw_base(MODE) == SW_GS_FWD ? gs_pu_slots(a) : (a->nCoopSlices ? 8 : 0);
     const size_t puBytes = sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE;
     if (use_slab(a, (sw_base(MODE) == SW_GS_FWD || sw_base(MODE) == SW_GS_BWD) ? 1 : 0))
     {
         SliceTab TS{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_colX};
+        if (a->nCoopSlices) TS.sliceT = a->d_sliceT;
         SlabCtl C;
         slab_ctl(a, P, C);
         C.list = a->d_slabList;
         for (int i = 0; i <= 8; i++) C.start[i] = a->slabStart[i];
         P.epoch++;
         if (P.epoch == 0) P.epoch = 1;
-        const int grid = ctx->numCUs * (puBytes ? std::min(slab_bpc(a, 1), 3) : slab_bpc(a, 1));
+        const int grid = ctx->numCUs * (puSlots > 8 ? std::min(slab_bpc(a, 1), 3) : slab_bpc(a, 1));
         for (int i = 0; i < a->nSlabs; i++)
             C.window[i] = p2p_window(a, cdiv(a->slabStart[i + 1] - a->slabStart[i], P2P_CHUNK), 1,
                                      grid / std::max(1, a->nSlabs), a->slabLevelSpan[i]);
@@ -1425,6 +1608,7 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
         return 0;
     }
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    if (a->nCoopSlices) T.sliceT = a->d_sliceT;
     if (ctx->p2pGate)
     {
         T.gate = DESC ? a->d_gateB : a->d_gateF;
@@ -1492,6 +1676,7 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
     for (int q = 0; q < 4; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
     u32x4 g0, g1, g2, g3;
     unsigned spins = 0;
+            unsigned long long tw0 = 0;
     const unsigned spinLimit = g_p2p_spin_limit;
     for (;;)
     {
@@ -1502,7 +1687,7 @@ __device__ __forceinline__ bool gs_gather_old4(const SliceTab& T, const uint4* _
         if (BASE + 2 < nu) ok &= (g2.y == t) & (g2.w == t);
         if (BASE + 3 < nu) ok &= (g3.y == t) & (g3.w == t);
         if (ok) break;
-        if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+        if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0))
         {
             if (spins > spinLimit)
             {
@@ -1547,6 +1732,7 @@ __device__ __forceinline__ bool gs_gather_old8(const SliceTab& T, const uint4* _
     for (int q = 0; q < 8; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
     u32x4 g[8];
     unsigned spins = 0;
+            unsigned long long tw0 = 0;
     const unsigned spinLimit = g_p2p_spin_limit;
     for (;;)
     {
@@ -1556,7 +1742,7 @@ __device__ __forceinline__ bool gs_gather_old8(const SliceTab& T, const uint4* _
         for (int q = 0; q < 8; q++)
             if (q < nu) ok &= (g[q].y == t) & (g[q].w == t);
         if (ok) break;
-        if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+        if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0))
         {
             if (spins > spinLimit)
             {
@@ -1613,6 +1799,7 @@ __device__ __forceinline__ bool gs_upper_block(const SliceTab& T, const uint4* _
     for (int q = 0; q < 8; q++) gp[q] = SLAB ? (c[q] < 0 ? X : G) + (c[q] & 0x7fffffff) : G + c[q];
     u32x4 g[8];
     unsigned spins = 0;
+            unsigned long long tw0 = 0;
     const unsigned spinLimit = g_p2p_spin_limit;
     for (;;)
     {
@@ -1622,7 +1809,7 @@ __device__ __forceinline__ bool gs_upper_block(const SliceTab& T, const uint4* _
         for (int q = 0; q < 8; q++)
             if (active && base + q < nu) ok &= (g[q].y == t) & (g[q].w == t);
         if (ok) break;
-        if (++spins > spinLimit || ((spins & 255u) == LDU_ABORT_POLL && *abortFlag))
+        if (ldu_wait_expired(spins, spinLimit, abortFlag, tw0))
         {
             if (spins > spinLimit)
             {
@@ -1662,8 +1849,21 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
                                             const double* __restrict__ val, P2PStat& waitEst,
                                             double* __restrict__ puLds = nullptr, int puSlots = 0)
 {
+    if (T.sliceT)
+    {
+        const int Tl = T.sliceT[s];   // wave-uniform
+        if (Tl > 1)
+        {
+            ldu_debug_stall(s == 0 && j == 0);
+            (void)coop_rows<SW_GS_FWD, SLAB, true>(T, s, Tl, lane, G, X, xflag, tag0 + (unsigned)j, j > 0, j == k - 1, abortFlag,
+                                                   psi, rhs, diag, val, nullptr, nullptr, puLds,
+                                                   g_gsm_trace ? g_gsm_trace + ((size_t)j * (size_t)g_gsm_trace_stride + (size_t)s) * 8 : nullptr);
+            return;
+        }
+    }
     const int cnt = T.sliceCnt[s];
     if (lane >= cnt) return;
+    ldu_debug_stall(s == 0 && j == 0);
     unsigned long long* const trc = g_gsm_trace ? g_gsm_trace + ((size_t)j * (size_t)g_gsm_trace_stride + (size_t)s) * 8 : nullptr;
     if (trc && lane == 0) trc[0] = (unsigned long long)wall_clock64();
     const int r = T.sliceRow[s] + lane;
@@ -2266,6 +2466,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         it = a->gsTasks.emplace(k, gt).first;
     }
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
+    if (a->nCoopSlices) T.sliceT = a->d_sliceT;
     if (ctx->p2pGate)
     {
         T.gate = a->d_gateF;
@@ -2276,7 +2477,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     // k sweeps are in flight at once: keep the same look-ahead (in levels) as a single sweep
     int bpc = ctx->p2pBlocksPerCU * k;
     if (bpc > ctx->p2pMaxBlocksPerCU) bpc = ctx->p2pMaxBlocksPerCU;
-    if (gs_pu_slots(a) && bpc > 3) bpc = 3;   // 48 KB of LDS per workgroup
+    if (gs_pu_slots(a) > 8 && bpc > 3) bpc = 3;   // 48 KB of LDS per workgroup
     int grid = ctx->numCUs * bpc * 256 / P2P_BLK;
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
@@ -2301,6 +2502,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     if (it->second.d_slabTasks && use_slab(a, 2, k))
     {
         SliceTab TS{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_colX};
+        if (a->nCoopSlices) TS.sliceT = a->d_sliceT;
         SlabCtl C;
         slab_ctl(a, P, C);
         C.list = it->second.d_slabTasks;
@@ -2308,7 +2510,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         const int puSlots = gs_pu_slots(a);
         const size_t puBytes = sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE;
         int sbpc = slab_bpc(a, k);
-        if (puBytes) sbpc = std::min(sbpc, 3);   // 48 KB of LDS per workgroup
+        if (puSlots > 8) sbpc = std::min(sbpc, 3);   // 48 KB of LDS per workgroup
         const int sgrid = ctx->numCUs * sbpc;
         for (int i = 0; i < a->nSlabs; i++)
             C.window[i] = p2p_window(a, cdiv(it->second.slabStart[i + 1] - it->second.slabStart[i], P2P_CHUNK), k,
@@ -2447,6 +2649,35 @@ int k_apply_patches(ldu_addr* a, double* result, const double* coeffs, double si
     if (comm_wait_halo(a->ctx, s)) return -1;   // updateMatrixInterfaces: the received values are needed from here on
     apply_patches_kernel<<<ewGrid(a->nBRows), BLK, 0, s>>>(a->nBRows, a->d_bRow, a->d_bStart, a->d_bFace,
                                                           coeffs, a->d_recvAll, sign, result);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[r] = in[r] - sum coeffs*pnf for the boundary rows only (same order as apply_patches_kernel)
+__global__ void apply_patches_from_kernel(int nBRows, const int* __restrict__ bRow,
+                                          const int* __restrict__ bStart, const int* __restrict__ bFace,
+                                          const double* __restrict__ coeffs, const double* __restrict__ recv,
+                                          double sign, const double* __restrict__ in, double* __restrict__ out)
+{
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < nBRows; j += gridDim.x * BLK)
+    {
+        const int r = bRow[j];
+        double acc = in[r];
+        for (int t = bStart[j]; t < bStart[j + 1]; t++)
+        {
+            const int i = bFace[t];
+            const double c = sign < 0 ? -coeffs[i] : coeffs[i];
+            acc -= c * recv[i];
+        }
+        out[r] = acc;
+    }
+}
+int k_apply_patches_from(ldu_addr* a, double* out, const double* in, const double* coeffs, double sign, hipStream_t s)
+{
+    if (!a->nPatchFaces) return 0;
+    if (comm_wait_halo(a->ctx, s)) return -1;
+    apply_patches_from_kernel<<<ewGrid(a->nBRows), BLK, 0, s>>>(a->nBRows, a->d_bRow, a->d_bStart, a->d_bFace,
+                                                               coeffs, a->d_recvAll, sign, in, out);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -3018,5 +3249,12 @@ int k_fv_div_coeffs(int nFaces, const double* w, const double* phi, double* lowe
     if (nFaces == 0) return 0;
     fv_div_kernel<<<ewGrid(nFaces), BLK, 0, s>>>(nFaces, w, phi, lower, upper);
     LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int k_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks)
+{
+    const unsigned long long v[2] = {budgetTicks, stallTicks};
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wait_budget), v, sizeof(v)));
     return 0;
 }

@@ -8,6 +8,20 @@
 #include "ldu_internal.hpp"
 #include "ldu_cluster_greedy.hpp"
 
+// Width class of a row (lower + upper neighbours): the rows of a dependency level are stored class by class.
+//   0..3  narrow: at most 8 on each side (one lane per row: eight granule polls in flight cover the dependencies);
+//         total <= 6 | <= 8 | <= 12 | <= 16
+//   4..6  wide: more than 8 on one side, total <= 16 | <= 32 | <= 64 -> COOPERATIVE rows: 2 | 4 | 8 lanes per row
+//         (each lane loads, polls and multiplies eight entries, one lane subtracts the products in face order)
+//   7     more than 64 entries: one lane per row, serial (never seen on a mesh; the layout allows 255 + 255)
+static inline int row_width_class(int cl, int cu)
+{
+    const int t = cl + cu;
+    if (cl <= 8 && cu <= 8) return t <= 6 ? 0 : (t <= 8 ? 1 : (t <= 12 ? 2 : 3));
+    return t <= 16 ? 4 : (t <= 32 ? 5 : (t <= 64 ? 6 : 7));
+}
+static inline int class_lanes(int cls) { return cls == 4 ? 2 : (cls == 5 ? 4 : (cls == 6 ? 8 : 1)); }
+
 template <class T>
 static int upload(T** dst, const std::vector<T>& src)
 {
@@ -174,16 +188,13 @@ int plan_build(ldu_addr* a)
         // order, then the wider ones class by class (stable): a slice is padded to its widest row, and on meshes
         // with hanging faces / agglomerated levels ~1 % wide rows scattered over the level would sit in half of its
         // slices (octree twin of the motorBike mesh: 50 % of the slices padded from 6 to 9..25 entries per row).
-        // Class = entries per row (lower + upper): <= 6 | <= 8 | <= 12 | <= 16 | more, or more than 8 on one side.
+        // Classes: row_width_class above.
         const bool sortRows = a->ctx->sortRowsByWidth;
         auto widthClass = [&](int c) -> int {
             if (!sortRows) return 0;
-            const int cl = a->losortStart[c + 1] - a->losortStart[c], cu = a->ownerStart[c + 1] - a->ownerStart[c];
-            if (cl > 8 || cu > 8) return 4;
-            const int t = cl + cu;
-            return t <= 6 ? 0 : (t <= 8 ? 1 : (t <= 12 ? 2 : 3));
+            return row_width_class(a->losortStart[c + 1] - a->losortStart[c], a->ownerStart[c + 1] - a->ownerStart[c]);
         };
-        constexpr int NCLS = 5;
+        constexpr int NCLS = 8;
         std::vector<long> cnt((size_t)nLevels * NCLS + 1, 0);
         std::vector<unsigned char> cls(nC);
         for (int c = 0; c < nC; c++)
@@ -229,11 +240,10 @@ int plan_build(ldu_addr* a)
         a->maxUpper = std::max(a->maxUpper, cu);
     }
     std::vector<unsigned char> rowClass(nC, 0);
-    for (int r = 0; r < nC; r++)
-    {
-        const int t = (int)nL[r] + (int)nU[r];
-        rowClass[r] = (nL[r] > 8 || nU[r] > 8) ? 4 : (t <= 6 ? 0 : (t <= 8 ? 1 : (t <= 12 ? 2 : 3)));
-    }
+    for (int r = 0; r < nC; r++) rowClass[r] = (unsigned char)row_width_class(nL[r], nU[r]);
+    // cooperative rows need the rows of a level grouped by class
+    const bool coop = a->ctx->sortRowsByWidth && a->ctx->coopRows;
+    std::vector<unsigned char> sliceT;
     long ent = 0;
     for (int L = 0; L < nLevels; L++)
     {
@@ -244,8 +254,14 @@ int plan_build(ldu_addr* a)
             // (a slice also ends where the width class changes, on levels wide enough not to care about one more
             //  slice: the single-wavefront kernels of the small levels walk the slices one after the other)
             const bool cutAtClass = a->ctx->sortRowsByWidth && a->levelStart[L + 1] - a->levelStart[L] >= 256;
-            while (cnt < LDU_WAVE && r0 + cnt < a->levelStart[L + 1] && rowSlab[r0 + cnt] == rowSlab[r0]
-                   && !(cutAtClass && rowClass[r0 + cnt] != rowClass[r0])) cnt++;
+            // a cooperative slice holds rows of ONE wide class, 64 / lanes-per-row of them
+            const int Tl = coop ? class_lanes(rowClass[r0]) : 1;
+            const int maxCnt = LDU_WAVE / Tl;
+            while (cnt < maxCnt && r0 + cnt < a->levelStart[L + 1] && rowSlab[r0 + cnt] == rowSlab[r0]
+                   && !((cutAtClass || (coop && (Tl > 1 || class_lanes(rowClass[r0 + cnt]) > 1)))
+                        && rowClass[r0 + cnt] != rowClass[r0])) cnt++;
+            sliceT.push_back((unsigned char)Tl);
+            if (Tl > 1) a->nCoopSlices++;
             sliceSlab.push_back(rowSlab[r0]);
             int W = 0;
             for (int i = 0; i < cnt; i++) W = std::max(W, (int)nL[r0 + i] + (int)nU[r0 + i]);
@@ -417,6 +433,7 @@ int plan_build(ldu_addr* a)
     if (upload(&a->d_sliceCnt, sliceCnt)) return -1;
     if (upload(&a->d_sliceEnt, sliceEnt)) return -1;
     if (upload(&a->d_sliceW, sliceW)) return -1;
+    if (upload(&a->d_sliceT, sliceT)) return -1;
     if (upload(&a->d_levelSliceStart, a->levelSliceStart)) return -1;
     if (upload(&a->d_nL, nL)) return -1;
     if (upload(&a->d_nU, nU)) return -1;
@@ -529,7 +546,7 @@ void plan_free(ldu_addr* a)
         if (kv.second.d_slabTasks) (void)hipFree(kv.second.d_slabTasks);
     }
     a->gsTasks.clear();
-    void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW,
+    void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW, a->d_sliceT,
                     a->d_levelSliceStart, a->d_nL, a->d_nU, a->d_col, a->d_face, a->d_l, a->d_u,
                     a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,
                     a->d_pfCell, a->d_sendAll, a->d_recvAll, a->p2p[0].d_granule, a->p2p[0].d_ticket,

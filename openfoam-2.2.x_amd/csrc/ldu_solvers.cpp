@@ -25,6 +25,7 @@ double* ldu_matrix::workVec(int i)
 int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
 {
     if (comm_allreduce_abort(ctx, ctx->stream)) return -1;
+    ctx->nScalarReadbacks++;
     // scalars and the abort flag (stored behind them) in one copy: a second small copy costs ~20 us of latency
     LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * (S_NSLOTS + 1), hipMemcpyDeviceToHost,
                                  ctx->stream));
@@ -236,6 +237,9 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         if (pipelined && left == 0) return 0;
         nSweeps = left;
     }
+    // bPrime differs from the source in the boundary rows only: one copy per call, then the boundary rows are
+    // rewritten from the source before every sweep (one small kernel per sweep instead of copy + apply)
+    if (a->nPatchFaces && !sym && nSweeps > 0 && k_ew(a->nCells, EW_COPY, bPrime, source, nullptr, s)) return -1;
     for (int sweep = 0; sweep < nSweeps; sweep++)
     {
         const double* rhs = source;
@@ -244,9 +248,23 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
             // bPrime = source; coupled boundaries Jacobi-style with negated coefficients
             // (GaussSeidelSmoother.C:98-145)
             if (dev_halo_start(m, psi)) return -1;
-            if (k_ew(a->nCells, EW_COPY, bPrime, source, nullptr, s)) return -1;
-            if (k_apply_patches(a, bPrime, m->d_bou, -1.0, s)) return -1;
+            if (sym)
+            {
+                // (the symmetric smoother's forward sweep overwrites bPrime: full copy every sweep)
+                if (k_ew(a->nCells, EW_COPY, bPrime, source, nullptr, s)) return -1;
+                if (k_apply_patches(a, bPrime, m->d_bou, -1.0, s)) return -1;
+            }
+            else if (k_apply_patches_from(a, bPrime, source, m->d_bou, -1.0, s)) return -1;
             rhs = bPrime;
+            if (!sym && a->ctx->sweepP2P)
+            {
+                // small matrix with coupled patches: the frozen interface terms are in bPrime, so the single-wavefront
+                // kernel can take this sweep like any other right-hand side (one sweep per launch: the neighbour
+                // values change between sweeps, GaussSeidelSmoother.C:98-145)
+                const int rc = k_sweep_gs_small(a, 1, psi, rhs, m->d_diag, m->d_valA);
+                if (rc < 0) return rc;
+                if (rc == 0) continue;
+            }
         }
         SweepArgs g{};
         g.mode = SW_GS_FWD; g.w = psi; g.rhs = rhs; g.scale = m->d_diag; g.val = m->d_valA;

@@ -240,6 +240,19 @@ def problem(m=None, seed=12345, **kw):
     if m is None:
         m = generate(**kw)
     l, u, area, dn, dirs = faces(m)
+    # snappyHexMesh keeps the region reachable from locationInMesh (snappyHexMeshDict:159-162): pockets of cells cut off
+    # by the castellation (all their neighbours inside the body) are dropped, the labels compacted in order
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    nC = m["level"].size
+    ncomp, comp = connected_components(coo_matrix((np.ones(l.size, dtype=np.int8), (l, u)), shape=(nC, nC)), directed=False)
+    if ncomp > 1:
+        keep = comp == np.argmax(np.bincount(comp))
+        new = np.cumsum(keep) - 1
+        fk = keep[l] & keep[u]
+        l, u = new[l[fk]].astype(np.int32), new[u[fk]].astype(np.int32)
+        area, dn, dirs = area[fk], dn[fk], dirs[fk]
+        m = dict(m, level=m["level"][keep], i=m["i"][keep], j=m["j"][keep], k=m["k"][keep])
     nC, nF = m["level"].size, l.size
     hmin = m["h0"] / (1 << m["maxLevel"])
     upper = -(1.0 + 0.5 * _cases.u01(seed, nF)) * (area / dn) / hmin

@@ -28,7 +28,13 @@ def _amul(sp, x):
     send_all = np.concatenate([x[q["faceCells"]] for q in dev]) if dev else np.zeros(0)   # pack_kernel
     recv_all = torch.zeros(send_all.size, dtype=torch.float64)
     reqs = []
-    for i, q in enumerate(dev):                   # comm_exchange: grouped send/recv in patch order
+    # comm_exchange: grouped send/recv in the LIBRARY's issue order (ldu_comm.cpp comm_remote_order through the C ABI:
+    # a change of that order, or of which patches are exchanged, changes what this test sends)
+    from openfoam_amd import capi
+    order = capi.comm_exchange_order([len(q["faceCells"]) for q in dev], [-1] * len(dev))
+    assert sorted(order.tolist()) == list(range(len(dev)))
+    for i in order.tolist():
+        q = dev[i]
         reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(send_all[offs[i]:offs[i + 1]])), q["nbrRank"]))
         reqs.append(dist.irecv(recv_all[offs[i]:offs[i + 1]], q["nbrRank"]))
     l, u = sp["lowerAddr"], sp["upperAddr"]
@@ -80,6 +86,16 @@ def _worker(rank, world, port, out):
     subs, maps = decompose.decompose(p, cr, world, only_rank=rank)
     sp = subs[rank]
     assert [q["nbrRank"] for q in sp["patches_dev"]] == [1 - rank]       # one processor patch towards the other rank
+    # the pairing rule of the library (ldu_comm.cpp paired_patch) against what decomposePar-style pairing means: both
+    # ranks list the same global faces on paired patches.  Patch lists travel over gloo like the restrict maps do.
+    from openfoam_amd import capi
+    mine = [dict(nbr=q["nbrRank"], faces=np.asarray(q["faces"])) for q in sp["patches"]]
+    lists = [None] * world
+    dist.all_gather_object(lists, mine)
+    for pi, q in enumerate(mine):
+        theirs = lists[q["nbr"]]
+        j = capi.comm_paired_patch([m_["nbr"] for m_ in mine], pi, [t["nbr"] for t in theirs], rank)
+        assert j >= 0 and np.array_equal(theirs[j]["faces"], q["faces"]), (rank, pi, j)
     res = {}
     for pre in ("diagonal", "DIC"):
         x = np.zeros(sp["nCells"]); b = sp["source"]
@@ -140,3 +156,16 @@ def test_two_rank_gloo_pcg(oracle):
     np.testing.assert_allclose(np.concatenate([out[r][3] for r in range(world)]), xd, rtol=1e-7, atol=1e-9)
     x2, p2 = oracle.System(p).solve(p["psi"], p["source"], solver="PCG", precond="DIC", tolerance=1e-8, relTol=0)
     assert not np.allclose(histd[:len(p2["history"])][1:4], p2["history"][1:4], rtol=1e-6)
+
+
+def test_pairing_rule_with_several_patches_per_rank_pair():
+    """ldu_comm.cpp paired_patch: the k-th patch of rank b towards a pairs with the k-th patch of rank a towards b
+    (two patches between one rank pair: a ring of four slabs on two ranks, processorCyclic-like)."""
+    from openfoam_amd import capi
+    a = [1, 2, 1, 3, 1]          # rank 0's patches: neighbour ranks
+    b = [0, 0, 4, 0]             # rank 1's patches
+    assert [capi.comm_paired_patch(a, p, b, 0) for p in (0, 2, 4)] == [0, 1, 3]
+    assert [capi.comm_paired_patch(b, p, a, 1) for p in (0, 1, 3)] == [0, 2, 4]
+    assert capi.comm_paired_patch(a, 3, [5, 6], 0) == -1     # rank 3 lists no patch towards rank 0: unpaired
+    # exchange order: patches with faces that are not cyclic, ascending
+    assert capi.comm_exchange_order([5, 0, 3, 7], [-1, -1, 3, -1]).tolist() == [0, 3]

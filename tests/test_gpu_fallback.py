@@ -99,3 +99,43 @@ def test_forced_abort_falls_back_to_level_engine(ctx, oracle, fuzz8723, what):
     assert np.array_equal(m.smooth("GaussSeidel", v, w, 2), S.smooth("GaussSeidel", v, w, 2))
     assert ctx.fallback_count() == before
     m.close(); a.close()
+
+
+@pytest.mark.parametrize("what", ["GS2_cluster", "DIC_cluster", "GS3_level_engine", "GAMG"])
+def test_crawling_sweep_trips_the_time_watchdog(ctx, oracle, what):
+    """the spin bound counts polls, so a launch that merely CRAWLS never reached it.  Every wait is
+    now bounded in wall-clock time as well (ldu_ctx_set_watchdog).  Injected here: the wave that runs the first task of
+    each sweep launch stalls for 60 ms under a 10 ms budget - every wave behind it gives up, the operation is re-run on
+    the level-kernel engine and must still return what the reference computes."""
+    p = cases.box3d(44) if what != "GS3_level_engine" else cases.random_graph(30000, 4, 60)
+    S = oracle.System(p)
+    a, m = capi.from_problem(ctx, p)
+    if what.endswith("cluster"):
+        assert a.sweep_engine(0) == "clusters"
+    n = p["nCells"]
+    rng = np.random.RandomState(11)
+    v, w = rng.randn(n), rng.randn(n)
+    before = ctx.fallback_count()
+    ctx.set_watchdog(10.0, 60.0)
+    try:
+        if what == "GS2_cluster":
+            assert np.array_equal(m.smooth("GaussSeidel", v, w, 2), S.smooth("GaussSeidel", v, w, 2))
+        elif what == "DIC_cluster":
+            assert np.array_equal(m.precondition("DIC", v), S.precondition("DIC", v)[0])
+        elif what == "GS3_level_engine":
+            assert np.array_equal(m.smooth("GaussSeidel", v, w, 3), S.smooth("GaussSeidel", v, w, 3))
+        else:
+            kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
+                      mergeLevels=1, tolerance=1e-7, relTol=0.01)
+            x, perf = m.solve(p["psi"], p["source"], cacheAgglomeration=1, **kw)
+            xo, po = S.solve(p["psi"], p["source"], **kw)
+            assert perf["nIterations"] == po["nIterations"]
+            np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+        assert ctx.fallback_count() > before, "the stalled launch must have tripped the watchdog"
+    finally:
+        ctx.set_watchdog(200.0, 0.0)
+    # the fast engines are back, and quiet
+    before = ctx.fallback_count()
+    assert np.array_equal(m.smooth("GaussSeidel", v, w, 2), S.smooth("GaussSeidel", v, w, 2))
+    assert ctx.fallback_count() == before
+    m.close(); a.close()

@@ -282,3 +282,57 @@ def test_rccl_two_processes():
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "rccl_2rank_check (2 ranks)" in r.stdout
+
+
+@pytest.mark.parametrize("what", ["GS", "PCG", "GAMG"])
+def test_engine_fallback_is_collective_across_ranks(oracle, what):
+    """the engine fallback used to be rank-local - a rank whose sweep gave up re-ran the whole
+    operation (halo exchanges, all-reduces) while its peers did not, and the collective sequence fell out of step.
+    The abort flag is now max-reduced over the ranks before it is read (comm_allreduce_abort), so every rank takes the
+    fallback or none.  Two ranks, the stall injected into RANK 1's sweeps only would need per-context device state; the
+    process-wide knob stalls both, with different timing per rank - either way the ranks must stay in step, finish,
+    and return what the oracle's 2-rank emulation computes."""
+    size = 26
+    p = cases.box3d(size)
+    cr = decompose.block_ranks(size, size, size, 1, 1, 2)
+    subs, maps = decompose.decompose(p, cr, 2)
+    rng = np.random.RandomState(2)
+    xs = [rng.randn(s["nCells"]) for s in subs]
+    bs = [rng.randn(s["nCells"]) for s in subs]
+    S = oracle.System(subs)
+    X, B = np.concatenate(xs), np.concatenate(bs)
+    X0 = np.concatenate([s["psi"] for s in subs]); B0 = np.concatenate([s["source"] for s in subs])
+    kw = (dict(solver="PCG", preconditioner="DIC", tolerance=1e-9, relTol=0) if what == "PCG" else
+          dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4))
+    barrier = threading.Barrier(2)
+
+    def fn(r, ctx, a, m):
+        barrier.wait()
+        if r == 0:
+            ctx.set_spin_limit(1)       # process-wide: every dependency wait of both ranks gives up at once
+        barrier.wait()
+        before = ctx.fallback_count()
+        try:
+            if what == "GS":
+                out = m.smooth("GaussSeidel", xs[r], bs[r], 3)
+            else:
+                out = m.solve(subs[r]["psi"], subs[r]["source"], **kw)
+        finally:
+            barrier.wait()
+            if r == 0:
+                ctx.set_spin_limit(0)
+            barrier.wait()
+        return out, ctx.fallback_count() - before
+    res = run_ranks(subs, fn)
+    assert all(r[1] > 0 for r in res) or all(r[1] == 0 for r in res), [r[1] for r in res]
+    assert sum(r[1] for r in res) > 0, "the one-poll spin bound must have tripped the fallback"
+    if what == "GS":
+        assert np.array_equal(np.concatenate([r[0] for r in res]), S.smooth("GaussSeidel", X, B, 3))
+    else:
+        okw = dict(kw)
+        if "preconditioner" in okw:
+            okw["precond"] = okw.pop("preconditioner")
+        xo, po = S.solve(X0, B0, **okw)
+        for (x, perf), _ in res:
+            assert perf["nIterations"] == po["nIterations"]
+            np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)

@@ -27,9 +27,11 @@ ENGINES = {
     "small8192": {"LDU_SMALL_MAX": "8192"},
     "small16384": {"LDU_SMALL_MAX": "16384"},
     "small_nopipe": {"LDU_SMALL_PIPE": "0"},
+    "nocoop": {"LDU_COOP_ROWS": "0"},
+    "nosort": {"LDU_SORT_ROWS": "0"},
 }
 KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
-        "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE")
+        "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS")
 
 
 def _problems():
@@ -51,6 +53,13 @@ def _problems():
     p = cases.random_graph(5000, 11, 300, asym=True)   # rows wider than the 8-entry fast path
     p["psi"] = rng.randn(p["nCells"])
     out["graph_small"] = p
+    # rows with up to ~40 lower / upper neighbours: the cooperative rows of the level engines (2 / 4 / 8 lanes per row)
+    p = cases.random_graph(12000, 30, 500, asym=True)
+    p["psi"] = rng.randn(p["nCells"])
+    out["graph_wide"] = p
+    p = cases.random_graph(9000, 22, 300)
+    p["psi"] = rng.randn(p["nCells"])
+    out["graph_wide_sym"] = p
     p = cases.random_graph(20000, 2, 60)   # irregular, <= 6 lower / upper neighbours: cluster-eligible
     p["psi"] = rng.randn(p["nCells"])
     out["graph_sparse"] = p

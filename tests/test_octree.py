@@ -1,0 +1,116 @@
+"""The octree-castellated motorBike twin (openfoam-2.2.x_amd/octree.py): what snappyHexMesh's castellation hands the
+solver - hexRef8 numbering, hanging faces, 2:1 balance (snappyHexMeshDict:64-162, hexRef8.C).
+CPU: structural properties of the generator and the oracle on it.  GPU (-m gpu): a ~1.2 M-cell instance against the
+oracle - kernels bit for bit in both numberings, the benchmark's GAMG p-solve and PCG/DIC by history."""
+import numpy as np
+import pytest
+
+from openfoam_amd import capi, cases, octree
+
+
+def renumber(p):
+    order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+    nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+    return cases.renumbered(p, order, fmap, flip, nl, nu)
+
+
+@pytest.fixture(scope="module")
+def small():
+    m = octree.generate(base=(10, 4, 4), surface_levels=(4, 5), box_level=3)
+    return m, octree.problem(m)
+
+
+def test_octree_structure(small):
+    m, p = small
+    nC, l, u = p["nCells"], p["lowerAddr"].astype(np.int64), p["upperAddr"].astype(np.int64)
+    lvl = m["level"].astype(np.int64)
+    assert nC == lvl.size and nC > 10000
+    # upper-triangular order, one face per cell pair
+    key = l * nC + u
+    assert np.all(l < u) and np.all(np.diff(key) > 0)
+    # 2:1 balance across faces (hexRef8::consistentRefinement)
+    assert np.max(np.abs(lvl[l] - lvl[u])) == 1
+    # every refinement level is present, the finest around the body only
+    assert np.all(np.bincount(m["level"]) > 0) and lvl.max() == 5
+    # hanging faces: a coarse cell sees four quarter faces on a refined side -> rows with more than 6 neighbours,
+    # never more than 24
+    deg = np.bincount(l, minlength=nC) + np.bincount(u, minlength=nC)
+    assert deg.max() > 6 and deg.max() <= 24 and np.median(deg) == 6
+    # a face between two levels has the fine cell's area: areas are powers of 1/4 of the coarsest
+    w = p["faceWeights"]
+    assert np.allclose(np.log2(w) % 2, 0)
+    # hexRef8 numbering: a split parent keeps its label for child 0 (deep cells among the first labels), the other seven
+    # children are appended pass by pass (the tail of the numbering is the last pass: the deepest levels)
+    nBase = 10 * 4 * 4
+    assert lvl[:nBase].max() == lvl.max() and lvl[:nBase].min() == 0
+    assert lvl[-nC // 100:].min() >= lvl.max() - 1
+    # symmetric M-matrix, diagonally dominant, strictly so on the outlet
+    assert np.all(p["upper"] < 0)
+    off = np.bincount(l, weights=-p["upper"], minlength=nC) + np.bincount(u, weights=-p["upper"], minlength=nC)
+    assert np.all(p["diag"] >= off * (1 - 1e-12)) and np.any(p["diag"] > off * (1 + 1e-9))
+
+
+def test_octree_is_deterministic(small):
+    m, p = small
+    q = octree.problem(octree.generate(base=(10, 4, 4), surface_levels=(4, 5), box_level=3))
+    for k in ("lowerAddr", "upperAddr", "upper", "diag", "source"):
+        assert np.array_equal(p[k], q[k])
+
+
+def test_octree_dag_statistics(small):
+    """what the numbering does to the sequential sweeps of the reference (GaussSeidelSmoother.C:147-176): hexRef8's
+    appended children give a shallow, very wide dependency DAG; bandCompression a narrower one"""
+    m, p = small
+    d0 = capi.dag_stats(p["nCells"], p["lowerAddr"], p["upperAddr"])
+    pr = renumber(p)
+    d1 = capi.dag_stats(pr["nCells"], pr["lowerAddr"], pr["upperAddr"])
+    assert d0["maxLower"] <= 6 and d0["maxUpper"] > 8         # child 0 keeps the low label: all its finer neighbours are upper
+    assert d1["widestLevel"] < d0["widestLevel"]
+    assert d0["levels"] > 50 and d1["levels"] > 50
+
+
+def test_oracle_solves_the_octree(small, oracle):
+    m, p = small
+    S = oracle.System(p)
+    kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
+              mergeLevels=1, tolerance=1e-7, relTol=0.01)
+    x, perf = S.solve(p["psi"], p["source"], **kw)
+    assert perf["converged"] and perf["nIterations"] <= 12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def million():
+    p = octree.problem(base=(35, 14, 14), surface_levels=(6, 7))
+    p.pop("cellLevel")
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("numbering", ["bandCompression", "hexRef8"])
+def test_octree_million_cells_against_the_oracle(million, numbering, oracle):
+    p = renumber(million) if numbering == "bandCompression" else million
+    assert p["nCells"] > 1000000
+    ctx = capi.Context(0)
+    a, m = capi.from_problem(ctx, p)
+    try:
+        S = oracle.System(p)
+        src = p["source"]
+        assert np.array_equal(m.Amul(src), S.Amul(src))
+        assert np.array_equal(m.residual(src, src), S.residual(src, src))
+        for k in (1, 2, 4):
+            assert np.array_equal(m.smooth("GaussSeidel", p["psi"], src, k), S.smooth("GaussSeidel", p["psi"], src, k)), k
+        assert np.array_equal(m.precondition("DIC", src), S.precondition("DIC", src)[0])
+        kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
+                  mergeLevels=1, tolerance=1e-7, relTol=0.01)
+        x, perf = m.solve(p["psi"], p["source"], cacheAgglomeration=1, **kw)
+        xo, po = S.solve(p["psi"], p["source"], **kw)
+        assert perf["nIterations"] == po["nIterations"]
+        np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+        assert np.max(np.abs(x - xo)) <= 1e-8 * np.max(np.abs(xo))
+        x, perf = m.solve(p["psi"], p["source"], solver="PCG", preconditioner="DIC", tolerance=0, relTol=0, maxIter=25)
+        xo, po = S.solve(p["psi"], p["source"], solver="PCG", precond="DIC", tolerance=0, relTol=0, maxIter=25)
+        np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+        assert ctx.fallback_count() == 0
+    finally:
+        m.close(); a.close(); ctx.close()

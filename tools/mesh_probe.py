@@ -1,7 +1,8 @@
 """Probe: GaussSeidel (1 and k pipelined sweeps), DIC half sweep and Amul on one mesh for several engine settings,
 with an optional per-level timeline of the pipelined sweeps on the level engines.
 usage: python tools/mesh_probe.py MESH [cfg ...]
-  MESH = box:N | octree:Q:Lmin:Lmax[:hexref] | irregular:N
+  MESH = box:N | octree:Q:Lmin:Lmax[:hexref] | irregular:N, optionally followed by @K = the K-th GAMG coarse level of that
+         matrix (faceAreaPair agglomeration by the CPU oracle - tools only), e.g. octree:14:6:7@1
   cfg  = name:ENV=VAL,ENV=VAL        (PROBE_SWEEPS=k, PROBE_TRACE=1 are read per configuration)"""
 import ctypes as C
 import os
@@ -41,7 +42,17 @@ def make(spec):
 spec = sys.argv[1]
 cfgs = sys.argv[2:] or ["default:"]
 t0 = time.perf_counter()
-p = make(spec)
+base_spec, _, coarse = spec.partition("@")
+p = make(base_spec)
+if coarse:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    lv = oracle_py.System(p).gamg_levels(smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
+                                         mergeLevels=1)[int(coarse) - 1]
+    q = dict(nCells=lv["nCells"], lowerAddr=lv["lowerAddr"], upperAddr=lv["upperAddr"], diag=lv["diag"], upper=lv["upper"])
+    q["source"] = cases.amul(q, np.sin(1e-3 * np.arange(q["nCells"])))
+    q["psi"] = np.zeros(q["nCells"])
+    p = q
 nC, nF = p["nCells"], p["lowerAddr"].size
 print("mesh %s: %d cells %d faces (%.1f s)" % (spec, nC, nF, time.perf_counter() - t0), flush=True)
 dev = torch.device("cuda", 0)
