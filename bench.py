@@ -31,7 +31,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what this chip streams is measured: roofline.peak_measured
+
+
+def kernel_source_hash():
+    """hash of the kernel / plan sources a PMC traffic figure belongs to (same function as tools/pmc_traffic.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ldu_kernels.hip", "ldu_cluster.hip", "ldu_internal.hpp", "ldu_plan.cpp"):
+        h.update(open(os.path.join(ROOT, "openfoam-2.2.x_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(mesh_spec, kernel, k):
+    """HBM bytes per launch of the dominant kernel from a recorded PMC pass (profiles/*_pmc_traffic.json, written by
+    tools/pmc_traffic.py: separate rocprofv3 --pmc passes) - quoted only when workload, kernel AND the kernel sources are
+    the ones the pass ran on; otherwise (None, why)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            pj = json.load(open(f))
+        except Exception:
+            continue
+        if not str(pj.get("workload", "")).startswith(mesh_spec + ",") or pj.get("kernel") != kernel:
+            continue
+        if "%d pipelined" % k not in pj.get("workload", ""):
+            continue
+        best = (pj, os.path.basename(f))
+    if best is None:
+        return None, "no PMC pass recorded for this workload and kernel (tools/pmc_traffic.py)"
+    pj, name = best
+    if pj.get("source_hash") != kernel_source_hash():
+        return None, "profiles/%s is stale: the kernel sources changed since that PMC pass (hash %s, now %s)" % (
+            name, pj.get("source_hash"), kernel_source_hash())
+    return pj["bytes_per_launch"], "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % name
 
 GAMG_CONTROLS = dict(solver="GAMG", tolerance=1e-7, relTol=0.01, smoother="GaussSeidel",
                      nPreSweeps=0, nPostSweeps=2, nFinestSweeps=2, cacheAgglomeration=1,
@@ -67,7 +101,9 @@ def resident_pipeline(torch, capi, cases, ctx, addr, mat, n, dev, reps=3):
     nB = b.n
     iC = torch.zeros(nB, **f64)
     o0, o1 = fcs[0].size, fcs[0].size + fcs[1].size
-    iC[o0:o1] = 2.0 * rAU[torch.from_numpy(fcs[1]).to(dev)]      # gamma*magSf*deltaCoeffs of the outlet faces (delta = 1/(h/2))
+    # fixedValue outlet: internalCoeffs = -gamma*magSf*deltaCoeffs (fvm::laplacian: gradientInternalCoeffs = -delta,
+    # fixedValueFvPatchField.C:108-113, gaussLaplacianScheme.C:75-85), delta = 1/(h/2); boundaryCoeffs = -iC*value = 0
+    iC[o0:o1] = -2.0 * rAU[torch.from_numpy(fcs[1]).to(dev)]
     bC = torch.zeros(nB, **f64)                                   # fixedValue 0
     mphiB = torch.zeros(nB, **f64)                                # no flux through the walls / outlet of this test field
     rAUf, gms, diag, upper, mphi, source, psi, fluxI, fluxB, phi = (torch.empty(nF, **f64), torch.empty(nF, **f64),
@@ -286,6 +322,16 @@ def main():
     prof = mat.profile_end()
     comm1 = ctx.comm_counters()
     comm_per_vcycle = {k: round((comm1[k] - comm0[k]) / float(max(1, iters)), 2) for k in comm1}
+    # what this chip streams (SURVEY.md 8d "bound"): McCalpin copy / triad with the library's own f64 stream kernels,
+    # 10 M and 80 M doubles per array (the 256 MiB Infinity Cache holds the small case: the large one is the HBM figure)
+    stream = None
+    if rank == 0:
+        try:
+            stream = {"%s_%dM" % (nm, sz // 1000000): round(ctx.stream(md, sz, 20), 1)
+                      for sz in (10000000, 80000000) for md, nm in ((0, "copy"), (1, "triad"))}
+            stream["unit"] = "GB/s"
+        except Exception as e:  # pragma: no cover
+            stream = dict(error=str(e)[:200])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -310,21 +356,20 @@ def main():
                  % (kernels[0], eng, per_launch)) if key == "gs_multi" else \
             "%s (%s engine): one GaussSeidel sweep of the rank's finest level" % (kernels[1], eng)
         # traffic: HBM bytes per launch from the PMC counters.  NOT measured by this run: counters need their own
-        # rocprofv3 --pmc passes (MI355X_MICROARCH.md); the recorded value is only quoted when kernel, size and mesh
-        # are the ones it was recorded for, and the line says where it comes from.
-        traffic, traffic_source = None, None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if (key == "gs_multi" and n == 216 and world == 1 and args.mesh == "box"
-                    and pj.get("kernel", "") == kernels[0]):
-                traffic = pj["bytes_per_launch"]
-                traffic_source = pj.get("source", "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)")
-        except Exception:
-            pass
+        # rocprofv3 --pmc passes (MI355X_MICROARCH.md); a recorded value is only quoted when workload, kernel and kernel
+        # sources are the ones it was recorded for, and the line says where it comes from.
+        mesh_spec = {"box": "box:%d" % n, "octree": "octree:%d:%d:%d" % (args.octree_q, args.octree_levels[0], args.octree_levels[1]),
+                     "octree_hexref": "octree:%d:%d:%d:hexref" % (args.octree_q, args.octree_levels[0], args.octree_levels[1])}.get(args.mesh)
+        traffic, traffic_source = (None, None)
+        if mesh_spec and world == 1 and key == "gs_multi":
+            traffic, traffic_source = pmc_traffic(mesh_spec, kernels[0], per_launch)
         roof = dict(bound="hbm", kernel=kname + " (%d dependency levels)" % info["nLevels"],
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                    traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
+                    peak_measured=None, traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
                     bytes_per_launch=per_launch * gs_bytes, launches=prof[key]["count"])
+    if roof is not None and stream and "triad_80M" in stream:
+        roof["peak_measured"] = stream["triad_80M"]
+        roof["frac_of_measured"] = round(roof["achieved"] / stream["triad_80M"], 4)
     amul = None
     if "amul" in prof and prof["amul"]["count"]:
         ms = prof["amul"]["ms"] / prof["amul"]["count"]
@@ -540,6 +585,7 @@ def main():
                        # engines carried every sweep of the timed region)
                        "engine_fallbacks": ctx.fallback_count()},
             "roofline": roof,
+            "stream": stream,
             "roofline_vcycle": roof_v,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,

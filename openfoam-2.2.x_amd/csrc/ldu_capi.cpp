@@ -171,6 +171,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     e = getenv("LDU_WATCHDOG_MS");
     if (e && (k_set_watchdog((unsigned long long)(atof(e) * 1e5), 0) || k_cluster_set_watchdog((unsigned long long)(atof(e) * 1e5), 0)))
         return -1;
+    e = getenv("LDU_LAG_BUCKETS");
+    if (e) c->lagBucketWidth = atoi(e);
     e = getenv("LDU_COOP_ROWS");
     if (e) c->coopRows = atoi(e);
     e = getenv("LDU_SORT_ROWS");

@@ -86,6 +86,7 @@ struct ldu_ctx {
     unsigned long long valStamp = 1; // bumped whenever a SELL value array is rewritten
     int smallKernels = 1;            // single-wavefront LDS kernel for tiny matrices (LDU_SMALL=0: off)
     long nHaloExchanges = 0, nAllReduces = 0, nScalarReadbacks = 0;   // communication counters (ldu_ctx_comm_counters)
+    int lagBucketWidth = 8;          // LDU_LAG_BUCKETS: width (levels) of the lag buckets rows are grouped by; 0 = off
     int coopRows = 1;                // LDU_COOP_ROWS: several lanes per row for rows with more than 8 lower / upper neighbours
     int sortRowsByWidth = 1;         // LDU_SORT_ROWS: rows of a level ordered by width class (narrow slices stay narrow)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
@@ -155,6 +156,8 @@ struct ldu_addr {
     int* d_sliceCnt = nullptr;             // [nSlices] rows in slice (<= 64)
     int* d_sliceEnt = nullptr;             // [nSlices] first entry
     int* d_sliceW = nullptr;               // [nSlices] width (max nL+nU)
+    bool lagBuckets = false;               // rows of a level also grouped by their pipelined-sweep lag (ldu_plan.cpp)
+    std::vector<unsigned short> rowKey;    // [nCells] level row -> (width class, lag bucket) key
     unsigned char* d_sliceT = nullptr;     // [nSlices] lanes per row: 1, or 2 / 4 / 8 in a cooperative slice (ldu_plan.cpp)
     int nCoopSlices = 0;
     int* d_levelSliceStart = nullptr;      // [nLevels+1]

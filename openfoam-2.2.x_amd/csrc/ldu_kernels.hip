@@ -2410,26 +2410,65 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
             it = a->gsTasks.emplace(k, none).first;
             return 1;
         }
+        // Task order = (sweep, slice) pairs sorted by their time in the slice-level DAG of the k sweeps:
+        //   T(0, s) = dependency level of s;   T(j, s) = 1 + max( T(j, slices holding lower neighbours of s's rows),
+        //                                                      T(j-1, slices holding their upper neighbours), T(j-1, s) )
+        // - a topological order (T grows along every dependency), in which a task appears as early as its slice can
+        // run.  (Until round 3 sweep j+1 took a whole LEVEL once sweep j had passed the running maximum of the levels
+        // holding upper neighbours: on irregular graphs one far-reaching row per level serialised the sweeps.)
         std::vector<int> tasks;
-        tasks.reserve((size_t)k * a->nSlices + 4 * (size_t)nLev * k);
-        std::vector<int> next(k, 0);   // next level to emit per sweep
-        bool progress = true;
-        while (progress)
+        tasks.reserve((size_t)k * a->nSlices);
         {
-            progress = false;
-            // one round = tasks that can run at the same time: sweep j may take level L once sweep j-1 has
-            // emitted every level <= M[L] in an EARLIER round (last sweep first, so that next[j-1] is the count
-            // before this round; see k_sweep_cluster_gs_multi)
-            for (int j = k - 1; j >= 0; j--)
+            const int nS = a->nSlices;
+            std::vector<int> rowSlice(a->nCells);
             {
-                const int L = next[j];
-                if (L >= nLev) continue;
-                if (j > 0 && next[j - 1] <= M[L]) continue;
-                for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++)
-                    tasks.push_back((j << 28) | sl);
-                next[j]++;
-                progress = true;
+                std::vector<int> sliceRow(nS + 1);
+                LDU_CHECK_HIP(hipMemcpy(sliceRow.data(), a->d_sliceRow, sizeof(int) * (size_t)(nS + 1), hipMemcpyDeviceToHost));
+                for (int sl = 0; sl < nS; sl++)
+                    for (int r = sliceRow[sl]; r < sliceRow[sl + 1]; r++) rowSlice[r] = sl;
             }
+            std::vector<std::vector<int>> T(k, std::vector<int>(nS, 0));
+            for (int L = 0; L < nLev; L++)
+                for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++) T[0][sl] = L;
+            int maxT = nLev - 1;
+            for (int j = 1; j < k; j++)
+            {
+                std::vector<int>& Tj = T[j];
+                const std::vector<int>& Tp = T[j - 1];
+                for (int sl = 0; sl < nS; sl++) Tj[sl] = Tp[sl];
+                for (int f = 0; f < a->nFaces; f++)   // previous sweep's values of the upper neighbours
+                {
+                    const int sl = rowSlice[a->iperm[a->l[f]]], su = rowSlice[a->iperm[a->u[f]]];
+                    if (Tp[su] > Tj[sl]) Tj[sl] = Tp[su];
+                }
+                for (int sl = 0; sl < nS; sl++) Tj[sl]++;
+                // this sweep's values of the lower neighbours: rows in level order (a slice never straddles a level, so
+                // every slice is final before a slice of a higher level reads it)
+                for (int r = 0; r < a->nCells; r++)
+                {
+                    const int c = a->perm[r], sr = rowSlice[r];
+                    int t = Tj[sr];
+                    for (int q = a->losortStart[c]; q < a->losortStart[c + 1]; q++)
+                    {
+                        const int tl = Tj[rowSlice[a->iperm[a->l[a->losort[q]]]]] + 1;
+                        if (tl > t) t = tl;
+                    }
+                    Tj[sr] = t;
+                }
+                for (int sl = 0; sl < nS; sl++) maxT = std::max(maxT, Tj[sl]);
+            }
+            // counting sort by T; inside one T the sweeps ascend and the slices keep their order
+            std::vector<long> start((size_t)maxT + 2, 0);
+            for (int j = 0; j < k; j++)
+                for (int sl = 0; sl < nS; sl++) start[(size_t)T[j][sl] + 1]++;
+            for (size_t i = 0; i + 1 < start.size(); i++) start[i + 1] += start[i];
+            tasks.assign((size_t)k * nS, 0);
+            for (int j = 0; j < k; j++)
+                for (int sl = 0; sl < nS; sl++) tasks[(size_t)start[T[j][sl]]++] = (j << 28) | sl;
+            if (getenv("LDU_VERBOSE"))
+                fprintf(stderr, "[ldugpu] GS pipeline plan: %d cells, %d slices, k = %d: %d steps in the slice-level DAG "
+                                "(one sweep: %d levels; level-granular order: ~%d)\n",
+                        a->nCells, nS, k, maxT + 1, nLev, nLev + (k - 1) * maxSkew);
         }
         if (tasks.size() != (size_t)k * (size_t)a->nSlices)
         {

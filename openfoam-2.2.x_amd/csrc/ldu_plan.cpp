@@ -194,20 +194,51 @@ int plan_build(ldu_addr* a)
             if (!sortRows) return 0;
             return row_width_class(a->losortStart[c + 1] - a->losortStart[c], a->ownerStart[c + 1] - a->ownerStart[c]);
         };
+        // Lag buckets.  Pipelined GaussSeidel sweeps: sweep j+1 of a row needs sweep j's values of its UPPER neighbours,
+        // so it trails sweep j by t1 - level, t1 = the row's dependency level in the two-sweep DAG.  On a mesh numbering
+        // with locality that lag is the same everywhere (hex box: 2); on irregular graphs (bandCompression numberings
+        // of octree meshes, agglomerated GAMG levels) most rows trail by a few levels and a few by hundreds - and one
+        // such row holds back its whole slice (a wave waits for ALL its rows), and with it everything downstream of the
+        // slice in the later sweep: k sweeps cost k times one (octree twin, GAMG level 3: 1124 steps for 4 sweeps
+        // against 335 for one; 424 with every row on its own).  Rows of a level are therefore also grouped by
+        // (t1 - level) / lagWidth: slices hold rows that become runnable together (same level 3: 696 steps).
+        const int lagW = (sortRows && a->ctx->lagBucketWidth > 0 && nC > a->ctx->smallMaxCells) ? a->ctx->lagBucketWidth : 0;
+        int NLAG = 1;
+        std::vector<unsigned char> lagB(nC, 0);
+        if (lagW)
+        {
+            std::vector<int> t1(nC, 0);
+            for (int f = 0; f < nF; f++) t1[l[f]] = std::max(t1[l[f]], a->level[u[f]]);          // sweep 0's upper neighbours
+            for (int c = 0; c < nC; c++) t1[c] = std::max(t1[c], a->level[c]) + 1;
+            for (int f = 0; f < nF; f++) t1[u[f]] = std::max(t1[u[f]], t1[l[f]] + 1);             // sweep 1's lower neighbours
+            int maxLag = 0;
+            for (int c = 0; c < nC; c++) maxLag = std::max(maxLag, t1[c] - a->level[c]);
+            if (maxLag > 2 * lagW)   // (a uniform lag - structured numberings - needs no buckets)
+            {
+                // linear buckets all the way (half-octave buckets above 32 levels were tried on the octree twin's GAMG
+                // levels: 1072 instead of 696 steps for 4 sweeps of level 3 - the far-reaching rows matter too)
+                NLAG = std::min(256, maxLag / lagW + 1);
+                for (int c = 0; c < nC; c++) lagB[c] = (unsigned char)std::min((t1[c] - a->level[c]) / lagW, NLAG - 1);
+                a->lagBuckets = true;
+            }
+        }
         constexpr int NCLS = 8;
-        std::vector<long> cnt((size_t)nLevels * NCLS + 1, 0);
-        std::vector<unsigned char> cls(nC);
+        const int NKEY = NCLS * (a->lagBuckets ? NLAG : 1);
+        std::vector<int> cnt((size_t)nLevels * NKEY + 1, 0);
+        std::vector<unsigned short> cls(nC);
+        a->rowKey.assign(nC, 0);
         for (int c = 0; c < nC; c++)
         {
-            cls[c] = (unsigned char)widthClass(c);
-            cnt[(size_t)a->level[c] * NCLS + cls[c] + 1]++;
+            cls[c] = (unsigned short)(widthClass(c) * (a->lagBuckets ? NLAG : 1) + lagB[c]);
+            cnt[(size_t)a->level[c] * NKEY + cls[c] + 1]++;
         }
         for (size_t i = 0; i + 1 < cnt.size(); i++) cnt[i + 1] += cnt[i];
-        for (int c = 0; c < nC; c++)   // stable: original order inside a (level, class)
+        for (int c = 0; c < nC; c++)   // stable: original order inside a (level, class, lag bucket)
         {
-            const int r = (int)cnt[(size_t)a->level[c] * NCLS + cls[c]]++;
+            const int r = (int)cnt[(size_t)a->level[c] * NKEY + cls[c]]++;
             a->perm[r] = c;
             a->iperm[c] = r;
+            a->rowKey[r] = cls[c];
         }
     }
 
@@ -259,7 +290,8 @@ int plan_build(ldu_addr* a)
             const int maxCnt = LDU_WAVE / Tl;
             while (cnt < maxCnt && r0 + cnt < a->levelStart[L + 1] && rowSlab[r0 + cnt] == rowSlab[r0]
                    && !((cutAtClass || (coop && (Tl > 1 || class_lanes(rowClass[r0 + cnt]) > 1)))
-                        && rowClass[r0 + cnt] != rowClass[r0])) cnt++;
+                        && rowClass[r0 + cnt] != rowClass[r0])
+                   && !(a->lagBuckets && a->rowKey[r0 + cnt] != a->rowKey[r0])) cnt++;
             sliceT.push_back((unsigned char)Tl);
             if (Tl > 1) a->nCoopSlices++;
             sliceSlab.push_back(rowSlab[r0]);

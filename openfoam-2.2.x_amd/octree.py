@@ -235,8 +235,8 @@ def faces(m):
 def problem(m=None, seed=12345, **kw):
     """The p-equation twin on the octree: laplacian coefficient |Sf|/(n.d) per face times the box stand-in's random
     factor (1 + 0.5 u01(seed, f)), diag = negSumDiag + fixedValue outlet (x = max) faces, the walls and
-    the body zeroGradient as in motorBike/0.org/p; b = A x*, x* smooth in space; faceWeights = mag(Sf) (what
-    faceAreaPairGAMGAgglomeration uses)."""
+    the body zeroGradient as in motorBike/0.org/p; b = A x*, x* smooth in space; faceWeights = what
+    faceAreaPairGAMGAgglomeration computes from the face area vectors (direction factors 1 / 1.01 / 1.02)."""
     if m is None:
         m = generate(**kw)
     l, u, area, dn, dirs = faces(m)
@@ -263,7 +263,9 @@ def problem(m=None, seed=12345, **kw):
     x = m["lo"][0] + (m["i"] + 0.5) * h
     y = m["lo"][1] + (m["j"] + 0.5) * h
     z = m["lo"][2] + (m["k"] + 0.5) * h
-    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, upper=upper, diag=diag, faceWeights=area / (hmin * hmin))
+    # faceAreaPairGAMGAgglomeration.C:59-72: mag(cmptMultiply(Sf/sqrt(magSf), vector(1, 1.01, 1.02))), Sf = area * e_dir
+    comp = (area / np.sqrt(area)) * np.array([1.0, 1.01, 1.02])[dirs]
+    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, upper=upper, diag=diag, faceWeights=np.sqrt(comp * comp))
     xstar = np.sin(0.9 * x) * np.cos(1.7 * y) + 0.3 * np.sin(2.3 * z + 0.5 * x)
     p["source"] = _cases.amul(p, xstar)
     p["psi"] = np.zeros(nC)

@@ -15,7 +15,7 @@ ctx = capi.Context(0)
 t0 = time.time()
 n_cases = n_checks = 0
 while time.time() - t0 < budget:
-    kind = rng.randint(4)
+    kind = rng.randint(6)   # (round 3: + wide-row graphs and small octree meshes - cooperative rows, lag buckets)
     asym = bool(rng.randint(2))
     if kind == 0:
         n = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 130, 257, 700, 2999, 3001, 5000]))
@@ -26,9 +26,21 @@ while time.time() - t0 < budget:
     elif kind == 2:
         n = int(rng.randint(1000, 70000))
         p = cases.random_graph(n, int(rng.randint(2, 7)), int(rng.randint(5, 600)), asym=asym)
-    else:
+    elif kind == 3:
         n = int(rng.randint(200, 20000))
         p = cases.random_graph(n, int(rng.randint(6, 15)), int(rng.randint(20, n - 1)), asym=asym)
+    elif kind == 4:
+        n = int(rng.randint(3000, 40000))
+        p = cases.random_graph(n, int(rng.randint(16, 44)), int(rng.randint(100, 900)), asym=asym)
+    else:
+        from openfoam_amd import octree
+        b = int(rng.randint(1, 4))
+        p = octree.problem(base=(5 * b, 2 * b, 2 * b), surface_levels=(int(rng.randint(3, 5)), 5), box_level=int(rng.randint(2, 4)))
+        p.pop("cellLevel")
+        if rng.randint(2):
+            order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+            nl_, nu_, fm_, fl_ = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+            p = cases.renumbered(p, order, fm_, fl_, nl_, nu_)
     n = p["nCells"]
     psi, src = rng.randn(n), rng.randn(n)
     start = int(os.environ.get("FUZZ_START", "0"))
