@@ -1516,6 +1516,7 @@ static bool use_slab(const ldu_addr* a, int kind, int k = 1)
     // time, each front on its own XCD with same-XCD hand-offs.  The chip-wide engine, with all k fronts polled for
     // by the whole chip, took 9-11 us per level there (irregular 216^3 graph, tools/gsm_trace.py: 4 sweeps 40.8 ms).
     if (slabs_sequential(a)) return (double)a->nCells / LDU_WAVE / std::max(1, a->nLevels) <= 96.0;
+    if (a->lagBuckets && a->nCells <= 150000) return true;   // (see choose_slabs: eight slabs on mid-size irregular levels)
     return a->nSlabs == 1 && k * a->slabWidth <= 10.0;
 }
 

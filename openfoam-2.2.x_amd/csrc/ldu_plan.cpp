@@ -97,7 +97,10 @@ static int choose_slabs(const ldu_addr* a, std::vector<int>& slabCell)
     {
         // measured (tools/det_probe.py, profiles/r01_xcd_slab_probe.md): one XCD up to ~150k cells,
         // all of them above; intermediate counts never won
-        S = nC <= 150000 ? 1 : ctx->nXcd;
+        // (irregular graphs whose rows are grouped by lag - many small slices per level - keep all XCDs busy down to
+        //  ~12 k cells: octree twin's GAMG levels 6-9, 144 k ... 17 k cells, 4 sweeps: 2.7 / 1.9 / 1.6 / 1.4 ms on one
+        //  slab, 2.1 / 1.4 / 1.3 / 1.1 ms on eight)
+        S = nC <= (a->lagBuckets ? 12000 : 150000) ? 1 : ctx->nXcd;
     }
     // equal shares of the entries
     slabCell.assign(S + 1, nC);
@@ -202,7 +205,13 @@ int plan_build(ldu_addr* a)
         // slice in the later sweep: k sweeps cost k times one (octree twin, GAMG level 3: 1124 steps for 4 sweeps
         // against 335 for one; 424 with every row on its own).  Rows of a level are therefore also grouped by
         // (t1 - level) / lagWidth: slices hold rows that become runnable together (same level 3: 696 steps).
-        const int lagW = (sortRows && a->ctx->lagBucketWidth > 0 && nC > a->ctx->smallMaxCells) ? a->ctx->lagBucketWidth : 0;
+        // (not for matrices the single-wavefront kernels take - up to smallMaxCells cells, rows up to 16 entries: they
+        //  walk the slices one after the other, more slices only cost them)
+        int widestRow = 0;
+        for (int c = 0; c < nC; c++)
+            widestRow = std::max(widestRow, a->losortStart[c + 1] - a->losortStart[c] + a->ownerStart[c + 1] - a->ownerStart[c]);
+        const bool smallKernels = nC <= a->ctx->smallMaxCells && widestRow <= 16;
+        const int lagW = (sortRows && a->ctx->lagBucketWidth > 0 && !smallKernels && nC >= 512) ? a->ctx->lagBucketWidth : 0;
         int NLAG = 1;
         std::vector<unsigned char> lagB(nC, 0);
         if (lagW)

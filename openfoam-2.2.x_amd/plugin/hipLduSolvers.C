@@ -42,7 +42,11 @@ namespace Foam
 
 // One entry per lduAddressing the solvers have seen.  The key is the address of the addressing object; an
 // entry is only reused when its fingerprint still matches: the two address arrays (pointer, size, a strided
-// sample of their contents) and every coupled patch's faceCells (size + sample).  An lduAddressing freed and
+// sample of their contents) and every coupled patch's faceCells (size + sample).  The sample cannot see a local
+// topology change that keeps sizes, base pointers and the sampled entries: on a mesh that says it is changing
+// (polyMesh::changing(): points moved or topology changed this time step) the WHOLE lists are hashed and compared
+// with the hash taken when the entry was built, and the geometric agglomeration weights are taken again when the
+// points move (polyMesh::moving()).  An lduAddressing freed and
 // re-allocated at the same address (GAMG levels without cacheAgglomeration, a topology change that keeps the
 // cell and face counts) therefore rebuilds its device plan instead of silently reusing a stale one.
 // Entries are evicted least-recently-used beyond hipMaxEntries_ and all freed when the library is unloaded.
@@ -52,6 +56,7 @@ struct hipLduEntry
     ldu_matrix* mat;
     label nCells, nFaces;
     uint64_t fingerprint;
+    uint64_t fullFingerprint;     // every entry of every list (taken at construction, re-checked on changing meshes)
     uint64_t lastUse;
     bool weightsSet;
 };
@@ -74,29 +79,37 @@ static inline void hipMix(uint64_t& h, uint64_t v)
     h ^= v + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
 }
 
-static void hipMixList(uint64_t& h, const labelUList& l)
+static void hipMixList(uint64_t& h, const labelUList& l, const bool full)
 {
     hipMix(h, uint64_t(l.size()));
     hipMix(h, uint64_t(reinterpret_cast<uintptr_t>(l.begin())));
     const label n = l.size();
-    const label step = n > 4096 ? n/4096 : 1;
+    const label step = (!full && n > 4096) ? n/4096 : 1;
     for (label i = 0; i < n; i += step) hipMix(h, uint64_t(l[i]));
     if (n) hipMix(h, uint64_t(l[n - 1]));
 }
 
 template<class InterfaceList>
-static uint64_t hipFingerprint(const lduAddressing& la, const InterfaceList& interfaces)
+static uint64_t hipFingerprint(const lduAddressing& la, const InterfaceList& interfaces, const bool full = false)
 {
     uint64_t h = 0x243F6A8885A308D3ULL;
     hipMix(h, uint64_t(la.size()));
-    hipMixList(h, la.lowerAddr());
-    hipMixList(h, la.upperAddr());
+    hipMixList(h, la.lowerAddr(), full);
+    hipMixList(h, la.upperAddr(), full);
     forAll(interfaces, patchi)
     {
         hipMix(h, interfaces.set(patchi) ? 1 : 0);
-        if (interfaces.set(patchi)) hipMixList(h, la.patchAddr(patchi));
+        if (interfaces.set(patchi)) hipMixList(h, la.patchAddr(patchi), full);
     }
     return h;
+}
+
+// the polyMesh behind a matrix (fvMesh is one; the GAMG levels' lduPrimitiveMesh is not)
+static const polyMesh* hipPolyMesh(const lduMesh& mesh)
+{
+    const polyMesh* pm = dynamic_cast<const polyMesh*>(&mesh);
+    if (!pm) pm = dynamic_cast<const polyMesh*>(&mesh.thisDb());
+    return pm;
 }
 
 static void hipFreeEntry(hipLduEntry& e)
@@ -191,13 +204,21 @@ template<class InterfaceList>
 static hipLduEntry& hipLookupAddr
 (
     const lduAddressing& la,
-    const InterfaceList& interfaces
+    const InterfaceList& interfaces,
+    const polyMesh* pm = NULL
 )
 {
     std::map<const lduAddressing*, hipLduEntry>::iterator it = hipEntries_.find(&la);
     const label nCells = la.size();
     const label nFaces = la.lowerAddr().size();
     const uint64_t fp = hipFingerprint(la, interfaces);
+    const bool changing = pm && pm->changing();
+    if (it != hipEntries_.end() && it->second.fingerprint == fp && changing)
+    {
+        // a mesh in motion / with topology changes: the sample is not enough
+        if (hipFingerprint(la, interfaces, true) != it->second.fullFingerprint) it->second.fingerprint = ~fp;
+        if (pm->moving()) it->second.weightsSet = false;   // face areas changed: faceAreaPair weights again
+    }
     if (it != hipEntries_.end() && it->second.fingerprint != fp)
     {
         hipFreeEntry(it->second);
@@ -211,6 +232,7 @@ static hipLduEntry& hipLookupAddr
         e.nCells = nCells;
         e.nFaces = nFaces;
         e.fingerprint = fp;
+        e.fullFingerprint = hipFingerprint(la, interfaces, true);
         e.lastUse = 0;
         e.weightsSet = false;
         hipCheck
@@ -290,7 +312,7 @@ static hipLduEntry& hipLookup
     const lduInterfaceFieldPtrsList& interfaces
 )
 {
-    return hipLookupAddr(matrix.lduAddr(), interfaces);
+    return hipLookupAddr(matrix.lduAddr(), interfaces, hipPolyMesh(matrix.mesh()));
 }
 
 // Coefficients are re-read every solve (fvScalarMatrix.C:152-174 changes diag around the call).
@@ -414,8 +436,7 @@ static void hipReadControls(const dictionary& dict, int solverKind, ldu_controls
 static void hipEnsureFaceWeights(hipLduEntry& e, const lduMatrix& matrix)
 {
     if (e.weightsSet) return;
-    const polyMesh* pm = dynamic_cast<const polyMesh*>(&matrix.mesh());
-    if (!pm) pm = dynamic_cast<const polyMesh*>(&matrix.mesh().thisDb());
+    const polyMesh* pm = hipPolyMesh(matrix.mesh());
     if (!pm || pm->nInternalFaces() != e.nFaces)
     {
         // the reference: refCast<const fvMesh>(mesh) fails the same way on anything that is not an fvMesh

@@ -148,3 +148,78 @@ if [ -f "$ICO/icoFoam.C" ]; then
         echo "build_ref_fv.sh: OK -> $OUT/icoFoam (the reference's icoFoam.C, unchanged)"
     fi
 fi
+# The reference's own simpleFoam (BASELINE config C2; SURVEY 8d tier 3): applications/solvers/incompressible/simpleFoam/
+# simpleFoam.C compiled where it lies, with the units of libincompressibleRASModels / libincompressibleTurbulenceModel /
+# libincompressibleTransportModels / libfvOptions / libmeshTools / libsampling it reaches for the pitzDaily case
+# (kEpsilon + its wall functions, Newtonian transport, the fvOption list, cellDistFuncs / cellSet / tetOverlapVolume,
+# meshToMeshNew) - 27 units of the reference, compiled from their own sources; nothing stands in for anything.
+SIM="$REF/applications/solvers/incompressible/simpleFoam"
+if [ -f "$SIM/simpleFoam.C" ] && [ -z "$NO_SIMPLEFOAM" ]; then
+    for lib in turbulenceModels/incompressible/RAS turbulenceModels/incompressible/turbulenceModel transportModels/incompressible fvOptions sampling; do
+        d="$W/inc_$(echo $lib | tr '/' '_')"
+        if [ ! -f "$d/.done" ]; then
+            mkdir -p "$d"
+            find "$REF/src/$lib" \( -name '*.[CH]' -o -name '*.h' \) -exec ln -sf {} "$d/" \;
+            touch "$d/.done"
+        fi
+    done
+    SFLAGS="$CXXFLAGS -I$W/inc_turbulenceModels_incompressible_RAS -I$W/inc_turbulenceModels_incompressible_turbulenceModel -I$W/inc_transportModels_incompressible -I$W/inc_fvOptions -I$W/inc_sampling -I$REF/src/turbulenceModels -I$REF/src/transportModels"
+    mkdir -p "$W/sfobj"
+    i=0
+    for u in turbulenceModels/incompressible/turbulenceModel/turbulenceModel.C \
+             turbulenceModels/incompressible/turbulenceModel/laminar/laminar.C \
+             turbulenceModels/incompressible/RAS/RASModel/RASModel.C \
+             turbulenceModels/incompressible/RAS/laminar/laminar.C \
+             turbulenceModels/incompressible/RAS/kEpsilon/kEpsilon.C \
+             turbulenceModels/incompressible/RAS/derivedFvPatchFields/wallFunctions/nutWallFunctions/nutWallFunction/nutWallFunctionFvPatchScalarField.C \
+             turbulenceModels/incompressible/RAS/derivedFvPatchFields/wallFunctions/nutWallFunctions/nutkWallFunction/nutkWallFunctionFvPatchScalarField.C \
+             turbulenceModels/incompressible/RAS/derivedFvPatchFields/wallFunctions/nutWallFunctions/nutLowReWallFunction/nutLowReWallFunctionFvPatchScalarField.C \
+             turbulenceModels/incompressible/RAS/derivedFvPatchFields/wallFunctions/epsilonWallFunctions/epsilonWallFunction/epsilonWallFunctionFvPatchScalarField.C \
+             turbulenceModels/incompressible/RAS/derivedFvPatchFields/wallFunctions/omegaWallFunctions/omegaWallFunction/omegaWallFunctionFvPatchScalarField.C \
+             turbulenceModels/incompressible/RAS/derivedFvPatchFields/wallFunctions/kqRWallFunctions/kqRWallFunction/kqRWallFunctionFvPatchFields.C \
+             turbulenceModels/incompressible/RAS/backwardsCompatibility/wallFunctions/backwardsCompatibilityWallFunctions.C \
+             transportModels/incompressible/viscosityModels/viscosityModel/viscosityModel.C \
+             transportModels/incompressible/viscosityModels/viscosityModel/viscosityModelNew.C \
+             transportModels/incompressible/viscosityModels/Newtonian/Newtonian.C \
+             transportModels/incompressible/transportModel/transportModel.C \
+             transportModels/incompressible/singlePhaseTransportModel/singlePhaseTransportModel.C \
+             fvOptions/fvOptions/fvOption.C fvOptions/fvOptions/fvOptionIO.C fvOptions/fvOptions/fvOptionList.C \
+             fvOptions/fvOptions/fvIOoptionList.C \
+             meshTools/cellDist/cellDistFuncs.C meshTools/sets/topoSets/topoSet.C meshTools/sets/topoSets/cellSet.C \
+             meshTools/tetOverlapVolume/tetOverlapVolume.C \
+             sampling/meshToMeshInterpolation/meshToMeshNew/meshToMeshNewParallelOps.C \
+             sampling/meshToMeshInterpolation/meshToMeshNew/meshToMeshNew.C; do
+        i=$((i+1))
+        [ -f "$W/sfobj/s$i.o" ] || g++ $SFLAGS -c "$REF/src/$u" -o "$W/sfobj/s$i.o" &
+        [ $((i % JOBS)) -eq 0 ] && wait
+    done
+    wait
+    FORCE_SIM=""
+    for u in fvMesh/fvPatches/derived/wall/wallFvPatch.C \
+             fvMesh/fvPatches/constraint/empty/emptyFvPatch.C \
+             fields/fvPatchFields/constraint/empty/emptyFvPatchFields.C \
+             fields/fvsPatchFields/constraint/empty/emptyFvsPatchFields.C \
+             fields/fvPatchFields/basic/fixedValue/fixedValueFvPatchFields.C \
+             fields/fvPatchFields/basic/zeroGradient/zeroGradientFvPatchFields.C \
+             fields/fvPatchFields/basic/calculated/calculatedFvPatchFields.C \
+             fields/fvsPatchFields/basic/calculated/calculatedFvsPatchFields.C \
+             finiteVolume/gradSchemes/gaussGrad/gaussGrads.C \
+             interpolation/surfaceInterpolation/schemes/linear/linear.C \
+             interpolation/surfaceInterpolation/limitedSchemes/upwind/upwind.C \
+             finiteVolume/ddtSchemes/steadyStateDdtScheme/steadyStateDdtSchemes.C \
+             finiteVolume/convectionSchemes/gaussConvectionScheme/gaussConvectionSchemes.C \
+             finiteVolume/convectionSchemes/boundedConvectionScheme/boundedConvectionSchemes.C \
+             finiteVolume/laplacianSchemes/gaussLaplacianScheme/gaussLaplacianSchemes.C \
+             finiteVolume/snGradSchemes/correctedSnGrad/correctedSnGrads.C \
+             finiteVolume/divSchemes/gaussDivScheme/gaussDivSchemes.C \
+             fvMatrices/solvers/GAMGSymSolver/GAMGAgglomerations/faceAreaPairGAMGAgglomeration/faceAreaPairGAMGAgglomeration.C; do
+        i=$(grep -n "/$u\$" "$W/fvsources.txt" | head -1 | cut -d: -f1)
+        if [ -n "$i" ] && [ -f "$W/fvobj/f$i.o" ]; then FORCE_SIM="$FORCE_SIM $W/fvobj/f$i.o"
+        else echo "build_ref_fv.sh: unit $u is not built - simpleFoam cannot be linked (no stand-ins)" >&2; FORCE_SIM="MISSING"; break; fi
+    done
+    if [ "$FORCE_SIM" != "MISSING" ]; then
+        g++ $SFLAGS -I"$SIM" -c "$SIM/simpleFoam.C" -o "$W/simpleFoam.o"
+        g++ -o "$OUT/simpleFoam" "$W/simpleFoam.o" "$W"/sfobj/*.o $FORCE_SIM "$W/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm -Wl,-rpath,'$ORIGIN' \
+            && echo "build_ref_fv.sh: OK -> $OUT/simpleFoam (the reference's simpleFoam.C, unchanged)"
+    fi
+fi

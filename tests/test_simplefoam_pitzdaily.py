@@ -1,0 +1,64 @@
+"""BASELINE config C2 - "simpleFoam pitzDaily ~12k cells, GAMG p-solve on 1 MI355X (correctness vs CPU residuals)" -
+through an UNCHANGED reference application: oracle/_ref/simpleFoam is the reference's own simpleFoam.C with the units of
+its turbulence / transport / fvOptions libraries it reaches (oracle/build_ref_fv.sh, no stand-ins); the case is the
+tutorial's, restated (oracle/pitzdaily_case.py), on the mesh the reference's blockMesh made.
+ * CPU: the stock run reproduces the committed log fixtures (tests/golden/simplefoam_pitzdaily*.json).
+ * GPU (-m gpu): the same binary and case plus `libs ("libhipLduSolvers.so");`: 40 SIMPLE iterations - every solve of
+   Ux, Uy, p, epsilon, k on the GPU library (PBiCG/DILU; p: PCG/DIC or GAMG with faceAreaPair weights the shim takes from
+   the fvMesh) against the reference's residual history.  This is SURVEY 8d tier 3: the p-matrices come from real SIMPLE
+   iterations, not from an analytic rAU / HbyA."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import cavity_case as cc
+import pitzdaily_case as pc
+
+PLUGIN = os.path.abspath(os.path.join(HERE, "..", "openfoam-2.2.x_amd", "lib", "libhipLduSolvers.so"))
+STEPS = 40
+needs_ref = pytest.mark.skipif(not pc.available(), reason="needs oracle/_ref/simpleFoam (oracle/build_ref_fv.sh)")
+CASES = [("", None), ("_gamg", pc.GAMG)]
+
+
+def golden(tag):
+    return [tuple(l) for l in json.load(open(os.path.join(HERE, "golden", "simplefoam_pitzdaily%s.json" % tag)))["lines"]]
+
+
+@needs_ref
+@pytest.mark.parametrize("tag,psolver", CASES, ids=["pcg", "gamg"])
+def test_stock_simplefoam_reproduces_the_fixture(tag, psolver, tmp_path):
+    case = str(tmp_path / "pitzDaily")
+    pc.write(case, STEPS, p_solver=psolver)
+    assert cc.solve_lines(pc.run(case)) == golden(tag)
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.skipif(not os.path.exists(PLUGIN), reason="needs the prebuilt plugin")
+@pytest.mark.parametrize("tag,psolver", CASES, ids=["pcg", "gamg"])
+def test_simplefoam_through_the_plugin(tag, psolver, tmp_path):
+    case = str(tmp_path / "pitzDaily")
+    pc.write(case, STEPS, libs=[PLUGIN], p_solver=psolver)
+    log = pc.run(case, extra_env={"LDU_VERBOSE": "1"})
+    assert "[hipLduSolvers]" in log, log[-2000:]
+    lines, gold = cc.solve_lines(log), golden(tag)
+    assert len(lines) == len(gold) == 5 * STEPS
+    # SIMPLE feeds every solve with the previous iterations' fields, each of them stopped at a relative tolerance: the
+    # comparison is by solver name, field, iteration count (within one: a residual that lands on the relTol threshold) and
+    # residuals to 1e-3 - the flow itself is the same, as the last iterations' initial residuals show
+    worst, off = 0.0, 0
+    for got, ref in zip(lines, gold):
+        assert got[0] == ref[0] and got[1] == ref[1], (got, ref)
+        assert abs(got[4] - ref[4]) <= max(1, ref[4] // 50), (got, ref)
+        off += int(got[4] != ref[4])
+        assert abs(got[2] - ref[2]) <= 1e-3 * abs(ref[2]) + 1e-9, (got, ref)
+        if ref[2]:
+            worst = max(worst, abs(got[2] - ref[2]) / abs(ref[2]))
+    print("simpleFoam pitzDaily through the plugin (%s): %d solver lines, %d with a different iteration count, worst relative "
+          "difference of an initial residual %.2e" % (tag or "pcg", len(lines), off, worst))
+    assert off <= len(lines) // 20

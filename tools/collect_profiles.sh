@@ -12,6 +12,8 @@ O=$R/gpurun_out/${TAG}_profiles
 mkdir -p $O /tmp/prof_$TAG
 export TMPDIR=/tmp
 run() { echo "== $*"; "$@"; }
+timeout 1500 python tools/pmc_traffic.py ${TAG}_box box:216 2 > $O/pmc_box.log 2>&1; echo "pmc box rc=$?"; tail -1 $O/pmc_box.log | cut -c1-300
+timeout 1500 python tools/pmc_traffic.py ${TAG}_octree octree:14:6:7 2 > $O/pmc_octree.log 2>&1; echo "pmc octree rc=$?"; tail -1 $O/pmc_octree.log | cut -c1-300
 SECONDS=0
 timeout 1500 python bench.py > $P/${TAG}_bench_box.json 2> $O/bench_box.err; echo "bench box rc=$? ($SECONDS s)"
 for m in octree octree_hexref; do
@@ -31,12 +33,11 @@ done
   python $R/tools/trace_steady.py /tmp/prof_$TAG/bench_box_kernel_trace.csv --longest "row_kernel<0>" 40
   python -c "
 import json;d=json.load(open('$O/bench_box_rocprof.json'));print('box bench under rocprofv3: finest launch avg by HIP events', d['roofline']['avg_launch_ms'], 'ms; Amul', d['amul']['avg_launch_ms'], 'ms; value', d['value'])"
-  python $R/tools/trace_steady.py /tmp/prof_$TAG/bench_octree_kernel_trace.csv --longest sweep_p2p_gs_multi_kernel 30
+  python $R/tools/trace_steady.py /tmp/prof_$TAG/bench_octree_kernel_trace.csv --hist sweep_p2p_gs_multi_kernel
+  python $R/tools/trace_steady.py /tmp/prof_$TAG/bench_octree_kernel_trace.csv --hist sweep_slab_gs_multi_kernel
   python -c "
 import json;d=json.load(open('$O/bench_octree_rocprof.json'));print('octree bench under rocprofv3: finest launch avg by HIP events', d['roofline']['avg_launch_ms'], 'ms; value', d['value'])"
 } > $P/${TAG}_dominant_kernel_durations.txt 2>&1
 cd $R
-timeout 1500 python tools/pmc_traffic.py ${TAG}_box box:216 2 > $O/pmc_box.log 2>&1; echo "pmc box rc=$?"; tail -1 $O/pmc_box.log | cut -c1-300
-timeout 1500 python tools/pmc_traffic.py ${TAG}_octree octree:14:6:7 2 > $O/pmc_octree.log 2>&1; echo "pmc octree rc=$?"; tail -1 $O/pmc_octree.log | cut -c1-300
 cp $P/${TAG}_* $O/ 2>/dev/null
 ls -la $P | grep ${TAG}_

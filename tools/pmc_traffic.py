@@ -60,7 +60,7 @@ def main():
     dom = max(dom, key=lambda n: kernels[n]["fetch_kib"]) if dom else None
     cal = {n: kernels[n] for n in kernels if n.startswith("reduce_partial_kernel") or n.startswith("reciprocal_kernel")}
     out = dict(tag=tag, workload="%s, %d pipelined GaussSeidel sweeps per launch" % (mesh, k), nCells=nC, nFaces=nF,
-               source_hash=source_hash(), kernel=dom.split("<")[0] if dom else None, kernel_full=dom,
+               source_hash=source_hash(), kernel=dom.split("<")[0].replace("void ", "").strip() if dom else None, kernel_full=dom,
                fetch_kib=kernels[dom]["fetch_kib"] if dom else None, write_kib=kernels[dom]["write_kib"] if dom else None,
                bytes_per_launch=int((kernels[dom]["fetch_kib"] + kernels[dom]["write_kib"]) * 1024) if dom else None,
                algorithmic_bytes_per_launch=k * (60 * nC + 12 * nF),

@@ -8,7 +8,12 @@ steady state (no agglomeration, no plan uploads).  Output: the columns of rocpro
 import csv, sys, collections, math
 path = sys.argv[1]
 longest = None
-if len(sys.argv) > 2 and sys.argv[2] == "--longest":
+hist = None
+if len(sys.argv) > 2 and sys.argv[2] == "--hist":
+    # dispatch durations of one kernel name after the marker, grouped (a name that serves several GAMG levels)
+    hist = sys.argv[3]
+    marker = "xcc_census_kernel"
+elif len(sys.argv) > 2 and sys.argv[2] == "--longest":
     longest = (sys.argv[3], int(sys.argv[4]))
     marker = "xcc_census_kernel"
 else:
@@ -22,6 +27,17 @@ agg = collections.defaultdict(list)
 for r in rows:
     if int(r[ts]) > t0 and marker not in r[kn]:
         agg[r[kn]].append(int(r[te]) - int(r[ts]))
+if hist:
+    d = sorted(x * 1e-6 for k, v in agg.items() if hist in k for x in v)
+    print("%s: %d dispatches after the marker; durations [ms] in groups of equal launches (count x mean):" % (hist, len(d)))
+    groups, cur = [], []
+    for x in d:
+        if cur and x > 1.12 * cur[0] + 0.01:
+            groups.append(cur); cur = []
+        cur.append(x)
+    if cur: groups.append(cur)
+    print("  " + "  ".join("%d x %.4f" % (len(g), sum(g) / len(g)) for g in groups))
+    sys.exit(0)
 if longest:
     d = sorted((x for k, v in agg.items() if longest[0] in k for x in v), reverse=True)[:longest[1]]
     print("%s: the %d longest dispatches after the marker [ms]" % (longest[0], len(d)))
