@@ -178,6 +178,17 @@ static ldu_ctx* hipContext()
         if (Pstream::parRun())
         {
             hipParallelRun_ = true;
+            // lduMatrixUpdateMatrixInterfaces.C:30-266: `blocking` and `nonBlocking` update the coupled patches in patch
+            // order - the order this library applies them in, whatever moves the data; `scheduled` walks the patch
+            // schedule instead, which changes the order in which the contributions of SEVERAL coupled patches reach
+            // one cell (last-bit differences there).  Said once, not an error: the exchange itself is ours (RCCL).
+            if (Pstream::defaultCommsType == Pstream::scheduled)
+            {
+                WarningIn("hipContext()")
+                    << "commsType scheduled: libhipLduSolvers updates coupled patches in patch order (the blocking / "
+                    << "nonBlocking order of lduMatrix::updateMatrixInterfaces); cells on several coupled patches may "
+                    << "differ from the scheduled order in the last bits" << endl;
+            }
             // RCCL communicator bootstrapped over the existing Pstream (replaces MPI on the hot path)
             labelList id(128/sizeof(label), 0);      // 128-byte ncclUniqueId as labels
             uint8_t raw[128];
