@@ -227,6 +227,8 @@ int plan_build(ldu_addr* a)
                 // linear buckets all the way (half-octave buckets above 32 levels were tried on the octree twin's GAMG
                 // levels: 1072 instead of 696 steps for 4 sweeps of level 3 - the far-reaching rows matter too)
                 NLAG = std::min(256, maxLag / lagW + 1);
+                // (the counting sort below holds levels x classes x buckets counters: very deep DAGs get fewer buckets)
+                while (NLAG > 1 && (size_t)nLevels * 8 * (size_t)NLAG > ((size_t)1 << 26)) NLAG /= 2;
                 for (int c = 0; c < nC; c++) lagB[c] = (unsigned char)std::min((t1[c] - a->level[c]) / lagW, NLAG - 1);
                 a->lagBuckets = true;
             }
