@@ -681,11 +681,6 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
               double* resHistory)
 {
     NEED_COEFFS(m);
-    if (c->directSolveCoarsest)
-    {
-        ldu_set_error("directSolveCoarsest is not supported");
-        return -17;
-    }
     return run_with_fallback(m, [&]() -> int {
         memset(perf, 0, sizeof(*perf));
         Stager S(m);

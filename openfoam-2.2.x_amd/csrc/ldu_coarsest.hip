@@ -164,3 +164,131 @@ int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------- directSolveCoarsest
+// GAMGSolver.C:95-106 / GAMGSolverSolve.C:436-440: the coarsest level as a dense matrix (LUscalarMatrix.C:128-187
+// convert), Crout LU with implicit scaled partial pivoting (scalarMatrices.C:31-134 LUDecompose) and
+// LUBacksubstitute (scalarMatricesTemplates.C:119-164).  One wavefront, the matrix in LDS.  Decomposition: lane i owns
+// row i; element (i, j) is  sum -= M[i][k] * M[k][j]  for k ascending (the reference's order) - M[k][j] is final once
+// lane k has taken its k-1 earlier subtractions, so the k loop runs for all rows at once with lane k's sum broadcast
+// at step k: the same products subtracted in the same order, n^2/2 steps instead of n^3/3.  Back-substitution is a
+// chain from row to row (row i starts with the x just computed): one lane, the reference's loops literally.
+// Serial systems without coupled patches, coarsest level <= 64 cells (nCellsInCoarsestLevel of the tutorials: 10-50).
+#define LU_STRIDE (CO_MAXC + 1)
+__global__ void __launch_bounds__(LDU_WAVE)
+coarsest_lu_kernel(int n, int nF, const int* __restrict__ gl, const int* __restrict__ gu,
+                   const double* __restrict__ gdiag, const double* __restrict__ gupper, const double* __restrict__ glower,
+                   const int* __restrict__ perm, double* __restrict__ corrNew, const double* __restrict__ srcNew,
+                   int* __restrict__ singular)
+{
+    __shared__ double M[CO_MAXC * LU_STRIDE];
+    __shared__ double vv[CO_MAXC], x[CO_MAXC];
+    __shared__ int piv[CO_MAXC];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < CO_MAXC * LU_STRIDE; e += LDU_WAVE) M[e] = 0.0;
+    __syncthreads();
+    for (int c = lane; c < n; c += LDU_WAVE) M[c * LU_STRIDE + c] = gdiag[c];
+    for (int f = lane; f < nF; f += LDU_WAVE)
+    {
+        M[gu[f] * LU_STRIDE + gl[f]] = glower[f];
+        M[gl[f] * LU_STRIDE + gu[f]] = gupper[f];
+    }
+    for (int i = lane; i < n; i += LDU_WAVE) x[perm[i]] = srcNew[i];   // coarsestCorrField = coarsestSource (original numbering)
+    __syncthreads();
+    const bool row = lane < n;
+    if (row)
+    {
+        double largest = 0.0;
+        for (int j = 0; j < n; j++)
+        {
+            const double t = fabs(M[lane * LU_STRIDE + j]);
+            if (t > largest) largest = t;
+        }
+        if (largest == 0.0) *singular = 1;   // the reference: FatalError "Singular matrix"
+        vv[lane] = 1.0 / largest;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; j++)
+    {
+        double sum = row ? M[lane * LU_STRIDE + j] : 0.0;
+        for (int k = 0; k < j; k++)
+        {
+            const double mkj = __shfl(sum, k);                 // M[k][j]: final after lane k's k-1 subtractions
+            if (row && lane > k) sum -= M[lane * LU_STRIDE + k] * mkj;
+        }
+        if (row) M[lane * LU_STRIDE + j] = sum;
+        // iMax: the LAST row i >= j with vv[i]*|sum| equal to the largest (the reference's `>=` scan)
+        const double t = (row && lane >= j) ? vv[lane] * fabs(sum) : -1.0;
+        double m = t;
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = o > m ? o : m; }
+        if (!(m > 0.0)) m = 0.0;
+        const unsigned long long hit = __ballot(row && lane >= j && t >= m);
+        const int iMax = hit ? 63 - __builtin_clzll(hit) : j;
+        __syncthreads();
+        if (lane == 0) piv[j] = iMax;
+        if (iMax != j)
+        {
+            if (row)
+            {
+                const double a = M[j * LU_STRIDE + lane], b = M[iMax * LU_STRIDE + lane];
+                M[j * LU_STRIDE + lane] = b; M[iMax * LU_STRIDE + lane] = a;
+            }
+            __syncthreads();
+            if (lane == 0) vv[iMax] = vv[j];
+        }
+        __syncthreads();
+        if (lane == 0 && M[j * LU_STRIDE + j] == 0.0) M[j * LU_STRIDE + j] = 1e-15;   // SMALL
+        __syncthreads();
+        if (j != n - 1)
+        {
+            const double rDiag = 1.0 / M[j * LU_STRIDE + j];
+            if (row && lane > j) M[lane * LU_STRIDE + j] *= rDiag;
+        }
+        __syncthreads();
+    }
+    if (lane == 0)
+    {
+        int ii = 0;
+        for (int i = 0; i < n; i++)
+        {
+            const int ip = piv[i];
+            double sum = x[ip];
+            x[ip] = x[i];
+            if (ii != 0) { for (int j = ii - 1; j < i; j++) sum -= M[i * LU_STRIDE + j] * x[j]; }
+            else if (sum != 0.0) ii = i + 1;
+            x[i] = sum;
+        }
+        for (int i = n - 1; i >= 0; i--)
+        {
+            double sum = x[i];
+            for (int j = i + 1; j < n; j++) sum -= M[i * LU_STRIDE + j] * x[j];
+            x[i] = sum / M[i * LU_STRIDE + i];
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += LDU_WAVE) corrNew[i] = x[perm[i]];
+}
+
+// 0 = solved; -1 = error (said); directSolveCoarsest has no iterative fall-back
+int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src)
+{
+    ldu_addr* a = A->a;
+    ldu_ctx* ctx = a->ctx;
+    if (ctx->nRanks > 1 || a->nPatchFaces)
+    {
+        ldu_set_error("directSolveCoarsest: coupled patches / several ranks (the reference gathers the ranks' matrices on the "
+                      "master, LUscalarMatrix.C:52-107) are not implemented");
+        return -1;
+    }
+    if (a->nCells > CO_MAXC || a->nCells == 0)
+    {
+        ldu_set_error("directSolveCoarsest: the coarsest level has " + std::to_string(a->nCells) + " cells; the device LU holds up to "
+                      + std::to_string(CO_MAXC));
+        return -1;
+    }
+    hipStream_t s = ctx->stream;
+    coarsest_lu_kernel<<<1, LDU_WAVE, 0, s>>>(a->nCells, a->nFaces, a->d_l, a->d_u, A->d_diagO, A->d_upperO,
+        A->sym ? A->d_upperO : A->d_lowerO, a->d_perm, corr, src, ctx->d_abort + 1);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}

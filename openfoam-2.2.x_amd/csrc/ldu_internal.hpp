@@ -337,6 +337,7 @@ void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converte
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);
 int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src);
+int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src);   // directSolveCoarsest (ldu_coarsest.hip)
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_set_p2p_backoff(unsigned n);
 int k_set_p2p_backoff_cap(unsigned n);

@@ -31,6 +31,14 @@ int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
                                  ctx->stream));
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < count; i++) out[i] = ctx->h_scalars[ctx->sb + slot + i];
+    if (ctx->h_abort[1])
+    {
+        // LUDecompose's FatalError("Singular matrix") (scalarMatrices.C:52-56): a zero row of the coarsest level
+        (void)hipMemsetAsync(ctx->d_abort + 1, 0, sizeof(int), ctx->stream);
+        ctx->h_abort[1] = 0;
+        ldu_set_error("directSolveCoarsest: singular coarsest-level matrix");
+        return -17;
+    }
     if (*ctx->h_abort)
     {
         // a point-to-point sweep gave up waiting (bounded spin): fail loudly, never hang

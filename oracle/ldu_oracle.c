@@ -38,6 +38,7 @@ void orc_default_opts(orc_opts* o)
     o->mergeLevels = 1;
     o->agglomerator = ORC_AGG_FACEAREAPAIR;
     o->nVcycles = 2;                  /* GAMGPreconditioner.C:60 */
+    o->directSolveCoarsest = 0;       /* GAMGSolver.C:76 */
 }
 
 /* ------------------------------------------------------------------ addressing */

@@ -698,10 +698,98 @@ static void ws_free(const orc_gamg* g, vcycle_ws* w)
 
 static int imin(int a, int b) { return a < b ? a : b; }
 
+/* directSolveCoarsest (GAMGSolver.C:95-106, GAMGSolverSolve.C:436-440): the coarsest level as a dense matrix
+ * (LUscalarMatrix.C:128-187 convert: diag, lower/upper by face, cyclic interfaces: A[faceCells][nbr faceCells] -= the
+ * neighbour patch's interfaceBouCoeffs), Crout LU with implicit scaled partial pivoting (scalarMatrices.C:31-134
+ * LUDecompose) and LUBacksubstitute (scalarMatricesTemplates.C:119-164) - every loop in the reference's order.
+ * Serial systems only: in a parallel run the reference gathers all ranks' matrices on the master (not emulated). */
+static void lu_direct_solve(const orc_sys* A, double* x, const double* src)
+{
+    if (A->nDom != 1) { fprintf(stderr, "oracle: directSolveCoarsest is restated for serial systems only\n"); abort(); }
+    const orc_dom* D = &A->dom[0];
+    const int n = D->nCells;
+    double* M = (double*)calloc((size_t)n * n, sizeof(double));
+    int* piv = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    double* vv = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+#define MM(i, j) M[(size_t)(i) * n + (j)]
+    for (int c = 0; c < n; c++) MM(c, c) = D->diag[c];
+    for (int f = 0; f < D->nFaces; f++)
+    {
+        MM(D->u[f], D->l[f]) = D->lower[f];
+        MM(D->l[f], D->u[f]) = D->upper[f];
+    }
+    for (int p = 0; p < D->nPatches; p++)
+    {
+        const orc_patch* P = &D->patches[p];
+        const orc_patch* N = &D->patches[P->nbrPatch];      /* serial: coupled patches are cyclic pairs */
+        for (int f = 0; f < P->n; f++) MM(P->faceCells[f], N->faceCells[f]) -= N->bouCoeffs[f];
+    }
+    /* LUDecompose */
+    for (int i = 0; i < n; i++)
+    {
+        double largest = 0.0, t;
+        for (int j = 0; j < n; j++) if ((t = fabs(MM(i, j))) > largest) largest = t;
+        if (largest == 0.0) { fprintf(stderr, "oracle: LUdecompose: Singular matrix\n"); abort(); }
+        vv[i] = 1.0 / largest;
+    }
+    for (int j = 0; j < n; j++)
+    {
+        for (int i = 0; i < j; i++)
+        {
+            double sum = MM(i, j);
+            for (int k = 0; k < i; k++) sum -= MM(i, k) * MM(k, j);
+            MM(i, j) = sum;
+        }
+        int iMax = 0;
+        double largest = 0.0;
+        for (int i = j; i < n; i++)
+        {
+            double sum = MM(i, j);
+            for (int k = 0; k < j; k++) sum -= MM(i, k) * MM(k, j);
+            MM(i, j) = sum;
+            const double t = vv[i] * fabs(sum);
+            if (t >= largest) { largest = t; iMax = i; }
+        }
+        piv[j] = iMax;
+        if (j != iMax)
+        {
+            for (int k = 0; k < n; k++) { const double t = MM(j, k); MM(j, k) = MM(iMax, k); MM(iMax, k) = t; }
+            vv[iMax] = vv[j];
+        }
+        if (MM(j, j) == 0.0) MM(j, j) = 1e-15;   /* SMALL */
+        if (j != n - 1)
+        {
+            const double rDiag = 1.0 / MM(j, j);
+            for (int i = j + 1; i < n; i++) MM(i, j) *= rDiag;
+        }
+    }
+    /* coarsestCorrField = coarsestSource; LUBacksubstitute */
+    for (int i = 0; i < n; i++) x[i] = src[i];
+    int ii = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const int ip = piv[i];
+        double sum = x[ip];
+        x[ip] = x[i];
+        if (ii != 0) { for (int j = ii - 1; j < i; j++) sum -= MM(i, j) * x[j]; }
+        else if (sum != 0.0) ii = i + 1;
+        x[i] = sum;
+    }
+    for (int i = n - 1; i >= 0; i--)
+    {
+        double sum = x[i];
+        for (int j = i + 1; j < n; j++) sum -= MM(i, j) * x[j];
+        x[i] = sum / MM(i, i);
+    }
+#undef MM
+    free(M); free(piv); free(vv);
+}
+
 /* GAMGSolverSolve.C:430-487 */
 static void solve_coarsest(const orc_gamg* g, const orc_opts* o, double* corr, const double* src)
 {
     const orc_sys* A = &g->lev[g->nLevels - 1].sys;
+    if (o->directSolveCoarsest) { lu_direct_solve(A, corr, src); return; }
     for (int i = 0; i < A->nCellsTotal; i++) corr[i] = 0;
     orc_opts co;
     orc_default_opts(&co);

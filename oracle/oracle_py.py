@@ -60,7 +60,7 @@ class Opts(C.Structure):
                 ("nPostSweeps", C.c_int), ("postSweepsLevelMultiplier", C.c_int), ("maxPostSweeps", C.c_int),
                 ("nFinestSweeps", C.c_int), ("interpolateCorrection", C.c_int), ("scaleCorrection", C.c_int),
                 ("nCellsInCoarsestLevel", C.c_int), ("mergeLevels", C.c_int), ("agglomerator", C.c_int),
-                ("nVcycles", C.c_int)]
+                ("nVcycles", C.c_int), ("directSolveCoarsest", C.c_int)]
 
 
 class Perf(C.Structure):

@@ -141,6 +141,9 @@ GAMG = [
          mergeLevels=1, tolerance=1e-8, relTol=0, interpolateCorrection=1, nFinestSweeps=1, nPostSweeps=1),
     dict(solver="GAMG", smoother="DICGaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
          mergeLevels=1, tolerance=1e-8, relTol=0, cacheAgglomeration=1),
+    # directSolveCoarsest (GAMGSolver.C:95-106): the coarsest level by the device LU (ldu_coarsest.hip)
+    dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=30,
+         mergeLevels=1, tolerance=1e-9, relTol=0, directSolveCoarsest=1),
 ]
 
 
@@ -172,6 +175,32 @@ def test_gamg(prob, ctx, oracle, kw):
     xo2, po2 = oracle.System(p2).solve(psi0, prob["source"], **okw)
     x2, perf2 = m.solve(psi0, prob["source"], **kw)
     _compare_solve(x2, perf2, xo2, po2)
+    m.close(); a.close()
+
+
+def test_gamg_direct_solve_coarsest(ctx, oracle):
+    """directSolveCoarsest on symmetric and asymmetric matrices, coarsest levels of 6..60 cells: histories and psi as the
+    oracle's (whose LU is pinned bit-for-bit on the reference's, tests/test_oracle_vs_ref.py); one V-cycle of a
+    2-level hierarchy is compared bit-for-bit through psi after maxIter=1."""
+    for p, nC in ((cases.box3d(12), 10), (cases.box3d(12, asym=True), 40), (cases.irregular_box(9), 30),
+                  (cases.box3d(16, asym=True), 64)):
+        S = oracle.System(p)
+        kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=nC, mergeLevels=1,
+                  tolerance=1e-10, relTol=0, directSolveCoarsest=1)
+        a, m = capi.from_problem(ctx, p)
+        assert m.gamg_levels(**kw)[-1]["nCells"] <= 64
+        psi0 = np.zeros(p["nCells"])
+        xo, po = S.solve(psi0, p["source"], **kw)
+        x, perf = m.solve(psi0, p["source"], **kw)
+        _compare_solve(x, perf, xo, po)
+        assert perf["nIterations"] == po["nIterations"]
+        m.close(); a.close()
+    # a coarsest level beyond the device LU's size is refused, loudly (no iterative stand-in)
+    p = cases.box3d(12)
+    a, m = capi.from_problem(ctx, p)
+    with pytest.raises(capi.LduError, match="directSolveCoarsest"):
+        m.solve(np.zeros(p["nCells"]), p["source"], solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                nCellsInCoarsestLevel=200, mergeLevels=1, directSolveCoarsest=1)
     m.close(); a.close()
 
 

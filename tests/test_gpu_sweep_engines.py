@@ -28,10 +28,11 @@ ENGINES = {
     "small16384": {"LDU_SMALL_MAX": "16384"},
     "small_nopipe": {"LDU_SMALL_PIPE": "0"},
     "nocoop": {"LDU_COOP_ROWS": "0"},
+    "nolag": {"LDU_LAG_BUCKETS": "0"},
     "nosort": {"LDU_SORT_ROWS": "0"},
 }
 KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
-        "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS")
+        "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS", "LDU_LAG_BUCKETS")
 
 
 def _problems():

@@ -158,6 +158,27 @@ def test_gamg_bitexact(prob, oracle, kw):
     assert np.array_equal(x, ref["psi"])
 
 
+@pytest.mark.parametrize("gen", [lambda: cases.box3d(12), lambda: cases.box3d(9, 11, 10, asym=True),
+                                 lambda: cases.random_graph(900, 5, 40), lambda: cases.jump2d(30, 30)],
+                         ids=["box", "box_asym", "graph", "jump2d"])
+@pytest.mark.parametrize("ncoarse", [10, 40])
+def test_gamg_direct_solve_coarsest(oracle, gen, ncoarse):
+    """directSolveCoarsest (GAMGSolver.C:95-106): the coarsest level by the reference's LUscalarMatrix instead of
+    ICCG / BICCG - pins the oracle's dense LU (Crout, implicit scaled pivoting, LUBacksubstitute) bit for bit"""
+    p = dict(gen())
+    p["psi"] = np.zeros(p["nCells"])
+    kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="algebraicPair", nCellsInCoarsestLevel=ncoarse,
+              mergeLevels=1, cacheAgglomeration=False, tolerance=1e-9, relTol=0, directSolveCoarsest=True)
+    ref, out = oracle.run_ref("solve", p, oracle.dict_string(**kw))
+    okw = _okw(kw)
+    okw["directSolveCoarsest"] = 1
+    x, perf = oracle.System(p).solve(p["psi"], p["source"], **okw)
+    rp = ref["perf"]
+    assert perf["nIterations"] == int(rp[2])
+    assert perf["initialResidual"] == rp[0] and perf["finalResidual"] == rp[1]
+    assert np.array_equal(x, ref["psi"])
+
+
 def test_gamg_preconditioned_pcg(oracle):
     p = cases.box3d(10)
     kw = dict(solver="PCG", tolerance=1e-9, relTol=0)
