@@ -290,7 +290,7 @@ class Addressing:
         _chk(lib().ldu_addr_get_face_weights(self.h, _ptr(w)))
         return w
 
-    ENGINES = ("chip-wide point-to-point", "XCD slabs", "clusters", "single wavefront", "level kernels")
+    ENGINES = ("chip-wide point-to-point", "XCD slabs", "clusters", "single wavefront", "level kernels", "one workgroup")
 
     def sweep_engine(self, kind):
         rc = lib().ldu_addr_sweep_engine(self.h, int(kind))

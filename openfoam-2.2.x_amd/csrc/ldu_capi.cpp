@@ -154,6 +154,16 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e) > 0) { c->clusterBlocksPerCU = atoi(e); c->clusterBpcForced = 1; }
     e = getenv("LDU_SMALL");
     if (e) c->smallKernels = atoi(e);
+    e = getenv("LDU_WG");
+    if (e) c->wgEngine = atoi(e);
+    e = getenv("LDU_WG_MAX");
+    if (e) c->wgMaxCells = atoi(e);
+    e = getenv("LDU_WG_MIN");
+    if (e) c->wgMinCells = atoi(e);
+    e = getenv("LDU_WG_WIDE");
+    if (e) c->wgWide = atoi(e);
+    e = getenv("LDU_WG_WAVES");
+    if (e) c->wgWaves = atoi(e);
     e = getenv("LDU_SMALL_MAX");
     if (e) c->smallMaxCells = std::min(atoi(e), 16384);
     e = getenv("LDU_P2P_WIDE");

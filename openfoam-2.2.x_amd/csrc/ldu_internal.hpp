@@ -91,6 +91,11 @@ struct ldu_ctx {
     int sortRowsByWidth = 1;         // LDU_SORT_ROWS: rows of a level ordered by width class (narrow slices stay narrow)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
     int gsWideUpper = 1;             // LDU_GS_WIDE_UPPER=0: upper parts of more than 8 entries after the lower part (round-1 order)
+    int wgEngine = 1;                // LDU_WG=0: no one-workgroup engine (solution vector in LDS, k sweeps as LDS-synchronised tasks)
+    int wgMaxCells = 6000;           // LDU_WG_MAX (<= 18 000: 9 bytes of LDS per cell; above ~6000 cells one CU is too little)
+    int wgMinCells = 0;              // LDU_WG_MIN
+    int wgWaves = 8;                 // LDU_WG_WAVES (4 / 8)
+    int wgWide = 0;                  // LDU_WG_WIDE=1: also levels with rows wider than 16 entries
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
@@ -230,6 +235,9 @@ struct ldu_addr {
     // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
     struct GsTasks { int* d_tasks = nullptr; int n = 0; int* d_slabTasks = nullptr; int slabStart[9] = {0}; };
     std::map<int, GsTasks> gsTasks;
+    struct WgTasks { int* d_tasks = nullptr; int n = 0; int steps = 0; };   // one-workgroup engine: 4 ints per (sweep, slice) task
+    std::map<int, WgTasks> wgTasks;
+    bool wgLevel = false;                  // small enough for the one-workgroup engine: plain full slices (no lag buckets, no cooperative rows)
 
     // cached graphs of level-scheduled sweeps, keyed by (mode, pointer arguments)
     std::map<std::string, hipGraphExec_t> graphs;
@@ -338,6 +346,7 @@ int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const
                            const double* bou);
 int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src);
 int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src);   // directSolveCoarsest (ldu_coarsest.hip)
+int k_sweep_gs_wg(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_set_p2p_backoff(unsigned n);
 int k_set_p2p_backoff_cap(unsigned n);
@@ -588,4 +597,9 @@ __device__ __forceinline__ bool ldu_abort_seen(volatile int* abortFlag, int it)
 #else
 #define LDU_STEP_FENCE() asm volatile("" ::: "memory")
 #endif
+// Release / acquire fences between the wavefronts of ONE workgroup, for LDS only: the fence's address-space operand keeps
+// the global loads a wave has in flight (its prefetches) out of the ordering - a workgroup-scope release fence or atomic
+// without it waits for them (s_waitcnt vmcnt(0)) in every step.
+#define LDU_LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define LDU_LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 #endif

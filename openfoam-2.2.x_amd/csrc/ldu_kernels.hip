@@ -1521,11 +1521,12 @@ static bool use_slab(const ldu_addr* a, int kind, int k = 1)
 }
 
 // which engine serves a sweep kind on this addressing (introspection for bench.py / tests):
-// 0 chip-wide point-to-point, 1 XCD slabs, 2 clusters, 3 single wavefront (tiny), 4 level kernels
+// 0 chip-wide point-to-point, 1 XCD slabs, 2 clusters, 3 single wavefront (tiny), 4 level kernels, 5 one workgroup (LDS)
 int k_engine_of(ldu_addr* a, int kind /* 0 triangular, 1 one GaussSeidel sweep, 2 two pipelined sweeps */)
 {
     ldu_ctx* ctx = a->ctx;
     if (!ctx->sweepP2P) return 4;
+    if (kind >= 1 && !a->nPatchFaces && ctx->wgEngine && a->wgLevel && 9 * (size_t)a->nCells + 64 <= 160 * 1024) return 5;
     if (kind >= 1 && ctx->smallKernels && a->maxRowWidth <= 16 && !a->nPatchFaces
         && a->nCells <= ((kind == 2 && ctx->smallPipe) ? ctx->smallMaxCells : std::min(ctx->smallMaxCells, 3000)))
         return 3;
@@ -1647,8 +1648,10 @@ static int launch_p2p(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 // 8 x u64 per (sweep, slice): tStart, tUpperDone, tLowerDone, tStored [100 MHz wall clock], XCC id, workgroup, 0, 0
 __device__ unsigned long long* g_gsm_trace = nullptr;
 __device__ int g_gsm_trace_stride = 0;
+static bool g_wg_trace_on = false;   // host copy: the one-workgroup engine launches its traced variant
 int k_set_gs_multi_trace(unsigned long long* buf, int nSlices)
 {
+    g_wg_trace_on = buf != nullptr;
     LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gsm_trace), &buf, sizeof(buf)));
     LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gsm_trace_stride), &nSlices, sizeof(int)));
     return 0;
@@ -2210,8 +2213,9 @@ gs_small_pipe_kernel(SliceTab T, int nSlices, int nCells, const int* __restrict_
         if (wave > 0)                                                                     \
         {                                                                                 \
             const unsigned want = (unsigned)sNeed[sCur];                                  \
-            while (__hip_atomic_load(prog + wave - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) \
+            while (__hip_atomic_load(prog + wave - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) \
                 __builtin_amdgcn_s_sleep(1);                                              \
+            LDU_LDS_ACQUIRE();                                                            \
         }                                                                                 \
         {                                                                                 \
             double acc = (CUR).b;                                                         \
@@ -2225,10 +2229,11 @@ gs_small_pipe_kernel(SliceTab T, int nSlices, int nCells, const int* __restrict_
             _Pragma("unroll") for (int q = 0; q < W; q++) acc -= pr[q];                   \
             if ((CUR).r >= 0) x[(CUR).r] = ldu_div(acc, (CUR).d, rd_);                                 \
         }                                                                                 \
-        LDU_STEP_FENCE();                                \
         ++sCur;                                                                           \
-        /* release: the slice's x[] stores are ordered before the progress word (acquire on the consumer's load) */ \
-        if (lane == 0) __hip_atomic_store(prog + wave, (unsigned)sCur, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        /* release fence on LDS only: the slice's x[] stores are ordered before the progress word (acquire fence after the  \
+           consumer's load).  A release ATOMIC would order the global prefetches too: s_waitcnt vmcnt(0) in every step */ \
+        LDU_LDS_RELEASE();                                                                \
+        if (lane == 0) __hip_atomic_store(prog + wave, (unsigned)sCur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         --left;                                                                           \
     } while (0)
         PIPE_FILL(R0);
@@ -2369,6 +2374,299 @@ int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const d
     return 0;
 }
 
+// Times of the (sweep, slice) tasks of k pipelined GaussSeidel sweeps in their slice-level dependency DAG:
+//   T(0, s) = dependency level of s;   T(j, s) = 1 + max( T(j, slices holding lower neighbours of s's rows),
+//                                                      T(j-1, slices holding their upper neighbours), T(j-1, s) )
+// Sorting the tasks by T gives a topological order in which a task appears as early as its slice can run.
+static int gs_slice_dag_times(ldu_addr* a, int k, std::vector<std::vector<int>>& T, int& maxT)
+{
+    const int nLev = a->nLevels;
+    const int nS = a->nSlices;
+    std::vector<int> rowSlice(a->nCells);
+    {
+        std::vector<int> sliceRow(nS + 1);
+        LDU_CHECK_HIP(hipMemcpy(sliceRow.data(), a->d_sliceRow, sizeof(int) * (size_t)(nS + 1), hipMemcpyDeviceToHost));
+        for (int sl = 0; sl < nS; sl++)
+            for (int r = sliceRow[sl]; r < sliceRow[sl + 1]; r++) rowSlice[r] = sl;
+    }
+    T.assign(k, std::vector<int>(nS, 0));
+    for (int L = 0; L < nLev; L++)
+        for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++) T[0][sl] = L;
+    maxT = nLev - 1;
+    for (int j = 1; j < k; j++)
+    {
+        std::vector<int>& Tj = T[j];
+        const std::vector<int>& Tp = T[j - 1];
+        for (int sl = 0; sl < nS; sl++) Tj[sl] = Tp[sl];
+        for (int f = 0; f < a->nFaces; f++)   // previous sweep's values of the upper neighbours
+        {
+            const int sl = rowSlice[a->iperm[a->l[f]]], su = rowSlice[a->iperm[a->u[f]]];
+            if (Tp[su] > Tj[sl]) Tj[sl] = Tp[su];
+        }
+        for (int sl = 0; sl < nS; sl++) Tj[sl]++;
+        // this sweep's values of the lower neighbours: rows in level order (a slice never straddles a level, so
+        // every slice is final before a slice of a higher level reads it)
+        for (int r = 0; r < a->nCells; r++)
+        {
+            const int c = a->perm[r], sr = rowSlice[r];
+            int t = Tj[sr];
+            for (int q = a->losortStart[c]; q < a->losortStart[c + 1]; q++)
+            {
+                const int tl = Tj[rowSlice[a->iperm[a->l[a->losort[q]]]]] + 1;
+                if (tl > t) t = tl;
+            }
+            Tj[sr] = t;
+        }
+        for (int sl = 0; sl < nS; sl++) maxT = std::max(maxT, Tj[sl]);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- one-workgroup engine (solution vector in LDS)
+// The GAMG levels below ~6 000 cells are all dependency depth and no width: 20 ... 90 levels of 1 ... 2 slices.  The
+// single-wavefront kernels above walk the slices one after the other and let sweep j+1 trail sweep j by the worst
+// upper-neighbour reach of the whole level (agglomerated levels: half the depth); the chip-wide / slab engines hand over
+// through L2 / memory (2-3 us per level).  Here ONE workgroup of NW wavefronts holds the solution vector AND a sweep
+// stamp per row in LDS (9 bytes per cell of 160 KB) and runs the k sweeps of a smoothing call as (sweep, slice) tasks
+// dealt round-robin to its wavefronts in the order of their time in the slice-level dependency DAG
+// (gs_slice_dag_times).  A row of sweep j is ready when its lower neighbours carry stamp j+1 and its upper neighbours
+// stamp j - the exact dependencies of the reference's sequential loop (GaussSeidelSmoother.C:147-176), row by row: a
+// lane adds up the stamps of its neighbours (a stamp can never be AHEAD of what the row needs, so the sum reaches
+// W*j + nLower exactly when every neighbour is ready; entries past the row's end point at the row itself, stamp j).
+// The value is written before the stamp and read after it (LDS is in order within a wave).  Global loads of a task
+// (its record one step, its rows two steps ahead) are in flight while other wavefronts compute.  Arithmetic per row
+// exactly as gs_small_kernel.  Rows of any width: 16 entries from registers, a wider slice's tail in chunks of 8.
+#define WG_MAX_LDS (160 * 1024)
+struct WgRow { int r, nl, nn, W, j; long ent; int c[16]; double v[16]; double b, d; };
+
+__device__ __forceinline__ void wg_rec_load(const int4* __restrict__ tasks, int nTasks, int i, int4& Q)
+{
+    Q = tasks[i < nTasks ? i : nTasks];    // (one idle record past the end)
+}
+
+__device__ __forceinline__ void wg_row_load(const int4& Q, int lane, const unsigned char* __restrict__ nLv,
+                                            const unsigned char* __restrict__ nUv, const int* __restrict__ col,
+                                            const double* __restrict__ rhs, const double* __restrict__ diag,
+                                            const double* __restrict__ val, WgRow& R)
+{
+    const int r0 = Q.x, cnt = Q.y & 255;
+    const bool have = lane < cnt;
+    const int r = have ? r0 + lane : 0;
+    const long ent = (long)Q.z + (have ? lane : 0);
+    R.nl = nLv[r];
+    R.nn = nUv[r];    // (+ nl at the point of use: no arithmetic on loaded values here, it would wait for them)
+    R.b = rhs[r];
+    R.d = diag[r];
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+    {
+        const long e = ent + (long)q * LDU_WAVE;   // the entry arrays are padded: always readable
+        R.c[q] = col[e];
+        R.v[q] = val[e];
+    }
+    R.r = have ? r : -1;
+    R.W = Q.y >> 8;
+    R.j = Q.w;
+    R.ent = ent;
+}
+
+template <int NW, bool TRACE>
+__global__ void __launch_bounds__(LDU_WAVE * NW)
+gs_wg_kernel(const unsigned char* __restrict__ nLv, const unsigned char* __restrict__ nUv, const int* __restrict__ col,
+             const int4* __restrict__ tasks, int nTasks, int nCells, int* abortFlag, double* __restrict__ psi,
+             const double* __restrict__ rhs, const double* __restrict__ diag, const double* __restrict__ val)
+{
+    extern __shared__ double smem[];
+    double* x = smem;
+    unsigned char* stamp = (unsigned char*)(x + nCells);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // the first records and rows are on their way while the vector moves into LDS
+    WgRow R0, R1, R2;
+    int4 Q;
+    int iNext = wave;
+    wg_rec_load(tasks, nTasks, iNext, Q); iNext += NW;
+#define WG_FILL(R)                                                                        \
+    do {                                                                                  \
+        wg_row_load(Q, lane, nLv, nUv, col, rhs, diag, val, (R));                         \
+        wg_rec_load(tasks, nTasks, iNext, Q);                                             \
+        iNext += NW;                                                                      \
+    } while (0)
+    WG_FILL(R0);
+    WG_FILL(R1);
+    for (int i = tid; i < nCells; i += LDU_WAVE * NW) { x[i] = psi[i]; stamp[i] = 0; }
+    __syncthreads();
+    bool alive = true;
+    int left = (nTasks - wave + NW - 1) / NW;      // this wavefront's tasks
+    // (debug timeline, ldu_debug_gs_multi_trace: per task 8 x u64 = step start, loads issued, dependencies seen, stored
+    //  [100 MHz wall clock], wavefront, sweep)
+    unsigned long long* trc = TRACE && g_gsm_trace ? g_gsm_trace + (size_t)wave * 8 : nullptr;
+#define WG_TRC(k) do { if (TRACE && trc && lane == 0) trc[k] = wall_clock64(); } while (0)
+    // wait until the stamps of the N entries cc[] add up to `want` (every neighbour ready), then fetch their values
+#define WG_WAIT(N, cc, want, xv)                                                          \
+    do {                                                                                  \
+        unsigned spins = 0;                                                               \
+        unsigned long long tw0 = 0;                                                       \
+        while (alive)                                                                     \
+        {                                                                                 \
+            int st[N];                                                                    \
+            _Pragma("unroll") for (int q = 0; q < N; q++) st[q] = stamp[cc[q]];           \
+            int sum = 0;                                                                  \
+            _Pragma("unroll") for (int q = 0; q < N; q++) sum += st[q];                   \
+            if (__builtin_amdgcn_ballot_w64(have && sum != (want)) == 0ull) break;        \
+            /* (sixteen LDS reads per round already pace this loop; tighter polling - one watched byte, values fetched \
+               with the stamps - took the LDS and the issue slots from the wavefront everybody waits for: 2x slower) */ \
+            if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; alive = false; } \
+        }                                                                                 \
+        LDU_LDS_ACQUIRE();                                                                \
+        _Pragma("unroll") for (int q = 0; q < N; q++) xv[q] = x[cc[q]];                   \
+    } while (0)
+#define WG_STEP(CUR, FILL)                                                                \
+    do {                                                                                  \
+        WG_TRC(0);                                                                        \
+        WG_FILL(FILL);                                                                    \
+        WG_TRC(1);                                                                        \
+        const double rd_ = ldu_div_prepare((CUR).d);                                      \
+        {                                                                                 \
+            const bool have = (CUR).r >= 0;                                               \
+            const int self = have ? (CUR).r : 0;                                          \
+            const int nl = (CUR).nl, nn = have ? nl + (CUR).nn : 0, j = (CUR).j;          \
+            int cc[16];                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) cc[q] = q < nn ? (CUR).c[q] : self; \
+            /* (a lane without a row reads stamp 0 sixteen times over and does not vote) */ \
+            const int want = 16 * j + (nl < 16 ? nl : 16);                                \
+            double acc = (CUR).b;                                                         \
+            double xv[16], pr[16];                                                        \
+            WG_WAIT(16, cc, want, xv);                                                    \
+            WG_TRC(2);                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) asm volatile("" : "+v"(xv[q])); \
+            _Pragma("unroll") for (int q = 0; q < 16; q++)                                \
+                pr[q] = q < nn ? (CUR).v[q] * xv[q] : 0.0;                                \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) acc -= pr[q];                  \
+            if ((CUR).W > 16)                                                             \
+                for (int q0 = 16; q0 < (CUR).W; q0 += 8)                                  \
+                {                                                                         \
+                    int c8[8]; double v8[8];                                              \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++)                         \
+                    {                                                                     \
+                        const long e = (CUR).ent + (long)(q0 + q) * LDU_WAVE;             \
+                        c8[q] = col[e]; v8[q] = val[e];                                   \
+                    }                                                                     \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++) c8[q] = q0 + q < nn ? c8[q] : self; \
+                    const int lo = nl - q0 < 0 ? 0 : (nl - q0 > 8 ? 8 : nl - q0);         \
+                    const int want8 = 8 * j + lo;                                         \
+                    WG_WAIT(8, c8, want8, xv);                                            \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++)                         \
+                        pr[q] = q0 + q < nn ? v8[q] * xv[q] : 0.0;                        \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++) acc -= pr[q];           \
+                }                                                                         \
+            if (have)                                                                     \
+            {                                                                             \
+                x[(CUR).r] = ldu_div(acc, (CUR).d, rd_);                                  \
+                /* release (LDS only): the value is in LDS before its stamp moves */      \
+                LDU_LDS_RELEASE();                                                        \
+                stamp[(CUR).r] = (unsigned char)(j + 1);                                  \
+            }                                                                             \
+        }                                                                                 \
+        LDU_STEP_FENCE();                                                                 \
+        if (TRACE && trc && lane == 0) { trc[3] = wall_clock64(); trc[4] = wave; trc[5] = (CUR).j; trc += (size_t)NW * 8; } \
+        --left;                                                                           \
+    } while (0)
+    while (left > 0)
+    {
+        WG_STEP(R0, R2);
+        if (left == 0) break;
+        WG_STEP(R1, R0);
+        if (left == 0) break;
+        WG_STEP(R2, R1);
+    }
+#undef WG_STEP
+#undef WG_WAIT
+#undef WG_FILL
+#undef WG_TRC
+    __syncthreads();
+    for (int i = tid; i < nCells; i += LDU_WAVE * NW) psi[i] = x[i];
+}
+
+template <int NW>
+static int launch_gs_wg(ldu_addr* a, const ldu_addr::WgTasks& W, size_t lds, double* psi, const double* rhs, const double* diag,
+                        const double* val)
+{
+    static bool attrSet = false;
+    if (!attrSet)
+    {
+        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_wg_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_MAX_LDS));
+        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_wg_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_MAX_LDS));
+        attrSet = true;
+    }
+    if (g_wg_trace_on)
+        gs_wg_kernel<NW, true><<<1, LDU_WAVE * NW, lds, a->ctx->stream>>>(a->d_nL, a->d_nU, a->d_col, (const int4*)W.d_tasks, W.n,
+                                                                        a->nCells, a->ctx->d_abort, psi, rhs, diag, val);
+    else
+        gs_wg_kernel<NW, false><<<1, LDU_WAVE * NW, lds, a->ctx->stream>>>(a->d_nL, a->d_nU, a->d_col, (const int4*)W.d_tasks, W.n,
+                                                                         a->nCells, a->ctx->d_abort, psi, rhs, diag, val);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static inline bool wg_qualifies(const ldu_addr* a)
+{
+    const ldu_ctx* ctx = a->ctx;
+    return ctx->wgEngine && a->wgLevel && a->nCells > 0 && 9 * (size_t)a->nCells + 64 <= WG_MAX_LDS;
+}
+
+// k GaussSeidel sweeps (k = 1 ... 4) of a small matrix in one workgroup; returns 1 when the addressing does not qualify
+int k_sweep_gs_wg(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!wg_qualifies(a) || k <= 0 || k > 4) return 1;
+    const size_t lds = 9 * (size_t)a->nCells + 64;
+    auto it = a->wgTasks.find(k);
+    if (it == a->wgTasks.end())
+    {
+        std::vector<std::vector<int>> T;
+        int maxT = 0;
+        if (gs_slice_dag_times(a, k, T, maxT)) return -1;
+        const int nS = a->nSlices;
+        std::vector<int> sliceRow(nS + 1), sliceCnt(nS), sliceEnt(nS), sliceW(nS);
+        LDU_CHECK_HIP(hipMemcpy(sliceRow.data(), a->d_sliceRow, sizeof(int) * (size_t)(nS + 1), hipMemcpyDeviceToHost));
+        LDU_CHECK_HIP(hipMemcpy(sliceCnt.data(), a->d_sliceCnt, sizeof(int) * (size_t)nS, hipMemcpyDeviceToHost));
+        LDU_CHECK_HIP(hipMemcpy(sliceEnt.data(), a->d_sliceEnt, sizeof(int) * (size_t)nS, hipMemcpyDeviceToHost));
+        LDU_CHECK_HIP(hipMemcpy(sliceW.data(), a->d_sliceW, sizeof(int) * (size_t)nS, hipMemcpyDeviceToHost));
+        // counting sort by T; inside one T the sweeps ascend (the earlier sweep is what everything else waits for)
+        std::vector<long> start((size_t)maxT + 2, 0);
+        for (int j = 0; j < k; j++)
+            for (int sl = 0; sl < nS; sl++) start[(size_t)T[j][sl] + 1]++;
+        for (size_t i = 0; i + 1 < start.size(); i++) start[i + 1] += start[i];
+        std::vector<int> rec((size_t)4 * ((size_t)k * nS + 1), 0);
+        for (int j = 0; j < k; j++)
+            for (int sl = 0; sl < nS; sl++)
+            {
+                int* r4 = rec.data() + 4 * (size_t)start[T[j][sl]]++;
+                r4[0] = sliceRow[sl]; r4[1] = sliceCnt[sl] | (sliceW[sl] << 8); r4[2] = sliceEnt[sl];
+                r4[3] = j;
+            }
+        ldu_addr::WgTasks W;
+        W.n = k * nS;       // (the record past the end stays zero: no rows)
+        W.steps = maxT + 1;
+        LDU_CHECK_HIP(hipMalloc((void**)&W.d_tasks, sizeof(int) * rec.size()));
+        LDU_CHECK_HIP(hipMemcpy(W.d_tasks, rec.data(), sizeof(int) * rec.size(), hipMemcpyHostToDevice));
+        if (getenv("LDU_VERBOSE"))
+            fprintf(stderr, "[ldugpu] workgroup engine plan: %d cells, %d slices, %d levels, k = %d: %d steps in the slice-level DAG\n",
+                    a->nCells, nS, a->nLevels, k, maxT + 1);
+        it = a->wgTasks.emplace(k, W).first;
+    }
+    ctx->profStart(a, 4);
+    int rc;
+    switch (ctx->wgWaves)
+    {
+    case 4: rc = launch_gs_wg<4>(a, it->second, lds, psi, rhs, diag, val); break;
+    default: rc = launch_gs_wg<8>(a, it->second, lds, psi, rhs, diag, val); break;
+    }
+    ctx->profStop(a, 4);
+    return rc ? -1 : 0;
+}
+
 // Host side: topological task order for k pipelined sweeps (cached per k in the addressing).
 int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
                      const double* val)
@@ -2421,43 +2719,9 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         tasks.reserve((size_t)k * a->nSlices);
         {
             const int nS = a->nSlices;
-            std::vector<int> rowSlice(a->nCells);
-            {
-                std::vector<int> sliceRow(nS + 1);
-                LDU_CHECK_HIP(hipMemcpy(sliceRow.data(), a->d_sliceRow, sizeof(int) * (size_t)(nS + 1), hipMemcpyDeviceToHost));
-                for (int sl = 0; sl < nS; sl++)
-                    for (int r = sliceRow[sl]; r < sliceRow[sl + 1]; r++) rowSlice[r] = sl;
-            }
-            std::vector<std::vector<int>> T(k, std::vector<int>(nS, 0));
-            for (int L = 0; L < nLev; L++)
-                for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++) T[0][sl] = L;
-            int maxT = nLev - 1;
-            for (int j = 1; j < k; j++)
-            {
-                std::vector<int>& Tj = T[j];
-                const std::vector<int>& Tp = T[j - 1];
-                for (int sl = 0; sl < nS; sl++) Tj[sl] = Tp[sl];
-                for (int f = 0; f < a->nFaces; f++)   // previous sweep's values of the upper neighbours
-                {
-                    const int sl = rowSlice[a->iperm[a->l[f]]], su = rowSlice[a->iperm[a->u[f]]];
-                    if (Tp[su] > Tj[sl]) Tj[sl] = Tp[su];
-                }
-                for (int sl = 0; sl < nS; sl++) Tj[sl]++;
-                // this sweep's values of the lower neighbours: rows in level order (a slice never straddles a level, so
-                // every slice is final before a slice of a higher level reads it)
-                for (int r = 0; r < a->nCells; r++)
-                {
-                    const int c = a->perm[r], sr = rowSlice[r];
-                    int t = Tj[sr];
-                    for (int q = a->losortStart[c]; q < a->losortStart[c + 1]; q++)
-                    {
-                        const int tl = Tj[rowSlice[a->iperm[a->l[a->losort[q]]]]] + 1;
-                        if (tl > t) t = tl;
-                    }
-                    Tj[sr] = t;
-                }
-                for (int sl = 0; sl < nS; sl++) maxT = std::max(maxT, Tj[sl]);
-            }
+            std::vector<std::vector<int>> T;
+            int maxT = 0;
+            if (gs_slice_dag_times(a, k, T, maxT)) return -1;
             // counting sort by T; inside one T the sweeps ascend and the slices keep their order
             std::vector<long> start((size_t)maxT + 2, 0);
             for (int j = 0; j < k; j++)

@@ -210,7 +210,12 @@ int plan_build(ldu_addr* a)
         int widestRow = 0;
         for (int c = 0; c < nC; c++)
             widestRow = std::max(widestRow, a->losortStart[c + 1] - a->losortStart[c] + a->ownerStart[c + 1] - a->ownerStart[c]);
-        const bool smallKernels = nC <= a->ctx->smallMaxCells && widestRow <= 16;
+        // (nor for the levels of the one-workgroup engine: every slice is a task there, full slices are what it wants.
+        //  LDU_WG_WIDE=1 lets it take rows of any width - measured on the octree twin's coarse levels it loses to the slab
+        //  engine with cooperative rows and lag buckets there, 1.2-2.3 against 0.6-1.1 ms for four sweeps)
+        a->wgLevel = a->ctx->wgEngine && nC <= std::min(a->ctx->wgMaxCells, 18000) && nC >= a->ctx->wgMinCells
+                     && (widestRow <= 16 || a->ctx->wgWide);
+        const bool smallKernels = (nC <= a->ctx->smallMaxCells && widestRow <= 16) || a->wgLevel;
         const int lagW = (sortRows && a->ctx->lagBucketWidth > 0 && !smallKernels && nC >= 512) ? a->ctx->lagBucketWidth : 0;
         int NLAG = 1;
         std::vector<unsigned char> lagB(nC, 0);
@@ -284,7 +289,7 @@ int plan_build(ldu_addr* a)
     std::vector<unsigned char> rowClass(nC, 0);
     for (int r = 0; r < nC; r++) rowClass[r] = (unsigned char)row_width_class(nL[r], nU[r]);
     // cooperative rows need the rows of a level grouped by class
-    const bool coop = a->ctx->sortRowsByWidth && a->ctx->coopRows;
+    const bool coop = a->ctx->sortRowsByWidth && a->ctx->coopRows && !a->wgLevel;
     std::vector<unsigned char> sliceT;
     long ent = 0;
     for (int L = 0; L < nLevels; L++)
@@ -589,6 +594,9 @@ void plan_free(ldu_addr* a)
         if (kv.second.d_slabTasks) (void)hipFree(kv.second.d_slabTasks);
     }
     a->gsTasks.clear();
+    for (auto& kv : a->wgTasks)
+        if (kv.second.d_tasks) (void)hipFree(kv.second.d_tasks);
+    a->wgTasks.clear();
     void* ptrs[] = {a->d_perm, a->d_iperm, a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_sliceW, a->d_sliceT,
                     a->d_levelSliceStart, a->d_nL, a->d_nU, a->d_col, a->d_face, a->d_l, a->d_u,
                     a->d_losort, a->d_ownerStart, a->d_losortStart, a->d_bRow, a->d_bStart, a->d_bFace,

@@ -224,7 +224,22 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     if (!sym && !a->nPatchFaces && a->ctx->sweepP2P)
     {
         // small matrix: every sweep inside one workgroup, solution vector in LDS
-        const int rc = k_sweep_gs_small(a, nSweeps, psi, source, m->d_diag, m->d_valA);
+        int rc = 1;
+        if (nSweeps <= 4) rc = k_sweep_gs_wg(a, nSweeps, psi, source, m->d_diag, m->d_valA);
+        else
+        {
+            // (more than four sweeps: launches of 4 / 3 / 2, never a single sweep left over)
+            int left = nSweeps;
+            rc = 0;
+            while (left > 0 && rc == 0)
+            {
+                const int kk = left > 4 ? (left == 5 ? 3 : 4) : left;
+                rc = k_sweep_gs_wg(a, kk, psi, source, m->d_diag, m->d_valA);
+                if (rc > 0 && left != nSweeps) { ldu_set_error("workgroup engine: refused after the first launch"); return -1; }
+                left -= kk;
+            }
+        }
+        if (rc > 0) rc = k_sweep_gs_small(a, nSweeps, psi, source, m->d_diag, m->d_valA);
         if (rc <= 0) return rc;
     }
     if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && a->ctx->gsPipeline && nSweeps >= 2)
@@ -269,7 +284,8 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
                 // small matrix with coupled patches: the frozen interface terms are in bPrime, so the single-wavefront
                 // kernel can take this sweep like any other right-hand side (one sweep per launch: the neighbour
                 // values change between sweeps, GaussSeidelSmoother.C:98-145)
-                const int rc = k_sweep_gs_small(a, 1, psi, rhs, m->d_diag, m->d_valA);
+                int rc = k_sweep_gs_wg(a, 1, psi, rhs, m->d_diag, m->d_valA);
+                if (rc > 0) rc = k_sweep_gs_small(a, 1, psi, rhs, m->d_diag, m->d_valA);
                 if (rc < 0) return rc;
                 if (rc == 0) continue;
             }

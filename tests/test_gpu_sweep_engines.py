@@ -30,9 +30,14 @@ ENGINES = {
     "nocoop": {"LDU_COOP_ROWS": "0"},
     "nolag": {"LDU_LAG_BUCKETS": "0"},
     "nosort": {"LDU_SORT_ROWS": "0"},
+    "nowg": {"LDU_WG": "0"},
+    "wg4": {"LDU_WG_WAVES": "4"},
+    "nowg_small16384": {"LDU_WG": "0", "LDU_SMALL_MAX": "16384"},
+    "wg_wide18000": {"LDU_WG_MAX": "18000", "LDU_WG_WIDE": "1"},
 }
 KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
-        "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS", "LDU_LAG_BUCKETS")
+        "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS", "LDU_LAG_BUCKETS", "LDU_WG", "LDU_WG_WAVES",
+        "LDU_WG_MAX", "LDU_WG_MIN", "LDU_WG_WIDE")
 
 
 def _problems():
@@ -130,6 +135,7 @@ def test_small_pipelined_sweeps_bitexact(oracle, pipe):
     bit-exact against the sequential sweeps; LDU_SMALL_PIPE=0 = the single-wavefront kernel."""
     saved = {k: os.environ.pop(k, None) for k in KEYS}
     os.environ["LDU_SMALL_PIPE"] = pipe
+    os.environ["LDU_WG"] = "0"
     try:
         ctx = capi.Context(0)
         rng = np.random.RandomState(4)
@@ -146,6 +152,40 @@ def test_small_pipelined_sweeps_bitexact(oracle, pipe):
             for k in (2, 3, 4, 5, 6, 7, 8):
                 for rep in range(2):
                     assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k)
+            m.close(); a.close()
+        ctx.close()
+    finally:
+        for k in KEYS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("waves", ["8", "4"])
+def test_workgroup_engine_bitexact(oracle, waves):
+    """gs_wg_kernel: k = 1 ... 8 GaussSeidel sweeps of a matrix of up to 20 000 cells as LDS-synchronised (sweep, slice)
+    tasks of ONE workgroup (solution vector in LDS, level counters); tiny to 19 683 cells, rows of up to ~60 entries (the
+    chunked tail), hex / random / chain / octree-coarse-like graphs; bit-exact against the sequential sweeps."""
+    saved = {k: os.environ.pop(k, None) for k in KEYS}
+    os.environ["LDU_WG_WAVES"] = waves
+    os.environ["LDU_WG_MAX"] = "18000"
+    os.environ["LDU_WG_WIDE"] = "1"
+    try:
+        ctx = capi.Context(0)
+        rng = np.random.RandomState(5)
+        probs = [cases.box3d(3, 4, 3), cases.box3d(1, 1, 2), cases.box3d(11, 12, 13), cases.box3d(26, 26, 26),
+                 cases.random_graph(2999, 9, 200), cases.random_graph(5900, 5, 150, asym=True), cases.random_graph(700, 13, 60),
+                 cases.laplacian2d(1, 50), cases.laplacian2d(100, 100), cases.irregular_box(25),
+                 cases.random_graph(12000, 30, 500, asym=True), cases.random_graph(17900, 12, 3000)]
+        for p in probs:
+            a, m = capi.from_problem(ctx, p)
+            assert a.sweep_engine(2) == "one workgroup", p["nCells"]
+            S = oracle.System(p)
+            psi, src = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+            for k in (1, 2, 3, 4, 5, 6, 7, 8):
+                for rep in range(2):
+                    assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k)
+            assert ctx.fallback_count() == 0
             m.close(); a.close()
         ctx.close()
     finally:
