@@ -286,16 +286,44 @@ fs_surfaceIntegrate_kernel(int nCells, const int* __restrict__ cs, const int* __
     double acc[NC];
 #pragma unroll
     for (int q = 0; q < NC; q++) acc[q] = 0.0;
-    for (int t = losortStart[c]; t < losortStart[c + 1]; t++)
+    // faces four at a time: index loads, then value loads, in flight together (the sums stay in face order)
+    const int t1 = losortStart[c + 1];
+    for (int t = losortStart[c]; t < t1; t += 4)
     {
-        const long f = losort[t];
+        long f[4];
+        double v[4][NC];
 #pragma unroll
-        for (int q = 0; q < NC; q++) acc[q] -= ssf[NC * f + q];
+        for (int k = 0; k < 4; k++) f[k] = losort[t + k < t1 ? t + k : t1 - 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int q = 0; q < NC; q++) v[k][q] = ssf[NC * f[k] + q];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (t + k < t1)
+            {
+#pragma unroll
+                for (int q = 0; q < NC; q++) acc[q] -= v[k][q];
+            }
     }
-    for (long f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+    const long f1 = ownerStart[c + 1];
+    for (long f0 = ownerStart[c]; f0 < f1; f0 += 4)
     {
+        double v[4][NC];
 #pragma unroll
-        for (int q = 0; q < NC; q++) acc[q] += ssf[NC * f + q];
+        for (int k = 0; k < 4; k++)
+        {
+            const long f = f0 + k < f1 ? f0 + k : f1 - 1;
+#pragma unroll
+            for (int q = 0; q < NC; q++) v[k][q] = ssf[NC * f + q];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (f0 + k < f1)
+            {
+#pragma unroll
+                for (int q = 0; q < NC; q++) acc[q] += v[k][q];
+            }
     }
     if (cs)
         for (int j = cs[c]; j < cs[c + 1]; j++)

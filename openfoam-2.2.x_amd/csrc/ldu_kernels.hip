@@ -3420,26 +3420,52 @@ int k_patch_agglomerate(int nCoarse, const int* start, const int* fine, const do
 // ---------------------------------------------------------------- fv stencils (original numbering)
 
 // surfaceInterpolationScheme.C:293-296: sf = lambda*(vf[P]-vf[N]) + vf[N]
-__global__ void fv_interpolate_kernel(int nFaces, int nComp, const int* __restrict__ P,
-                                      const int* __restrict__ N, const double* __restrict__ lambda,
-                                      const double* __restrict__ vf, double* __restrict__ sf)
+// One lane per (face, component): the stores of a wave are one contiguous run, the 24 / 72 bytes of a cell's value arrive
+// through adjacent lanes (a lane per face walking its components touched every cache line nComp times: 37 % of HBM peak
+// for vectors against 61 % for scalars).
+template <int NC>
+__global__ void fv_interpolate_kernel(long n, const int* __restrict__ P, const int* __restrict__ N,
+                                      const double* __restrict__ lambda, const double* __restrict__ vf,
+                                      double* __restrict__ sf)
 {
-    for (int f = blockIdx.x * BLK + threadIdx.x; f < nFaces; f += gridDim.x * BLK)
+    for (long e = (long)blockIdx.x * BLK + threadIdx.x; e < n; e += (long)gridDim.x * BLK)
     {
-        const int p = P[f], q = N[f];
+        const long f = e / NC;
+        const int c = (int)(e - f * NC);
+        const long p = P[f], q = N[f];
         const double lam = lambda[f];
-        for (int c = 0; c < nComp; c++)
-        {
-            const double a = vf[(long)p * nComp + c], b = vf[(long)q * nComp + c];
-            sf[(long)f * nComp + c] = lam * (a - b) + b;
-        }
+        const double a = vf[p * NC + c], b = vf[q * NC + c];
+        sf[e] = lam * (a - b) + b;
+    }
+}
+__global__ void fv_interpolate_any_kernel(long n, int nComp, const int* __restrict__ P, const int* __restrict__ N,
+                                          const double* __restrict__ lambda, const double* __restrict__ vf,
+                                          double* __restrict__ sf)
+{
+    for (long e = (long)blockIdx.x * BLK + threadIdx.x; e < n; e += (long)gridDim.x * BLK)
+    {
+        const long f = e / nComp;
+        const int c = (int)(e - f * nComp);
+        const long p = P[f], q = N[f];
+        const double lam = lambda[f];
+        const double a = vf[p * nComp + c], b = vf[q * nComp + c];
+        sf[e] = lam * (a - b) + b;
     }
 }
 int k_fv_interpolate(ldu_addr* a, int nComp, const double* lambdas, const double* vf, double* sf,
                      hipStream_t s)
 {
     if (a->nFaces == 0) return 0;
-    fv_interpolate_kernel<<<ewGrid(a->nFaces), BLK, 0, s>>>(a->nFaces, nComp, a->d_l, a->d_u, lambdas, vf, sf);
+    const long n = (long)a->nFaces * nComp;
+    const int grid = (int)std::min<long>((n + BLK - 1) / BLK, 1 << 20);
+    switch (nComp)
+    {
+    case 1: fv_interpolate_kernel<1><<<grid, BLK, 0, s>>>(n, a->d_l, a->d_u, lambdas, vf, sf); break;
+    case 3: fv_interpolate_kernel<3><<<grid, BLK, 0, s>>>(n, a->d_l, a->d_u, lambdas, vf, sf); break;
+    case 6: fv_interpolate_kernel<6><<<grid, BLK, 0, s>>>(n, a->d_l, a->d_u, lambdas, vf, sf); break;
+    case 9: fv_interpolate_kernel<9><<<grid, BLK, 0, s>>>(n, a->d_l, a->d_u, lambdas, vf, sf); break;
+    default: fv_interpolate_any_kernel<<<grid, BLK, 0, s>>>(n, nComp, a->d_l, a->d_u, lambdas, vf, sf); break;
+    }
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -3507,8 +3533,30 @@ __global__ void fv_negSumDiag_kernel(int nCells, const int* __restrict__ losortS
     for (int c = blockIdx.x * BLK + threadIdx.x; c < nCells; c += gridDim.x * BLK)
     {
         double acc = 0.0;
-        for (int t = losortStart[c]; t < losortStart[c + 1]; t++) acc -= upper[losort[t]];
-        for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++) acc -= lower[f];
+        // (four faces at a time: the index loads, then the coefficient loads, are in flight together)
+        const int t1 = losortStart[c + 1];
+        for (int t = losortStart[c]; t < t1; t += 4)
+        {
+            int f[4];
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[i] = losort[t + i < t1 ? t + i : t1 - 1];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = upper[f[i]];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (t + i < t1) acc -= v[i];
+        }
+        const int f1 = ownerStart[c + 1];
+        for (int f = ownerStart[c]; f < f1; f += 4)
+        {
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = lower[f + i < f1 ? f + i : f1 - 1];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (f + i < f1) acc -= v[i];
+        }
         diag[c] = acc;
     }
 }
