@@ -154,6 +154,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e) > 0) { c->clusterBlocksPerCU = atoi(e); c->clusterBpcForced = 1; }
     e = getenv("LDU_SMALL");
     if (e) c->smallKernels = atoi(e);
+    e = getenv("LDU_CLUSTER_DIRECT");
+    if (e) c->clusterDirectFill = atoi(e);
     e = getenv("LDU_WG");
     if (e) c->wgEngine = atoi(e);
     e = getenv("LDU_WG_MAX");
@@ -393,7 +395,7 @@ void matrix_free(ldu_matrix* m)
     // the cluster engine keeps converted copies of this matrix's value arrays, keyed by their addresses
     for (const double* v : {(const double*)m->d_valA, (const double*)m->d_valT, (const double*)m->d_valP,
                             (const double*)m->d_valPT})
-        if (v) cluster_forget(m->a, v);
+        if (v) { cluster_forget(m->a, v); m->a->valOrigin.erase(v); }
     if (m->d_lowerO && m->d_lowerO != m->d_upperO) (void)hipFree(m->d_lowerO);
     if (m->d_valT && m->d_valT != m->d_valA) (void)hipFree(m->d_valT);
     void* ptrs[] = {m->d_diagO, m->d_upperO, m->d_diag, m->d_valA, m->d_bou, m->d_int, m->d_rD,
@@ -411,13 +413,17 @@ int matrix_refresh_layout(ldu_matrix* m)
     const size_t nE = (size_t)(a->nEntries > 0 ? a->nEntries : 1);
     if (k_permute_in(a, m->d_diag, m->d_diagO, s)) return -1;
     if (k_fill_sell(a, m->d_lowerO, m->d_upperO, m->d_valA, s)) return -1;
+    a->valOrigin[m->d_valA] = {m->d_lowerO, m->d_upperO};
     if (!m->sym)
     {
         if (m->d_valT == m->d_valA) LDU_CHECK_HIP(hipMalloc((void**)&m->d_valT, sizeof(double) * nE));
         if (k_fill_sell(a, m->d_upperO, m->d_lowerO, m->d_valT, s)) return -1;
+        a->valOrigin[m->d_valT] = {m->d_upperO, m->d_lowerO};
     }
     else if (m->d_valT != m->d_valA)
     {
+        cluster_forget(a, m->d_valT);
+        a->valOrigin.erase(m->d_valT);
         (void)hipFree(m->d_valT);
         m->d_valT = m->d_valA;
     }

@@ -102,6 +102,7 @@ struct ClusterPlan {
     int* d_colF = nullptr;            // [nEntries] lower part: cluster-row of the column; upper part: level row
     int* d_colB = nullptr;            // [nEntries] lower part: level row; upper part: cluster-row
     int* d_src = nullptr;             // [nEntries] index of the entry in the level-ordered SELL arrays
+    int* d_srcFace = nullptr;         // [nEntries] face << 1 | (1: the upper-triangle coefficient of an owner row), -1: padding
     uint4* d_granule = nullptr;       // [nCells+1]
     unsigned* d_ticket = nullptr;
     ClBase ticketBase{};
@@ -142,7 +143,7 @@ void cluster_free(ldu_addr* a)
     ClusterPlan* P = a->cluster;
     if (!P) return;
     void* ptrs[] = {P->d_sliceEnt, P->d_sliceDepth, P->d_rowMeta,
-                    P->d_colF, P->d_colB, P->d_src, P->d_granule, P->d_ticket, P->d_granule1, P->d_ticket1,
+                    P->d_colF, P->d_colB, P->d_src, P->d_srcFace, P->d_granule, P->d_ticket, P->d_granule1, P->d_ticket1,
                     P->d_granuleV[0], P->d_ticketV[0], P->d_granuleV[1], P->d_ticketV[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : P->conv) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -273,6 +274,7 @@ static int cluster_build(ldu_addr* a)
             for (int r = lvlSliceRow[s]; r < lvlSliceRow[s + 1]; r++) lvlSliceOfRow[r] = s;
     }
     std::vector<int> colF((size_t)P->nEntries, 0), colB((size_t)P->nEntries, 0), src((size_t)P->nEntries, 0);
+    std::vector<int> srcFace((size_t)P->nEntries, -1);
     // the clusters write disjoint ranges of the tables: host threads over cluster ranges
     auto fillRange = [&](int s0, int s1) {
     for (int s = s0; s < s1; s++)
@@ -293,6 +295,7 @@ static int cluster_build(ldu_addr* a)
                 colF[base + (long)k * LDU_WAVE] = crowOf[nb];
                 colB[base + (long)k * LDU_WAVE] = a->iperm[nb];
                 src[base + (long)k * LDU_WAVE] = (int)(lbase + (long)k * LDU_WAVE);
+                srcFace[base + (long)k * LDU_WAVE] = a->losort[j] << 1;
             }
             for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++, k++)
             {
@@ -300,6 +303,7 @@ static int cluster_build(ldu_addr* a)
                 colF[base + (long)k * LDU_WAVE] = a->iperm[nb];
                 colB[base + (long)k * LDU_WAVE] = crowOf[nb];
                 src[base + (long)k * LDU_WAVE] = (int)(lbase + (long)k * LDU_WAVE);
+                srcFace[base + (long)k * LDU_WAVE] = (f << 1) | 1;
             }
             for (; k < sliceW[s]; k++)
             {
@@ -323,7 +327,8 @@ static int cluster_build(ldu_addr* a)
     }
     const auto tTables = std::chrono::steady_clock::now();
     if (cl_upload(&P->d_sliceEnt, sliceEnt) || cl_upload(&P->d_sliceDepth, sliceDepth) || cl_upload(&P->d_rowMeta, rowMeta)
-        || cl_upload(&P->d_colF, colF) || cl_upload(&P->d_colB, colB) || cl_upload(&P->d_src, src))
+        || cl_upload(&P->d_colF, colF) || cl_upload(&P->d_colB, colB) || cl_upload(&P->d_src, src)
+        || (a->nFaces < (1 << 30) && cl_upload(&P->d_srcFace, srcFace)))
         return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(P->nRows + 1)));
     LDU_CHECK_HIP(hipMemset(P->d_granule, 0, sizeof(uint4) * (size_t)(P->nRows + 1)));
@@ -349,6 +354,21 @@ __global__ void __launch_bounds__(CL_BLK)
 cl_convert_kernel(long n, const int* __restrict__ src, const double* __restrict__ in, double* __restrict__ out)
 {
     for (long i = (long)blockIdx.x * CL_BLK + threadIdx.x; i < n; i += (long)gridDim.x * CL_BLK) out[i] = in[src[i]];
+}
+
+// the cluster layout straight from the face-ordered coefficients (same values as fill_sell + cl_convert; the gather has
+// the locality of the clusters instead of the level order's: a cluster's faces lie together)
+__global__ void __launch_bounds__(CL_BLK)
+cl_fill_kernel(long n, const int* __restrict__ srcFace, const double* __restrict__ lowerO, const double* __restrict__ upperO,
+               double* __restrict__ out)
+{
+    for (long i = (long)blockIdx.x * CL_BLK + threadIdx.x; i < n; i += (long)gridDim.x * CL_BLK)
+    {
+        const int code = srcFace[i];
+        double v = 0.0;
+        if (code >= 0) v = (code & 1) ? upperO[code >> 1] : lowerO[code >> 1];
+        out[i] = v;
+    }
 }
 
 __device__ __forceinline__ void cl_store(uint4* G, int row, double v, unsigned tag)
@@ -650,7 +670,11 @@ static const double* cluster_values(ldu_addr* a, const double* levelVal, hipStre
     if (C.stamp != a->ctx->valStamp)
     {
         int grid = (int)std::min<long>((P->nEntries + CL_BLK - 1) / CL_BLK, 8192);
-        cl_convert_kernel<<<grid, CL_BLK, 0, s>>>(P->nEntries - 1024, P->d_src, levelVal, C.d);
+        auto org = a->valOrigin.find(levelVal);
+        if (org != a->valOrigin.end() && P->d_srcFace && a->ctx->clusterDirectFill)
+            cl_fill_kernel<<<grid, CL_BLK, 0, s>>>(P->nEntries - 1024, P->d_srcFace, org->second.first, org->second.second, C.d);
+        else
+            cl_convert_kernel<<<grid, CL_BLK, 0, s>>>(P->nEntries - 1024, P->d_src, levelVal, C.d);
         C.stamp = a->ctx->valStamp;
     }
     return C.d;

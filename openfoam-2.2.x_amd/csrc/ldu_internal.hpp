@@ -91,6 +91,7 @@ struct ldu_ctx {
     int sortRowsByWidth = 1;         // LDU_SORT_ROWS: rows of a level ordered by width class (narrow slices stay narrow)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
     int gsWideUpper = 1;             // LDU_GS_WIDE_UPPER=0: upper parts of more than 8 entries after the lower part (round-1 order)
+    int clusterDirectFill = 1;       // LDU_CLUSTER_DIRECT=0: cluster layout via the level layout (cl_convert) instead of from the faces
     int wgEngine = 1;                // LDU_WG=0: no one-workgroup engine (solution vector in LDS, k sweeps as LDS-synchronised tasks)
     int wgMaxCells = 6000;           // LDU_WG_MAX (<= 18 000: 9 bytes of LDS per cell; above ~6000 cells one CU is too little)
     int wgMinCells = 0;              // LDU_WG_MIN
@@ -234,6 +235,8 @@ struct ldu_addr {
 
     // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
     struct GsTasks { int* d_tasks = nullptr; int n = 0; int* d_slabTasks = nullptr; int slabStart[9] = {0}; };
+    // level-layout coefficient arrays filled from face-ordered ones (fill_sell): value array -> (lower-side, upper-side source)
+    std::map<const double*, std::pair<const double*, const double*>> valOrigin;
     std::map<int, GsTasks> gsTasks;
     struct WgTasks { int* d_tasks = nullptr; int n = 0; int steps = 0; };   // one-workgroup engine: 4 ints per (sweep, slice) task
     std::map<int, WgTasks> wgTasks;
