@@ -22,6 +22,7 @@ done
 timeout 900 python bench.py --mesh jump2d --n 2000 --no-extras > $P/${TAG}_bench_jump2d.json 2> $O/bench_jump2d.err; echo "bench jump2d rc=$?"
 timeout 900 python bench.py --mesh renumbered --no-cpu --no-extras > $P/${TAG}_bench_renumbered.json 2> $O/bench_renumbered.err; echo "bench renumbered rc=$?"
 timeout 900 python bench.py --mesh irregular --no-cpu --no-extras > $P/${TAG}_bench_irregular.json 2> $O/bench_irregular.err; echo "bench irregular rc=$?"
+{ echo '```'; timeout 900 python tools/fv_probe.py 216 20 2>&1 | grep -v amdgpu.ids; echo '```'; } > $P/${TAG}_fv_probe.md; echo "fv probe rc=$?"
 timeout 900 python bench.py --rank-of 8 2> $O/bench_rank8.err | grep '^{' > $P/${TAG}_rank_of_8_projection.json; echo "rank-of 8 rc=$?"
 cd /tmp
 for m in box octree; do
