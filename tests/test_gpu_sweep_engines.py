@@ -34,10 +34,11 @@ ENGINES = {
     "wg4": {"LDU_WG_WAVES": "4"},
     "nowg_small16384": {"LDU_WG": "0", "LDU_SMALL_MAX": "16384"},
     "wg_wide18000": {"LDU_WG_MAX": "18000", "LDU_WG_WIDE": "1"},
+    "cluster_via_level_layout": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1", "LDU_CLUSTER_DIRECT": "0"},
 }
 KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
         "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS", "LDU_LAG_BUCKETS", "LDU_WG", "LDU_WG_WAVES",
-        "LDU_WG_MAX", "LDU_WG_MIN", "LDU_WG_WIDE")
+        "LDU_WG_MAX", "LDU_WG_MIN", "LDU_WG_WIDE", "LDU_CLUSTER_DIRECT")
 
 
 def _problems():
