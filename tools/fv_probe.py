@@ -58,10 +58,13 @@ def bench(name, nbytes, fn):
           % (name, dt * 1e3, nbytes / dt / 1e9, 100 * nbytes / dt / 8e12, k * 1e3, 100 * nbytes / k / 8e12), flush=True)
 
 B8 = 8.0
-# every C-ABI call ends with a stream synchronisation: launch + sync of a call that moves next to nothing (the boundary-diagonal
-# update of 0.28 M patch faces, ~3 us of kernel) is the overhead each wall time below contains
-OVERHEAD[0] = min(wall(lambda: L.ldu_fvm_addBoundaryDiag(b.h, P(iC), P(oC))) for _ in range(3))
-print("call overhead (launch + stream sync, measured on ldu_fvm_addBoundaryDiag): %.1f us" % (OVERHEAD[0] * 1e6))
+# every C-ABI call ends with a stream synchronisation: launch + sync of the same entry point on a 2-cell mesh is the overhead each
+# wall time below contains (rocprofv3's kernel times of this script: profiles/r03_fv_probe_kernel_stats.csv)
+_l0, _u0 = np.array([0], dtype=np.int32), np.array([1], dtype=np.int32)
+_a0 = capi.Addressing(ctx, 2, _l0, _u0)
+_w0, _v0, _o0 = R(1), R(2), Z(1)
+OVERHEAD[0] = min(wall(lambda: L.ldu_fv_interpolate(_a0.h, 1, P(_w0), P(_v0), P(_o0))) for _ in range(3))
+print("call overhead (launch + stream sync, ldu_fv_interpolate on a 2-cell mesh): %.1f us" % (OVERHEAD[0] * 1e6))
 print("fv / glue kernels, %d^3 box: %d cells, %d faces, %d boundary faces, %d reps" % (n, nC, nF, nB, reps))
 bench("ldu_fv_interpolate (scalar)", nF * (8 + 8 + B8) + nC * 8, lambda: L.ldu_fv_interpolate(a.h, 1, P(w), P(vf), P(oF)))
 bench("ldu_fv_interpolate (vector)", nF * (8 + 8 + 24) + nC * 24, lambda: L.ldu_fv_interpolate(a.h, 3, P(w), P(vf3), P(oF3)))
