@@ -154,6 +154,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e) > 0) { c->clusterBlocksPerCU = atoi(e); c->clusterBpcForced = 1; }
     e = getenv("LDU_SMALL");
     if (e) c->smallKernels = atoi(e);
+    e = getenv("LDU_STAGE_OVERLAP");
+    if (e) c->stageOverlap = atoi(e);
     e = getenv("LDU_CLUSTER_DIRECT");
     if (e) c->clusterDirectFill = atoi(e);
     e = getenv("LDU_WG");
@@ -509,8 +511,17 @@ struct Stager {
         {
             double* st = a->scratchVec(nextScratch++);
             if (!st) return nullptr;
-            if (a->nCells && hipMemcpyAsync(st, user, sizeof(double) * a->nCells, hipMemcpyHostToDevice, s) != hipSuccess)
+            // host vectors travel on the second stream: device work already queued on the main stream (the GAMG coarse
+            // matrices of this solve, ldu_solve) runs while they cross PCIe; the main stream waits for the copy only
+            ldu_ctx* ctx = a->ctx;
+            hipStream_t sc = ctx->stageOverlap ? ctx->stream2 : s;
+            if (a->nCells && hipMemcpyAsync(st, user, sizeof(double) * a->nCells, hipMemcpyHostToDevice, sc) != hipSuccess)
                 return nullptr;
+            if (sc != s)
+            {
+                if (hipEventRecord(ctx->evFork, sc) != hipSuccess || hipStreamWaitEvent(s, ctx->evFork, 0) != hipSuccess)
+                    return nullptr;
+            }
             devOrig = st;
         }
         double* w = m->workVec(nextWork++);
@@ -699,6 +710,10 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
     NEED_COEFFS(m);
     return run_with_fallback(m, [&]() -> int {
         memset(perf, 0, sizeof(*perf));
+        // GAMG: the coarse matrices of this solve first (device work only), so that host vectors are uploaded meanwhile
+        if (m->a->ctx->stageOverlap && (c->solver == LDU_SOLVER_GAMG || c->preconditioner == LDU_PRE_GAMG)
+            && (!is_device_ptr(psi) || !is_device_ptr(source)))
+            if (gamg_precondition_setup(m, c)) return -1;
         Stager S(m);
         double* x = S.in(psi);
         double* b = S.in(source);

@@ -91,6 +91,7 @@ struct ldu_ctx {
     int sortRowsByWidth = 1;         // LDU_SORT_ROWS: rows of a level ordered by width class (narrow slices stay narrow)
     int smallMaxCells = 6000;        // LDU_SMALL_MAX (<= 16384); single sweeps: the one-wavefront kernel up to 3000 cells
     int gsWideUpper = 1;             // LDU_GS_WIDE_UPPER=0: upper parts of more than 8 entries after the lower part (round-1 order)
+    int stageOverlap = 1;            // LDU_STAGE_OVERLAP=0: host vectors of a solve uploaded on the main stream, before any device work
     int clusterDirectFill = 1;       // LDU_CLUSTER_DIRECT=0: cluster layout via the level layout (cl_convert) instead of from the faces
     int wgEngine = 1;                // LDU_WG=0: no one-workgroup engine (solution vector in LDS, k sweeps as LDS-synchronised tasks)
     int wgMaxCells = 6000;           // LDU_WG_MAX (<= 18 000: 9 bytes of LDS per cell; above ~6000 cells one CU is too little)
