@@ -148,6 +148,8 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && atoi(e) > 0) c->clusterBlocksPerCUMulti = atoi(e);
     e = getenv("LDU_CLUSTER_MULTI");
     if (e) c->clusterMulti = atoi(e);
+    e = getenv("LDU_CLUSTER_PAYS");
+    if (e) c->clusterPaysFactor = atof(e);
     e = getenv("LDU_CLUSTER_MIN");
     if (e) c->clusterMinCells = atoi(e);
     e = getenv("LDU_CLUSTER_BPC");

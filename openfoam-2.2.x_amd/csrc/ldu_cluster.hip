@@ -1067,12 +1067,14 @@ int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
 // ~0.1 us per step for the triangular sweeps, ~0.2 (3 dependencies) / 0.25 (6) for GaussSeidel (division).
 // kind: 0 = triangular sweeps, 1 = one GaussSeidel sweep, 2 = pipelined GaussSeidel sweeps.
 // Pipelined sweeps: with k sweeps in flight the level engines cost ~1.8-2.3 us per level, the cluster engine
-// ~4-5 us per cluster level (GAMG hierarchy of the 216^3 box: wins at 2.6x fewer levels, loses at 1.8x).
+// ~4-5 us per cluster level (GAMG hierarchy of the 216^3 box, round 2: wins at 2.6x fewer levels, loses at 1.8x; round 3,
+// against the level engines as they are now: wins at 1.8x too - levels of 78 732 ... 19 683 cells, 0.250 / 0.190 / 0.149 ->
+// 0.226 / 0.166 / 0.137 ms per 4 sweeps; factor 1.75, LDU_CLUSTER_PAYS).
 static bool cluster_pays(const ldu_addr* a, int kind)
 {
     const ClusterPlan& P = *a->cluster;
     if (a->ctx->clusterEngine > 1) return true;   // LDU_CLUSTER=2: forced
-    if (kind == 2) return 2.4 * P.nClusterLevels <= a->nLevels;
+    if (kind == 2) return a->ctx->clusterPaysFactor * P.nClusterLevels <= a->nLevels;
     const double S = kind == 0 ? 0.1 : (P.maxDep <= 3 ? 0.2 : (P.maxDep <= 6 ? 0.25 : 0.35));
     const double perLevel = (a->nSlabs > 0 && a->slabWidth <= (kind == 0 ? 24.0 : 16.0)) ? 1.0 : 1.4;
     return P.nClusterLevels * (1.4 + P.avgDepth * S) < 0.85 * a->nLevels * perLevel;

@@ -78,7 +78,8 @@ struct ldu_ctx {
     double p2pWindowLevels = 8.0;    // run-ahead window of the level engines in dependency levels (LDU_P2P_WINDOW; 0 = off)
     // cluster (row-blocking) sweep engine, ldu_cluster.hip
     int clusterEngine = 1;           // LDU_CLUSTER=0: off
-    int clusterMinCells = 50000;     // LDU_CLUSTER_MIN
+    int clusterMinCells = 15000;     // LDU_CLUSTER_MIN
+    double clusterPaysFactor = 1.75; // LDU_CLUSTER_PAYS: pipelined sweeps go to the cluster engine when it has this many times fewer levels
     int clusterBlocksPerCU = 3;      // LDU_CLUSTER_BPC (216^3 DIC half sweep: 0.494 / 0.467 / 0.487 / 0.526 ms at 2 / 3 / 4 / 6)
     int clusterBlocksPerCUMulti = 3; // LDU_CLUSTER_BPC_MULTI (pipelined sweeps; 216^3 bench with one ticket counter: 106 / 118.4 / 119.8 / 119.1 V-cycles/s at 1 / 2 / 3 / 4; with eight: 133.2 / 132.6 at 3 / 4)
     int clusterBpcForced = 0;
