@@ -104,6 +104,23 @@ int ldu_ctx_comm_init(ldu_ctx* ctx, int rank, int nRanks, const uint8_t id[128])
 /* Test facility for 1-GPU boxes: nRanks contexts of ONE process (one host thread each) form a
  * local group that exchanges halos / reductions through device copies instead of RCCL. */
 int ldu_ctx_comm_init_local(ldu_ctx* ctx, int rank, int nRanks, int groupId);
+/* Peer-store backend (intra-node, xGMI): every rank owns a window of fine-grained device memory that all other ranks
+ * map (hipIpc across processes); processor-patch values (lduMatrixUpdateMatrixInterfaces.C:30-160) and the partial sums
+ * of reduce(scalar, sumOp) (FieldFunctions.C:514-533) are STORED into the neighbour's window by the producing kernel
+ * and polled by the consuming one - no collective library, no extra launches in the steady state, sums formed in rank
+ * order on every rank.  The few set-up-time messages (window handles, receive offsets, restrict maps of
+ * processorGAMGInterface.C:137-154, the and-reduce of GAMGAgglomeration.C:53-62) go through `oob`, a pairwise exchange
+ * the HOST application provides on its own transport (OpenFOAM: Pstream; Python tests: torch.distributed / gloo):
+ *   oob(user, nPeers, peers[], sendBufs[], sendBytes[], recvBufs[], recvBytes[]) sends sendBytes[i] bytes to rank
+ *   peers[i] and receives recvBytes[i] bytes from it, for all i, and returns 0; every rank of a pair makes the
+ *   matching call (sizes agree by construction).  nRanks = 1 needs no callback.
+ * With an RCCL communicator on the same context (ldu_ctx_comm_init, either order) RCCL stays the default carrier and
+ * LDU_HALO=p2p / LDU_REDUCE=p2p or ldu_ctx_comm_select move the halo exchanges / the global sums to peer stores;
+ * without one everything travels by peer stores.  LDU_PEER_WINDOW_MB (256), LDU_PEER_TIMEOUT_S (20). */
+typedef int (*ldu_oob_exchange_fn)(void* user, int32_t nPeers, const int32_t* peers, const void* const* sendBufs,
+                                   const int64_t* sendBytes, void* const* recvBufs, const int64_t* recvBytes);
+int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oob_exchange_fn oob, void* user);
+int ldu_ctx_comm_select(ldu_ctx* ctx, int peerHalo, int peerReduce);
 
 /* ---- addressing (lduAddressing.H:111-199, lduPrimitiveMesh.H:83-99) ------------ */
 /* lower/upper = lowerAddr()/upperAddr(), upper-triangular order (sorted by owner).  */

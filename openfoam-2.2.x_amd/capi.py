@@ -21,7 +21,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
     "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_slice_levels",
-    "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_addr_create", "ldu_addr_add_patch",
+    "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_ctx_comm_init_peer", "ldu_ctx_comm_select", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
@@ -144,6 +144,53 @@ def make_controls(**kw):
     return c
 
 
+OOB_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                     C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+
+
+def oob_torch(group=None):
+    """out-of-band exchange over a torch.distributed group of CPU tensors (gloo): isend / irecv per peer"""
+    import torch
+    import torch.distributed as dist
+
+    def exchange(peers, send, recv_sizes):
+        bufs = [torch.empty(max(1, n), dtype=torch.uint8) for n in recv_sizes]
+        ops = []
+        for p, b, n, r in zip(peers, send, recv_sizes, bufs):
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8) if len(b) else torch.zeros(1, dtype=torch.uint8)
+            ops.append(dist.P2POp(dist.isend, t, dist.get_global_rank(group, p) if group is not None else p, group))
+            ops.append(dist.P2POp(dist.irecv, r, dist.get_global_rank(group, p) if group is not None else p, group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return [bytes(r[:n].numpy().tobytes()) for r, n in zip(bufs, recv_sizes)]
+    return exchange
+
+
+class OobThreads:
+    """out-of-band exchange between the threads of ONE process (ranks as threads on one GPU, tests): a mailbox per
+    (source, destination) pair"""
+
+    def __init__(self, n):
+        import threading
+        self.n = n
+        self.cv = threading.Condition()
+        self.box = {}
+
+    def for_rank(self, me):
+        def exchange(peers, send, recv_sizes):
+            with self.cv:
+                for p, b in zip(peers, send):
+                    self.box.setdefault((me, p), []).append(b)
+                self.cv.notify_all()
+            out = []
+            for p in peers:
+                with self.cv:
+                    self.cv.wait_for(lambda: self.box.get((p, me)), timeout=120)
+                    out.append(self.box[(p, me)].pop(0))
+            return out
+        return exchange
+
+
 class Context:
     def __init__(self, device=0):
         self.h = C.c_void_p()
@@ -156,6 +203,35 @@ class Context:
     def comm_init_local(self, rank, n_ranks, group_id):
         """Test facility: ranks = threads of this process sharing one GPU (no RCCL)."""
         _chk(lib().ldu_ctx_comm_init_local(self.h, int(rank), int(n_ranks), int(group_id)))
+
+    def comm_init_peer(self, rank, n_ranks, exchange=None):
+        """Peer-store backend (ldu_ctx_comm_init_peer).  exchange(peers, send_blobs, recv_sizes) -> list of bytes: the
+        pairwise out-of-band exchange of the set-up messages (oob_torch / OobThreads below); None for one rank."""
+        cb = None
+        if exchange is not None:
+            def _cb(user, n, peers, sbufs, sbytes, rbufs, rbytes):
+                try:
+                    pl = [int(peers[i]) for i in range(n)]
+                    send = [C.string_at(sbufs[i], int(sbytes[i])) for i in range(n)]
+                    got = exchange(pl, send, [int(rbytes[i]) for i in range(n)])
+                    for i in range(n):
+                        if len(got[i]) != int(rbytes[i]):
+                            return 2
+                        C.memmove(rbufs[i], got[i], len(got[i]))
+                    return 0
+                except Exception as e:  # pragma: no cover
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = OOB_FN(_cb)
+        self._oob_cb = cb   # keep the trampoline alive as long as the context
+        f = lib().ldu_ctx_comm_init_peer
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _chk(f(self.h, int(rank), int(n_ranks), C.cast(cb, C.c_void_p) if cb else None, None))
+
+    def comm_select(self, peer_halo, peer_reduce):
+        """which operations travel by peer stores when an RCCL communicator exists as well (ldu_ctx_comm_select)"""
+        _chk(lib().ldu_ctx_comm_select(self.h, int(bool(peer_halo)), int(bool(peer_reduce))))
 
     @staticmethod
     def unique_id():

@@ -109,6 +109,62 @@ def box3d(nx, ny=None, nz=None, asym=False, seed=12345, seed_asym=54321):
     return p
 
 
+def _u01_key(seed, key):
+    """uniform double in [0,1) per 64-bit key (a global cell id * 3 + face direction): the same on every rank"""
+    with np.errstate(over="ignore"):
+        z = _splitmix64(key.astype(np.uint64) + (np.uint64(seed) << np.uint64(44)))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def box3d_block(n, blocks, rank, seed=12345):
+    """One rank's sub-domain of a (px n) x (py n) x (pz n) hex box cut into px x py x pz blocks of n^3 cells (weak scaling:
+    every rank holds n^3 cells whatever the rank count), generated WITHOUT the global matrix: the coefficient of a face is a
+    function of (global owner cell, direction), so both ranks of a cut face compute the same value.  Same operator family as
+    box3d: upper = -(1 + 0.5 u01) a_dir, diag = -sum(offdiag) over internal AND cut faces, diag of global cell 0 doubled,
+    b = A x*, x*_g = sin(1e-3 g).  Patches as decomposePar orders them (ascending neighbour rank, faces in ascending global
+    face order = ascending boundary cell): device form `patches_dev` and the coefficient arrays in `patches`."""
+    px, py, pz = blocks
+    NX, NY = px * n, py * n
+    bi, bj, bk = rank % px, (rank // px) % py, rank // (px * py)
+    l, u, d = box_addressing(n, n, n)
+    nC = n ** 3
+    c = np.arange(nC, dtype=np.int64)
+    i, j, k = c % n, (c // n) % n, c // (n * n)
+    g = (bi * n + i) + NX * ((bj * n + j) + NY * (bk * n + k))           # global cell ids of the local cells
+    a_dir = np.array([1.0, 1.01, 1.02])
+    stride = np.array([1, NX, NX * NY], dtype=np.int64)
+
+    def coeff(owner_g, dirn):
+        return -(1.0 + 0.5 * _u01_key(seed, owner_g * 3 + dirn)) * a_dir[dirn]
+
+    upper = coeff(g[l], d.astype(np.int64))
+    diag = _neg_sum_diag(nC, l, u, upper, upper)
+    xs = np.sin(1e-3 * g)
+    src_cut = np.zeros(nC)
+    patches = []
+    # ascending neighbour rank: -z, -y, -x, +x, +y, +z
+    for dirn, sign in ((2, -1), (1, -1), (0, -1), (0, 1), (1, 1), (2, 1)):
+        b = (bi, bj, bk)[dirn] + sign
+        if b < 0 or b >= blocks[dirn]:
+            continue
+        idx = (i, j, k)[dirn]
+        cells = np.nonzero(idx == (0 if sign < 0 else n - 1))[0]
+        gn = g[cells] + sign * stride[dirn]                               # the cell across the cut
+        owner_g = np.where(sign > 0, g[cells], gn)
+        cf = coeff(owner_g, np.full(cells.size, dirn, dtype=np.int64))
+        nb = rank + sign * (1, px, px * py)[dirn]
+        np.subtract.at(diag, cells, cf)
+        np.add.at(src_cut, cells, cf * np.sin(1e-3 * gn))
+        patches.append(dict(faceCells=cells.astype(np.int32), bouCoeffs=-cf, intCoeffs=-cf, nbrDom=int(nb), nbrRank=int(nb)))
+    if rank == 0:
+        diag[0] *= 2.0
+    p = dict(nCells=nC, lowerAddr=l, upperAddr=u, upper=upper, diag=diag, faceWeights=a_dir[d].copy(), psi=np.zeros(nC))
+    p["source"] = amul(p, xs) + src_cut
+    p["patches"] = patches
+    p["patches_dev"] = [dict(faceCells=q["faceCells"], nbrRank=q["nbrRank"]) for q in patches]
+    return p
+
+
 def jump2d(nx, ny, ratio=1000.0):
     """SURVEY.md 8d C5 twin (damBreak p_rgh): 2-D 5-point with the face coefficient jumping
     1 <-> ratio across the diagonal i+j = (nx+ny)/2 (two-phase density ratio)."""

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <unistd.h>
 
 #include "ldu_internal.hpp"
 
@@ -41,13 +42,61 @@ struct LocalGroup {
     }
 };
 
+// Backend 3: "peer" - windows of fine-grained device memory mapped by every rank of the node (hipIpc between
+// processes, the plain pointer inside one process); halo values and partial sums are STORED into the neighbour's
+// window by the producing kernel (ldu_peer.hip).  Set-up-time exchanges (window handles, region offsets, restrict
+// maps, the and-reduce of continueAgglomerating) travel through an out-of-band callback of the host application -
+// OpenFOAM's own Pstream in the shim, torch.distributed in the Python tests - exactly where the reference sends them
+// (processorGAMGInterface.C:137-154 uses the same Pstream as everything else).
+struct PeerWindow {
+    uint4* base = nullptr;
+    size_t bytes = 0;
+    std::vector<uint4*> peer;                          // [nRanks] every rank's window as mapped here
+    std::vector<bool> opened;                          // mapped with hipIpcOpenMemHandle (to be closed)
+    std::map<size_t, size_t> freeList;                 // offset -> bytes (first fit, coalescing)
+    size_t redOff = 0;                                 // [2][LDU_MAX_PEERS][16] granules of the all-reduce
+    unsigned redSeq = 0;
+    ldu_oob_exchange_fn oob = nullptr;
+    void* oobUser = nullptr;
+    size_t alloc(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (auto it = freeList.begin(); it != freeList.end(); ++it)
+            if (it->second >= bytes)
+            {
+                const size_t off = it->first, rest = it->second - bytes;
+                freeList.erase(it);
+                if (rest) freeList[off + bytes] = rest;
+                return off;
+            }
+        return (size_t)-1;
+    }
+    void release(size_t off, size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = freeList.emplace(off, bytes).first;
+        auto nx = std::next(it);
+        if (nx != freeList.end() && it->first + it->second == nx->first) { it->second += nx->second; freeList.erase(nx); }
+        if (it != freeList.begin())
+        {
+            auto pv = std::prev(it);
+            if (pv->first + pv->second == it->first) { pv->second += it->second; freeList.erase(it); }
+        }
+    }
+};
+
 struct ldu_comm_impl {
     ncclComm_t comm = nullptr;
     LocalGroup* local = nullptr;
+    PeerWindow* peer = nullptr;
+    bool peerHalo = false, peerReduce = false;   // which operations the peer backend carries (LDU_HALO / LDU_REDUCE)
     int* d_ibuf = nullptr;       // staging for int exchanges (RCCL)
     size_t ibufCap = 0;
 };
 
+static int paired_patch(const std::vector<Patch>& mine, int p, const std::vector<Patch>& theirs, int me);
+static int peer_oob(ldu_ctx* ctx, const std::vector<int>& peers, const std::vector<const void*>& send,
+                    const std::vector<int64_t>& sendBytes, const std::vector<void*>& recv, const std::vector<int64_t>& recvBytes);
 static std::mutex g_groupsMu;
 static std::map<int, LocalGroup*> g_groups;
 
@@ -74,7 +123,12 @@ extern "C" int ldu_ctx_comm_init(ldu_ctx* ctx, int rank, int nRanks, const uint8
     LDU_CHECK_HIP(hipSetDevice(ctx->device));
     ncclUniqueId u;
     memcpy(&u, id, 128);
-    ctx->comm = new ldu_comm_impl();
+    if (!ctx->comm) ctx->comm = new ldu_comm_impl();
+    if (ctx->comm->peer && (ctx->rank != rank || ctx->nRanks != nRanks))
+    {
+        ldu_set_error("ldu_ctx_comm_init: rank / size differ from the peer windows'");
+        return -2;
+    }
     LDU_CHECK_NCCL(ncclCommInitRank(&ctx->comm->comm, nRanks, u, rank));
     ctx->rank = rank;
     ctx->nRanks = nRanks;
@@ -103,11 +157,232 @@ extern "C" int ldu_ctx_comm_init_local(ldu_ctx* ctx, int rank, int nRanks, int g
     return 0;
 }
 
+
+// ---------------------------------------------------------------- peer backend: bootstrap and per-addressing set-up
+
+static int peer_oob(ldu_ctx* ctx, const std::vector<int>& peers, const std::vector<const void*>& send,
+                    const std::vector<int64_t>& sendBytes, const std::vector<void*>& recv, const std::vector<int64_t>& recvBytes)
+{
+    PeerWindow* W = ctx->comm->peer;
+    if (peers.empty()) return 0;
+    if (!W->oob) { ldu_set_error("peer backend: no out-of-band exchange callback"); return -4; }
+    const int rc = W->oob(W->oobUser, (int32_t)peers.size(), peers.data(), send.data(), sendBytes.data(), recv.data(),
+                          recvBytes.data());
+    if (rc) { ldu_set_error("peer backend: the out-of-band exchange callback failed (" + std::to_string(rc) + ")"); return -4; }
+    return 0;
+}
+
+struct PeerHello { int64_t pid; uint64_t ptr; int32_t device; int32_t pad; hipIpcMemHandle_t handle; };
+
+extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oob_exchange_fn oob, void* user)
+{
+    if (nRanks < 1 || nRanks > LDU_MAX_PEERS || rank < 0 || rank >= nRanks)
+    {
+        ldu_set_error("ldu_ctx_comm_init_peer: 1 ... 16 ranks");
+        return -2;
+    }
+    if (nRanks > 1 && !oob) { ldu_set_error("ldu_ctx_comm_init_peer: an out-of-band exchange callback is required"); return -2; }
+    LDU_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!ctx->comm) ctx->comm = new ldu_comm_impl();
+    if (ctx->comm->local) { ldu_set_error("ldu_ctx_comm_init_peer: the context already has a local group"); return -2; }
+    if (ctx->comm->comm && (ctx->rank != rank || ctx->nRanks != nRanks))
+    {
+        ldu_set_error("ldu_ctx_comm_init_peer: rank / size differ from the RCCL communicator's");
+        return -2;
+    }
+    PeerWindow* W = new PeerWindow();
+    ctx->comm->peer = W;
+    W->oob = oob;
+    W->oobUser = user;
+    size_t mb = 256;
+    if (const char* e = getenv("LDU_PEER_WINDOW_MB")) mb = (size_t)std::max(8, atoi(e));
+    W->bytes = mb << 20;
+    // fine-grained: coherent across agents while kernels run (coarse-grained memory is only guaranteed at kernel
+    // boundaries); what RCCL allocates for its own peer-to-peer buffers
+    LDU_CHECK_HIP(hipExtMallocWithFlags((void**)&W->base, W->bytes, hipDeviceMallocFinegrained));
+    LDU_CHECK_HIP(hipMemset(W->base, 0, W->bytes));
+    LDU_CHECK_HIP(hipDeviceSynchronize());
+    W->freeList[0] = W->bytes;
+    W->redOff = W->alloc(sizeof(uint4) * 2 * LDU_MAX_PEERS * 16);
+    W->peer.assign(nRanks, nullptr);
+    W->opened.assign(nRanks, false);
+    W->peer[rank] = W->base;
+    ctx->rank = rank;
+    ctx->nRanks = nRanks;
+    if (nRanks > 1)
+    {
+        PeerHello me;
+        memset(&me, 0, sizeof(me));
+        me.pid = (int64_t)getpid();
+        me.ptr = (uint64_t)(uintptr_t)W->base;
+        me.device = ctx->device;
+        LDU_CHECK_HIP(hipIpcGetMemHandle(&me.handle, W->base));
+        std::vector<PeerHello> all(nRanks);
+        std::vector<int> peers;
+        std::vector<const void*> sp;
+        std::vector<void*> rp;
+        std::vector<int64_t> nb;
+        for (int r = 0; r < nRanks; r++)
+            if (r != rank) { peers.push_back(r); sp.push_back(&me); rp.push_back(&all[r]); nb.push_back(sizeof(PeerHello)); }
+        if (peer_oob(ctx, peers, sp, nb, rp, nb)) return -1;
+        for (int r = 0; r < nRanks; r++)
+        {
+            if (r == rank) continue;
+            if (all[r].pid == me.pid) { W->peer[r] = (uint4*)(uintptr_t)all[r].ptr; continue; }   // same process: the pointer itself
+            void* p = nullptr;
+            LDU_CHECK_HIP(hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess));
+            W->peer[r] = (uint4*)p;
+            W->opened[r] = true;
+        }
+    }
+    // what travels by peer stores: everything unless an RCCL communicator exists as well, in which case RCCL stays the
+    // default and LDU_HALO=p2p / LDU_REDUCE=p2p move the halo exchanges / the global sums over
+    const bool haveRccl = ctx->comm->comm != nullptr;
+    const char* eh = getenv("LDU_HALO");
+    const char* er = getenv("LDU_REDUCE");
+    ctx->comm->peerHalo = !haveRccl || (eh && !strcmp(eh, "p2p"));
+    ctx->comm->peerReduce = !haveRccl || (er && !strcmp(er, "p2p"));
+    if (const char* e = getenv("LDU_PEER_TIMEOUT_S")) if (k_peer_set_timeout(atof(e))) return -1;
+    return 0;
+}
+
+// which operations the peer backend carries (0 / 1 each); both need ldu_ctx_comm_init_peer first
+extern "C" int ldu_ctx_comm_select(ldu_ctx* ctx, int peerHalo, int peerReduce)
+{
+    if (!ctx->comm || !ctx->comm->peer) { ldu_set_error("ldu_ctx_comm_select: no peer windows (ldu_ctx_comm_init_peer)"); return -2; }
+    if ((!peerHalo || !peerReduce) && !ctx->comm->comm)
+    {
+        ldu_set_error("ldu_ctx_comm_select: no RCCL communicator to carry what the peer backend does not");
+        return -2;
+    }
+    ctx->comm->peerHalo = peerHalo != 0;
+    ctx->comm->peerReduce = peerReduce != 0;
+    return 0;
+}
+
+// Plan time, every addressing with processor patches: a receive region in my window ([patch][parity][n] granules), its
+// offsets told to the neighbours out of band, theirs received, and the per-face pointer tables uploaded.
+int comm_peer_setup_addr(ldu_addr* a)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->comm || !ctx->comm->peer) return 0;
+    bool remote = false;
+    for (auto& P : a->patches) if (P.nbrPatch < 0 && P.n) remote = true;
+    // (an addressing without remote faces still takes part in no exchange: its neighbours have none towards it either)
+    if (!remote) return 0;
+    PeerWindow* W = ctx->comm->peer;
+    PeerHalo* H = new PeerHalo();
+    a->peer = H;
+    const int nPF = a->nPatchFaces;
+    size_t granules = 0;
+    std::vector<size_t> myOff(a->patches.size(), 0);
+    for (size_t p = 0; p < a->patches.size(); p++)
+        if (a->patches[p].nbrPatch < 0) { myOff[p] = granules; granules += 2 * (size_t)a->patches[p].n; }
+    H->winBytes = granules * sizeof(uint4);
+    H->winOff = W->alloc(H->winBytes);
+    if (H->winOff == (size_t)-1)
+    {
+        ldu_set_error("peer backend: window exhausted (LDU_PEER_WINDOW_MB, default 256)");
+        return -5;
+    }
+    // a region that is reused must not hold tags of its previous owner that a new sequence could reach: zero it
+    LDU_CHECK_HIP(hipMemsetAsync((char*)W->base + H->winOff, 0, H->winBytes, ctx->stream));
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    // tell each neighbour where its k-th patch towards me lands: one message per neighbour rank, patch order
+    std::map<int, std::vector<int>> byRank;
+    for (int p = 0; p < (int)a->patches.size(); p++)
+        if (a->patches[p].nbrPatch < 0 && a->patches[p].n > 0) byRank[a->patches[p].nbrRank].push_back(p);
+    std::vector<int> peers;
+    std::vector<std::vector<int64_t>> sb, rb;
+    for (auto& kv : byRank)
+    {
+        std::vector<int64_t> buf;
+        for (int p : kv.second)
+        {
+            buf.push_back((int64_t)(H->winOff / sizeof(uint4) + myOff[p]));
+            buf.push_back((int64_t)a->patches[p].n);
+        }
+        peers.push_back(kv.first);
+        rb.emplace_back(buf.size());
+        sb.push_back(std::move(buf));
+    }
+    {
+        std::vector<const void*> sp;
+        std::vector<void*> rp;
+        std::vector<int64_t> nb;
+        for (size_t i = 0; i < peers.size(); i++)
+        {
+            sp.push_back(sb[i].data()); rp.push_back(rb[i].data()); nb.push_back((int64_t)(sizeof(int64_t) * sb[i].size()));
+        }
+        if (ctx->nRanks > 1)
+        {
+            if (peer_oob(ctx, peers, sp, nb, rp, nb)) return -1;
+        }
+        else rb = sb;   // one rank whose patches face each other (projection / tests): handled below
+    }
+    std::vector<uint4*> dst(2 * (size_t)nPF, nullptr);
+    std::vector<const uint4*> src(2 * (size_t)nPF, nullptr);
+    size_t i = 0;
+    for (auto& kv : byRank)
+    {
+        const int nbr = kv.first;
+        for (size_t k = 0; k < kv.second.size(); k++)
+        {
+            const int p = kv.second[k];
+            const Patch& P = a->patches[p];
+            int64_t roff = rb[i][2 * k], rn = rb[i][2 * k + 1];
+            if (ctx->nRanks == 1)
+            {
+                // self-coupled: the k-th patch towards "rank 0" pairs with the patch paired_patch names (itself when alone)
+                const int q = paired_patch(a->patches, p, a->patches, ctx->rank);
+                const int qq = q < 0 ? p : q;
+                roff = (int64_t)(H->winOff / sizeof(uint4) + myOff[qq]);
+                rn = a->patches[qq].n;
+            }
+            if (rn != P.n)
+            {
+                ldu_set_error("peer backend: patch sizes differ between neighbours (" + std::to_string(P.n) + " vs " +
+                              std::to_string(rn) + ")");
+                return -4;
+            }
+            for (int par = 0; par < 2; par++)
+                for (int f = 0; f < P.n; f++)
+                {
+                    dst[(size_t)par * nPF + P.offset + f] = W->peer[nbr] + roff + (size_t)par * P.n + f;
+                    src[(size_t)par * nPF + P.offset + f] = W->base + H->winOff / sizeof(uint4) + myOff[p] + (size_t)par * P.n + f;
+                }
+        }
+        i++;
+    }
+    LDU_CHECK_HIP(hipMalloc((void**)&H->d_dst, sizeof(uint4*) * dst.size()));
+    LDU_CHECK_HIP(hipMalloc((void**)&H->d_src, sizeof(uint4*) * src.size()));
+    LDU_CHECK_HIP(hipMemcpy(H->d_dst, dst.data(), sizeof(uint4*) * dst.size(), hipMemcpyHostToDevice));
+    LDU_CHECK_HIP(hipMemcpy(H->d_src, src.data(), sizeof(uint4*) * src.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void comm_peer_free_addr(ldu_addr* a)
+{
+    if (!a->peer) return;
+    if (a->ctx->comm && a->ctx->comm->peer && a->peer->winBytes) a->ctx->comm->peer->release(a->peer->winOff, a->peer->winBytes);
+    if (a->peer->d_dst) (void)hipFree(a->peer->d_dst);
+    if (a->peer->d_src) (void)hipFree((void*)a->peer->d_src);
+    delete a->peer;
+    a->peer = nullptr;
+}
+
 void comm_destroy(ldu_ctx* ctx)
 {
     if (!ctx->comm) return;
     if (ctx->comm->comm) ncclCommDestroy(ctx->comm->comm);
     if (ctx->comm->d_ibuf) (void)hipFree(ctx->comm->d_ibuf);
+    if (PeerWindow* W = ctx->comm->peer)
+    {
+        for (size_t r = 0; r < W->peer.size(); r++)
+            if (W->opened[r] && W->peer[r]) (void)hipIpcCloseMemHandle(W->peer[r]);
+        if (W->base) (void)hipFree(W->base);
+        delete W;
+    }
     delete ctx->comm;
     ctx->comm = nullptr;
 }
@@ -118,6 +393,14 @@ int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s)
     static const bool force = getenv("LDU_FORCE_COMM") && atoi(getenv("LDU_FORCE_COMM"));
     if (!ctx->comm || (ctx->nRanks <= 1 && !force)) return 0;
     ctx->nAllReduces++;
+    if (ctx->comm->peerReduce)
+    {
+        PeerWindow* W = ctx->comm->peer;
+        PeerRed P;
+        for (int r = 0; r < LDU_MAX_PEERS; r++) P.win[r] = r < ctx->nRanks ? W->peer[r] : nullptr;
+        return k_peer_allreduce(ctx, P, W->redOff / sizeof(uint4), ctx->rank, ctx->nRanks, count, ++W->redSeq, ctx->S() + slot,
+                                nullptr, s);
+    }
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;
@@ -149,6 +432,14 @@ int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s)
 {
     static const bool force = getenv("LDU_FORCE_COMM") && atoi(getenv("LDU_FORCE_COMM"));
     if (!ctx->comm || (ctx->nRanks <= 1 && !force)) return 0;
+    if (ctx->comm->peerReduce)
+    {
+        PeerWindow* W = ctx->comm->peer;
+        PeerRed P;
+        for (int r = 0; r < LDU_MAX_PEERS; r++) P.win[r] = r < ctx->nRanks ? W->peer[r] : nullptr;
+        return k_peer_allreduce(ctx, P, W->redOff / sizeof(uint4), ctx->rank, ctx->nRanks, 1, ++W->redSeq, nullptr,
+                                ctx->d_abort, s);
+    }
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;
@@ -209,6 +500,31 @@ extern "C" int ldu_comm_exchange_order(int32_t nPatches, const int32_t* nFaces, 
     const std::vector<int> o = comm_remote_order(patches);
     for (size_t i = 0; i < o.size(); i++) order[i] = o[i];
     return (int)o.size();
+}
+
+bool comm_is_peer(const ldu_ctx* ctx) { return ctx->comm && ctx->comm->peerHalo; }
+
+// initMatrixInterfaces (lduMatrixUpdateMatrixInterfaces.C:30-93): pack the coupled faces' cell values and start the exchange
+int comm_halo_pack_exchange(ldu_addr* a, const double* x, hipStream_t s)
+{
+    if (!a->nPatchFaces) return 0;
+    if (a->peer)
+    {
+        // peer stores: the pack kernel IS the send (ldu_peer.hip); the receive is polled in comm_wait_halo
+        ldu_ctx* ctx = a->ctx;
+        if (a->peer->pending) { ldu_set_error("halo exchange started twice without an update in between"); return -4; }
+        if (k_peer_pack(a, x, ++a->peer->seq, s)) return -1;
+        for (auto& P : a->patches)
+            if (P.nbrPatch >= 0 && P.n)
+                LDU_CHECK_HIP(hipMemcpyAsync(P.d_recv, a->patches[P.nbrPatch].d_send, sizeof(double) * P.n,
+                                             hipMemcpyDeviceToDevice, s));
+        a->peer->pending = true;
+        ctx->nHaloExchanges++;
+        ctx->nHaloOverlapped++;   // the interior rows run between pack and unpack on the same stream
+        return 0;
+    }
+    if (k_pack_patches(a, x, s)) return -1;
+    return comm_exchange(a, s);
 }
 
 int comm_exchange(ldu_addr* a, hipStream_t s)
@@ -280,8 +596,15 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
 }
 
 // the compute stream waits for the exchange started by the last comm_exchange (no-op when none is in flight)
-int comm_wait_halo(ldu_ctx* ctx, hipStream_t s)
+int comm_wait_halo(ldu_addr* a, hipStream_t s)
 {
+    ldu_ctx* ctx = a->ctx;
+    if (a->peer)
+    {
+        if (!a->peer->pending) return 0;
+        a->peer->pending = false;
+        return k_peer_unpack(a, a->peer->seq, s);
+    }
     if (!ctx->haloInFlight) return 0;
     LDU_CHECK_HIP(hipStreamWaitEvent(s, ctx->evHalo, 0));
     if (s == ctx->stream) ctx->haloInFlight = false;
@@ -292,6 +615,20 @@ int comm_wait_halo(ldu_ctx* ctx, hipStream_t s)
 int comm_allreduce_min_int(ldu_ctx* ctx, int* v)
 {
     if (!ctx->comm || ctx->nRanks <= 1) return 0;
+    if (ctx->comm->peer && !ctx->comm->comm)
+    {
+        // out-of-band: every rank sends its value to every other rank
+        const int n = ctx->nRanks;
+        std::vector<int> peers, vals(n, 0), mine(n, *v);
+        std::vector<const void*> sp;
+        std::vector<void*> rp;
+        std::vector<int64_t> nb;
+        for (int r = 0; r < n; r++)
+            if (r != ctx->rank) { peers.push_back(r); sp.push_back(&mine[r]); rp.push_back(&vals[r]); nb.push_back(sizeof(int)); }
+        if (peer_oob(ctx, peers, sp, nb, rp, nb)) return -1;
+        for (int r = 0; r < n; r++) if (r != ctx->rank) *v = std::min(*v, vals[r]);
+        return 0;
+    }
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;
@@ -329,6 +666,44 @@ int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
     }
     if (!remote) return 0;
     if (!ctx->comm) { ldu_set_error("processor patches present but no communicator"); return -4; }
+    if (ctx->comm->peer && !ctx->comm->comm)
+    {
+        // out-of-band, one message per neighbour rank: the int lists of all patches towards it, in patch order - the
+        // neighbour lists its patches towards me in the paired order (paired_patch: k-th with k-th), equal sizes
+        std::map<int, std::vector<int>> byRank;
+        for (int p = 0; p < (int)patches.size(); p++)
+            if (patches[p].nbrPatch < 0 && patches[p].n > 0) byRank[patches[p].nbrRank].push_back(p);
+        std::vector<int> peers;
+        std::vector<std::vector<int>> sb, rb;
+        for (auto& kv : byRank)
+        {
+            std::vector<int> buf;
+            for (int p : kv.second) buf.insert(buf.end(), send[p].begin(), send[p].end());
+            peers.push_back(kv.first);
+            rb.emplace_back(buf.size());
+            sb.push_back(std::move(buf));
+        }
+        std::vector<const void*> sp;
+        std::vector<void*> rp;
+        std::vector<int64_t> nb;
+        for (size_t i = 0; i < peers.size(); i++)
+        {
+            sp.push_back(sb[i].data()); rp.push_back(rb[i].data()); nb.push_back((int64_t)(sizeof(int) * sb[i].size()));
+        }
+        if (peer_oob(ctx, peers, sp, nb, rp, nb)) return -1;
+        size_t i = 0;
+        for (auto& kv : byRank)
+        {
+            size_t off = 0;
+            for (int p : kv.second)
+            {
+                recv[p].assign(rb[i].begin() + off, rb[i].begin() + off + send[p].size());
+                off += send[p].size();
+            }
+            i++;
+        }
+        return 0;
+    }
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;

@@ -24,6 +24,7 @@
 #include "../../include/ldugpu.h"
 
 #define LDU_WAVE 64
+#define LDU_MAX_PEERS 16
 
 void ldu_set_error(const std::string& msg);
 #define LDU_CHECK_HIP(expr)                                                        \
@@ -140,6 +141,17 @@ struct Patch {
     int offset = 0;               // offset of this patch in the concatenated patch-face arrays
 };
 
+// peer-store halo of an addressing (communication backend "peer", ldu_comm.cpp / ldu_peer.hip): the receive granules of
+// every processor patch live in THIS rank's window ([patch][parity][n] x 16 bytes); the neighbour's pack kernel writes
+// them directly (xGMI peer stores), this rank's unpack kernel polls them.  Tables are per patch face.
+struct PeerHalo {
+    size_t winOff = 0, winBytes = 0;       // my receive region in my window
+    uint4** d_dst = nullptr;               // [2][nPatchFaces] destination granule per face and parity (null: cyclic face)
+    const uint4** d_src = nullptr;         // [2][nPatchFaces] my receive granule per face and parity (null: cyclic face)
+    unsigned seq = 0;                      // exchanges started on this addressing (tag of the granules; parity = seq & 1)
+    bool pending = false;                  // pack ran, unpack did not yet
+};
+
 struct ldu_addr {
     ldu_ctx* ctx = nullptr;
     int nCells = 0, nFaces = 0;
@@ -195,6 +207,7 @@ struct ldu_addr {
     unsigned char* d_nbK0 = nullptr;       // [nCells]
     double* d_sendAll = nullptr;           // [nPatchFaces]
     double* d_recvAll = nullptr;           // [nPatchFaces]
+    PeerHalo* peer = nullptr;              // peer-store backend only
 
     // point-to-point sweep state: one 16-byte {value lo, tag, value hi, tag} granule per row,
     // a chunk ticket counter and the launch epoch (= tag; never 0)
@@ -433,7 +446,18 @@ void plan_free(ldu_addr* a);
 
 int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s);   // ldu_comm.cpp
 int comm_exchange(ldu_addr* a, hipStream_t s);                                   // halo send/recv (may return before it ran)
-int comm_wait_halo(ldu_ctx* ctx, hipStream_t s);                                 // s waits for the exchange started last
+int comm_wait_halo(ldu_addr* a, hipStream_t s);                                  // s waits for the exchange started last on a
+bool comm_is_peer(const ldu_ctx* ctx);                                            // peer-store backend active for halos
+int comm_peer_setup_addr(ldu_addr* a);                                            // plan time: receive region + tables
+void comm_peer_free_addr(ldu_addr* a);
+int comm_halo_pack_exchange(ldu_addr* a, const double* x, hipStream_t s);         // initMatrixInterfaces: pack + start the exchange
+// ldu_peer.hip
+int k_peer_pack(ldu_addr* a, const double* x, unsigned seq, hipStream_t s);
+int k_peer_unpack(ldu_addr* a, unsigned seq, hipStream_t s);
+int k_peer_set_timeout(double seconds);
+struct PeerRed { uint4* win[LDU_MAX_PEERS]; };
+int k_peer_allreduce(ldu_ctx* ctx, const PeerRed& P, size_t redOff, int me, int n, int count, unsigned seq, double* vals,
+                     int* abortWord, hipStream_t s);
 int comm_allreduce_min_int(ldu_ctx* ctx, int* v);
 int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s);                             // abort flag := max over the ranks
 int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,

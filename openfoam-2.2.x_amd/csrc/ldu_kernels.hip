@@ -488,7 +488,7 @@ int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const
 {
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
     hipStream_t s = a->ctx->stream;
-    if (comm_wait_halo(a->ctx, s)) return -1;
+    if (comm_wait_halo(a, s)) return -1;
     for (int L = 0; L < a->nLevels; L++)
     {
         const int s0 = a->levelSliceStart[L], s1 = a->levelSliceStart[L + 1];
@@ -2950,7 +2950,7 @@ __global__ void apply_patches_kernel(int nBRows, const int* __restrict__ bRow,
 int k_apply_patches(ldu_addr* a, double* result, const double* coeffs, double sign, hipStream_t s)
 {
     if (!a->nPatchFaces) return 0;
-    if (comm_wait_halo(a->ctx, s)) return -1;   // updateMatrixInterfaces: the received values are needed from here on
+    if (comm_wait_halo(a, s)) return -1;   // updateMatrixInterfaces: the received values are needed from here on
     apply_patches_kernel<<<ewGrid(a->nBRows), BLK, 0, s>>>(a->nBRows, a->d_bRow, a->d_bStart, a->d_bFace,
                                                           coeffs, a->d_recvAll, sign, result);
     LDU_CHECK_HIP(hipGetLastError());
@@ -2979,7 +2979,7 @@ __global__ void apply_patches_from_kernel(int nBRows, const int* __restrict__ bR
 int k_apply_patches_from(ldu_addr* a, double* out, const double* in, const double* coeffs, double sign, hipStream_t s)
 {
     if (!a->nPatchFaces) return 0;
-    if (comm_wait_halo(a->ctx, s)) return -1;
+    if (comm_wait_halo(a, s)) return -1;
     apply_patches_from_kernel<<<ewGrid(a->nBRows), BLK, 0, s>>>(a->nBRows, a->d_bRow, a->d_bStart, a->d_bFace,
                                                                coeffs, a->d_recvAll, sign, in, out);
     LDU_CHECK_HIP(hipGetLastError());

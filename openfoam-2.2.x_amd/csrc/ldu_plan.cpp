@@ -579,11 +579,14 @@ int plan_finalize_patches(ldu_addr* a)
         p.d_faceCells = a->d_pfCell + p.offset;
     }
     a->finalized = true;
-    return 0;
+    // peer-store backend: receive region in this rank's window, offsets exchanged with the neighbours (collective over
+    // the ranks that share patches: every rank finalizes its addressings in the same order)
+    return comm_peer_setup_addr(a);
 }
 
 void plan_free(ldu_addr* a)
 {
+    comm_peer_free_addr(a);
     cluster_free(a);
     for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
     a->graphs.clear();

@@ -109,8 +109,7 @@ int dev_halo_start(ldu_matrix* m, const double* x)
 {
     ldu_addr* a = m->a;
     if (!a->nPatchFaces) return 0;
-    if (k_pack_patches(a, x, a->ctx->stream)) return -1;
-    return comm_exchange(a, a->ctx->stream);
+    return comm_halo_pack_exchange(a, x, a->ctx->stream);
 }
 
 int dev_amul(ldu_matrix* m, double* y, const double* x, bool transpose, hipStream_t s2)

@@ -1,0 +1,101 @@
+"""Worker of tests/test_gpu_peer.py: ONE PROCESS PER RANK (launched by torch.distributed.run, gloo for the out-of-band
+messages), every rank with its own context, the ranks sharing the visible GPUs round-robin (on a 1-GPU box all of
+them share device 0: the windows are mapped across processes with hipIpc exactly as between GPUs).  Communication
+backend "peer" (ldu_ctx_comm_init_peer): halo values and partial sums stored into the neighbour's window.
+
+Every rank builds the same decomposition, runs the operations on its own sub-domain and compares its slice with the
+oracle's serial emulation of the N-rank algorithm (oracle_py.System(subs)); a mismatch exits non-zero.
+    python -m torch.distributed.run --nproc-per-node N tests/peer_worker.py <n_ranks> <asym 0|1> [size]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import __graft_entry__ as entry  # noqa: E402
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    n, asym = int(sys.argv[1]), bool(int(sys.argv[2]))
+    size = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert world == n
+    dist.init_process_group("gloo")
+    entry.load_package()
+    from openfoam_amd import capi, cases, decompose
+    import oracle_py
+    oracle_py.build()
+    p = cases.box3d(size, asym=asym)
+    shape = {2: (1, 1, 2), 3: (1, 1, 3), 4: (1, 2, 2), 8: (2, 2, 2)}[n]
+    subs, maps = decompose.decompose(p, decompose.block_ranks(size, size, size, *shape), n)
+    S = oracle_py.System(subs)
+    sp = subs[rank]
+    off = sum(s["nCells"] for s in subs[:rank])
+    sl = slice(off, off + sp["nCells"])
+    ctx = capi.Context(rank % max(1, torch.cuda.device_count()))
+    ctx.comm_init_peer(rank, n, capi.oob_torch())
+    a = capi.Addressing(ctx, sp["nCells"], sp["lowerAddr"], sp["upperAddr"], sp.get("faceWeights"), patches=sp["patches_dev"])
+    m = capi.Matrix(a)
+    m.set_coeffs(sp["diag"], sp["upper"], sp.get("lower"))
+    for i, q in enumerate(sp["patches"]):
+        m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+    rng = np.random.RandomState(5)
+    xs = [rng.randn(s["nCells"]) for s in subs]
+    bs = [rng.randn(s["nCells"]) for s in subs]
+    X, B = np.concatenate(xs), np.concatenate(bs)
+    bad = []
+
+    def same(name, got, want):
+        if not np.array_equal(got, want[sl]):
+            bad.append(name)
+    for rep in range(3):   # repeated: the double-buffered receive regions are reused
+        same("Amul", m.Amul(xs[rank]), S.Amul(X))
+        same("Tmul", m.Tmul(xs[rank]), S.Tmul(X))
+        same("residual", m.residual(xs[rank], bs[rank]), S.residual(X, B))
+        same("GaussSeidel", m.smooth("GaussSeidel", xs[rank], bs[rank], 2), S.smooth("GaussSeidel", X, B, 2))
+    same("sumA", m.sumA(), S.sumA())
+    same("symGaussSeidel", m.smooth("symGaussSeidel", xs[rank], bs[rank], 1), S.smooth("symGaussSeidel", X, B, 1))
+    if abs(m.gSumProd(xs[rank], bs[rank]) - S.gSumProd(X, B)) > 1e-10:
+        bad.append("gSumProd")
+    X0 = np.concatenate([s["psi"] for s in subs]); B0 = np.concatenate([s["source"] for s in subs])
+    solves = [dict(solver="PBiCG", preconditioner="DILU", tolerance=1e-9, relTol=0),
+              dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-8, relTol=0, nCellsInCoarsestLevel=4)] if asym else \
+             [dict(solver="PCG", preconditioner="DIC", tolerance=1e-9, relTol=0),
+              dict(solver="smoothSolver", smoother="GaussSeidel", nSweeps=2, tolerance=1e-6, relTol=0, maxIter=200),
+              dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4),
+              dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4, mergeLevels=2,
+                   nPreSweeps=1)]
+    its = []
+    for kw in solves:
+        okw = dict(kw)
+        if "preconditioner" in okw:
+            okw["precond"] = okw.pop("preconditioner")
+        xo, po = S.solve(X0, B0, **okw)
+        x, perf = m.solve(sp["psi"], sp["source"], **kw)
+        tag = kw["solver"] + str(kw.get("mergeLevels", ""))
+        its.append((tag, perf["nIterations"]))
+        if perf["nIterations"] != po["nIterations"]:
+            bad.append("%s iterations %d vs %d" % (tag, perf["nIterations"], po["nIterations"]))
+        elif not np.allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12):
+            bad.append(tag + " history")
+        elif np.max(np.abs(x - xo[sl])) > 1e-8 * np.max(np.abs(xo)):
+            bad.append(tag + " solution")
+    counters = ctx.comm_counters()
+    fallbacks = ctx.fallback_count()
+    m.close(); a.close(); ctx.close()
+    allbad = [None] * n
+    dist.all_gather_object(allbad, bad)
+    if rank == 0:
+        print(json.dumps(dict(n_ranks=n, asym=asym, devices=torch.cuda.device_count(), mismatches=allbad, solves=its,
+                              counters=counters, fallbacks=fallbacks)))
+    dist.destroy_process_group()
+    sys.exit(1 if any(allbad) else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""GPU (-m gpu): the peer-store communication backend (ldu_ctx_comm_init_peer, ldu_peer.hip) - halo values and partial
+sums written into the neighbour's window instead of RCCL messages.
+
+* one PROCESS per rank (tests/peer_worker.py under torch.distributed.run, gloo for the set-up messages), windows mapped
+  across processes with hipIpc: on a 1-GPU box the ranks share device 0, with N GPUs visible rank r takes GPU r % N -
+  the N > 1 path executed for real, checked against the oracle's emulation of the N-rank algorithm
+  (lduMatrixUpdateMatrixInterfaces.C:30-160, GAMGSolverSolve.C:120-364 across processor patches);
+* one rank whose patches are wired to itself (what bench.py --rank-of measures) in this process."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from openfoam_amd import capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_worker(n, asym, size=10, env=None, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "peer_worker.py"), str(n),
+           str(int(asym)), str(size)]
+    e = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, "peer worker failed (rc %d)\n%s\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("n,asym", [(2, False), (4, False), (3, True)])
+def test_ranks_as_processes_against_the_multidomain_oracle(n, asym):
+    out = run_worker(n, asym)
+    assert not any(out["mismatches"]), out
+    assert out["fallbacks"] == 0
+    assert out["counters"]["halo_exchanges"] > 0 and out["counters"]["all_reduces"] > 0
+
+
+def test_eight_ranks_2x2x2_blocks():
+    """BASELINE config C4's decomposition (2 x 2 x 2 blocks, three processor patches per rank) on whatever GPUs are visible"""
+    out = run_worker(8, False, size=12, timeout=900)
+    assert not any(out["mismatches"]), out
+
+
+def _self_coupled(oracle, asym):
+    from test_gpu_multidomain import _self_coupled_problem
+    return _self_coupled_problem(asym)
+
+
+@pytest.mark.parametrize("asym", [False, True])
+def test_one_rank_wired_to_itself(oracle, monkeypatch, asym):
+    """one sub-domain whose two processor patches receive what they sent, through the window of this rank (the
+    projection bench.py --rank-of measures): bit-exact operators, solver histories against the oracle's emulation"""
+    monkeypatch.setenv("LDU_FORCE_COMM", "1")
+    p = _self_coupled(oracle, asym)
+    S = oracle.System([p])
+    ctx = capi.Context(0)
+    ctx.comm_init_peer(0, 1)
+    a = capi.Addressing(ctx, p["nCells"], p["lowerAddr"], p["upperAddr"], p.get("faceWeights"), patches=p["patches_dev"])
+    m = capi.Matrix(a)
+    m.set_coeffs(p["diag"], p["upper"], p.get("lower"))
+    for i, q in enumerate(p["patches"]):
+        m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+    rng = np.random.RandomState(8)
+    x, b = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+    for rep in range(3):
+        assert np.array_equal(m.Amul(x), S.Amul(x))
+        assert np.array_equal(m.Tmul(x), S.Tmul(x))
+        assert np.array_equal(m.residual(x, b), S.residual(x, b))
+        assert np.array_equal(m.smooth("GaussSeidel", x, b, 2), S.smooth("GaussSeidel", x, b, 2))
+    kw = dict(tolerance=1e-9, relTol=0)
+    names = ("PBiCG", "DILU") if asym else ("PCG", "DIC")
+    xs, perf = m.solve(p["psi"], p["source"], solver=names[0], preconditioner=names[1], **kw)
+    xo, po = S.solve(p["psi"], p["source"], solver=names[0], precond=names[1], **kw)
+    assert perf["nIterations"] == po["nIterations"]
+    np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+    c = ctx.comm_counters()
+    assert c["halo_exchanges"] > 0 and c["all_reduces"] > 0
+    m.close(); a.close(); ctx.close()
