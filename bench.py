@@ -162,9 +162,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
-    ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random", "octree", "octree_hexref", "jump2d"],
+    ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random", "octree", "octree_hexref", "jump2d",
+                                       "motorbike", "motorbike_rcm"],
                     default="box",
-                    help="box: the SURVEY 8d C3 stand-in in blockMesh's natural ordering (the metric's workload); "
+                    help="motorbike: the REAL mesh of the metric's workload - the reference's own blockMesh + snappyHexMesh "
+                         "(castellatedMesh) on the reference's motorBike.obj, refined to ~10 M cells "
+                         "(oracle/_ref/motorbike/<--motorbike-name>.npz, made by tools/make_motorbike.py), in the cell numbering "
+                         "snappyHexMesh produced; motorbike_rcm: the same renumbered by Foam::bandCompression (renumberMesh); "
+                         "box: the SURVEY 8d C3 stand-in in blockMesh's natural ordering; "
                          "renumbered: the same matrix under Foam::bandCompression (what renumberMesh applies); "
                          "irregular: the box plus random diagonal faces (6-12 neighbours per cell, 3-D locality), "
                          "renumbered by Foam::bandCompression - the unstructured stand-in; "
@@ -174,6 +179,7 @@ def main():
                          "octree_hexref: the same in hexRef8's own numbering (what the tutorial's Allrun solves on); "
                          "jump2d: BASELINE config C5's twin at its size - n x n 2-D 5-point matrix with the coefficient "
                          "jumping 1 <-> 1000 across the diagonal (damBreak p_rgh, --n 2000 = 4.0 M cells)")
+    ap.add_argument("--motorbike-name", default="mb12", help="which stored motorBike mesh (oracle/_ref/motorbike/<name>.npz)")
     ap.add_argument("--octree-q", type=int, default=14, help="octree background mesh 5q x 2q x 2q (14 -> ~10 M cells)")
     ap.add_argument("--octree-levels", type=int, nargs=2, default=[6, 7], help="octree surface refinement levels")
     ap.add_argument("--rank-of", type=int, default=0, metavar="N",
@@ -183,29 +189,68 @@ def main():
                          "sum: LDU_FORCE_COMM=1).  Prints the per-rank V-cycle time and the exchanges / all-reduces / "
                          "host read-backs per V-cycle.  Never the headline value: the coupling is to itself, the "
                          "inter-GPU latency is not in it.")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the SAME n^3 matrix decomposed N-way (BASELINE config C4: the 10 M-cell case at "
+                         "1/2/4/8 GPUs; default); weak = n^3 cells PER RANK (blocks of a (px n) x (py n) x (pz n) box)")
+    ap.add_argument("--comm", choices=["auto", "rccl", "peer"], default="auto",
+                    help="N > 1 carrier of halo exchanges and global sums: rccl (ncclSend/ncclRecv + ncclAllReduce), peer "
+                         "(values stored into the neighbour's window over xGMI, ldu_peer.hip), auto = measure both, "
+                         "cross-check their residual histories, report the faster as `value` and both in `comm_backends`")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than visible GPUs (ranks share GPUs round-robin; peer backend only - RCCL "
+                         "refuses two ranks on one device): executes the N-rank path on a 1-GPU box, NOT a scaling number")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCG / asymmetric / host-path legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=0, help="box edge of the CPU sample (0 = same)")
-    args = ap.parse_args()
+    # (ranks spawned by this script receive the command line through the environment: torch.distributed.run's own
+    # parser chokes on abbreviable options such as --n behind the script name)
+    args = ap.parse_args(json.loads(os.environ["LDU_BENCH_ARGV"]) if "LDU_BENCH_ARGV" in os.environ else None)
 
     if args.rank_of > 1:
-        os.environ["LDU_FORCE_COMM"] = "1"   # read once by the library: every reduction goes through RCCL
+        os.environ["LDU_FORCE_COMM"] = "1"   # read once by the library: every reduction goes through the communicator
         args.no_extras = args.no_cpu = True
     import torch
     import torch.distributed as dist
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand as `python bench.py --gpus N`: become the launcher of N ranks (what the driver does itself with
+        # torch.distributed.run); refuse loudly when the box cannot hold them
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not args.oversubscribe:
+            raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible (use --oversubscribe to run the %d-rank path on "
+                             "shared GPUs: a functional run, not a scaling number)" % (args.gpus, ndev, args.gpus))
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"),
+                                                      LDU_BENCH_ARGV=json.dumps(sys.argv[1:]))).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0 and world > 1:
-            print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d: start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the lduMatrix HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    shared_gpus = world > ndev
+    if shared_gpus and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (--oversubscribe runs them on shared GPUs)" % (world, ndev))
+    if shared_gpus and args.comm == "rccl":
+        raise SystemExit("bench.py: RCCL cannot put two ranks on one device; --oversubscribe needs --comm peer")
+    device_index = local_rank % ndev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    oob_group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if shared_gpus:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+            oob_group = dist.new_group(backend="gloo")   # set-up messages of the peer backend (CPU tensors)
 
     entry.load_package()
     from openfoam_amd import capi, cases, decompose
@@ -216,6 +261,15 @@ def main():
         p = cases.random_graph_fast(n ** 3, 7.0, 600)
     elif args.mesh == "jump2d":
         p = cases.jump2d(n, n)
+    elif args.mesh in ("motorbike", "motorbike_rcm"):
+        from openfoam_amd import motorbike
+        p = motorbike.problem(args.motorbike_name)
+        cell_level_hist = np.bincount(p.pop("cellLevel")).tolist()
+        mb_meta = p.pop("meta")
+        if args.mesh == "motorbike_rcm":
+            order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+            nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+            p = cases.renumbered(p, order, fmap, flip, nl, nu)
     elif args.mesh in ("octree", "octree_hexref"):
         from openfoam_amd import octree
         q = args.octree_q
@@ -225,24 +279,35 @@ def main():
             order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
             nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
             p = cases.renumbered(p, order, fmap, flip, nl, nu)
+    elif world > 1 and args.scaling == "weak":
+        p = None   # every rank generates its own block (cases.box3d_block)
     else:
         p = cases.irregular_box(n) if args.mesh == "irregular" else cases.box3d(n)
         if args.mesh in ("renumbered", "irregular"):
             order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
             nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
             p = cases.renumbered(p, order, fmap, flip, nl, nu)
-    t_gen = time.perf_counter() - t_gen
-    nC_total, nF_total = p["nCells"], int(p["lowerAddr"].size)
-    is_octree = args.mesh.startswith("octree")
+    is_octree = args.mesh.startswith("octree") or args.mesh.startswith("motorbike")
+    is_mb = args.mesh.startswith("motorbike")
     if world > 1 and args.mesh != "box":
         raise SystemExit("bench.py: --mesh %s is a single-GPU measurement" % args.mesh)
-
+    shape = None
     if world > 1 or args.rank_of > 1:
         # 2x2x2 blocks at 8 ranks, slabs/blocks otherwise
         nr = world if world > 1 else args.rank_of
         if args.mesh != "box":
             raise SystemExit("bench.py: the block decomposition is defined on the box")
         shape = {2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(nr, (1, 1, nr))
+    if p is None:
+        lp = cases.box3d_block(n, shape, rank)
+        nC_total = world * n ** 3
+        nF_total = sum(((shape[d] * n - 1) * (shape[(d + 1) % 3] * n) * (shape[(d + 2) % 3] * n)) for d in range(3))
+    else:
+        nC_total, nF_total = p["nCells"], int(p["lowerAddr"].size)
+    t_gen = time.perf_counter() - t_gen
+    if p is None:
+        pass
+    elif world > 1 or args.rank_of > 1:
         cell_rank = decompose.block_ranks(n, n, n, *shape)
         subs, cell_maps = decompose.decompose(p, cell_rank, nr, only_rank=rank)
         lp = subs[rank]
@@ -255,13 +320,26 @@ def main():
     else:
         lp = p
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(device_index)
+    # carriers: RCCL (one GPU per rank only) and / or the peer-store backend; with both on the context RCCL carries the
+    # set-up messages and whatever ctx.comm_select leaves to it
+    backends = []
     if world > 1:
-        uid = [capi.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(rank, world, uid[0])
+        if not shared_gpus and args.comm in ("auto", "rccl"):
+            uid = [capi.Context.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(rank, world, uid[0])
+            backends.append("rccl")
+        if args.comm in ("auto", "peer"):
+            ctx.comm_init_peer(rank, world, capi.oob_torch(oob_group))
+            backends.append("peer")
     elif args.rank_of > 1:
-        ctx.comm_init(0, 1, capi.Context.unique_id())
+        if args.comm in ("auto", "rccl"):
+            ctx.comm_init(0, 1, capi.Context.unique_id())
+            backends.append("rccl")
+        if args.comm in ("auto", "peer"):
+            ctx.comm_init_peer(0, 1)
+            backends.append("peer")
 
     t0 = time.perf_counter()
     addr = capi.Addressing(ctx, lp["nCells"], lp["lowerAddr"], lp["upperAddr"], lp.get("faceWeights"),
@@ -308,20 +386,65 @@ def main():
         # for rocprofv3 summaries of the TIMED region only: a second context runs the placement-census kernel, the
         # marker tools/trace_steady.py cuts the kernel trace at (set-up and warm-up, with their one-time table
         # uploads, lie before it)
-        marker_ctx = capi.Context(local_rank)
-    barrier()
-    comm0 = ctx.comm_counters()
-    mat.profile_begin()
-    t0 = time.perf_counter()
-    iters = 0
-    for _ in range(args.steps):
-        perf = step(GAMG_CONTROLS)
-        iters += perf["nIterations"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = mat.profile_end()
-    comm1 = ctx.comm_counters()
-    comm_per_vcycle = {k: round((comm1[k] - comm0[k]) / float(max(1, iters)), 2) for k in comm1}
+        marker_ctx = capi.Context(device_index)
+
+    def timed_region():
+        barrier()
+        c0 = ctx.comm_counters()
+        mat.profile_begin()
+        t0 = time.perf_counter()
+        its = 0
+        pf = None
+        for _ in range(args.steps):
+            pf = step(GAMG_CONTROLS)
+            its += pf["nIterations"]
+        barrier()
+        el = time.perf_counter() - t0
+        pr = mat.profile_end()
+        c1 = ctx.comm_counters()
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=oob_group)
+            el = float(t.item())
+        return dict(elapsed=el, iters=its, perf=pf, prof=pr,
+                    per_vcycle={k: round((c1[k] - c0[k]) / float(max(1, its)), 2) for k in c1})
+
+    # N > 1 (and the one-rank projection): every carrier on the context is measured; their residual histories must agree
+    # (the sums differ in the order of the ranks' partial sums only), `value` is the faster one
+    comm_backends = {}
+    best = None
+    if len(backends) == 2:
+        order = ["rccl", "peer"]
+    else:
+        order = backends or [None]
+    for bk in order:
+        if bk is not None and len(backends) == 2:
+            ctx.comm_select(bk == "peer", bk == "peer")
+            step(GAMG_CONTROLS)   # the carrier's own warm-up
+        try:
+            r = timed_region()
+        except Exception as e:  # pragma: no cover
+            if bk is None or len(backends) < 2:
+                raise
+            comm_backends[bk] = dict(error=str(e)[:300])
+            continue
+        r["backend"] = bk
+        if bk is not None:
+            comm_backends[bk] = dict(vcycles_per_s=round(r["iters"] / r["elapsed"], 3),
+                                     ms_per_vcycle=round(r["elapsed"] / max(1, r["iters"]) * 1e3, 3),
+                                     per_vcycle=r["per_vcycle"], carriers=ctx.comm_info(),
+                                     residual_history=[float("%.6e" % h) for h in r["perf"]["history"]])
+        if best is None or r["iters"] / r["elapsed"] > best["iters"] / best["elapsed"]:
+            best = r
+    if len(comm_backends) == 2 and all("error" not in v for v in comm_backends.values()):
+        ha, hb = (np.array(comm_backends[k]["residual_history"]) for k in ("rccl", "peer"))
+        comm_backends["histories_agree"] = bool(ha.size == hb.size and np.allclose(ha, hb, rtol=1e-5, atol=1e-12))
+        if not comm_backends["histories_agree"]:
+            ctx.comm_select(False, False)   # never report a carrier that disagrees with RCCL
+            best = timed_region()
+            best["backend"] = "rccl"
+    elapsed, iters, perf, prof, comm_per_vcycle = best["elapsed"], best["iters"], best["perf"], best["prof"], best["per_vcycle"]
+    comm_carrier = best["backend"]
     # what this chip streams (SURVEY.md 8d "bound"): McCalpin copy / triad with the library's own f64 stream kernels,
     # 10 M and 80 M doubles per array (the 256 MiB Infinity Cache holds the small case: the large one is the HBM figure)
     stream = None
@@ -332,11 +455,6 @@ def main():
             stream["unit"] = "GB/s"
         except Exception as e:  # pragma: no cover
             stream = dict(error=str(e)[:200])
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     nC, nF = lp["nCells"], int(lp["lowerAddr"].size)
     # algorithmic bytes: GaussSeidel sweep sym 60 nC + 12 nF ; Amul sym 24 nC + 16 nF
     gs_bytes = 60.0 * nC + 12.0 * nF
@@ -359,7 +477,8 @@ def main():
         # traffic: HBM bytes per launch from the PMC counters.  NOT measured by this run: counters need their own
         # rocprofv3 --pmc passes (MI355X_MICROARCH.md); a recorded value is only quoted when workload, kernel and kernel
         # sources are the ones it was recorded for, and the line says where it comes from.
-        mesh_spec = {"box": "box:%d" % n, "octree": "octree:%d:%d:%d" % (args.octree_q, args.octree_levels[0], args.octree_levels[1]),
+        mesh_spec = {"box": "box:%d" % n, "motorbike": "motorbike:%s" % args.motorbike_name,
+                     "motorbike_rcm": "motorbike:%s:rcm" % args.motorbike_name, "octree": "octree:%d:%d:%d" % (args.octree_q, args.octree_levels[0], args.octree_levels[1]),
                      "octree_hexref": "octree:%d:%d:%d:hexref" % (args.octree_q, args.octree_levels[0], args.octree_levels[1])}.get(args.mesh)
         traffic, traffic_source = (None, None)
         if mesh_spec and world == 1 and key == "gs_multi":
@@ -557,13 +676,14 @@ def main():
         # a projection, not a measurement of N GPUs: its own line shape so that nobody mistakes it for the metric
         print(json.dumps({
             "projection": "ONE rank of a %d-rank run on one GPU (bench.py --rank-of %d): rank 0's %d-cell sub-domain of the "
-                          "%d^3 box, %d processor patches (%d faces) exchanging with itself through RCCL (size-1 communicator, "
-                          "LDU_FORCE_COMM=1); inter-GPU latency and load imbalance are NOT in it"
+                          "%d^3 box, %d processor patches (%d faces) exchanging with itself (size-1 RCCL communicator / its own "
+                          "peer window, LDU_FORCE_COMM=1); inter-GPU latency and load imbalance are NOT in it"
                           % (args.rank_of, args.rank_of, lp["nCells"], n, len(lp["patches_dev"]),
                              sum(len(q["faceCells"]) for q in lp["patches_dev"])),
             "per_rank_vcycles_per_s": round(iters / elapsed, 3), "ms_per_vcycle": round(elapsed / max(1, iters) * 1e3, 3),
             "vcycles_per_solve": perf["nIterations"], "steps": args.steps,
             "per_vcycle": comm_per_vcycle,
+            "carrier": comm_carrier, "comm_backends": comm_backends,
             "engine_fallbacks": ctx.fallback_count(),
             "levels": [[L["nCells"], L["nFaces"], L["nLevels"], L["engine_gs_multi"]] for L in (levels or [])],
             "finest": [nC, nF, info["nLevels"], addr.sweep_engine(1)],
@@ -578,11 +698,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": (("simpleFoam motorBike ~10M-cell p-solve twin: castellated octree (background %dx%dx%d, "
+            "config": {"workload": (("simpleFoam motorBike p-solve on the REAL mesh: the reference's blockMesh + snappyHexMesh "
+                                     "(castellatedMesh) on motorBike.obj, background %dx%dx%d, refinementBox level %d, surface "
+                                     "levels %d-%d, cells per refinement level %s; %d cells, %d faces; laplacian coefficients "
+                                     "|Sf|/(n.d) x (1 + 0.5 u01), fixedValue outlet, GAMG (GaussSeidel, faceAreaPair, tol 1e-7 "
+                                     "relTol 0.01)" % (5 * mb_meta["q"], 2 * mb_meta["q"], 2 * mb_meta["q"], mb_meta["box_level"],
+                                                       mb_meta["surface_levels"][0], mb_meta["surface_levels"][1],
+                                                       cell_level_hist, nC_total, nF_total)) if is_mb else
+                                    ("simpleFoam motorBike ~10M-cell p-solve twin: castellated octree (background %dx%dx%d, "
                                      "refinementBox level 4, surface levels %d-%d, hanging faces, cells per refinement level %s; "
                                      "%d cells, %d faces), laplacian coefficients |Sf|/|d| x (1 + 0.5 u01), GAMG "
                                      "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)"
@@ -591,18 +718,33 @@ def main():
                                     ("interFoam damBreak p_rgh twin (BASELINE config C5): %d x %d cells 2-D (%d cells, %d faces), "
                                      "GAMG (GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, n, nC_total, nF_total))
                                     if args.mesh == "jump2d" else
-                                    ("simpleFoam motorBike ~10M-cell p-solve stand-in: %d^3 hex box "
+                                    ("simpleFoam motorBike ~10M-cell p-solve stand-in: %s hex box "
                                      "(%d cells, %d faces) variable-coefficient Laplacian, GAMG "
-                                     "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)" % (n, nC_total, nF_total)))
+                                     "(GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01)"
+                                     % ("%d^3" % n if p is not None else "%dx%dx%d" % tuple(shape[d] * n for d in range(3)),
+                                        nC_total, nF_total)))
                                    + ({"box": "", "renumbered": "; cells renumbered by Foam::bandCompression",
                                        "irregular": "; NOT the plain box: random diagonal faces added (6-12 neighbours per cell), "
                                                     "renumbered by Foam::bandCompression",
                                        "random": "; NOT the box: band-limited random graph, 5-9 neighbours per cell",
                                        "jump2d": "; 5-point matrix, face coefficient jumping 1 <-> 1000 across the diagonal (two-phase density ratio)",
+                                       "motorbike": "; cell numbering as snappyHexMesh wrote it",
+                                       "motorbike_rcm": "; cells renumbered by Foam::bandCompression (renumberMesh)",
                                        "octree": "; hexRef8 cell numbering renumbered by Foam::bandCompression",
                                        "octree_hexref": "; hexRef8 cell numbering (parent keeps its label, 7 children appended)"}[args.mesh]),
                        "mesh": args.mesh,
-                       "parallelism": "domain decomposition x%d" % world,
+                       "parallelism": ("domain decomposition x%d" % world) + (
+                           "" if world == 1 else " (%s blocks, %s scaling: %s; halo exchanges and global sums by %s%s)" % (
+                               "x".join(str(v) for v in shape), args.scaling,
+                               ("%d^3 cells per rank" % n) if args.scaling == "weak" else "the same %d^3 matrix" % n,
+                               {"rccl": "RCCL (ncclSend/ncclRecv, ncclAllReduce)", "peer": "peer stores into the neighbour's "
+                                "window over xGMI (ldu_peer.hip)"}.get(comm_carrier, comm_carrier),
+                               "; RANKS SHARE GPUS (--oversubscribe): a functional run of the N-rank path, not a scaling number"
+                               if shared_gpus else "")),
+                       "rccl_ranks": ctx.comm_info()["rccl_ranks"] if world > 1 else 0,
+                       "gpus_visible": ndev,
+                       "comm_per_vcycle": comm_per_vcycle if world > 1 else None,
+                       "comm_backends": comm_backends or None,
                        "vcycles_per_solve": perf["nIterations"],
                        "dependency_levels_finest": info["nLevels"],
                        # sweeps that expired a dependency wait and were re-run on the level-kernel engine (0 = the fast

@@ -121,6 +121,9 @@ typedef int (*ldu_oob_exchange_fn)(void* user, int32_t nPeers, const int32_t* pe
                                    const int64_t* sendBytes, void* const* recvBufs, const int64_t* recvBytes);
 int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oob_exchange_fn oob, void* user);
 int ldu_ctx_comm_select(ldu_ctx* ctx, int peerHalo, int peerReduce);
+/* out[0] ranks of the RCCL communicator (ncclCommCount; 0 = none), [1] ranks whose windows are mapped (0 = no peer
+ * backend), [2] / [3] = 1 when the halo exchanges / the global sums travel by peer stores */
+int ldu_ctx_comm_info(const ldu_ctx* ctx, int32_t out[4]);
 
 /* ---- addressing (lduAddressing.H:111-199, lduPrimitiveMesh.H:83-99) ------------ */
 /* lower/upper = lowerAddr()/upperAddr(), upper-triangular order (sorted by owner).  */

@@ -21,7 +21,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
     "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_slice_levels",
-    "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_ctx_comm_init_peer", "ldu_ctx_comm_select", "ldu_addr_create", "ldu_addr_add_patch",
+    "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_ctx_comm_init_peer", "ldu_ctx_comm_select", "ldu_ctx_comm_info", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
@@ -232,6 +232,12 @@ class Context:
     def comm_select(self, peer_halo, peer_reduce):
         """which operations travel by peer stores when an RCCL communicator exists as well (ldu_ctx_comm_select)"""
         _chk(lib().ldu_ctx_comm_select(self.h, int(bool(peer_halo)), int(bool(peer_reduce))))
+
+    def comm_info(self):
+        out = (C.c_int32 * 4)()
+        _chk(lib().ldu_ctx_comm_info(self.h, out))
+        return dict(rccl_ranks=out[0], peer_ranks=out[1], halo="peer stores" if out[2] else ("rccl" if out[0] else None),
+                    sums="peer stores" if out[3] else ("rccl" if out[0] else None))
 
     @staticmethod
     def unique_id():

@@ -5,7 +5,9 @@
 // order, left-to-right sums: PCG.C:65-182, PBiCG.C:65-198, DICPreconditioner.C:57-123,
 // DILUPreconditioner.C:57-185, lduMatrixSolver.C:179-197), so this level is now also bit-identical to the CPU
 // reference (the general path sums by a tree).  Vectors come in and go out in the plan's numbering.
-#include "ldu_internal.hpp"
+#include <cstring>
+
+#include "ldu_peer_dev.hpp"
 
 #define CO_MAXC 64
 #define CO_MAXF 512
@@ -163,6 +165,346 @@ int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter
             A->d_upperO, A->d_lowerO, a->d_perm, corr, src, tolerance, relTol, maxIter);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+// ---------------------------------------------------------------- the same across ranks, in ONE kernel per rank
+// With processor patches (several ranks) the coarsest-level ICCG / BICCG of the reference is a distributed Krylov solve:
+// per iteration one interface update inside Amul (two for BICCG: Amul and Tmul) and three global sums (wArA, wApA, the
+// residual), ~10-40 cells per rank.  Through the general solver that is ~13 iterations x (a dozen launches, four
+// collectives, one host read-back) per V-cycle - the largest single latency item of a multi-GPU V-cycle (VERDICT r3:
+// 13 read-backs and ~50 of the ~140 collectives of a V-cycle).  With the peer-store backend a kernel can talk to the
+// other ranks itself: every rank launches this kernel once, lane 0 runs the reference's loops on its sub-domain as
+// above, and where the reference calls initMatrixInterfaces / updateMatrixInterfaces
+// (lduMatrixUpdateMatrixInterfaces.C:30-160) or reduce() (FieldFunctions.C:514-533) the wavefront stores its patch
+// values / partial sums into the neighbours' windows and polls its own (ldu_peer.hip: tagged granules, double-buffered
+// by sequence parity; the sequence numbers live on the device because the iteration count is only known there).
+// Sums are formed in rank order by every rank, so all ranks take the same convergence decisions - the arithmetic of the
+// multi-domain oracle (oracle/ldu_oracle.c: rank-local loops, rank-ordered sums).  No launch, no read-back, no
+// collective call inside the solve.
+struct CoarsePeer {
+    PeerKernelComm K;
+    uint4* const* kdst;        // [2][nPF] (null table when the rank has no remote faces)
+    const uint4* const* ksrc;
+    unsigned* kseq;
+    int nPF;
+    const int* pfCellNew;      // [nPF] faceCells, plan numbering
+    const int* cycPair;        // [nPF] cyclic faces: index of the paired face (own send value), -1 = remote
+    const double* bou;         // [nPF]
+    const double* intc;        // [nPF]
+    int* abortFlag;
+};
+
+// all lanes: out[r][i] of every rank's vals[i]; returns the rank-ordered sum of value i in lane i (i < count <= 4)
+__device__ __forceinline__ double co_allreduce(const CoarsePeer& C, unsigned& rseq, double mine, int count, double (*stage)[4])
+{
+    const int lane = threadIdx.x;
+    const int r = lane >> 2, i = lane & 3;
+    ++rseq;
+    const size_t par = (size_t)(rseq & 1u) * LDU_MAX_PEERS * 16;
+    const double v = __shfl(mine, i);     // lane i holds value i
+    if (r < C.K.n && i < count)
+    {
+        peer_store(C.K.P.win[r] + C.K.redOff + par + (size_t)C.K.me * 16 + i, v, rseq);
+        double x = 0.0;
+        unsigned spins = 0;
+        unsigned long long tw0 = 0;
+        const uint4* src = C.K.P.win[C.K.me] + C.K.redOff + par + (size_t)r * 16 + i;
+        while (!peer_load(src, rseq, x))
+        {
+            if (peer_wait_expired(spins, tw0, C.abortFlag)) { *C.abortFlag = 1; x = 0.0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        stage[r][i] = x;
+    }
+    __syncthreads();
+    double t = 0.0;
+    if (lane < count)
+    {
+        t = stage[0][lane];
+        for (int q = 1; q < C.K.n; q++) t += stage[q][lane];
+    }
+    __syncthreads();
+    return t;
+}
+
+// all lanes: the neighbour values of vec at the coupled faces -> pnf[] (LDS)
+__device__ __forceinline__ void co_halo(const CoarsePeer& C, unsigned& hseq, const double* vec, const int* pf, double* pnf)
+{
+    ++hseq;
+    const size_t par = (size_t)(hseq & 1u) * C.nPF;
+    for (int i = threadIdx.x; i < C.nPF; i += LDU_WAVE)
+    {
+        uint4* d = C.kdst ? C.kdst[par + i] : nullptr;
+        if (d) peer_store(d, vec[pf[i]], hseq);
+    }
+    for (int i = threadIdx.x; i < C.nPF; i += LDU_WAVE)
+    {
+        const int cp = C.cycPair[i];
+        double x = 0.0;
+        if (cp >= 0) x = vec[pf[cp]];
+        else
+        {
+            const uint4* s = C.ksrc[par + i];
+            unsigned spins = 0;
+            unsigned long long tw0 = 0;
+            while (!peer_load(s, hseq, x))
+            {
+                if (peer_wait_expired(spins, tw0, C.abortFlag)) { *C.abortFlag = 1; x = 0.0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        pnf[i] = x;
+    }
+    __syncthreads();
+}
+
+template <bool BI>
+__global__ void __launch_bounds__(LDU_WAVE)
+coarsest_krylov_peer_kernel(CoarsePeer C, int n, int nF, const int* __restrict__ gl, const int* __restrict__ gu,
+                            const int* __restrict__ glosort, const double* __restrict__ gdiag,
+                            const double* __restrict__ gupper, const double* __restrict__ glower,
+                            const int* __restrict__ perm, double* __restrict__ psiNew, const double* __restrict__ srcNew,
+                            double tolerance, double relTol, int maxIter)
+{
+    __shared__ int l[CO_MAXF], u[CO_MAXF], losort[CO_MAXF], pf[LDU_COARSEST_MAXP];
+    __shared__ double upper[CO_MAXF], lower[CO_MAXF], bou[LDU_COARSEST_MAXP], intc[LDU_COARSEST_MAXP], pnf[LDU_COARSEST_MAXP];
+    __shared__ double diag[CO_MAXC], psi[CO_MAXC], b[CO_MAXC], pA[CO_MAXC], wA[CO_MAXC], rA[CO_MAXC], rD[CO_MAXC];
+    __shared__ double pT[BI ? CO_MAXC : 1], wT[BI ? CO_MAXC : 1], rT[BI ? CO_MAXC : 1];
+    __shared__ double stage[LDU_MAX_PEERS][4];
+    __shared__ double sh[4];          // lane 0's partial sums / broadcast scalars
+    __shared__ int shStop;
+    const int lane = threadIdx.x;
+    const int nPF = C.nPF;
+    for (int f = lane; f < nF; f += LDU_WAVE)
+    {
+        l[f] = gl[f]; u[f] = gu[f];
+        upper[f] = gupper[f]; lower[f] = glower[f];
+        if (BI) losort[f] = glosort[f];
+    }
+    for (int i = lane; i < n; i += LDU_WAVE)
+    {
+        const int o = perm[i];
+        psi[o] = psiNew[i];
+        b[o] = srcNew[i];
+    }
+    for (int c = lane; c < n; c += LDU_WAVE) diag[c] = gdiag[c];
+    for (int i = lane; i < nPF; i += LDU_WAVE) { pf[i] = perm[C.pfCellNew[i]]; bou[i] = C.bou[i]; intc[i] = C.intc[i]; }
+    unsigned hseq = C.kseq ? *C.kseq : 0u, rseq = *C.K.d_redSeq;
+    __syncthreads();
+    const double great_ = 1e20, small_ = 1e-20, vsmall_ = 1e-300;
+
+    // wA = A psi (wT = T psi) with the interfaces, residuals, normFactor's local pieces
+    co_halo(C, hseq, psi, pf, pnf);
+    if (lane == 0)
+    {
+        for (int c = 0; c < n; c++) { wA[c] = diag[c] * psi[c]; if (BI) wT[c] = wA[c]; }
+        for (int f = 0; f < nF; f++)
+        {
+            wA[u[f]] += lower[f] * psi[l[f]];
+            wA[l[f]] += upper[f] * psi[u[f]];
+            if (BI)
+            {
+                wT[u[f]] += upper[f] * psi[l[f]];
+                wT[l[f]] += lower[f] * psi[u[f]];
+            }
+        }
+        for (int i = 0; i < nPF; i++) { wA[pf[i]] -= bou[i] * pnf[i]; if (BI) wT[pf[i]] -= intc[i] * pnf[i]; }
+        for (int c = 0; c < n; c++) { rA[c] = b[c] - wA[c]; if (BI) rT[c] = b[c] - wT[c]; }
+        // sumA (lduMatrixATmul.C:167-202): interior, then the interfaces' boundary coefficients
+        for (int c = 0; c < n; c++) pA[c] = diag[c];
+        for (int f = 0; f < nF; f++) { pA[u[f]] += lower[f]; pA[l[f]] += upper[f]; }
+        for (int i = 0; i < nPF; i++) pA[pf[i]] -= bou[i];
+        double sum = 0.0;
+        for (int c = 0; c < n; c++) sum += psi[c];
+        sh[0] = sum; sh[1] = (double)n;
+    }
+    __syncthreads();
+    double g = co_allreduce(C, rseq, lane < 2 ? sh[lane] : 0.0, 2, stage);   // gAverage(psi) = gSum / gSum(n)
+    const double avg = __shfl(g, 0) / __shfl(g, 1);
+    if (lane == 0)
+    {
+        for (int c = 0; c < n; c++) pA[c] *= avg;
+        double nfl = 0.0, res = 0.0;
+        for (int c = 0; c < n; c++) nfl += fabs(wA[c] - pA[c]) + fabs(b[c] - pA[c]);
+        for (int c = 0; c < n; c++) res += fabs(rA[c]);
+        sh[0] = nfl; sh[1] = res;
+    }
+    __syncthreads();
+    g = co_allreduce(C, rseq, lane < 2 ? sh[lane] : 0.0, 2, stage);
+    const double nf = __shfl(g, 0) + small_;
+    const double initial = __shfl(g, 1) / nf;
+    double final_ = initial;
+    bool converged = final_ < tolerance || (relTol > small_ && final_ < relTol * initial);
+    if (!converged)
+    {
+        if (lane == 0)
+        {
+            for (int c = 0; c < n; c++) rD[c] = diag[c];
+            for (int f = 0; f < nF; f++) rD[u[f]] -= upper[f] * lower[f] / rD[l[f]];
+            for (int c = 0; c < n; c++) rD[c] = 1.0 / rD[c];
+            if (BI) for (int c = 0; c < n; c++) pT[c] = 0.0;
+        }
+        double wArA = great_, wArAold;
+        int nIterations = 0;
+        do
+        {
+            wArAold = wArA;
+            if (lane == 0)
+            {
+                for (int c = 0; c < n; c++) wA[c] = rD[c] * rA[c];
+                for (int f = 0; f < nF; f++)
+                {
+                    const int sf = BI ? losort[f] : f;
+                    wA[u[sf]] -= rD[u[sf]] * lower[sf] * wA[l[sf]];
+                }
+                for (int f = nF - 1; f >= 0; f--) wA[l[f]] -= rD[l[f]] * upper[f] * wA[u[f]];
+                if (BI)
+                {
+                    for (int c = 0; c < n; c++) wT[c] = rD[c] * rT[c];
+                    for (int f = 0; f < nF; f++) wT[u[f]] -= rD[u[f]] * upper[f] * wT[l[f]];
+                    for (int f = nF - 1; f >= 0; f--)
+                    {
+                        const int sf = losort[f];
+                        wT[l[sf]] -= rD[l[sf]] * lower[sf] * wT[u[sf]];
+                    }
+                }
+                double t = 0.0;
+                for (int c = 0; c < n; c++) t += wA[c] * (BI ? rT[c] : rA[c]);
+                sh[0] = t;
+            }
+            __syncthreads();
+            g = co_allreduce(C, rseq, lane < 1 ? sh[0] : 0.0, 1, stage);
+            wArA = __shfl(g, 0);
+            if (lane == 0)
+            {
+                if (nIterations == 0)
+                {
+                    for (int c = 0; c < n; c++) { pA[c] = wA[c]; if (BI) pT[c] = wT[c]; }
+                }
+                else
+                {
+                    const double beta = wArA / wArAold;
+                    for (int c = 0; c < n; c++)
+                    {
+                        pA[c] = wA[c] + beta * pA[c];
+                        if (BI) pT[c] = wT[c] + beta * pT[c];
+                    }
+                }
+            }
+            __syncthreads();
+            // wA = A pA: interfaces initialised, interior, interfaces updated (lduMatrixATmul.C:34-92)
+            co_halo(C, hseq, pA, pf, pnf);
+            if (lane == 0)
+            {
+                for (int c = 0; c < n; c++) wA[c] = diag[c] * pA[c];
+                for (int f = 0; f < nF; f++)
+                {
+                    wA[u[f]] += lower[f] * pA[l[f]];
+                    wA[l[f]] += upper[f] * pA[u[f]];
+                }
+                for (int i = 0; i < nPF; i++) wA[pf[i]] -= bou[i] * pnf[i];
+            }
+            if (BI)
+            {
+                __syncthreads();
+                co_halo(C, hseq, pT, pf, pnf);     // Tmul (lduMatrixATmul.C:95-155): interfaceIntCoeffs
+                if (lane == 0)
+                {
+                    for (int c = 0; c < n; c++) wT[c] = diag[c] * pT[c];
+                    for (int f = 0; f < nF; f++)
+                    {
+                        wT[u[f]] += upper[f] * pT[l[f]];
+                        wT[l[f]] += lower[f] * pT[u[f]];
+                    }
+                    for (int i = 0; i < nPF; i++) wT[pf[i]] -= intc[i] * pnf[i];
+                }
+            }
+            if (lane == 0)
+            {
+                double t = 0.0;
+                for (int c = 0; c < n; c++) t += wA[c] * (BI ? pT[c] : pA[c]);
+                sh[0] = t;
+            }
+            __syncthreads();
+            g = co_allreduce(C, rseq, lane < 1 ? sh[0] : 0.0, 1, stage);
+            const double wApA = __shfl(g, 0);
+            if (fabs(wApA) / nf < vsmall_) break;   // checkSingularity (uniform: every rank holds the same sum)
+            const double alpha = wArA / wApA;
+            if (lane == 0)
+            {
+                double res = 0.0;
+                for (int c = 0; c < n; c++)
+                {
+                    psi[c] += alpha * pA[c];
+                    rA[c] -= alpha * wA[c];
+                    if (BI) rT[c] -= alpha * wT[c];
+                }
+                for (int c = 0; c < n; c++) res += fabs(rA[c]);
+                sh[0] = res;
+            }
+            __syncthreads();
+            g = co_allreduce(C, rseq, lane < 1 ? sh[0] : 0.0, 1, stage);
+            final_ = __shfl(g, 0) / nf;
+            converged = final_ < tolerance || (relTol > small_ && final_ < relTol * initial);
+            if (lane == 0) shStop = *C.abortFlag;   // a wait that gave up: leave instead of iterating on garbage
+            __syncthreads();
+            if (shStop) break;
+        } while (nIterations++ < maxIter && !converged);
+    }
+    __syncthreads();
+    if (lane == 0)
+    {
+        if (C.kseq) *C.kseq = hseq;
+        *C.K.d_redSeq = rseq;
+    }
+    for (int i = lane; i < n; i += LDU_WAVE) psiNew[i] = psi[perm[i]];
+}
+
+int k_coarsest_set_peer_timeout(unsigned long long ticks)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_peer_budget), &ticks, sizeof(ticks)));
+    return 0;
+}
+
+// the distributed coarsest-level solve; 1 = not taken.  `eligible` = every rank can take it (decided once per hierarchy
+// by the caller with an and-reduce: a kernel that communicates must be launched by all ranks or by none)
+int k_coarsest_solve_peer(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src,
+                          const int* d_cycPair)
+{
+    ldu_addr* a = A->a;
+    ldu_ctx* ctx = a->ctx;
+    CoarsePeer C;
+    memset(&C, 0, sizeof(C));
+    if (!comm_peer_kernel_comm(ctx, &C.K)) return 1;
+    C.nPF = a->nPatchFaces;
+    C.pfCellNew = a->d_pfCell;
+    C.cycPair = d_cycPair;
+    C.bou = A->d_bou;
+    C.intc = A->d_int;
+    C.abortFlag = ctx->d_abort;
+    if (a->peer) { C.kdst = a->peer->d_kdst; C.ksrc = a->peer->d_ksrc; C.kseq = a->peer->d_kseq; }
+    hipStream_t s = ctx->stream;
+    if (A->sym)
+        coarsest_krylov_peer_kernel<false><<<1, LDU_WAVE, 0, s>>>(C, a->nCells, a->nFaces, a->d_l, a->d_u, a->d_losort,
+            A->d_diagO, A->d_upperO, A->d_upperO, a->d_perm, corr, src, tolerance, relTol, maxIter);
+    else
+        coarsest_krylov_peer_kernel<true><<<1, LDU_WAVE, 0, s>>>(C, a->nCells, a->nFaces, a->d_l, a->d_u, a->d_losort,
+            A->d_diagO, A->d_upperO, A->d_lowerO, a->d_perm, corr, src, tolerance, relTol, maxIter);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// can THIS rank run its part of the distributed coarsest solve in the kernel above (sizes, peer regions)?
+bool k_coarsest_peer_eligible(ldu_matrix* A)
+{
+    ldu_addr* a = A->a;
+    static const bool off = getenv("LDU_COARSEST_KERNEL") && !atoi(getenv("LDU_COARSEST_KERNEL"));
+    PeerKernelComm K;
+    if (off || !comm_peer_kernel_comm(a->ctx, &K)) return false;
+    if (a->nCells > CO_MAXC || a->nFaces > CO_MAXF || a->nPatchFaces > LDU_COARSEST_MAXP || a->nCells == 0) return false;
+    bool remote = false;
+    for (auto& P : a->patches) if (P.nbrPatch < 0 && P.n) remote = true;
+    if (remote && !(a->peer && a->peer->kAll)) return false;
+    return true;
 }
 
 // ---------------------------------------------------------------- directSolveCoarsest

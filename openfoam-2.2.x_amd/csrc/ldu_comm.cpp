@@ -56,6 +56,8 @@ struct PeerWindow {
     std::map<size_t, size_t> freeList;                 // offset -> bytes (first fit, coalescing)
     size_t redOff = 0;                                 // [2][LDU_MAX_PEERS][16] granules of the all-reduce
     unsigned redSeq = 0;
+    size_t redOffK = 0;                                // the same for collectives done INSIDE a kernel (own sequence, on the device)
+    unsigned* d_redSeqK = nullptr;
     ldu_oob_exchange_fn oob = nullptr;
     void* oobUser = nullptr;
     size_t alloc(size_t bytes)
@@ -204,6 +206,9 @@ extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oo
     LDU_CHECK_HIP(hipDeviceSynchronize());
     W->freeList[0] = W->bytes;
     W->redOff = W->alloc(sizeof(uint4) * 2 * LDU_MAX_PEERS * 16);
+    W->redOffK = W->alloc(sizeof(uint4) * 2 * LDU_MAX_PEERS * 16);
+    LDU_CHECK_HIP(hipMalloc((void**)&W->d_redSeqK, sizeof(unsigned)));
+    LDU_CHECK_HIP(hipMemset(W->d_redSeqK, 0, sizeof(unsigned)));
     W->peer.assign(nRanks, nullptr);
     W->opened.assign(nRanks, false);
     W->peer[rank] = W->base;
@@ -246,6 +251,24 @@ extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oo
     return 0;
 }
 
+// out[0] ranks of the RCCL communicator (ncclCommCount; 0 = none), [1] ranks whose windows are mapped (0 = no peer
+// backend), [2] / [3] halo exchanges / global sums travel by peer stores
+extern "C" int ldu_ctx_comm_info(const ldu_ctx* ctx, int32_t out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!ctx->comm) return 0;
+    if (ctx->comm->comm)
+    {
+        int n = 0;
+        LDU_CHECK_NCCL(ncclCommCount(ctx->comm->comm, &n));
+        out[0] = n;
+    }
+    if (ctx->comm->peer) out[1] = (int32_t)ctx->comm->peer->peer.size();
+    out[2] = ctx->comm->peerHalo;
+    out[3] = ctx->comm->peerReduce;
+    return 0;
+}
+
 // which operations the peer backend carries (0 / 1 each); both need ldu_ctx_comm_init_peer first
 extern "C" int ldu_ctx_comm_select(ldu_ctx* ctx, int peerHalo, int peerReduce)
 {
@@ -257,6 +280,7 @@ extern "C" int ldu_ctx_comm_select(ldu_ctx* ctx, int peerHalo, int peerReduce)
     }
     ctx->comm->peerHalo = peerHalo != 0;
     ctx->comm->peerReduce = peerReduce != 0;
+    ctx->commEpoch++;
     return 0;
 }
 
@@ -285,6 +309,16 @@ int comm_peer_setup_addr(ldu_addr* a)
         ldu_set_error("peer backend: window exhausted (LDU_PEER_WINDOW_MB, default 256)");
         return -5;
     }
+    const bool small = a->nCells <= LDU_COARSEST_MAXC && a->nFaces <= LDU_COARSEST_MAXF && nPF <= LDU_COARSEST_MAXP;
+    if (small)
+    {
+        H->kWinBytes = H->winBytes;
+        H->kWinOff = W->alloc(H->kWinBytes);
+        if (H->kWinOff == (size_t)-1) { ldu_set_error("peer backend: window exhausted (LDU_PEER_WINDOW_MB, default 256)"); return -5; }
+        LDU_CHECK_HIP(hipMemsetAsync((char*)W->base + H->kWinOff, 0, H->kWinBytes, ctx->stream));
+        LDU_CHECK_HIP(hipMalloc((void**)&H->d_kseq, sizeof(unsigned)));
+        LDU_CHECK_HIP(hipMemsetAsync(H->d_kseq, 0, sizeof(unsigned), ctx->stream));
+    }
     // a region that is reused must not hold tags of its previous owner that a new sequence could reach: zero it
     LDU_CHECK_HIP(hipMemsetAsync((char*)W->base + H->winOff, 0, H->winBytes, ctx->stream));
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -301,6 +335,7 @@ int comm_peer_setup_addr(ldu_addr* a)
         {
             buf.push_back((int64_t)(H->winOff / sizeof(uint4) + myOff[p]));
             buf.push_back((int64_t)a->patches[p].n);
+            buf.push_back(small ? (int64_t)(H->kWinOff / sizeof(uint4) + myOff[p]) : (int64_t)-1);
         }
         peers.push_back(kv.first);
         rb.emplace_back(buf.size());
@@ -320,8 +355,9 @@ int comm_peer_setup_addr(ldu_addr* a)
         }
         else rb = sb;   // one rank whose patches face each other (projection / tests): handled below
     }
-    std::vector<uint4*> dst(2 * (size_t)nPF, nullptr);
-    std::vector<const uint4*> src(2 * (size_t)nPF, nullptr);
+    std::vector<uint4*> dst(2 * (size_t)nPF, nullptr), kdst(2 * (size_t)nPF, nullptr);
+    std::vector<const uint4*> src(2 * (size_t)nPF, nullptr), ksrc(2 * (size_t)nPF, nullptr);
+    H->kAll = small;
     size_t i = 0;
     for (auto& kv : byRank)
     {
@@ -330,15 +366,17 @@ int comm_peer_setup_addr(ldu_addr* a)
         {
             const int p = kv.second[k];
             const Patch& P = a->patches[p];
-            int64_t roff = rb[i][2 * k], rn = rb[i][2 * k + 1];
+            int64_t roff = rb[i][3 * k], rn = rb[i][3 * k + 1], rkoff = rb[i][3 * k + 2];
             if (ctx->nRanks == 1)
             {
                 // self-coupled: the k-th patch towards "rank 0" pairs with the patch paired_patch names (itself when alone)
                 const int q = paired_patch(a->patches, p, a->patches, ctx->rank);
                 const int qq = q < 0 ? p : q;
                 roff = (int64_t)(H->winOff / sizeof(uint4) + myOff[qq]);
+                rkoff = small ? (int64_t)(H->kWinOff / sizeof(uint4) + myOff[qq]) : -1;
                 rn = a->patches[qq].n;
             }
+            if (rkoff < 0) H->kAll = false;
             if (rn != P.n)
             {
                 ldu_set_error("peer backend: patch sizes differ between neighbours (" + std::to_string(P.n) + " vs " +
@@ -350,6 +388,11 @@ int comm_peer_setup_addr(ldu_addr* a)
                 {
                     dst[(size_t)par * nPF + P.offset + f] = W->peer[nbr] + roff + (size_t)par * P.n + f;
                     src[(size_t)par * nPF + P.offset + f] = W->base + H->winOff / sizeof(uint4) + myOff[p] + (size_t)par * P.n + f;
+                    if (small && rkoff >= 0)
+                    {
+                        kdst[(size_t)par * nPF + P.offset + f] = W->peer[nbr] + rkoff + (size_t)par * P.n + f;
+                        ksrc[(size_t)par * nPF + P.offset + f] = W->base + H->kWinOff / sizeof(uint4) + myOff[p] + (size_t)par * P.n + f;
+                    }
                 }
         }
         i++;
@@ -358,15 +401,38 @@ int comm_peer_setup_addr(ldu_addr* a)
     LDU_CHECK_HIP(hipMalloc((void**)&H->d_src, sizeof(uint4*) * src.size()));
     LDU_CHECK_HIP(hipMemcpy(H->d_dst, dst.data(), sizeof(uint4*) * dst.size(), hipMemcpyHostToDevice));
     LDU_CHECK_HIP(hipMemcpy(H->d_src, src.data(), sizeof(uint4*) * src.size(), hipMemcpyHostToDevice));
+    if (small)
+    {
+        LDU_CHECK_HIP(hipMalloc((void**)&H->d_kdst, sizeof(uint4*) * kdst.size()));
+        LDU_CHECK_HIP(hipMalloc((void**)&H->d_ksrc, sizeof(uint4*) * ksrc.size()));
+        LDU_CHECK_HIP(hipMemcpy(H->d_kdst, kdst.data(), sizeof(uint4*) * kdst.size(), hipMemcpyHostToDevice));
+        LDU_CHECK_HIP(hipMemcpy(H->d_ksrc, ksrc.data(), sizeof(uint4*) * ksrc.size(), hipMemcpyHostToDevice));
+    }
     return 0;
+}
+
+bool comm_peer_kernel_comm(ldu_ctx* ctx, PeerKernelComm* out)
+{
+    if (!ctx->comm || !ctx->comm->peer || !ctx->comm->peerHalo || !ctx->comm->peerReduce) return false;
+    PeerWindow* W = ctx->comm->peer;
+    for (int r = 0; r < LDU_MAX_PEERS; r++) out->P.win[r] = r < ctx->nRanks ? W->peer[r] : nullptr;
+    out->redOff = W->redOffK / sizeof(uint4);
+    out->d_redSeq = W->d_redSeqK;
+    out->me = ctx->rank;
+    out->n = ctx->nRanks;
+    return true;
 }
 
 void comm_peer_free_addr(ldu_addr* a)
 {
     if (!a->peer) return;
     if (a->ctx->comm && a->ctx->comm->peer && a->peer->winBytes) a->ctx->comm->peer->release(a->peer->winOff, a->peer->winBytes);
+    if (a->ctx->comm && a->ctx->comm->peer && a->peer->kWinBytes) a->ctx->comm->peer->release(a->peer->kWinOff, a->peer->kWinBytes);
     if (a->peer->d_dst) (void)hipFree(a->peer->d_dst);
     if (a->peer->d_src) (void)hipFree((void*)a->peer->d_src);
+    if (a->peer->d_kdst) (void)hipFree(a->peer->d_kdst);
+    if (a->peer->d_ksrc) (void)hipFree((void*)a->peer->d_ksrc);
+    if (a->peer->d_kseq) (void)hipFree(a->peer->d_kseq);
     delete a->peer;
     a->peer = nullptr;
 }
@@ -381,6 +447,7 @@ void comm_destroy(ldu_ctx* ctx)
         for (size_t r = 0; r < W->peer.size(); r++)
             if (W->opened[r] && W->peer[r]) (void)hipIpcCloseMemHandle(W->peer[r]);
         if (W->base) (void)hipFree(W->base);
+        if (W->d_redSeqK) (void)hipFree(W->d_redSeqK);
         delete W;
     }
     delete ctx->comm;
@@ -390,7 +457,8 @@ void comm_destroy(ldu_ctx* ctx)
 int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s)
 {
     // LDU_FORCE_COMM=1 sends even a 1-rank reduction through RCCL (exercises the backend on 1 GPU)
-    static const bool force = getenv("LDU_FORCE_COMM") && atoi(getenv("LDU_FORCE_COMM"));
+    const char* fe = getenv("LDU_FORCE_COMM");   // (read per call: tests switch it within one process)
+    const bool force = fe && atoi(fe);
     if (!ctx->comm || (ctx->nRanks <= 1 && !force)) return 0;
     ctx->nAllReduces++;
     if (ctx->comm->peerReduce)
@@ -430,7 +498,8 @@ int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s)
 // engine fallback at the same point of the same operation, or none does (run_with_fallback).
 int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s)
 {
-    static const bool force = getenv("LDU_FORCE_COMM") && atoi(getenv("LDU_FORCE_COMM"));
+    const char* fe = getenv("LDU_FORCE_COMM");   // (read per call: tests switch it within one process)
+    const bool force = fe && atoi(fe);
     if (!ctx->comm || (ctx->nRanks <= 1 && !force)) return 0;
     if (ctx->comm->peerReduce)
     {
@@ -508,7 +577,7 @@ bool comm_is_peer(const ldu_ctx* ctx) { return ctx->comm && ctx->comm->peerHalo;
 int comm_halo_pack_exchange(ldu_addr* a, const double* x, hipStream_t s)
 {
     if (!a->nPatchFaces) return 0;
-    if (a->peer)
+    if (a->peer && a->ctx->comm->peerHalo)
     {
         // peer stores: the pack kernel IS the send (ldu_peer.hip); the receive is polled in comm_wait_halo
         ldu_ctx* ctx = a->ctx;
@@ -599,9 +668,8 @@ int comm_exchange(ldu_addr* a, hipStream_t s)
 int comm_wait_halo(ldu_addr* a, hipStream_t s)
 {
     ldu_ctx* ctx = a->ctx;
-    if (a->peer)
+    if (a->peer && a->peer->pending)
     {
-        if (!a->peer->pending) return 0;
         a->peer->pending = false;
         return k_peer_unpack(a, a->peer->seq, s);
     }

@@ -52,6 +52,11 @@ struct GamgHierarchy {
     double* d_Apsi = nullptr;
     double* d_finestCorr = nullptr;
     double* d_finestRes = nullptr;
+    // distributed coarsest-level solve in one kernel per rank (ldu_coarsest.hip, peer-store backend): -1 = not decided yet
+    // (decided collectively: an and-reduce of every rank's own eligibility), 0 / 1
+    int coarsestPeer = -1;
+    int coarsestPeerEpoch = -1;          // ctx->commEpoch the decision belongs to (ldu_ctx_comm_select changes the carriers)
+    int* d_cycPair = nullptr;
 };
 
 template <class T>
@@ -79,6 +84,7 @@ void gamg_free(GamgHierarchy* g)
     if (g->d_Apsi) (void)hipFree(g->d_Apsi);
     if (g->d_finestCorr) (void)hipFree(g->d_finestCorr);
     if (g->d_finestRes) (void)hipFree(g->d_finestRes);
+    if (g->d_cycPair) (void)hipFree(g->d_cycPair);
     delete g;
 }
 
@@ -551,11 +557,41 @@ static int gamg_interpolate(ldu_matrix* A, double* psi, double* Apsi)
 }
 
 // coarsest level: ICCG / BICCG with the outer tolerances (GAMGSolverSolve.C:430-487, ICCG.C:46)
-static int solve_coarsest(ldu_matrix* A, const ldu_controls* c, double* corr, const double* src)
+static int solve_coarsest(GamgHierarchy* g, ldu_matrix* A, const ldu_controls* c, double* corr, const double* src)
 {
     hipStream_t s = A->a->ctx->stream;
     if (c->directSolveCoarsest) return k_coarsest_lu(A, corr, src);   // GAMGSolverSolve.C:436-440
     if (k_ew(A->a->nCells, EW_ZERO, corr, nullptr, nullptr, s)) return -1;
+    if (A->a->nPatchFaces || A->a->ctx->nRanks > 1)
+    {
+        // several ranks / coupled patches: the whole distributed Krylov solve in one kernel per rank when the peer-store
+        // backend carries halos and sums and every rank's coarsest level fits (collective decision, once per hierarchy)
+        if (g->coarsestPeer < 0 || g->coarsestPeerEpoch != A->a->ctx->commEpoch)
+        {
+            g->coarsestPeerEpoch = A->a->ctx->commEpoch;
+            if (g->d_cycPair) { (void)hipFree(g->d_cycPair); g->d_cycPair = nullptr; }
+            int ok = k_coarsest_peer_eligible(A) ? 1 : 0;
+            if (comm_allreduce_min_int(A->a->ctx, &ok)) return -1;
+            g->coarsestPeer = ok;
+            if (ok)
+            {
+                std::vector<int> cyc(A->a->nPatchFaces, -1);
+                for (auto& P : A->a->patches)
+                    if (P.nbrPatch >= 0)
+                        for (int f = 0; f < P.n; f++) cyc[P.offset + f] = A->a->patches[P.nbrPatch].offset + f;
+                if (up(&g->d_cycPair, cyc)) return -1;
+            }
+            if (getenv("LDU_VERBOSE"))
+                fprintf(stderr, "[ldugpu] coarsest level (%d cells, %d coupled faces): %s\n", A->a->nCells, A->a->nPatchFaces,
+                        ok ? "distributed Krylov solve in one kernel per rank (peer stores)" : "host-driven Krylov loop");
+        }
+        if (g->coarsestPeer)
+        {
+            const int rc = k_coarsest_solve_peer(A, c->tolerance, c->relTol, 1000, corr, src, g->d_cycPair);
+            if (rc <= 0) return rc;
+        }
+    }
+    else
     {
         // the whole Krylov solve of a tiny level in one single-wavefront kernel (ldu_coarsest.hip)
         const int rc = k_coarsest_solve(A, c->tolerance, c->relTol, 1000, corr, src);
@@ -616,7 +652,7 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
         static const bool timeCoarsest = getenv("LDU_GAMG_TIME") != nullptr;
         std::chrono::steady_clock::time_point t0;
         if (timeCoarsest) { (void)hipStreamSynchronize(s); t0 = std::chrono::steady_clock::now(); }
-        if (solve_coarsest(Lv[coarsestLevel].mat, c, Lv[coarsestLevel].d_corr, Lv[coarsestLevel].d_src)) return -1;
+        if (solve_coarsest(g, Lv[coarsestLevel].mat, c, Lv[coarsestLevel].d_corr, Lv[coarsestLevel].d_src)) return -1;
         if (timeCoarsest)
         {
             (void)hipStreamSynchronize(s);

@@ -115,6 +115,7 @@ struct ldu_ctx {
     // communicator
     int rank = 0, nRanks = 1;
     ldu_comm_impl* comm = nullptr;
+    int commEpoch = 0;               // bumped when the carriers of halos / sums change (ldu_ctx_comm_select)
     // per-kernel-class timing with HIP events on the compute stream (bench.py roofline)
     bool profOn = false;
     const struct ldu_addr* profAddr = nullptr;
@@ -150,7 +151,18 @@ struct PeerHalo {
     const uint4** d_src = nullptr;         // [2][nPatchFaces] my receive granule per face and parity (null: cyclic face)
     unsigned seq = 0;                      // exchanges started on this addressing (tag of the granules; parity = seq & 1)
     bool pending = false;                  // pack ran, unpack did not yet
+    // a second, kernel-private set for addressings small enough to be a coarsest GAMG level: the whole distributed
+    // Krylov solve of that level runs in ONE kernel per rank (coarsest_krylov_peer_kernel) that exchanges through these
+    // regions with its own sequence number kept on the device
+    size_t kWinOff = 0, kWinBytes = 0;
+    uint4** d_kdst = nullptr;              // [2][nPatchFaces]; entries stay null when the neighbour has no such region
+    const uint4** d_ksrc = nullptr;
+    unsigned* d_kseq = nullptr;            // device: exchanges the kernel has done so far
+    bool kAll = false;                     // every remote face has a kernel-private destination
 };
+#define LDU_COARSEST_MAXC 64
+#define LDU_COARSEST_MAXF 512
+#define LDU_COARSEST_MAXP 256
 
 struct ldu_addr {
     ldu_ctx* ctx = nullptr;
@@ -363,7 +375,10 @@ void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converte
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);
 int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src);
-int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src);   // directSolveCoarsest (ldu_coarsest.hip)
+int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src);
+int k_coarsest_solve_peer(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src,
+                          const int* d_cycPair);   // ldu_coarsest.hip: the distributed solve in one kernel per rank; 1 = not taken
+bool k_coarsest_peer_eligible(ldu_matrix* A);   // directSolveCoarsest (ldu_coarsest.hip)
 int k_sweep_gs_wg(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_set_p2p_backoff(unsigned n);
@@ -455,9 +470,13 @@ int comm_halo_pack_exchange(ldu_addr* a, const double* x, hipStream_t s);       
 int k_peer_pack(ldu_addr* a, const double* x, unsigned seq, hipStream_t s);
 int k_peer_unpack(ldu_addr* a, unsigned seq, hipStream_t s);
 int k_peer_set_timeout(double seconds);
+int k_coarsest_set_peer_timeout(unsigned long long ticks);   // ldu_coarsest.hip
 struct PeerRed { uint4* win[LDU_MAX_PEERS]; };
 int k_peer_allreduce(ldu_ctx* ctx, const PeerRed& P, size_t redOff, int me, int n, int count, unsigned seq, double* vals,
                      int* abortWord, hipStream_t s);
+// everything the in-kernel collectives of a context need (ldu_comm.cpp fills it)
+struct PeerKernelComm { PeerRed P; size_t redOff; unsigned* d_redSeq; int me, n; };
+bool comm_peer_kernel_comm(ldu_ctx* ctx, PeerKernelComm* out);   // false: peer stores do not carry halos AND sums
 int comm_allreduce_min_int(ldu_ctx* ctx, int* v);
 int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s);                             // abort flag := max over the ranks
 int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,

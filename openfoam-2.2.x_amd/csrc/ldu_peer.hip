@@ -17,42 +17,7 @@
 // Measured on one MI355X with 2 ... 4 PROCESSES sharing the GPU (tools/ipc_probe.hip): all-reduce of 4 doubles
 // 3.1-4.2 us per operation back to back, halo pack + unpack 6 us per exchange independent of the patch size up to
 // 46 656 faces, 1.2 us per ping-pong round trip between two running kernels.
-#include "ldu_internal.hpp"
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define PBLK 256
-
-__device__ __forceinline__ void peer_store(uint4* p, double v, unsigned tag)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    u32x4 d;
-    d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
-    // sc0 sc1 = system scope: written through this GPU's L2 towards the memory that owns the line (possibly another GPU's);
-    // s_nop 1: the data registers of a > 64-bit VMEM store are read late (two wait states on gfx940+)
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
-}
-__device__ __forceinline__ bool peer_load(const uint4* p, unsigned tag, double& v)
-{
-    u32x4 g;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
-    if (g.y != tag || g.w != tag) return false;
-    v = __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
-    return true;
-}
-
-// A wait for ANOTHER RANK is not a wait for another wave of the same launch: the peer may simply be late (its host is
-// still busy), so the 200 ms budget of the sweep engines does not apply.  Bound: LDU_PEER_TIMEOUT_S of wall clock
-// (default 20 s; 100 MHz s_memrealtime read every 256 polls) - past it the wave sets the abort flag, the operation
-// fails loudly (-20) instead of hanging the GPU.
-static __device__ unsigned long long g_peer_budget = 2000000000ull;
-__device__ __forceinline__ bool peer_wait_expired(unsigned& spins, unsigned long long& tw0, volatile int* abortFlag)
-{
-    if ((++spins & 255u) != 8u) return false;
-    if (*abortFlag) return true;
-    const unsigned long long now = wall_clock64();
-    if (!tw0) { tw0 = now; return false; }
-    return now - tw0 > g_peer_budget;
-}
+#include "ldu_peer_dev.hpp"
 
 // initMatrixInterfaces: send[i] = x[faceCells[i]] for every coupled face (cyclic patches read d_send), and for the
 // faces of processor patches the same value as a granule into the neighbour's receive region
@@ -167,5 +132,5 @@ int k_peer_set_timeout(double seconds)
 {
     const unsigned long long t = (unsigned long long)(seconds * 1e8);
     LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_peer_budget), &t, sizeof(t)));
-    return 0;
+    return k_coarsest_set_peer_timeout(t);   // (one copy of the budget per translation unit)
 }

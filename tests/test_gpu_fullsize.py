@@ -50,6 +50,56 @@ def test_benchmark_solve_history_at_full_size(full, oracle):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# BASELINE config C3's other half at its size: the ASYMMETRIC 216^3 matrix (the U-equation: lower = upper - phi) with the
+# solvers the motorBike case names for U (PBiCG/DILU in BASELINE's wording, smoothSolver/GaussSeidel in the tutorial's
+# fvSolution:33-40) - VERDICT r3 weak #1: benchmarked (bench.py extra.pbicg_dilu / smoothsolver_gs) but unchecked at this size.
+@pytest.fixture(scope="module")
+def full_asym():
+    p = cases.box3d(216, asym=True)
+    ctx = capi.Context(0)
+    a, m = capi.from_problem(ctx, p)
+    yield p, a, m, ctx
+    m.close(); a.close(); ctx.close()
+
+
+def test_asymmetric_kernels_bitexact_at_full_size(full_asym, oracle):
+    p, a, m, ctx = full_asym
+    S = oracle.System(p)
+    src = p["source"]
+    assert np.array_equal(m.Amul(src), S.Amul(src))
+    assert np.array_equal(m.Tmul(src), S.Tmul(src))
+    assert np.array_equal(m.precondition("DILU", src), S.precondition("DILU", src)[0])
+    assert np.array_equal(m.precondition("DILU", src, transpose=True), S.precondition("DILU", src, transpose=True)[0])
+    assert np.array_equal(m.smooth("GaussSeidel", p["psi"], src, 1), S.smooth("GaussSeidel", p["psi"], src, 1))
+    assert np.array_equal(m.smooth("GaussSeidel", p["psi"], src, 2), S.smooth("GaussSeidel", p["psi"], src, 2))
+    assert ctx.fallback_count() == 0
+
+
+def test_asymmetric_solves_by_history_at_full_size(full_asym, oracle):
+    """the benchmark's own legs: 19 PBiCG/DILU iterations and 20 smoothSolver sweeps, residual history against the oracle.
+    smoothSolver: |h_gpu - h_ref| <= 1e-6 h_ref + 1e-12.  PBiCG: the first 8 iterations to the same
+    bar, the rest to 2e-5 - the only difference between the two runs is the order in which the 10 M products of a
+    gSumProd are added (tree on the device, sequential in the reference: ~1e-13 relative per sum), and the BiCG
+    recurrence amplifies it where the residual climbs again (iterations 9-14 of this matrix: 3.5e-5 -> 1.4e-4);
+    measured 2.5e-6 at the worst of the 21 values."""
+    p, a, m, ctx = full_asym
+    S = oracle.System(p)
+    kw = dict(tolerance=0.0, relTol=0.0, maxIter=19)
+    x, perf = m.solve(p["psi"], p["source"], solver="PBiCG", preconditioner="DILU", **kw)
+    xo, po = S.solve(p["psi"], p["source"], solver="PBiCG", precond="DILU", **kw)
+    assert perf["nIterations"] == po["nIterations"] == 20
+    np.testing.assert_allclose(perf["history"][:9], po["history"][:9], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(perf["history"], po["history"], rtol=2e-5, atol=1e-12)
+    assert np.max(np.abs(x - xo)) <= 1e-6 * np.max(np.abs(xo))
+    kw = dict(solver="smoothSolver", smoother="GaussSeidel", nSweeps=1, tolerance=0.0, relTol=0.0, maxIter=20)
+    x, perf = m.solve(p["psi"], p["source"], **kw)
+    xo, po = S.solve(p["psi"], p["source"], **kw)
+    assert perf["nIterations"] == po["nIterations"] == 20
+    np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(x - xo)) <= 1e-8 * np.max(np.abs(xo))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # BASELINE config C5 at its stated size: interFoam damBreak refined to ~4 M cells (blockMeshDict:49-53 x 42^2), 2-D,
 # two-phase coefficient jump 1000.  The worst case for every sweep engine: ~4000 dependency levels of <= 2000 rows.
 @pytest.fixture(scope="module")

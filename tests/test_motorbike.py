@@ -1,0 +1,107 @@
+"""The REAL motorBike meshes: made by the reference's own blockMesh + snappyHexMesh
+from the reference's motorBike.obj (oracle/build_ref_mesh.sh, oracle/motorbike_case.py, tools/make_motorbike.py), stored
+under oracle/_ref/motorbike/ (not in git; the tests skip where the files are absent).
+
+CPU: the compact form loads, the matrix is a symmetric M-matrix in upper-triangular order, the oracle's GAMG converges on it.
+GPU (-m gpu): the HIP path against the oracle on the tutorial-size mesh (321 k cells) and the 1.7 M-cell mesh - Amul,
+residual, GaussSeidel, DIC bit for bit, GAMG and PCG histories - in snappyHexMesh's own numbering and under
+Foam::bandCompression; the product's device geometry (ldu_mesh_geometry) on the stored polyMesh against the geometry
+the mesh was verified with."""
+import numpy as np
+import pytest
+
+from openfoam_amd import capi, cases, motorbike
+
+GAMG = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10, mergeLevels=1,
+            tolerance=1e-7, relTol=0.01)
+
+
+def _need(name):
+    if not motorbike.available(name):
+        pytest.skip("oracle/_ref/motorbike/%s.npz not present (tools/make_motorbike.py makes it where /root/reference exists)" % name)
+
+
+def test_compact_form_and_matrix():
+    _need("mbtut")
+    m = motorbike.load("mbtut")
+    l, u = m["lowerAddr"], m["upperAddr"]
+    assert m["meta"]["nCells"] == m["nCells"] == 321362 and l.size == 960833
+    assert np.all(l < u) and np.all(np.diff(l.astype(np.int64) * m["nCells"] + u) > 0)      # upper-triangular order
+    assert np.abs(m["level"][l].astype(int) - m["level"][u]).max() == 1                      # 2:1 balance
+    assert np.bincount(m["level"]).tolist() == m["meta"]["cells_per_level"]
+    p = motorbike.problem(m=m)
+    assert np.all(p["upper"] < 0) and np.all(p["diag"] > 0)
+    rowsum = p["diag"] + np.bincount(l, weights=p["upper"], minlength=p["nCells"]) + np.bincount(u, weights=p["upper"], minlength=p["nCells"])
+    assert rowsum.min() > -1e-9 and (rowsum > 1e-9).sum() == np.unique(m["outletCells"]).size   # only the outlet pins the level
+
+
+def test_oracle_gamg_on_the_real_mesh(oracle):
+    _need("mbtut")
+    p = motorbike.problem("mbtut")
+    x, perf = oracle.System(p).solve(p["psi"], p["source"], **GAMG)
+    assert perf["converged"] and 2 <= perf["nIterations"] <= 8
+    assert np.all(np.diff(perf["history"]) < 0)
+
+
+def _renumber(p):
+    order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+    nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+    return cases.renumbered(p, order, fmap, flip, nl, nu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rcm", [("mbtut", False), ("mbtut", True), ("mb2", False), ("mb2", True)])
+def test_hip_path_against_the_oracle(oracle, name, rcm):
+    _need(name)
+    p = motorbike.problem(name)
+    p.pop("cellLevel"); p.pop("meta")
+    if rcm:
+        p = _renumber(p)
+    S = oracle.System(p)
+    ctx = capi.Context(0)
+    a, m = capi.from_problem(ctx, p)
+    rng = np.random.RandomState(3)
+    x, b = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+    assert np.array_equal(m.Amul(x), S.Amul(x))
+    assert np.array_equal(m.residual(x, b), S.residual(x, b))
+    for k in (1, 2, 4):
+        assert np.array_equal(m.smooth("GaussSeidel", x, b, k), S.smooth("GaussSeidel", x, b, k)), k
+    assert np.array_equal(m.precondition("DIC", b), S.precondition("DIC", b)[0])
+    xg, pg = m.solve(p["psi"], p["source"], **GAMG)
+    xo, po = S.solve(p["psi"], p["source"], **GAMG)
+    assert pg["nIterations"] == po["nIterations"]
+    np.testing.assert_allclose(pg["history"], po["history"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(xg - xo)) <= 1e-8 * np.max(np.abs(xo))
+    kw = dict(solver="PCG", preconditioner="DIC", tolerance=0.0, relTol=0.0, maxIter=20)
+    xp, pp = m.solve(p["psi"], p["source"], **kw)
+    xq, pq = S.solve(p["psi"], p["source"], solver="PCG", precond="DIC", tolerance=0.0, relTol=0.0, maxIter=20)
+    np.testing.assert_allclose(pp["history"], pq["history"], rtol=1e-6, atol=1e-12)
+    assert ctx.fallback_count() == 0
+    m.close(); a.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_geometry_on_the_real_polymesh():
+    """points / faces / owner / neighbour of the tutorial-size snappyHexMesh mesh (faces of 4 ... 8 points) through the
+    product's mesh kernels: volumes and face areas equal to the numpy evaluation of the same reference formulas the mesh
+    was verified with (tools/make_motorbike.py), cells are cubes of their level"""
+    import os
+    f = os.path.join(motorbike.STORE, "mbtut_polymesh.npz")
+    if not os.path.exists(f):
+        pytest.skip("mbtut_polymesh.npz not present")
+    z = np.load(f)
+    m = motorbike.load("mbtut")
+    ctx = capi.Context(0)
+    nC = m["nCells"]
+    Cf, Sf, C, V = capi.mesh_geometry(ctx, z["points"], z["faceStart"], z["facePoints"], z["owner"], z["neighbour"], nC)
+    magSf = np.sqrt((Sf * Sf).sum(axis=1))
+    np.testing.assert_allclose(V, z["V"], rtol=1e-12)
+    np.testing.assert_allclose(magSf, z["magSf"], rtol=1e-12)
+    h = m["h0"] / (1 << m["level"].astype(np.int64))
+    np.testing.assert_allclose(V, h ** 3, rtol=1e-11)
+    w, delta, ms = capi.mesh_interpolation_factors(ctx, z["owner"], z["neighbour"], Cf, Sf, C)
+    nI = z["neighbour"].size
+    l, u = z["owner"][:nI], z["neighbour"]
+    same = m["level"][l] == m["level"][u]
+    np.testing.assert_allclose(w[same], 0.5, rtol=1e-12)            # equal cubes: linear weights 1/2
+    ctx.close()

@@ -54,11 +54,14 @@ def test_simplefoam_through_the_plugin(tag, psolver, tmp_path):
     worst, off = 0.0, 0
     for got, ref in zip(lines, gold):
         assert got[0] == ref[0] and got[1] == ref[1], (got, ref)
-        assert abs(got[4] - ref[4]) <= max(1, ref[4] // 50), (got, ref)
+        # the stated tolerance of the application-level comparison: an iteration count may differ by
+        # at most 3 (a residual landing on the relTol threshold of a 170-270 iteration PCG solve), on at most 2 % of the
+        # solver lines; with GAMG for p every line is equal
+        assert abs(got[4] - ref[4]) <= (3 if tag != "gamg" else 0), (got, ref)
         off += int(got[4] != ref[4])
         assert abs(got[2] - ref[2]) <= 1e-3 * abs(ref[2]) + 1e-9, (got, ref)
         if ref[2]:
             worst = max(worst, abs(got[2] - ref[2]) / abs(ref[2]))
     print("simpleFoam pitzDaily through the plugin (%s): %d solver lines, %d with a different iteration count, worst relative "
           "difference of an initial residual %.2e" % (tag or "pcg", len(lines), off, worst))
-    assert off <= len(lines) // 20
+    assert off <= len(lines) // 50
