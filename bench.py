@@ -650,27 +650,41 @@ def main():
         except Exception as e:  # pragma: no cover
             cpu_all = dict(error=str(e)[:300], cores=cores)
 
-    # the octree twin of the motorBike mesh next to the headline (its own process: own context, own memory), so that the
-    # recorded line also says what an unstructured mesh of the metric's size gets
+    # the REAL motorBike mesh next to the headline (the 216^3 box is C3's primary input, the real
+    # snappyHexMesh mesh its "next"): its own processes (own context, own memory), in snappyHexMesh's cell numbering and
+    # renumbered by Foam::bandCompression.  Where the stored mesh is absent the analytic octree twin runs instead.
+    motorbike_leg = None
     octree_leg = None
     fallbacks_main = ctx.fallback_count()
     mem_in_use_gb = round((lambda fr, tot: (tot - fr) / 1e9)(*torch.cuda.mem_get_info()), 2)
     if rank == 0 and world == 1 and args.mesh == "box" and not args.no_extras and args.rank_of <= 1:
-        try:
-            import subprocess
-            mat.close(); addr.close(); ctx.close()
-            mat = addr = ctx = None
-            torch.cuda.empty_cache()
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mesh", "octree", "--no-cpu", "--no-extras",
-                                "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+        import subprocess
+        from openfoam_amd import motorbike as _mb
+        mat.close(); addr.close(); ctx.close()
+        mat = addr = ctx = None
+        torch.cuda.empty_cache()
+
+        def leg(mesh, extra=()):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mesh", mesh, "--no-extras", "--steps", "3",
+                                "--warmup", "1"] + list(extra), capture_output=True, text=True, timeout=900)
             oj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            octree_leg = dict(vcycles_per_s=oj["value"], ms_per_step=oj["ms_per_step"], workload=oj["config"]["workload"],
-                              vcycles_per_solve=oj["config"]["vcycles_per_solve"],
-                              finest_launch_ms=oj["roofline"]["avg_launch_ms"], roofline_frac=oj["roofline"]["frac"],
-                              roofline_vcycle_frac=oj["roofline_vcycle"]["frac"],
-                              engine_fallbacks=oj["config"]["engine_fallbacks"])
+            return dict(vcycles_per_s=oj["value"], ms_per_step=oj["ms_per_step"], workload=oj["config"]["workload"],
+                        vcycles_per_solve=oj["config"]["vcycles_per_solve"],
+                        dependency_levels_finest=oj["config"]["dependency_levels_finest"],
+                        finest_launch_ms=oj["roofline"]["avg_launch_ms"], roofline_frac=oj["roofline"]["frac"],
+                        roofline_kernel=oj["roofline"]["kernel"], roofline_vcycle_frac=oj["roofline_vcycle"]["frac"],
+                        amul_frac=(oj.get("amul") or {}).get("frac"),
+                        engine_fallbacks=oj["config"]["engine_fallbacks"], cpu_baseline=oj.get("cpu_baseline"),
+                        first_solve_s=oj["extra"]["first_solve_s"], residual_history=oj["extra"]["residual_history"])
+        try:
+            if _mb.available(args.motorbike_name):
+                motorbike_leg = dict(snappyHexMesh_numbering=leg("motorbike", ["--motorbike-name", args.motorbike_name]),
+                                     bandCompression_numbering=leg("motorbike_rcm", ["--motorbike-name", args.motorbike_name,
+                                                                                     "--no-cpu"]))
+            else:
+                octree_leg = leg("octree", ["--no-cpu"])
         except Exception as e:  # pragma: no cover
-            octree_leg = dict(error=str(e)[:300])
+            motorbike_leg = dict(error=str(e)[:300])
 
     if rank == 0 and args.rank_of > 1:
         # a projection, not a measurement of N GPUs: its own line shape so that nobody mistakes it for the metric
@@ -756,6 +770,7 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "amul": amul,
+            "motorbike": motorbike_leg,
             "octree_twin": octree_leg,
             "extra": dict(extra, device_memory_in_use_GB=mem_in_use_gb,
                           first_solve_s=round(t_first, 3), addressing_setup_s=round(t_addr, 3),

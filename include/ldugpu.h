@@ -86,7 +86,13 @@ int ldu_ctx_set_spin_limit(ldu_ctx* ctx, uint32_t polls);
  * that has waited longer than budgetMs (wall clock; default 200, 0 = no time bound) gives up, the sweep drains and the
  * operation is re-run on the level-kernel engine (ldu_ctx_fallback_count counts) - a launch that crawls cannot stall a
  * solve.  debugStallMs > 0 (tests only) makes the wave that runs the first task of every sweep launch sit still for
- * that long.  Process-wide like the spin limit (one device variable per kernel file). */
+ * that long.  The value is a device variable per kernel file: it applies to every context ON THE DEVICE OF `ctx` (a
+ * process that drives several devices sets it once per device).  A context whose fast engines gave up three operations
+ * in a row (a GPU shared with other processes, a profiler or a debugger can push healthy launches past the budget) keeps
+ * the level-kernel engine from then on instead of paying the failed attempt and the re-run on every operation.
+ * Multi-rank contract: ldu_smooth, ldu_precondition, ldu_solve and the scalar read-backs max-reduce the abort flag over
+ * the ranks before reading it, i.e. they are COLLECTIVE - every rank of the communicator must make the same sequence of
+ * these calls (as every rank of an OpenFOAM run does), a rank that skips one stalls the others. */
 int ldu_ctx_set_watchdog(ldu_ctx* ctx, double budgetMs, double debugStallMs);
 /* communication counters of a context since its creation: out[0] halo exchanges with other ranks (initMatrixInterfaces),
  * [1] scalar all-reduces (reduce(..., sumOp)), [2] device-to-host read-backs of solver scalars (one per convergence

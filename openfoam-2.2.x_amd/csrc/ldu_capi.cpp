@@ -86,6 +86,8 @@ void ldu_default_controls(ldu_controls* c)
 
 // ---------------------------------------------------------------- context
 
+static int ctx_init(ldu_ctx* c, int device);
+
 int ldu_ctx_create(ldu_ctx** out, int device)
 {
     int n = 0;
@@ -97,6 +99,20 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     LDU_CHECK_HIP(hipSetDevice(device));
     ldu_ctx* c = new ldu_ctx();
     c->device = device;
+    const int rc = ctx_init(c, device);
+    if (rc)
+    {
+        const std::string why = ldu_last_error_string();
+        ldu_ctx_destroy(c);          // (every member is null-safe there: nothing of a half-built context leaks)
+        ldu_set_error(why);
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+static int ctx_init(ldu_ctx* c, int device)
+{
     LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
@@ -197,7 +213,6 @@ int ldu_ctx_create(ldu_ctx** out, int device)
     if (e && (k_set_spin_limit((unsigned)strtoul(e, nullptr, 10)) || k_cluster_set_spin_limit((unsigned)strtoul(e, nullptr, 10))))
         return -1;
     if (c->sweepP2P && c->p2pSlabs != 0 && k_xcd_census(c)) return -1;
-    *out = c;
     return 0;
 }
 
@@ -205,19 +220,19 @@ int ldu_ctx_destroy(ldu_ctx* c)
 {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     comm_destroy(c);
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_scalars);
     (void)hipHostFree(c->h_scalars);
-    (void)hipEventDestroy(c->evFork);
-    (void)hipEventDestroy(c->evJoin);
-    (void)hipStreamSynchronize(c->streamComm);
-    (void)hipEventDestroy(c->evPacked);
-    (void)hipEventDestroy(c->evHalo);
-    (void)hipStreamDestroy(c->streamComm);
-    (void)hipStreamDestroy(c->stream);
-    (void)hipStreamDestroy(c->stream2);
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+    if (c->streamComm) (void)hipStreamSynchronize(c->streamComm);
+    if (c->evPacked) (void)hipEventDestroy(c->evPacked);
+    if (c->evHalo) (void)hipEventDestroy(c->evHalo);
+    if (c->streamComm) (void)hipStreamDestroy(c->streamComm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
     return 0;
 }
@@ -712,6 +727,10 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
     NEED_COEFFS(m);
     return run_with_fallback(m, [&]() -> int {
         memset(perf, 0, sizeof(*perf));
+        // (the clock starts here in both cases, so that solveSeconds is comparable between host- and device-pointer calls:
+        //  it contains the level-matrix build either way)
+        LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+        const double t0 = now_s();
         // GAMG: the coarse matrices of this solve first (device work only), so that host vectors are uploaded meanwhile
         if (m->a->ctx->stageOverlap && (c->solver == LDU_SOLVER_GAMG || c->preconditioner == LDU_PRE_GAMG)
             && (!is_device_ptr(psi) || !is_device_ptr(source)))
@@ -721,7 +740,6 @@ int ldu_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* s
         double* b = S.in(source);
         if (!x || !b) return -1;
         LDU_CHECK_HIP(hipStreamSynchronize(S.s));
-        const double t0 = now_s();
         int rc = dev_solve(m, c, x, b, perf, resHistory);
         LDU_CHECK_HIP(hipStreamSynchronize(S.s));
         perf->solveSeconds = now_s() - t0;

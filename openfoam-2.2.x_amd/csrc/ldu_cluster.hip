@@ -1016,6 +1016,13 @@ int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, si
 
 // Build the cluster plans of several addressings at once (one host thread each): the greedy clustering is
 // sequential per addressing but the levels of a GAMG hierarchy are independent.
+// the cluster plan of ONE addressing, where the engine would consider it (callable from a set-up thread of its own)
+int k_cluster_build_one(ldu_addr* a)
+{
+    if (!a || a->cluster || !a->ctx->clusterEngine || !a->ctx->sweepP2P || a->nCells < a->ctx->clusterMinCells) return 0;
+    return cluster_build(a) < 0 ? -1 : 0;
+}
+
 int k_cluster_prebuild(const std::vector<ldu_addr*>& addrs)
 {
     std::vector<ldu_addr*> todo;

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <thread>
@@ -213,11 +214,16 @@ struct HostLevel {
 // pairGAMGAgglomerate.C:201-292.  Every rank runs this loop in lock-step: the stop criterion is
 // and-reduced over the ranks and the restrict maps are exchanged across the processor patches
 // at every pair level (GAMGAgglomerateLduAddressing.C:201-268).
+// levelReady(i): out[i] is final (no later pair level merges into it) - the caller starts that level's plan while the next
+// levels are still being paired (out never reallocates: capacity is reserved up front)
 static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fineWeights,
-                           int nCellsInCoarsestLevel, int mergeLevels, std::vector<HostLevel>& out)
+                           int nCellsInCoarsestLevel, int mergeLevels, std::vector<HostLevel>& out,
+                           const std::function<void(size_t)>& levelReady)
 {
     ldu_ctx* ctx = fine->ctx;
     out.clear();
+    out.reserve(kMaxLevels);
+    size_t announced = 0;
     std::vector<double> w = fineWeights;
     int nPairLevels = 0;
     while ((int)out.size() < kMaxLevels - 1)
@@ -302,10 +308,14 @@ static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fine
         }
         else
         {
+            // a new level begins: everything before it is final
+            for (; announced < out.size(); announced++) levelReady(announced);
             out.push_back(std::move(L));
+            if (mergeLevels == 1) { levelReady(announced); announced++; }
         }
         nPairLevels++;
     }
+    for (; announced < out.size(); announced++) levelReady(announced);
     return 0;
 }
 
@@ -413,11 +423,44 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             }
             w = a->faceWeights;
         }
+        const bool verbose = getenv("LDU_VERBOSE") != nullptr;
+        const auto tSetup0 = std::chrono::steady_clock::now();
+        auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tSetup0).count(); };
         std::vector<HostLevel> hl;
-        if (agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl))
-        {
-            return -1;
-        }
+        const bool parallelPlans = !getenv("LDU_NO_PARALLEL_PLANS");
+        // The level plans (dependency levels, sliced-ELL tables) are independent of each other and of the pairing of the
+        // levels below them: each starts on its own host thread the moment its level's addressing is final, while
+        // agglomerate_all goes on pairing the next level (round 3 paired all levels first: 0.7 s of the 216^3 set-up
+        // with nothing else running).
+        g->levels.resize(kMaxLevels);
+        std::vector<int> rcs(kMaxLevels, 0);
+        std::vector<std::string> errs(kMaxLevels);
+        std::vector<std::thread> th;
+        const bool prebuild = parallelPlans && !getenv("LDU_NO_CLUSTER_PREBUILD");
+        int rcFinest = 0;
+        std::string errFinest;
+        if (prebuild)   // the finest level's cluster plan (the longest single piece, 1.4 s at 216^3) beside everything else
+            th.emplace_back([&]() {
+                if (hipSetDevice(a->ctx->device) != hipSuccess) { rcFinest = -1; errFinest = "hipSetDevice failed"; return; }
+                rcFinest = k_cluster_build_one(a);
+                if (rcFinest) errFinest = ldu_last_error_string();
+            });
+        auto levelReady = [&](size_t i) {
+            if (!parallelPlans) return;
+            th.emplace_back([&, i]() {
+                if (hipSetDevice(a->ctx->device) != hipSuccess) { rcs[i] = -1; errs[i] = "hipSetDevice failed"; return; }
+                rcs[i] = addr_create_internal(a->ctx, &g->levels[i].addr, hl[i].nCells, (int)hl[i].lower.size(),
+                                              hl[i].lower.data(), hl[i].upper.data());
+                // the cluster plan of the level right behind its level plan, on the same thread
+                if (!rcs[i] && prebuild && hl[i].patches.empty()) rcs[i] = k_cluster_build_one(g->levels[i].addr);
+                if (rcs[i]) errs[i] = ldu_last_error_string();
+            });
+        };
+        const int rcAgg = agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl, levelReady);
+        const double tAgg = since();
+        for (auto& t : th) t.join();
+        g->levels.resize(hl.size());
+        if (rcAgg) return -1;
         if (hl.empty())
         {
             // GAMGSolver.C:108-126
@@ -425,25 +468,10 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                           "nCellsInCoarsestLevel too large.");
             return -8;
         }
-        g->levels.resize(hl.size());
-        const bool parallelPlans = !getenv("LDU_NO_PARALLEL_PLANS");
-        if (parallelPlans)
-        {
-            // the level plans (dependency levels, sliced-ELL tables) are independent: one host thread each
-            std::vector<int> rcs(hl.size(), 0);
-            std::vector<std::string> errs(hl.size());
-            std::vector<std::thread> th;
-            for (size_t i = 0; i < hl.size(); i++)
-                th.emplace_back([&, i]() {
-                    if (hipSetDevice(a->ctx->device) != hipSuccess) { rcs[i] = -1; errs[i] = "hipSetDevice failed"; return; }
-                    rcs[i] = addr_create_internal(a->ctx, &g->levels[i].addr, hl[i].nCells, (int)hl[i].lower.size(),
-                                                  hl[i].lower.data(), hl[i].upper.data());
-                    if (rcs[i]) errs[i] = ldu_last_error_string();
-                });
-            for (auto& t : th) t.join();
-            for (size_t i = 0; i < hl.size(); i++)
-                if (rcs[i]) { ldu_set_error("GAMG level plan: " + errs[i]); return -1; }
-        }
+        for (size_t i = 0; i < hl.size(); i++)
+            if (rcs[i]) { ldu_set_error("GAMG level plan: " + errs[i]); return -1; }
+        if (rcFinest) { ldu_set_error("cluster plan: " + errFinest); return -1; }
+        const double tPlans = since();
         const ldu_addr* fineA = a;
         for (size_t i = 0; i < hl.size(); i++)
         {
@@ -482,12 +510,32 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 if (up(&L.d_pcStart, pcStart) || up(&L.d_pcFine, pcFine)) return -1;
             }
             if (matrix_alloc(L.addr, &L.mat)) return -1;
-            if (build_level_maps(L, fineA)) return -1;
             if (getenv("LDU_VERBOSE"))
                 fprintf(stderr, "[ldugpu] GAMG level %2zu: %9d cells %9d faces  %5d dependency levels  %7d slices\n",
                         i + 1, L.addr->nCells, L.addr->nFaces, L.addr->nLevels, L.addr->nSlices);
             fineA = L.addr;
         }
+        {
+            // restriction / prolongation / coefficient-agglomeration maps: independent per level (each needs its own and the
+            // finer level's plan only), one host thread each (0.6 s one after the other at 216^3)
+            std::vector<int> mrc(hl.size(), 0);
+            std::vector<std::string> merr(hl.size());
+            std::vector<std::thread> mth;
+            for (size_t i = 0; i < hl.size(); i++)
+            {
+                const ldu_addr* fa = i == 0 ? a : g->levels[i - 1].addr;
+                auto job = [&, i, fa]() {
+                    if (hipSetDevice(a->ctx->device) != hipSuccess) { mrc[i] = -1; merr[i] = "hipSetDevice failed"; return; }
+                    mrc[i] = build_level_maps(g->levels[i], fa);
+                    if (mrc[i]) merr[i] = ldu_last_error_string();
+                };
+                if (parallelPlans) mth.emplace_back(job); else job();
+            }
+            for (auto& t : mth) t.join();
+            for (size_t i = 0; i < hl.size(); i++)
+                if (mrc[i]) { ldu_set_error("GAMG level maps: " + merr[i]); return -1; }
+        }
+        const double tMaps = since();
         if (!getenv("LDU_NO_CLUSTER_PREBUILD"))
         {
             // the cluster plans of the large levels (and of the finest matrix), one host thread each
@@ -495,6 +543,9 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             for (auto& L : g->levels) big.push_back(L.addr);
             if (k_cluster_prebuild(big)) return -1;
         }
+        if (verbose)
+            fprintf(stderr, "[ldugpu] GAMG set-up: pairing %.3f s, level plans done at %.3f s, level maps at %.3f s, cluster plans "
+                            "at %.3f s (%zu levels)\n", tAgg, tPlans, tMaps, since(), hl.size());
         const size_t n = (size_t)a->nCells + 1;
         LDU_CHECK_HIP(hipMalloc((void**)&g->d_Apsi, sizeof(double) * n));
         LDU_CHECK_HIP(hipMalloc((void**)&g->d_finestCorr, sizeof(double) * n));

@@ -112,6 +112,7 @@ struct ldu_ctx {
     int p2pGen = 0;                  // bumped when a sweep aborted: addressings reset their tickets
     int abortSeen = 0;               // an aborted sweep was detected since run_with_fallback() cleared this
     long nFallbacks = 0;             // operations re-run on the level-kernel engine after an aborted sweep
+    int consecFallbacks = 0;         // ... in a row (three: the context stays on the level kernels)
     // communicator
     int rank = 0, nRanks = 1;
     ldu_comm_impl* comm = nullptr;
@@ -362,7 +363,8 @@ int k_sweep(ldu_addr* a, const SweepArgs& args);
 int k_set_p2p_sleep(int n);
 int k_xcd_census(ldu_ctx* ctx);
 int k_sweep_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s);   // 1 = not taken
-int k_cluster_prebuild(const std::vector<ldu_addr*>& addrs);            // cluster plans of several addressings, in parallel
+int k_cluster_prebuild(const std::vector<ldu_addr*>& addrs);
+int k_cluster_build_one(ldu_addr* a);                                   // one addressing (own set-up thread)            // cluster plans of several addressings, in parallel
 std::string ldu_last_error_string();
 int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, size_t stride, const double* scale,
                          const double* val, int lane, hipStream_t s);   // three component planes at once; 1 = not taken
@@ -509,11 +511,20 @@ static inline int run_with_fallback(ldu_matrix* m, F&& op)
     ldu_ctx* ctx = m->a->ctx;
     ctx->abortSeen = 0;
     int rc = op();
-    if (!ctx->abortSeen) return rc;
+    if (!ctx->abortSeen) { ctx->consecFallbacks = 0; return rc; }
     if (fallback_prepare(m)) return -1;
     const int p2p = ctx->sweepP2P;
     ctx->sweepP2P = 0;
     rc = op();
+    // a context whose fast engines gave up three operations in a row (a GPU shared with other processes, a profiler, a
+    // debugger: healthy launches that exceed the wait budget) stays on the level kernels instead of paying the failed
+    // attempt, the cache drop and the re-run on every operation
+    if (++ctx->consecFallbacks >= 3 && p2p)
+    {
+        fprintf(stderr, "[ldugpu] warning: three consecutive operations exceeded the dependency-wait budget; this context "
+                        "keeps the level-kernel engine from now on (LDU_WATCHDOG_MS / ldu_ctx_set_watchdog raise the budget)\n");
+        return rc;
+    }
     ctx->sweepP2P = p2p;
     return rc;
 }

@@ -2291,7 +2291,8 @@ template <int W, int NW>
 static int launch_gs_small_pipe(ldu_addr* a, const SliceTab& T, size_t lds, double* psi, const double* rhs,
                                 const double* diag, const double* val)
 {
-    static bool attrSet = false;
+    static bool attrSetDev[64] = {false};   // (the attribute is per device: one flag per device ordinal)
+    bool& attrSet = attrSetDev[a->ctx->device & 63];
     if (!attrSet)
     {
         LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_small_pipe_kernel<W, NW>,
@@ -2321,7 +2322,8 @@ template <int W>
 static int launch_gs_small(ldu_addr* a, const SliceTab& T, size_t lds, int k, double* psi, const double* rhs,
                            const double* diag, const double* val)
 {
-    static bool attrSet = false;
+    static bool attrSetDev[64] = {false};   // (the attribute is per device: one flag per device ordinal)
+    bool& attrSet = attrSetDev[a->ctx->device & 63];
     if (!attrSet)
     {
         LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_small_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2592,7 +2594,8 @@ template <int NW>
 static int launch_gs_wg(ldu_addr* a, const ldu_addr::WgTasks& W, size_t lds, double* psi, const double* rhs, const double* diag,
                         const double* val)
 {
-    static bool attrSet = false;
+    static bool attrSetDev[64] = {false};   // (the attribute is per device: one flag per device ordinal)
+    bool& attrSet = attrSetDev[a->ctx->device & 63];
     if (!attrSet)
     {
         LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_wg_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_MAX_LDS));

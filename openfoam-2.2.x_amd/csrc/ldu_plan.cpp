@@ -258,8 +258,10 @@ int plan_build(ldu_addr* a)
         }
     }
 
-    // XCD slabs (see choose_slabs); rowSlab is monotone in the original cell index, hence
-    // non-decreasing inside a level
+    // XCD slabs (see choose_slabs): contiguous ranges of the ORIGINAL cell index.  Inside a level the rows are ordered by
+    // (width class, lag bucket) first and by original index only within such a group, so rowSlab is non-decreasing inside a
+    // (level, class, bucket) group, not inside the level: slices are cut wherever it changes (below), and on multi-slab
+    // levels every group fragments at the slab boundaries
     std::vector<int> slabCell;
     const int S = choose_slabs(a, slabCell);
     a->nSlabs = S;

@@ -55,8 +55,15 @@ int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
 int dev_check_abort(ldu_ctx* ctx)
 {
     if (comm_allreduce_abort(ctx, ctx->stream)) return -1;
-    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_abort, ctx->d_abort, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_abort, ctx->d_abort, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_abort[1])
+    {
+        (void)hipMemsetAsync(ctx->d_abort + 1, 0, sizeof(int), ctx->stream);
+        ctx->h_abort[1] = 0;
+        ldu_set_error("directSolveCoarsest: singular coarsest-level matrix");
+        return -17;
+    }
     if (*ctx->h_abort)
     {
         (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), ctx->stream);
@@ -76,8 +83,8 @@ int fallback_prepare(ldu_matrix* m)
     if (ctx->streamComm) LDU_CHECK_HIP(hipStreamSynchronize(ctx->streamComm));   // a halo exchange of the failed attempt
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->haloInFlight = false;
-    LDU_CHECK_HIP(hipMemset(ctx->d_abort, 0, sizeof(int)));
-    *ctx->h_abort = 0;
+    LDU_CHECK_HIP(hipMemset(ctx->d_abort, 0, 2 * sizeof(int)));   // the abort flag and the singular flag behind it
+    ctx->h_abort[0] = ctx->h_abort[1] = 0;
     ctx->dualActive = 0;
     ctx->sb = 0;
     ctx->abortSeen = 0;

@@ -169,3 +169,70 @@ def test_pairing_rule_with_several_patches_per_rank_pair():
     assert capi.comm_paired_patch(a, 3, [5, 6], 0) == -1     # rank 3 lists no patch towards rank 0: unpaired
     # exchange order: patches with faces that are not cyclic, ascending
     assert capi.comm_exchange_order([5, 0, 3, 7], [-1, -1, 3, -1]).tolist() == [0, 3]
+
+
+def _oob_worker(rank, world, port, out):
+    """the out-of-band exchange the peer-store backend uses for its set-up messages (capi.oob_torch: isend / irecv of
+    byte blobs over gloo) + the weak-scaling block generator: every rank builds its own block and checks through the
+    exchange that both sides of every cut face computed the same coefficient"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest  # noqa: F401
+    from openfoam_amd import capi, cases
+    ex = capi.oob_torch()
+    # 1. blobs of different sizes to every other rank (what ldu_ctx_comm_init_peer does with the window handles)
+    peers = [r for r in range(world) if r != rank]
+    got = ex(peers, [bytes([rank]) * (10 + p) for p in peers], [10 + rank] * len(peers))
+    ok = all(g == bytes([p]) * (10 + rank) for p, g in zip(peers, got))
+    # 2. the patch coefficients of the blocks, pairwise (what comm_peer_setup_addr / comm_exchange_ints do per neighbour)
+    shape = {2: (1, 1, 2), 4: (1, 2, 2)}[world]
+    sp = cases.box3d_block(5, shape, rank)
+    nb = [q["nbrRank"] for q in sp["patches"]]
+    send = [q["bouCoeffs"].tobytes() for q in sp["patches"]]
+    recv = ex(nb, send, [len(s) for s in send])
+    same = all(np.array_equal(np.frombuffer(r, dtype=np.float64), q["bouCoeffs"]) for r, q in zip(recv, sp["patches"]))
+    out[rank] = (ok, same, len(nb))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_out_of_band_exchange_and_block_generator(world):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29950 + (os.getpid() % 40) + world
+    mp.spawn(_oob_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        ok, same, n = out[r]
+        assert ok and same and n >= 1, (r, out[r])
+
+
+def test_weak_scaling_blocks_assemble_to_one_symmetric_operator():
+    """cases.box3d_block: the 8 blocks of a 2 x 2 x 2 decomposition assemble (diag + internal faces + patch coefficients) to a
+    symmetric matrix whose A x* is the concatenated source - without ever building the global matrix on a rank"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from openfoam_amd import cases
+    n, blocks = 5, (2, 2, 2)
+    subs = [cases.box3d_block(n, blocks, r) for r in range(8)]
+    NX = NY = NZ = 2 * n
+
+    def gid(r):
+        bi, bj, bk = r % 2, (r // 2) % 2, r // 4
+        c = np.arange(n ** 3)
+        i, j, k = c % n, (c // n) % n, c // (n * n)
+        return (bi * n + i) + NX * ((bj * n + j) + NY * (bk * n + k))
+    nC = NX * NY * NZ
+    A = np.zeros((nC, nC)); b = np.zeros(nC)
+    for r, s in enumerate(subs):
+        g = gid(r)
+        A[g, g] += s["diag"]
+        A[g[s["lowerAddr"]], g[s["upperAddr"]]] += s["upper"]
+        A[g[s["upperAddr"]], g[s["lowerAddr"]]] += s["upper"]
+        b[g] = s["source"]
+        assert [q["nbrRank"] for q in s["patches"]] == sorted(q["nbrRank"] for q in s["patches"])
+        for q in s["patches"]:
+            q2 = [t for t in subs[q["nbrRank"]]["patches"] if t["nbrRank"] == r][0]
+            assert np.array_equal(q["bouCoeffs"], q2["bouCoeffs"])
+            A[g[q["faceCells"]], gid(q["nbrRank"])[q2["faceCells"]]] += -q["bouCoeffs"]
+    assert np.allclose(A, A.T)
+    assert np.abs(A @ np.sin(1e-3 * np.arange(nC)) - b).max() < 1e-12
