@@ -309,7 +309,8 @@ int comm_peer_setup_addr(ldu_addr* a)
         ldu_set_error("peer backend: window exhausted (LDU_PEER_WINDOW_MB, default 256)");
         return -5;
     }
-    const bool small = a->nCells <= LDU_COARSEST_MAXC && a->nFaces <= LDU_COARSEST_MAXF && nPF <= LDU_COARSEST_MAXP;
+    // kernel-private regions: coarsest-level candidates (<= 64 cells) and the levels of the one-workgroup engine
+    const bool small = a->nCells <= LDU_PEERK_MAXCELLS;
     if (small)
     {
         H->kWinBytes = H->winBytes;

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -56,7 +57,8 @@ struct GamgHierarchy {
     // distributed coarsest-level solve in one kernel per rank (ldu_coarsest.hip, peer-store backend): -1 = not decided yet
     // (decided collectively: an and-reduce of every rank's own eligibility), 0 / 1
     int coarsestPeer = -1;
-    int coarsestPeerEpoch = -1;          // ctx->commEpoch the decision belongs to (ldu_ctx_comm_select changes the carriers)
+    int coarsestPeerEpoch = -1;
+    int peerWgEpoch = -1;                // carrier epoch the levels' one-launch smoother decisions (ldu_addr::peerWg) belong to          // ctx->commEpoch the decision belongs to (ldu_ctx_comm_select changes the carriers)
     int* d_cycPair = nullptr;
 };
 
@@ -439,8 +441,15 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
         const bool prebuild = parallelPlans && !getenv("LDU_NO_CLUSTER_PREBUILD");
         int rcFinest = 0;
         std::string errFinest;
+        // cluster plans run on threads of their own (joined at the very end: nothing below needs them), so that the level
+        // maps can be built as soon as the level plans are there
+        std::vector<std::thread> cth;
+        std::mutex cthMu;
+        std::vector<int> crc(kMaxLevels, 0);
+        std::vector<std::string> cerr(kMaxLevels);
+        struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } joinClusters{cth};
         if (prebuild)   // the finest level's cluster plan (the longest single piece, 1.4 s at 216^3) beside everything else
-            th.emplace_back([&]() {
+            cth.emplace_back([&]() {
                 if (hipSetDevice(a->ctx->device) != hipSuccess) { rcFinest = -1; errFinest = "hipSetDevice failed"; return; }
                 rcFinest = k_cluster_build_one(a);
                 if (rcFinest) errFinest = ldu_last_error_string();
@@ -451,9 +460,17 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 if (hipSetDevice(a->ctx->device) != hipSuccess) { rcs[i] = -1; errs[i] = "hipSetDevice failed"; return; }
                 rcs[i] = addr_create_internal(a->ctx, &g->levels[i].addr, hl[i].nCells, (int)hl[i].lower.size(),
                                               hl[i].lower.data(), hl[i].upper.data());
-                // the cluster plan of the level right behind its level plan, on the same thread
-                if (!rcs[i] && prebuild && hl[i].patches.empty()) rcs[i] = k_cluster_build_one(g->levels[i].addr);
-                if (rcs[i]) errs[i] = ldu_last_error_string();
+                if (rcs[i]) { errs[i] = ldu_last_error_string(); return; }
+                // the cluster plan of the level right behind its level plan, on a thread of its own
+                if (prebuild && hl[i].patches.empty())
+                {
+                    std::lock_guard<std::mutex> lk(cthMu);
+                    cth.emplace_back([&, i]() {
+                        if (hipSetDevice(a->ctx->device) != hipSuccess) { crc[i] = -1; cerr[i] = "hipSetDevice failed"; return; }
+                        crc[i] = k_cluster_build_one(g->levels[i].addr);
+                        if (crc[i]) cerr[i] = ldu_last_error_string();
+                    });
+                }
             });
         };
         const int rcAgg = agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl, levelReady);
@@ -470,7 +487,6 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
         }
         for (size_t i = 0; i < hl.size(); i++)
             if (rcs[i]) { ldu_set_error("GAMG level plan: " + errs[i]); return -1; }
-        if (rcFinest) { ldu_set_error("cluster plan: " + errFinest); return -1; }
         const double tPlans = since();
         const ldu_addr* fineA = a;
         for (size_t i = 0; i < hl.size(); i++)
@@ -536,6 +552,13 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 if (mrc[i]) { ldu_set_error("GAMG level maps: " + merr[i]); return -1; }
         }
         const double tMaps = since();
+        {
+            std::lock_guard<std::mutex> lk(cthMu);     // (no plan thread is alive any more: the list is complete)
+            for (auto& t : cth) t.join();
+        }
+        for (size_t i = 0; i < hl.size(); i++)
+            if (crc[i]) { ldu_set_error("cluster plan: " + cerr[i]); return -1; }
+        if (rcFinest) { ldu_set_error("cluster plan: " + errFinest); return -1; }
         if (!getenv("LDU_NO_CLUSTER_PREBUILD"))
         {
             // the cluster plans of the large levels (and of the finest matrix), one host thread each
@@ -665,6 +688,41 @@ static int solve_coarsest(GamgHierarchy* g, ldu_matrix* A, const ldu_controls* c
     return rc;
 }
 
+// Which levels smooth with gs_wg_peer_kernel (k sweeps and their boundary exchanges in one launch): a launch that talks to
+// its neighbours must be taken by every rank or by none, so each level's own eligibility is and-reduced over the ranks -
+// here, where every rank passes with the same list of levels, not at the first use (a rank without coupled faces on a level
+// would never get there).  Repeated when the carriers of the context change (ldu_ctx_comm_select).
+static int gamg_decide_peer_smoothers(ldu_matrix* m)
+{
+    GamgHierarchy* g = m->gamg;
+    ldu_ctx* ctx = m->a->ctx;
+    if (g->peerWgEpoch == ctx->commEpoch) return 0;
+    g->peerWgEpoch = ctx->commEpoch;
+    if (!ctx->comm) return 0;
+    for (auto& L : g->levels)
+    {
+        ldu_addr* a = L.addr;
+        int ok = k_wg_peer_eligible(a) ? 1 : 0;
+        // (a rank without coupled faces on this level neither sends nor receives there: it does not veto)
+        if (!a->nPatchFaces) ok = 1;
+        if (comm_allreduce_min_int(ctx, &ok)) return -1;
+        a->peerWg = (ok && a->nPatchFaces) ? 1 : 0;
+        a->peerWgEpoch = ctx->commEpoch;
+        if (a->peerWg && !a->d_cycPair)
+        {
+            std::vector<int> cyc(a->nPatchFaces, -1);
+            for (auto& P : a->patches)
+                if (P.nbrPatch >= 0)
+                    for (int f = 0; f < P.n; f++) cyc[P.offset + f] = a->patches[P.nbrPatch].offset + f;
+            if (up(&a->d_cycPair, cyc)) return -1;
+        }
+        if (getenv("LDU_VERBOSE") && a->nPatchFaces)
+            fprintf(stderr, "[ldugpu] level of %d cells, %d coupled faces: GaussSeidel sweeps %s\n", a->nCells, a->nPatchFaces,
+                    a->peerWg ? "and their exchanges in one launch (peer stores)" : "one by one, exchange between them");
+    }
+    return 0;
+}
+
 // GAMGSolverSolve.C:120-364
 static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, double* Apsi,
                   double* finestCorrection, double* finestResidual)
@@ -675,6 +733,7 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
     const int coarsestLevel = (int)g->levels.size() - 1;
     const int scaleCorrection = c->scaleCorrection < 0 ? (m->sym ? 1 : 0) : c->scaleCorrection;
     auto& Lv = g->levels;
+    if (gamg_decide_peer_smoothers(m)) return -1;
 
     if (k_restrict(Lv[0].addr->nCells, Lv[0].d_childStart, Lv[0].d_child, finestResidual, Lv[0].d_src, s))
         return -1;

@@ -164,6 +164,7 @@ struct PeerHalo {
 #define LDU_COARSEST_MAXC 64
 #define LDU_COARSEST_MAXF 512
 #define LDU_COARSEST_MAXP 256
+#define LDU_PEERK_MAXCELLS 18000       // kernel-private window regions for addressings up to this size (one-workgroup engine)
 
 struct ldu_addr {
     ldu_ctx* ctx = nullptr;
@@ -221,6 +222,10 @@ struct ldu_addr {
     double* d_sendAll = nullptr;           // [nPatchFaces]
     double* d_recvAll = nullptr;           // [nPatchFaces]
     PeerHalo* peer = nullptr;              // peer-store backend only
+    // small patched level: the k sweeps of a smoothing and their exchanges in ONE launch (gs_wg_peer_kernel); the decision is
+    // collective (and-reduce over the ranks) and belongs to a carrier epoch of the context
+    int peerWg = -1, peerWgEpoch = -1;
+    int* d_cycPair = nullptr;              // [nPatchFaces] paired face of a cyclic face, -1 = remote (lazy)
 
     // point-to-point sweep state: one 16-byte {value lo, tag, value hi, tag} granule per row,
     // a chunk ticket counter and the launch epoch (= tag; never 0)
@@ -382,6 +387,10 @@ int k_coarsest_solve_peer(ldu_matrix* A, double tolerance, double relTol, int ma
                           const int* d_cycPair);   // ldu_coarsest.hip: the distributed solve in one kernel per rank; 1 = not taken
 bool k_coarsest_peer_eligible(ldu_matrix* A);   // directSolveCoarsest (ldu_coarsest.hip)
 int k_sweep_gs_wg(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
+int k_sweep_gs_wg_peer(ldu_addr* a, int k, double* psi, const double* source, const double* diag, const double* val,
+                       const double* bou, const int* d_cycPair);   // with coupled patches, k sweeps + exchanges in one launch; 1 = not taken
+bool k_wg_peer_eligible(ldu_addr* a);
+int k_set_peer_timeout_kernels(unsigned long long ticks);
 int k_sweep_gs_small(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);
 int k_set_p2p_backoff(unsigned n);
 int k_set_p2p_backoff_cap(unsigned n);

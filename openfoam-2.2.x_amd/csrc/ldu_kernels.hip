@@ -11,7 +11,7 @@
 #include <cmath>
 #include <algorithm>
 
-#include "ldu_internal.hpp"
+#include "ldu_peer_dev.hpp"
 
 #define BLK 256
 #define WPB (BLK / LDU_WAVE)   // waves per block
@@ -2590,6 +2590,191 @@ gs_wg_kernel(const unsigned char* __restrict__ nLv, const unsigned char* __restr
     for (int i = tid; i < nCells; i += LDU_WAVE * NW) psi[i] = x[i];
 }
 
+// GaussSeidel with processor patches on a small level, ALL k sweeps in one launch (peer-store backend): what the launch
+// needs to exchange the boundary values of every sweep itself (kernel-private window regions of the addressing, PeerHalo)
+struct WgPeer {
+    uint4* const* kdst;            // [2][nPF] (null: no remote faces)
+    const uint4* const* ksrc;
+    unsigned* kseq;
+    int nPF;
+    const int* pfCell;             // [nPF] row of the face's cell (plan numbering)
+    const int* cycPair;            // [nPF] paired face of a cyclic face, -1 = remote
+    const double* bou;             // [nPF] interfaceBouCoeffs
+    int nBRows;
+    const int* bRow; const int* bStart; const int* bFace;
+    const int* rowB;               // [nCells] row -> boundary row (-1)
+    int kSweeps;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(LDU_WAVE * NW)
+gs_wg_peer_kernel(WgPeer PS, const unsigned char* __restrict__ nLv, const unsigned char* __restrict__ nUv, const int* __restrict__ col,
+             const int4* __restrict__ tasks, int nTasks, int nCells, int* abortFlag, double* __restrict__ psi,
+             const double* __restrict__ rhs, const double* __restrict__ diag, const double* __restrict__ val)
+{
+    extern __shared__ double smem[];
+    double* x = smem;
+    unsigned char* stamp = (unsigned char*)(x + nCells);
+    double* bP = (double*)(stamp + ((nCells + 7) & ~7));      // [nBRows] this sweep's bPrime of the boundary rows
+    constexpr bool TRACE = false;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // the first records and rows are on their way while the vector moves into LDS
+    WgRow R0, R1, R2;
+    int4 Q;
+    int iNext = wave;
+#define WG_FILL(R)                                                                        \
+    do {                                                                                  \
+        wg_row_load(Q, lane, nLv, nUv, col, rhs, diag, val, (R));                         \
+        (R).j = sweep;                                                                    \
+        { const int sb_ = (R).r >= 0 ? PS.rowB[(R).r] : -1; if (sb_ >= 0) (R).b = bP[sb_]; } \
+        wg_rec_load(tasks, nTasks, iNext, Q);                                             \
+        iNext += NW;                                                                      \
+    } while (0)
+    for (int i = tid; i < nCells; i += LDU_WAVE * NW) { x[i] = psi[i]; stamp[i] = 0; }
+    unsigned hseq = PS.kseq ? *PS.kseq : 0u;
+    __syncthreads();
+    bool alive = true;
+    int left = 0;
+    for (int sweep = 0; sweep < PS.kSweeps; sweep++)
+    {
+    // ---- GaussSeidelSmoother.C:98-145 for this sweep: bPrime = source, the coupled boundaries Jacobi-style with negated
+    // coefficients, the neighbour values being the OTHER rank's psi after its previous sweep - stored into its window by
+    // that rank's workgroup right here (peer_store), polled from this rank's window (ldu_peer.hip's protocol, the
+    // sequence number kept on the device because the whole k-sweep smoothing is one launch)
+    {
+        ++hseq;
+        const size_t par = (size_t)(hseq & 1u) * PS.nPF;
+        for (int i = tid; i < PS.nPF; i += LDU_WAVE * NW)
+        {
+            uint4* d = PS.kdst ? PS.kdst[par + i] : nullptr;
+            if (d) peer_store(d, x[PS.pfCell[i]], hseq);
+        }
+        for (int jb = tid; jb < PS.nBRows; jb += LDU_WAVE * NW)
+        {
+            double acc = rhs[PS.bRow[jb]];
+            for (int t = PS.bStart[jb]; t < PS.bStart[jb + 1]; t++)
+            {
+                const int i = PS.bFace[t];
+                const int cp = PS.cycPair[i];
+                double pn = 0.0;
+                if (cp >= 0) pn = x[PS.pfCell[cp]];
+                else
+                {
+                    const uint4* sp = PS.ksrc[par + i];
+                    unsigned spins = 0;
+                    unsigned long long tw0 = 0;
+                    while (!peer_load(sp, hseq, pn))
+                    {
+                        if (peer_wait_expired(spins, tw0, abortFlag)) { *abortFlag = 1; pn = 0.0; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const double c = -PS.bou[i];
+                acc -= c * pn;
+            }
+            bP[jb] = acc;
+        }
+        __syncthreads();
+    }
+    iNext = wave;
+    wg_rec_load(tasks, nTasks, iNext, Q); iNext += NW;
+    WG_FILL(R0);
+    WG_FILL(R1);
+    left = (nTasks - wave + NW - 1) / NW;      // this wavefront's tasks
+    // (debug timeline, ldu_debug_gs_multi_trace: per task 8 x u64 = step start, loads issued, dependencies seen, stored
+    //  [100 MHz wall clock], wavefront, sweep)
+    unsigned long long* trc = TRACE && g_gsm_trace ? g_gsm_trace + (size_t)wave * 8 : nullptr;
+#define WG_TRC(k) do { if (TRACE && trc && lane == 0) trc[k] = wall_clock64(); } while (0)
+    // wait until the stamps of the N entries cc[] add up to `want` (every neighbour ready), then fetch their values
+#define WG_WAIT(N, cc, want, xv)                                                          \
+    do {                                                                                  \
+        unsigned spins = 0;                                                               \
+        unsigned long long tw0 = 0;                                                       \
+        while (alive)                                                                     \
+        {                                                                                 \
+            int st[N];                                                                    \
+            _Pragma("unroll") for (int q = 0; q < N; q++) st[q] = stamp[cc[q]];           \
+            int sum = 0;                                                                  \
+            _Pragma("unroll") for (int q = 0; q < N; q++) sum += st[q];                   \
+            if (__builtin_amdgcn_ballot_w64(have && sum != (want)) == 0ull) break;        \
+            /* (sixteen LDS reads per round already pace this loop; tighter polling - one watched byte, values fetched \
+               with the stamps - took the LDS and the issue slots from the wavefront everybody waits for: 2x slower) */ \
+            if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; alive = false; } \
+        }                                                                                 \
+        LDU_LDS_ACQUIRE();                                                                \
+        _Pragma("unroll") for (int q = 0; q < N; q++) xv[q] = x[cc[q]];                   \
+    } while (0)
+#define WG_STEP(CUR, FILL)                                                                \
+    do {                                                                                  \
+        WG_TRC(0);                                                                        \
+        WG_FILL(FILL);                                                                    \
+        WG_TRC(1);                                                                        \
+        const double rd_ = ldu_div_prepare((CUR).d);                                      \
+        {                                                                                 \
+            const bool have = (CUR).r >= 0;                                               \
+            const int self = have ? (CUR).r : 0;                                          \
+            const int nl = (CUR).nl, nn = have ? nl + (CUR).nn : 0, j = (CUR).j;          \
+            int cc[16];                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) cc[q] = q < nn ? (CUR).c[q] : self; \
+            /* (a lane without a row reads stamp 0 sixteen times over and does not vote) */ \
+            const int want = 16 * j + (nl < 16 ? nl : 16);                                \
+            double acc = (CUR).b;                                                         \
+            double xv[16], pr[16];                                                        \
+            WG_WAIT(16, cc, want, xv);                                                    \
+            WG_TRC(2);                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) asm volatile("" : "+v"(xv[q])); \
+            _Pragma("unroll") for (int q = 0; q < 16; q++)                                \
+                pr[q] = q < nn ? (CUR).v[q] * xv[q] : 0.0;                                \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) acc -= pr[q];                  \
+            if ((CUR).W > 16)                                                             \
+                for (int q0 = 16; q0 < (CUR).W; q0 += 8)                                  \
+                {                                                                         \
+                    int c8[8]; double v8[8];                                              \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++)                         \
+                    {                                                                     \
+                        const long e = (CUR).ent + (long)(q0 + q) * LDU_WAVE;             \
+                        c8[q] = col[e]; v8[q] = val[e];                                   \
+                    }                                                                     \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++) c8[q] = q0 + q < nn ? c8[q] : self; \
+                    const int lo = nl - q0 < 0 ? 0 : (nl - q0 > 8 ? 8 : nl - q0);         \
+                    const int want8 = 8 * j + lo;                                         \
+                    WG_WAIT(8, c8, want8, xv);                                            \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++)                         \
+                        pr[q] = q0 + q < nn ? v8[q] * xv[q] : 0.0;                        \
+                    _Pragma("unroll") for (int q = 0; q < 8; q++) acc -= pr[q];           \
+                }                                                                         \
+            if (have)                                                                     \
+            {                                                                             \
+                x[(CUR).r] = ldu_div(acc, (CUR).d, rd_);                                  \
+                /* release (LDS only): the value is in LDS before its stamp moves */      \
+                LDU_LDS_RELEASE();                                                        \
+                stamp[(CUR).r] = (unsigned char)(j + 1);                                  \
+            }                                                                             \
+        }                                                                                 \
+        LDU_STEP_FENCE();                                                                 \
+        if (TRACE && trc && lane == 0) { trc[3] = wall_clock64(); trc[4] = wave; trc[5] = (CUR).j; trc += (size_t)NW * 8; } \
+        --left;                                                                           \
+    } while (0)
+    while (left > 0)
+    {
+        WG_STEP(R0, R2);
+        if (left == 0) break;
+        WG_STEP(R1, R0);
+        if (left == 0) break;
+        WG_STEP(R2, R1);
+    }
+    __syncthreads();      // the sweep is complete in LDS before its boundary values travel / the next sweep's rows load
+    }
+#undef WG_STEP
+#undef WG_WAIT
+#undef WG_FILL
+#undef WG_TRC
+    if (tid == 0 && PS.kseq) *PS.kseq = hseq;
+    for (int i = tid; i < nCells; i += LDU_WAVE * NW) psi[i] = x[i];
+}
+
+
 template <int NW>
 static int launch_gs_wg(ldu_addr* a, const ldu_addr::WgTasks& W, size_t lds, double* psi, const double* rhs, const double* diag,
                         const double* val)
@@ -2619,11 +2804,9 @@ static inline bool wg_qualifies(const ldu_addr* a)
 }
 
 // k GaussSeidel sweeps (k = 1 ... 4) of a small matrix in one workgroup; returns 1 when the addressing does not qualify
-int k_sweep_gs_wg(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val)
+// the (sweep, slice) task list of k sweeps for the one-workgroup engine (cached per k in the addressing)
+static int wg_tasks(ldu_addr* a, int k, const ldu_addr::WgTasks** out)
 {
-    ldu_ctx* ctx = a->ctx;
-    if (!wg_qualifies(a) || k <= 0 || k > 4) return 1;
-    const size_t lds = 9 * (size_t)a->nCells + 64;
     auto it = a->wgTasks.find(k);
     if (it == a->wgTasks.end())
     {
@@ -2659,15 +2842,79 @@ int k_sweep_gs_wg(ldu_addr* a, int k, double* psi, const double* rhs, const doub
                     a->nCells, nS, a->nLevels, k, maxT + 1);
         it = a->wgTasks.emplace(k, W).first;
     }
+    *out = &it->second;
+    return 0;
+}
+
+int k_sweep_gs_wg(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!wg_qualifies(a) || k <= 0 || k > 4) return 1;
+    const size_t lds = 9 * (size_t)a->nCells + 64;
+    const ldu_addr::WgTasks* W = nullptr;
+    if (wg_tasks(a, k, &W)) return -1;
     ctx->profStart(a, 4);
     int rc;
     switch (ctx->wgWaves)
     {
-    case 4: rc = launch_gs_wg<4>(a, it->second, lds, psi, rhs, diag, val); break;
-    default: rc = launch_gs_wg<8>(a, it->second, lds, psi, rhs, diag, val); break;
+    case 4: rc = launch_gs_wg<4>(a, *W, lds, psi, rhs, diag, val); break;
+    default: rc = launch_gs_wg<8>(a, *W, lds, psi, rhs, diag, val); break;
     }
     ctx->profStop(a, 4);
     return rc ? -1 : 0;
+}
+
+// GaussSeidel with coupled patches on a small level: k sweeps AND their k boundary exchanges in one launch (peer-store
+// backend, kernel-private window regions).  `usable` = every rank of the communicator takes this path for this level
+// (decided collectively by the caller: a launch that talks to its neighbours needs all of them).  1 = not taken.
+int k_sweep_gs_wg_peer(ldu_addr* a, int k, double* psi, const double* source, const double* diag, const double* val,
+                       const double* bou, const int* d_cycPair)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!wg_qualifies(a) || k <= 0) return 1;
+    const ldu_addr::WgTasks* W = nullptr;
+    if (wg_tasks(a, 1, &W)) return -1;
+
+    WgPeer PS = WgPeer();
+    if (a->peer) { PS.kdst = a->peer->d_kdst; PS.ksrc = a->peer->d_ksrc; PS.kseq = a->peer->d_kseq; }
+    PS.nPF = a->nPatchFaces;
+    PS.pfCell = a->d_pfCell;
+    PS.cycPair = d_cycPair;
+    PS.bou = bou;
+    PS.nBRows = a->nBRows;
+    PS.bRow = a->d_bRow; PS.bStart = a->d_bStart; PS.bFace = a->d_bFace;
+    PS.rowB = a->d_nbRowB;
+    PS.kSweeps = k;
+    const size_t lds = 9 * (size_t)a->nCells + 64 + 8 * (size_t)a->nBRows + 16;
+    if (lds > WG_MAX_LDS) return 1;
+    static bool attrSetDev[64] = {false};
+    bool& attrSet = attrSetDev[ctx->device & 63];
+    if (!attrSet)
+    {
+        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_wg_peer_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_MAX_LDS));
+        attrSet = true;
+    }
+    ctx->profStart(a, 4);
+    gs_wg_peer_kernel<8><<<1, LDU_WAVE * 8, lds, ctx->stream>>>(PS, a->d_nL, a->d_nU, a->d_col, (const int4*)W->d_tasks, W->n,
+                                                                a->nCells, ctx->d_abort, psi, source, diag, val);
+    LDU_CHECK_HIP(hipGetLastError());
+    ctx->profStop(a, 4);
+    return 0;
+}
+bool k_wg_peer_eligible(ldu_addr* a)
+{
+    PeerKernelComm K;
+    if (!comm_peer_kernel_comm(a->ctx, &K) || !wg_qualifies(a) || !a->nPatchFaces) return false;
+    bool remote = false;
+    for (auto& P : a->patches) if (P.nbrPatch < 0 && P.n) remote = true;
+    if (remote && !(a->peer && a->peer->kAll)) return false;
+    return 9 * (size_t)a->nCells + 64 + 8 * (size_t)a->nBRows + 16 <= WG_MAX_LDS;
+}
+
+int k_set_peer_timeout_kernels(unsigned long long ticks)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_peer_budget), &ticks, sizeof(ticks)));
+    return 0;
 }
 
 // Host side: topological task order for k pipelined sweeps (cached per k in the addressing).

@@ -132,5 +132,6 @@ int k_peer_set_timeout(double seconds)
 {
     const unsigned long long t = (unsigned long long)(seconds * 1e8);
     LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_peer_budget), &t, sizeof(t)));
+    if (k_set_peer_timeout_kernels(t)) return -1;
     return k_coarsest_set_peer_timeout(t);   // (one copy of the budget per translation unit)
 }

@@ -589,6 +589,7 @@ int plan_finalize_patches(ldu_addr* a)
 void plan_free(ldu_addr* a)
 {
     comm_peer_free_addr(a);
+    if (a->d_cycPair) { (void)hipFree(a->d_cycPair); a->d_cycPair = nullptr; }
     cluster_free(a);
     for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
     a->graphs.clear();

@@ -266,6 +266,19 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         if (pipelined && left == 0) return 0;
         nSweeps = left;
     }
+    if (a->nPatchFaces && !sym && a->ctx->sweepP2P && a->peerWg == 1 && a->peerWgEpoch == a->ctx->commEpoch && nSweeps > 0)
+    {
+        // small GAMG level with coupled patches, peer-store backend: all sweeps of this smoothing AND their boundary
+        // exchanges in one launch (collective decision: gamg_decide_peer_smoothers)
+        const int rc = k_sweep_gs_wg_peer(a, nSweeps, psi, source, m->d_diag, m->d_valA, m->d_bou, a->d_cycPair);
+        if (rc <= 0)
+        {
+            if (rc == 0) { a->ctx->nHaloExchanges += nSweeps; a->ctx->nHaloOverlapped += nSweeps; }
+            return rc;
+        }
+        ldu_set_error("one-launch smoother: refused by an addressing that was declared eligible");
+        return -1;
+    }
     // bPrime differs from the source in the boundary rows only: one copy per call, then the boundary rows are
     // rewritten from the source before every sweep (one small kernel per sweep instead of copy + apply)
     if (a->nPatchFaces && !sym && nSweeps > 0 && k_ew(a->nCells, EW_COPY, bPrime, source, nullptr, s)) return -1;

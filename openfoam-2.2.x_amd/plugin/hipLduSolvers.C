@@ -168,6 +168,43 @@ static int hipDeviceForRank()
     return Pstream::myProcNo() % nDev;
 }
 
+// Out-of-band exchange of the peer-store backend's set-up messages (ldu_ctx_comm_init_peer, include/ldugpu.h) over the
+// application's own Pstream - where the reference itself sends the restrict maps of the coarse processor interfaces
+// (processorGAMGInterface.C:137-154) and reduces continueAgglomerating (GAMGAgglomeration.C:53-62).  Pairwise and
+// non-blocking: every rank of a pair posts the receive, then the send, then waits for both (UIPstream::read /
+// UOPstream::write with Pstream::nonBlocking, UPstream::waitRequests: lduMatrixUpdateMatrixInterfaces.C:127-160 uses the
+// same calls for the patch fields).
+static int hipOobExchange
+(
+    void*, int32_t nPeers, const int32_t* peers, const void* const* sendBufs, const int64_t* sendBytes,
+    void* const* recvBufs, const int64_t* recvBytes
+)
+{
+    const label startReq = UPstream::nRequests();
+    for (int32_t i = 0; i < nPeers; i++)
+    {
+        if (recvBytes[i] > 0)
+        {
+            UIPstream::read
+            (
+                Pstream::nonBlocking, peers[i], reinterpret_cast<char*>(recvBufs[i]), std::streamsize(recvBytes[i])
+            );
+        }
+    }
+    for (int32_t i = 0; i < nPeers; i++)
+    {
+        if (sendBytes[i] > 0)
+        {
+            UOPstream::write
+            (
+                Pstream::nonBlocking, peers[i], reinterpret_cast<const char*>(sendBufs[i]), std::streamsize(sendBytes[i])
+            );
+        }
+    }
+    UPstream::waitRequests(startReq);
+    return 0;
+}
+
 static ldu_ctx* hipContext()
 {
     if (!hipCtx_)
@@ -204,6 +241,28 @@ static ldu_ctx* hipContext()
                 ldu_ctx_comm_init(hipCtx_, Pstream::myProcNo(), Pstream::nProcs(), raw),
                 "hipContext()"
             );
+            // Intra-node runs (all ranks on the GPUs of one xGMI-connected node, <= 16 ranks): the peer-store windows next
+            // to the RCCL communicator.  RCCL stays the carrier unless LDU_HALO=p2p / LDU_REDUCE=p2p say otherwise
+            // (ldugpu.h); LDU_PEER=0 skips the windows.  Ranks on different hosts cannot map each other's memory: the
+            // host names are compared first and the windows are only opened when they are all equal.
+            const char* pe = getenv("LDU_PEER");
+            if ((!pe || atoi(pe)) && Pstream::nProcs() <= 16)
+            {
+                List<word> hosts(Pstream::nProcs());
+                hosts[Pstream::myProcNo()] = hostName();
+                Pstream::gatherList(hosts);
+                Pstream::scatterList(hosts);
+                bool oneNode = true;
+                forAll(hosts, i) oneNode = oneNode && hosts[i] == hosts[0];
+                if (oneNode)
+                {
+                    hipCheck
+                    (
+                        ldu_ctx_comm_init_peer(hipCtx_, Pstream::myProcNo(), Pstream::nProcs(), &hipOobExchange, NULL),
+                        "hipContext()"
+                    );
+                }
+            }
         }
     }
     return hipCtx_;
