@@ -65,7 +65,9 @@ def pmc_traffic(mesh_spec, kernel, k):
     if pj.get("source_hash") != kernel_source_hash():
         return None, "profiles/%s is stale: the kernel sources changed since that PMC pass (hash %s, now %s)" % (
             name, pj.get("source_hash"), kernel_source_hash())
-    return pj["bytes_per_launch"], "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % name
+    return (pj["bytes_per_launch"], pj.get("bytes_per_launch_corrected")), \
+        "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run; traffic = raw counters, " \
+        "traffic_corrected = with the gfx950 16-byte correction on the granule polls)" % name
 
 GAMG_CONTROLS = dict(solver="GAMG", tolerance=1e-7, relTol=0.01, smoother="GaussSeidel",
                      nPreSweeps=0, nPostSweeps=2, nFinestSweeps=2, cacheAgglomeration=1,
@@ -493,9 +495,12 @@ def main():
         traffic, traffic_source = (None, None)
         if mesh_spec and world == 1 and key == "gs_multi":
             traffic, traffic_source = pmc_traffic(mesh_spec, kernels[0], per_launch)
+        traffic_corrected = None
+        if isinstance(traffic, tuple):
+            traffic, traffic_corrected = traffic
         roof = dict(bound="hbm", kernel=kname + " (%d dependency levels)" % info["nLevels"],
                     achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                    peak_measured=None, traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
+                    peak_measured=None, traffic=traffic, traffic_corrected=traffic_corrected, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
                     bytes_per_launch=per_launch * gs_bytes, launches=prof[key]["count"])
     if roof is not None and stream and "triad_80M" in stream:
         roof["peak_measured"] = stream["triad_80M"]

@@ -20,6 +20,12 @@ def make(spec):
         return cases.box3d(int(f[1]))
     if f[0] == "irregular":
         p = cases.irregular_box(int(f[1]))
+    elif f[0] == "motorbike":
+        from openfoam_amd import motorbike
+        p = motorbike.problem(f[1])
+        p.pop("cellLevel"); p.pop("meta")
+        if not (len(f) > 2 and f[2] == "rcm"):
+            return p
     elif f[0] == "octree":
         q = int(f[1])
         p = octree.problem(base=(5 * q, 2 * q, 2 * q), surface_levels=(int(f[2]), int(f[3])))
