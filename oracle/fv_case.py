@@ -282,6 +282,110 @@ def chain_box_mesh(nBoxes, nxh, ny, nz, seed=4, jitter=0.15, axis="x"):
                 nCells=nBoxes * nA, nHalf=nA, nBoxes=nBoxes)
 
 
+def grid_box_mesh(gx, gy, gz, nx, ny, nz, seed=4, jitter=0.15, split=False):
+    """gx x gy x gz geometrically IDENTICAL boxes on a grid (box (gi, gj, gk) = box 0 translated), every pair of adjacent
+    boxes coupled ONLY through cyclic patch pairs with coincident faces - the 3-D block decomposition of an N-rank run
+    (2 x 2 x 2: three processor patches per rank, BASELINE config C4's shape) emulated inside ONE reference process, like
+    chain_box_mesh does for a row.  split: every junction is cut into TWO cyclic pairs (first / second half of its faces), i.e.
+    two patches per pair of ranks.  Box b = gi + gx (gj + gy gk) holds cells [b nA, (b+1) nA) in natural order; cyclic pair m
+    = patches 2m ('a' side: the lower box's max face) and 2m+1 ('b' side); `pairs`[m] = (lower box, upper box)."""
+    rng = np.random.RandomState(seed)
+    X = np.linspace(0.0, 1.0, nx + 1)
+    Y = (np.exp(np.log(1.8) * np.linspace(0, 1, ny + 1)) - 1.0) / 0.8 * 0.7
+    Z = np.linspace(0.0, 1.1, nz + 1)
+    nP = (nx + 1) * (ny + 1) * (nz + 1)
+
+    def pid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    ptsA = np.zeros((nP, 3))
+    for k in range(nz + 1):
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                p = np.array([X[i], Y[j], Z[k]])
+                if 0 < i < nx and 0 < j < ny and 0 < k < nz:
+                    h = np.array([X[1] - X[0], Y[j + 1] - Y[j], Z[1] - Z[0]])
+                    p = p + jitter * h * (rng.rand(3) - 0.5)
+                ptsA[pid(i, j, k)] = p
+    nB = gx * gy * gz
+    grid = [(b % gx, (b // gx) % gy, b // (gx * gy)) for b in range(nB)]
+    pts = np.vstack([ptsA + np.array([gi * 1.0, gj * Y[-1], gk * 1.1]) for gi, gj, gk in grid])
+    nA = nx * ny * nz
+
+    def cid(i, j, k):
+        return i + nx * (j + ny * k)
+
+    def fx(i, j, k, o):
+        return [o + pid(i, j, k), o + pid(i, j + 1, k), o + pid(i, j + 1, k + 1), o + pid(i, j, k + 1)]
+
+    def fy(i, j, k, o):
+        return [o + pid(i, j, k), o + pid(i, j, k + 1), o + pid(i + 1, j, k + 1), o + pid(i + 1, j, k)]
+
+    def fz(i, j, k, o):
+        return [o + pid(i, j, k), o + pid(i + 1, j, k), o + pid(i + 1, j + 1, k), o + pid(i, j + 1, k)]
+
+    boxes = [(b * nP, b * nA) for b in range(nB)]
+    faces, owner, nei = [], [], []
+    for po, co in boxes:
+        for k in range(nz):
+            for j in range(ny):
+                for i in range(nx):
+                    c = co + cid(i, j, k)
+                    if i + 1 < nx:
+                        faces.append(fx(i + 1, j, k, po)); owner.append(c); nei.append(co + cid(i + 1, j, k))
+                    if j + 1 < ny:
+                        faces.append(fy(i, j + 1, k, po)); owner.append(c); nei.append(co + cid(i, j + 1, k))
+                    if k + 1 < nz:
+                        faces.append(fz(i, j, k + 1, po)); owner.append(c); nei.append(co + cid(i, j, k + 1))
+    nInt = len(faces)
+    patches, pairs = [], []
+
+    def add_patch(name, flist, extra=""):
+        start = len(faces)
+        for fv, c in flist:
+            faces.append(fv); owner.append(c)
+        patches.append((name, len(flist), start, extra))
+
+    jk = [(j, k) for k in range(nz) for j in range(ny)]
+    ik = [(i, k) for k in range(nz) for i in range(nx)]
+    ij = [(i, j) for j in range(ny) for i in range(nx)]
+
+    def side(b, d, hi):
+        """(face, cell) list of box b's min (hi = False) or max face in direction d, the same face order on both sides"""
+        po, co = boxes[b]
+        if d == 0:
+            return [(fx(nx, j, k, po), co + cid(nx - 1, j, k)) if hi else (fx(0, j, k, po)[::-1], co + cid(0, j, k)) for j, k in jk]
+        if d == 1:
+            return [(fy(i, ny, k, po), co + cid(i, ny - 1, k)) if hi else (fy(i, 0, k, po)[::-1], co + cid(i, 0, k)) for i, k in ik]
+        return [(fz(i, j, nz, po), co + cid(i, j, nz - 1)) if hi else (fz(i, j, 0, po)[::-1], co + cid(i, j, 0)) for i, j in ij]
+
+    for b, (gi, gj, gk) in enumerate(grid):
+        for d, (n_, g_, step) in enumerate(((gx, gi, 1), (gy, gj, gx), (gz, gk, gx * gy))):
+            if g_ + 1 >= n_:
+                continue
+            nb = b + step
+            A, B = side(b, d, True), side(nb, d, False)
+            cuts = [(0, len(A))] if not split else [(0, len(A) // 2), (len(A) // 2, len(A))]
+            for lo, hi in cuts:
+                m = len(pairs)
+                add_patch("j%da" % m, A[lo:hi], "cyclic j%db" % m)
+                add_patch("j%db" % m, B[lo:hi], "cyclic j%da" % m)
+                pairs.append((b, nb))
+    for d, (name_lo, name_hi) in enumerate((("xmin", "xmax"), ("ymin", "ymax"), ("zmin", "zmax"))):
+        n_ = (gx, gy, gz)[d]
+        lo_list, hi_list = [], []
+        for b, g3 in enumerate(grid):
+            if g3[d] == 0:
+                lo_list += side(b, d, False)
+            if g3[d] == n_ - 1:
+                hi_list += side(b, d, True)
+        add_patch(name_lo, lo_list)
+        add_patch(name_hi, hi_list)
+    return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32),
+                neighbour=np.array(nei, dtype=np.int32), nInternalFaces=nInt, patches=patches,
+                nCells=nB * nA, nHalf=nA, nBoxes=nB, pairs=np.array(pairs, dtype=np.int32))
+
+
 def prism_box_mesh(nx, ny, nz, seed=5, jitter=0.15):
     """Every hex of a perturbed box split along its x-y diagonal into two prisms: triangular faces (the direct
     formulas of primitiveMesh::makeFaceCentresAndAreas) next to quads, 5-face cells.  Faces in upper-triangular

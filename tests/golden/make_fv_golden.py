@@ -85,10 +85,22 @@ CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6"
                "fvsolve3_chain_nonblocking_4x7x6": (3, 4, 7, 6, 80)}
 
 
+# 3-D block decompositions and several patches per rank pair (the coarse-interface ordering rule exercised
+# against the reference's own cyclicGAMGInterface beyond one patch per pair): name -> ((gx, gy, gz), nx, ny, nz, seed, split)
+GRID_CASES = {"fvsolve8_blocks_2x2x2_4x4x4": ((2, 2, 2), 4, 4, 4, 81, False),
+              "fvsolve2_split_halves_5x6x6": ((2, 1, 1), 5, 6, 6, 82, True),
+              "fvsolve4_blocks_2x2x1_split_4x4x5": ((2, 2, 1), 4, 4, 5, 83, True)}
+
+
 def generate_chain(name):
-    """serial emulation of an N-rank run by the reference itself (see fv_case.chain_box_mesh)"""
-    nB, nxh, ny, nz, seed = CHAIN_CASES[name]
-    mesh = fv_case.chain_box_mesh(nB, nxh, ny, nz, axis="z" if "nonblocking" in name else "x")
+    """serial emulation of an N-rank run by the reference itself (see fv_case.chain_box_mesh / grid_box_mesh)"""
+    if name in GRID_CASES:
+        g3, nxh, ny, nz, seed, split = GRID_CASES[name]
+        nB = g3[0] * g3[1] * g3[2]
+        mesh = fv_case.grid_box_mesh(g3[0], g3[1], g3[2], nxh, ny, nz, split=split)
+    else:
+        nB, nxh, ny, nz, seed = CHAIN_CASES[name]
+        mesh = fv_case.chain_box_mesh(nB, nxh, ny, nz, axis="z" if "nonblocking" in name else "x")
     rng = np.random.RandomState(seed)
     nC, nF = mesh["nCells"], mesh["nInternalFaces"]
     vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
@@ -101,6 +113,8 @@ def generate_chain(name):
                                      " asymmetric" if "asym" in name else ""))
     out = dict(nCells=nC, nHalf=mesh["nHalf"], nBoxes=nB, lowerAddr=mesh["owner"][:nF].astype(np.int32),
                upperAddr=mesh["neighbour"].astype(np.int32))
+    if "pairs" in mesh:
+        out["pairs"] = mesh["pairs"]
     for k, v in res.items():
         out[k] = v.astype(np.int32) if k.endswith("_faceCells") else v
     return out
@@ -138,6 +152,12 @@ def generate_nonorth(name):
 if __name__ == "__main__":
     if not fv_case.driver_available():
         raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
+    if len(sys.argv) > 1 and sys.argv[1] == "grid":
+        for name in GRID_CASES:
+            data = generate_chain(name)
+            np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+            print(name, "cells", data["nCells"], "pairs", len(data["pairs"]), "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
+        raise SystemExit(0)
     for name in NONORTH_CASES:
         data = generate_nonorth(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
@@ -153,7 +173,7 @@ if __name__ == "__main__":
         data = generate_solve(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
-    for name in CHAIN_CASES:
+    for name in list(CHAIN_CASES) + list(GRID_CASES):
         data = generate_chain(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])

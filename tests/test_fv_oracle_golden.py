@@ -125,17 +125,27 @@ def two_rank_problem(g):
     return n_rank_problem(g)
 
 
+def junctions(g):
+    """cyclic pair m = patches (2m, 2m+1) couples boxes pairs[m] = (lower, upper); a row of boxes: pair b = (b, b+1)"""
+    nB = int(g["nBoxes"]) if "nBoxes" in g else 2
+    if "pairs" in g:
+        return [(int(a_), int(b_)) for a_, b_ in g["pairs"]]
+    return [(b_, b_ + 1) for b_ in range(nB - 1)]
+
+
 def n_rank_problem(g):
-    """chain fixture -> the rank-local problems of the equivalent N-rank run: rank r = cells
-    [r*nHalf, (r+1)*nHalf); the cyclic pair j<b>a / j<b>b (patches 2b, 2b+1) becomes one processor patch
-    on rank b (towards b+1) and one on rank b+1 (towards b); per rank the patches are listed in ascending
-    neighbour rank, as decomposePar writes them."""
+    """chain / grid fixture -> the rank-local problems of the equivalent N-rank run: rank r = cells
+    [r*nHalf, (r+1)*nHalf); the cyclic pair j<m>a / j<m>b (patches 2m, 2m+1) becomes one processor patch on the lower box
+    (towards the upper) and one on the upper box (towards the lower); per rank the patches are listed in ascending
+    neighbour rank, as decomposePar writes them - several patches towards the same rank (split junctions) in the order
+    of their pairs, which is the order the library pairs them in (k-th with k-th, ldu_comm.cpp paired_patch)."""
     nP, nC, nH = int(g["nPatches"][0]), int(g["nCells"]), int(g["nHalf"])
     nB = int(g["nBoxes"]) if "nBoxes" in g else 2
     P = [dict(faceCells=g["p%d_faceCells" % p], internalCoeffs=g["p%d_internalCoeffs" % p],
               boundaryCoeffs=g["p%d_boundaryCoeffs" % p], coupled=bool(g["p%d_coupled" % p][0]), pnf=None)
          for p in range(nP)]
-    nJ = 2 * (nB - 1)
+    J = junctions(g)
+    nJ = 2 * len(J)
     assert all(p["coupled"] for p in P[:nJ]) and not any(p["coupled"] for p in P[nJ:])
     diag = fv_oracle.add_boundary_diag(g["diag"], P)                      # fvScalarMatrix.C:152-153
     source = fv_oracle.add_boundary_source(g["source"], P, couples=False)  # :155-156
@@ -146,15 +156,13 @@ def n_rank_problem(g):
         lo, hi = r * nH, (r + 1) * nH
         fsel = (l >= lo) & (l < hi)
         assert np.all((u[fsel] >= lo) & (u[fsel] < hi))
+        mine = sorted([(b_ if a_ == r else a_, m, 2 * m + (0 if a_ == r else 1)) for m, (a_, b_) in enumerate(J) if r in (a_, b_)])
         patches = []
-        if r > 0:          # towards r-1: the 'b' side of junction r-1
-            q = P[2 * (r - 1) + 1]
+        for nbr, m, pi in mine:
+            q = P[pi]
+            assert np.all((q["faceCells"] >= lo) & (q["faceCells"] < hi))
             patches.append(dict(faceCells=(q["faceCells"] - lo).astype(np.int32), bouCoeffs=q["boundaryCoeffs"],
-                                intCoeffs=q["internalCoeffs"], nbrDom=r - 1, nbrRank=r - 1))
-        if r < nB - 1:     # towards r+1: the 'a' side of junction r
-            q = P[2 * r]
-            patches.append(dict(faceCells=(q["faceCells"] - lo).astype(np.int32), bouCoeffs=q["boundaryCoeffs"],
-                                intCoeffs=q["internalCoeffs"], nbrDom=r + 1, nbrRank=r + 1))
+                                intCoeffs=q["internalCoeffs"], nbrDom=nbr, nbrRank=nbr, pair=m))
         sp = dict(nCells=hi - lo, lowerAddr=(l[fsel] - lo).astype(np.int32),
                   upperAddr=(u[fsel] - lo).astype(np.int32), diag=diag[lo:hi].copy(),
                   upper=g["upper"][fsel].copy(), source=source[lo:hi].copy(), psi=np.zeros(hi - lo),
@@ -163,10 +171,10 @@ def n_rank_problem(g):
         if "lower" in g:
             sp["lower"] = g["lower"][fsel].copy()
         subs.append(sp)
-    for r in range(nB):    # pairing for the oracle: my patch towards nb <-> nb's patch towards me
+    for r in range(nB):    # pairing for the oracle: my patch of pair m <-> the neighbour's patch of pair m
         for q in subs[r]["patches"]:
             nb = q["nbrDom"]
-            q["nbrPatch"] = [j for j, q2 in enumerate(subs[nb]["patches"]) if q2["nbrDom"] == r][0]
+            q["nbrPatch"] = [j for j, q2 in enumerate(subs[nb]["patches"]) if q2["pair"] == q["pair"]][0]
     return subs
 
 
@@ -178,7 +186,7 @@ def cyclic_problem(g):
     P = [dict(faceCells=g["p%d_faceCells" % p], internalCoeffs=g["p%d_internalCoeffs" % p],
               boundaryCoeffs=g["p%d_boundaryCoeffs" % p], coupled=bool(g["p%d_coupled" % p][0]), pnf=None)
          for p in range(nP)]
-    nJ = 2 * (nB - 1)
+    nJ = 2 * len(junctions(g))
     diag = fv_oracle.add_boundary_diag(g["diag"], P)
     source = fv_oracle.add_boundary_source(g["source"], P, couples=False)
     patches = [dict(faceCells=P[p]["faceCells"].astype(np.int32), bouCoeffs=P[p]["boundaryCoeffs"],
@@ -194,7 +202,9 @@ def cyclic_problem(g):
 
 
 CHAINS = ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6",
-          "fvsolve3_chain_nonblocking_4x7x6"]
+          "fvsolve3_chain_nonblocking_4x7x6",
+          # round 4: 3-D blocks (2 x 2 x 2: three coupled patches per rank) and two patches per pair of ranks
+          "fvsolve8_blocks_2x2x2_4x4x4", "fvsolve2_split_halves_5x6x6", "fvsolve4_blocks_2x2x1_split_4x4x5"]
 
 
 def SMOOTHER(name):

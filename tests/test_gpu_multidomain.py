@@ -128,7 +128,8 @@ def test_rccl_backend_single_rank(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6",
-                                  "fvsolve3_chain_nonblocking_4x7x6"])
+                                  "fvsolve3_chain_nonblocking_4x7x6", "fvsolve8_blocks_2x2x2_4x4x4",
+                                  "fvsolve2_split_halves_5x6x6", "fvsolve4_blocks_2x2x1_split_4x4x5"])
 def test_two_ranks_against_reference_cyclic_emulation(name):
     """8(e) pin on the device: 2 / 4 ranks (threads, local communicator) with processor patches against the
     reference's own single-process solve of the same system coupled by cyclic pairs
@@ -152,12 +153,17 @@ def test_two_ranks_against_reference_cyclic_emulation(name):
         perf = res[0][ip]
         ref = g["ref_%s_perf" % key]
         assert perf["nIterations"] == int(ref[2]), key
-        np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], ref[:2], rtol=1e-6)
+        # (1e-6 on the initial residual; 5e-6 on the final one: eleven orders of magnitude down, after 12-30 iterations in
+        #  which the ranks' tree sums and the reference's single sequence differ in the last bits - 1.1e-6 measured on the
+        #  split 2 x 2 blocks)
+        np.testing.assert_allclose(perf["initialResidual"], ref[0], rtol=1e-6)
+        np.testing.assert_allclose(perf["finalResidual"], ref[1], rtol=5e-6)
         xr = g["ref_%s_psi" % key]
         assert np.max(np.abs(x - xr)) <= 1e-8 * np.max(np.abs(xr)), key
 
 
-@pytest.mark.parametrize("name", ["fvsolve4_chain_5x6x6", "fvsolve3_chain_nonblocking_4x7x6"])
+@pytest.mark.parametrize("name", ["fvsolve4_chain_5x6x6", "fvsolve3_chain_nonblocking_4x7x6", "fvsolve8_blocks_2x2x2_4x4x4",
+                                  "fvsolve4_blocks_2x2x1_split_4x4x5"])
 def test_smoothers_n_ranks_bitexact_against_reference(name):
     """GaussSeidel / nonBlockingGaussSeidel across ranks (processor patches): bit-exact against the
     reference's own smoothers on the cyclic-coupled emulation."""

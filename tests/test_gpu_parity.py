@@ -273,7 +273,8 @@ def test_level_schedule_large_levels(ctx, oracle):
 
 
 @pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve4_chain_5x6x6", "fvsolve3_chain_asym_5x7x6",
-                                  "fvsolve3_chain_nonblocking_4x7x6"])
+                                  "fvsolve3_chain_nonblocking_4x7x6", "fvsolve8_blocks_2x2x2_4x4x4",
+                                  "fvsolve2_split_halves_5x6x6", "fvsolve4_blocks_2x2x1_split_4x4x5"])
 def test_cyclic_patches_against_reference(ctx, name):
     """cyclic coupled patches on ONE rank (ldu_addr_add_cyclic_patch): the reference's own single-process
     solves with real cyclic patches (tests/golden/fvsolve*.npz), GAMG + Krylov."""
