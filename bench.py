@@ -315,7 +315,12 @@ def main():
         # the real mesh, N-way: equal contiguous ranges of the cell numbering (decomposePar's `simple`-like cut along the
         # numbering; under Foam::bandCompression the ranges are breadth-first shells around the bike)
         shape = (1, 1, world)
-        cell_rank = (np.arange(p["nCells"], dtype=np.int64) * world) // p["nCells"]
+        cell_rank = motorbike.decomposition(args.motorbike_name, world) if args.mesh == "motorbike" else None
+        mb_decomp = "the reference's hierarchical decomposition of the cell centres (motorBike/system/decomposeParDict)"
+        if cell_rank is None:
+            # (a renumbered mesh, or no stored decomposition: equal contiguous ranges of the numbering)
+            cell_rank = (np.arange(p["nCells"], dtype=np.int64) * world) // p["nCells"]
+            mb_decomp = "%d contiguous ranges of the cell numbering" % world
         subs, cell_maps = decompose.decompose(p, cell_rank, world, only_rank=rank)
         lp = subs[rank]
         del subs
@@ -764,7 +769,7 @@ def main():
                        "mesh": args.mesh,
                        "parallelism": ("domain decomposition x%d" % world) + (
                            "" if world == 1 else " (%s, %s scaling: %s; halo exchanges and global sums by %s%s)" % (
-                               ("%d contiguous ranges of the cell numbering" % world) if is_mb else
+                               mb_decomp if is_mb else
                                "x".join(str(v) for v in shape) + " blocks", args.scaling,
                                "the same mesh" if is_mb else
                                ("%d^3 cells per rank" % n) if args.scaling == "weak" else "the same %d^3 matrix" % n,

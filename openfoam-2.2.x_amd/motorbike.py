@@ -50,6 +50,17 @@ def load(name):
                 outletCells=z["outletCells"], h0=float(meta["h0"]), meta=meta)
 
 
+def decomposition(name, n_ranks):
+    """rank of every cell for an n_ranks-way run: the reference's own `hierarchical` decomposition of the cell centres
+    (decomposeParDict of the tutorial; made by tools/make_motorbike.py through oracle/decomp_driver.C) - None when not stored"""
+    f = os.path.join(STORE, name + "_decomp.npz")
+    if not os.path.exists(f):
+        return None
+    z = np.load(f)
+    key = "proc%d" % n_ranks
+    return z[key].astype(np.int64) if key in z else None
+
+
 def smooth_field(nC, l, u, seed=777, passes=12):
     """a spatially smooth field whatever the cell numbering: u01 noise relaxed `passes` times towards the average of the face
     neighbours (x <- (x + mean of neighbours) / 2)"""

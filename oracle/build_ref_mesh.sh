@@ -103,3 +103,5 @@ g++ $CXXFLAGS -I"$APP/blockMesh" -c "$APP/blockMesh/blockMeshApp.C" -o "$W/block
 g++ -o "$OUT/blockMesh" "$W/blockMeshApp.o" $LINK && echo "build_ref_mesh.sh: OK -> $OUT/blockMesh (the reference's blockMeshApp.C, unchanged)"
 g++ $CXXFLAGS -I"$APP/snappyHexMesh" -c "$APP/snappyHexMesh/snappyHexMesh.C" -o "$W/snappyHexMesh.o"
 g++ -o "$OUT/snappyHexMesh" "$W/snappyHexMesh.o" $LINK && echo "build_ref_mesh.sh: OK -> $OUT/snappyHexMesh (the reference's snappyHexMesh.C, unchanged)"
+# the reference's geometric decomposition methods on a list of cell centres (oracle/decomp_driver.C; decomposePar's `hierarchical`)
+g++ $CXXFLAGS -o "$OUT/decomp_driver" "$HERE/decomp_driver.C" $LINK && echo "build_ref_mesh.sh: OK -> $OUT/decomp_driver"

@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--surface", type=int, nargs=2, default=[6, 7])
     ap.add_argument("--case", default=None, help="use an existing meshed case directory instead of running the generators")
     ap.add_argument("--small", action="store_true", help="also store the whole polyMesh (device-geometry test)")
+    ap.add_argument("--only-decomp", action="store_true", help="only (re)write <name>_decomp.npz")
     args = ap.parse_args()
     entry.load_package()
     from openfoam_amd import polymesh
@@ -158,6 +159,27 @@ def main():
                 patches=[(p["name"], p["type"], p["nFaces"]) for p in m["patches"] if p["nFaces"]][:12],
                 source="the reference's blockMesh + snappyHexMesh (castellatedMesh only) on tutorials/resources/geometry/"
                        "motorBike.obj.gz; dictionaries: oracle/motorbike_case.py")
+    # the reference's own hierarchical decomposition of the cell centres (libdecompositionMethods through oracle/decomp_driver.C;
+    # motorBike/system/decomposeParDict:17-33: method hierarchical, n (3 2 1), delta 0.001, order xyz) for 2 / 4 / 6 / 8 ranks
+    import subprocess
+    drv = os.path.join(ROOT, "oracle", "_ref", "decomp_driver")
+    if os.path.exists(drv):
+        cfile = os.path.join("/tmp", "centres_%s.bin" % args.name)
+        np.ascontiguousarray(C).tofile(cfile)
+        dec = {}
+        for nr, nn in ((2, "2 1 1"), (4, "2 2 1"), (6, "3 2 1"), (8, "2 2 2")):
+            ofile = cfile + ".proc%d" % nr
+            r = subprocess.run([drv, cfile, str(nC), ofile, "numberOfSubdomains %d; method hierarchical; hierarchicalCoeffs { n (%s); "
+                                "delta 0.001; order xyz; }" % (nr, nn)], env=mb.env(), capture_output=True, text=True)
+            if r.returncode:
+                raise SystemExit("decomp_driver failed:\n" + r.stdout[-1000:] + r.stderr[-1000:])
+            dec["proc%d" % nr] = np.fromfile(ofile, dtype=np.int32).astype(np.uint8)
+            print(r.stdout.strip().splitlines()[-1][:200])
+            os.remove(ofile)
+        os.remove(cfile)
+        np.savez_compressed(os.path.join(out_dir, args.name + "_decomp.npz"), **dec)
+    if args.only_decomp:
+        return
     path = os.path.join(out_dir, args.name + ".npz")
     np.savez_compressed(path, ownerCount=ownerCount, upper=u.astype(np.int32), dirs=dirs, cellLevel=level.astype(np.uint8),
                         outletCells=out_cells, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
