@@ -123,7 +123,7 @@ static int ctx_init(ldu_ctx* c, int device)
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * 2 * (size_t)c->maxRedBlocks));
     // the abort flag lives behind the scalar slots so that ONE device-to-host copy brings both
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * (S_NSLOTS + 1)));
-    LDU_CHECK_HIP(hipMemset(c->d_scalars, 0, sizeof(double) * (S_NSLOTS + 1)));
+    LDU_CHECK_HIP(ldu_memset_sync(c->d_scalars, 0, sizeof(double) * (S_NSLOTS + 1)));
     LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * (S_NSLOTS + 1), hipHostMallocDefault));
     c->d_abort = (int*)(c->d_scalars + S_NSLOTS);
     c->h_abort = (int*)(c->h_scalars + S_NSLOTS);
@@ -399,8 +399,8 @@ int matrix_alloc(ldu_addr* a, ldu_matrix** out)
     {
         LDU_CHECK_HIP(hipMalloc((void**)&m->d_bou, sizeof(double) * (size_t)a->nPatchFaces));
         LDU_CHECK_HIP(hipMalloc((void**)&m->d_int, sizeof(double) * (size_t)a->nPatchFaces));
-        LDU_CHECK_HIP(hipMemset(m->d_bou, 0, sizeof(double) * (size_t)a->nPatchFaces));
-        LDU_CHECK_HIP(hipMemset(m->d_int, 0, sizeof(double) * (size_t)a->nPatchFaces));
+        LDU_CHECK_HIP(ldu_memset_sync(m->d_bou, 0, sizeof(double) * (size_t)a->nPatchFaces));
+        LDU_CHECK_HIP(ldu_memset_sync(m->d_int, 0, sizeof(double) * (size_t)a->nPatchFaces));
     }
     *out = m;
     return 0;

@@ -331,9 +331,9 @@ static int cluster_build(ldu_addr* a)
         || (a->nFaces < (1 << 30) && cl_upload(&P->d_srcFace, srcFace)))
         return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(P->nRows + 1)));
-    LDU_CHECK_HIP(hipMemset(P->d_granule, 0, sizeof(uint4) * (size_t)(P->nRows + 1)));
+    LDU_CHECK_HIP(ldu_memset_sync(P->d_granule, 0, sizeof(uint4) * (size_t)(P->nRows + 1)));
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
-    LDU_CHECK_HIP(hipMemset(P->d_ticket, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
+    LDU_CHECK_HIP(ldu_memset_sync(P->d_ticket, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
     LDU_CHECK_HIP(hipDeviceSynchronize());
     P->gen = a->ctx->p2pGen;
     P->eligible = true;
@@ -709,9 +709,9 @@ static int launch_cluster(ldu_addr* a, const SweepArgs& g, hipStream_t s)
         if (!P.d_granule1)
         {
             LDU_CHECK_HIP(hipMalloc((void**)&P.d_granule1, sizeof(uint4) * (size_t)(P.nRows + 1)));
-            LDU_CHECK_HIP(hipMemset(P.d_granule1, 0, sizeof(uint4) * (size_t)(P.nRows + 1)));
+            LDU_CHECK_HIP(ldu_memset_sync(P.d_granule1, 0, sizeof(uint4) * (size_t)(P.nRows + 1)));
             LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticket1, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
-            LDU_CHECK_HIP(hipMemset(P.d_ticket1, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
+            LDU_CHECK_HIP(ldu_memset_sync(P.d_ticket1, 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
             // hipMemset on device memory may return before the fill ran, and the compute streams do not wait
             // for the null stream: without this the first sweep can publish tags that the fill then erases
             LDU_CHECK_HIP(hipDeviceSynchronize());
@@ -967,9 +967,9 @@ static int launch_cluster_vec(ldu_addr* a, double* w, const double* rhs, size_t 
     if (!P.d_granuleV[lane])
     {
         LDU_CHECK_HIP(hipMalloc((void**)&P.d_granuleV[lane], sizeof(uint4) * 3 * gStride));
-        LDU_CHECK_HIP(hipMemset(P.d_granuleV[lane], 0, sizeof(uint4) * 3 * gStride));
+        LDU_CHECK_HIP(ldu_memset_sync(P.d_granuleV[lane], 0, sizeof(uint4) * 3 * gStride));
         LDU_CHECK_HIP(hipMalloc((void**)&P.d_ticketV[lane], sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
-        LDU_CHECK_HIP(hipMemset(P.d_ticketV[lane], 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
+        LDU_CHECK_HIP(ldu_memset_sync(P.d_ticketV[lane], 0, sizeof(unsigned) * CL_NQ * CL_QSTRIDE));
         LDU_CHECK_HIP(hipDeviceSynchronize());   // see d_granule1: the fill must have run before the first sweep
         P.genV[lane] = ctx->p2pGen;
     }

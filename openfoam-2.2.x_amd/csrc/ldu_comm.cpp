@@ -202,13 +202,13 @@ extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oo
     // fine-grained: coherent across agents while kernels run (coarse-grained memory is only guaranteed at kernel
     // boundaries); what RCCL allocates for its own peer-to-peer buffers
     LDU_CHECK_HIP(hipExtMallocWithFlags((void**)&W->base, W->bytes, hipDeviceMallocFinegrained));
-    LDU_CHECK_HIP(hipMemset(W->base, 0, W->bytes));
+    LDU_CHECK_HIP(ldu_memset_sync(W->base, 0, W->bytes));
     LDU_CHECK_HIP(hipDeviceSynchronize());
     W->freeList[0] = W->bytes;
     W->redOff = W->alloc(sizeof(uint4) * 2 * LDU_MAX_PEERS * 16);
     W->redOffK = W->alloc(sizeof(uint4) * 2 * LDU_MAX_PEERS * 16);
     LDU_CHECK_HIP(hipMalloc((void**)&W->d_redSeqK, sizeof(unsigned)));
-    LDU_CHECK_HIP(hipMemset(W->d_redSeqK, 0, sizeof(unsigned)));
+    LDU_CHECK_HIP(ldu_memset_sync(W->d_redSeqK, 0, sizeof(unsigned)));
     W->peer.assign(nRanks, nullptr);
     W->opened.assign(nRanks, false);
     W->peer[rank] = W->base;

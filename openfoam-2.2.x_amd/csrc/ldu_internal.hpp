@@ -36,6 +36,17 @@ void ldu_set_error(const std::string& msg);
         }                                                                          \
     } while (0)
 
+// hipMemset on device memory is ASYNCHRONOUS with respect to the host and runs on the null stream, which the library's
+// non-blocking streams do not wait for: a set-up memset could land AFTER an upload or a sweep enqueued behind it on the
+// context's stream (found by tools/fuzz_peer.py in round 4: interfaceIntCoeffs zeroed again after ldu_matrix_set_patch_coeffs,
+// one case in ~100 with several processes on one GPU).  Every set-up memset goes through this: set, then drain the null stream.
+static inline hipError_t ldu_memset_sync(void* p, int v, size_t n)
+{
+    hipError_t e = hipMemset(p, v, n);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(nullptr);
+}
+
 struct ldu_comm_impl;  // RCCL wrapper (ldu_comm.cpp)
 struct ClusterPlan;    // ldu_cluster.hip
 #define LDU_PROF_NCAT 8

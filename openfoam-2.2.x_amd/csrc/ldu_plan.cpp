@@ -39,17 +39,17 @@ ldu_addr::P2PLane* ldu_addr::lane(int i)
     {
         // tags start at 0 = never published
         if (hipMalloc((void**)&P.d_granule, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
-        if (hipMemset(P.d_granule, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
+        if (ldu_memset_sync(P.d_granule, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
         // [0] chunk tickets, [32] chunks reported complete (run-ahead window), each on its own cache line
         if (hipMalloc((void**)&P.d_ticket, sizeof(unsigned) * 64) != hipSuccess) return nullptr;
-        if (hipMemset(P.d_ticket, 0, sizeof(unsigned) * 64) != hipSuccess) return nullptr;
+        if (ldu_memset_sync(P.d_ticket, 0, sizeof(unsigned) * 64) != hipSuccess) return nullptr;
         if (nSlabs > 0)
         {
             if (hipMalloc((void**)&P.d_X, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
-            if (hipMemset(P.d_X, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
+            if (ldu_memset_sync(P.d_X, 0, sizeof(uint4) * (size_t)(nCells + 1)) != hipSuccess) return nullptr;
             // [2][8] per-slab tickets, [2][8] per-slab completed chunks, double-buffered by launch parity
             if (hipMalloc((void**)&P.d_ctl, sizeof(unsigned) * 32) != hipSuccess) return nullptr;
-            if (hipMemset(P.d_ctl, 0, sizeof(unsigned) * 32) != hipSuccess) return nullptr;
+            if (ldu_memset_sync(P.d_ctl, 0, sizeof(unsigned) * 32) != hipSuccess) return nullptr;
             P.par = 0;
         }
         // hipMemset on device memory may return before the fill ran and the compute streams do not wait for
@@ -505,7 +505,7 @@ int plan_build(ldu_addr* a)
     if (upload(&a->d_gateF, gateF)) return -1;
     if (upload(&a->d_gateB, gateB)) return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&a->d_sliceDone, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
-    LDU_CHECK_HIP(hipMemset(a->d_sliceDone, 0, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
+    LDU_CHECK_HIP(ldu_memset_sync(a->d_sliceDone, 0, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
     return 0;
 }
 
@@ -573,7 +573,7 @@ int plan_finalize_patches(ldu_addr* a)
     if (upload(&a->d_pfCell, pfCell)) return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&a->d_sendAll, sizeof(double) * (size_t)off));
     LDU_CHECK_HIP(hipMalloc((void**)&a->d_recvAll, sizeof(double) * (size_t)off));
-    LDU_CHECK_HIP(hipMemset(a->d_recvAll, 0, sizeof(double) * (size_t)off));
+    LDU_CHECK_HIP(ldu_memset_sync(a->d_recvAll, 0, sizeof(double) * (size_t)off));
     for (auto& p : a->patches)
     {
         p.d_send = a->d_sendAll + p.offset;

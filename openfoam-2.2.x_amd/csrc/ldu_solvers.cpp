@@ -83,7 +83,7 @@ int fallback_prepare(ldu_matrix* m)
     if (ctx->streamComm) LDU_CHECK_HIP(hipStreamSynchronize(ctx->streamComm));   // a halo exchange of the failed attempt
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->haloInFlight = false;
-    LDU_CHECK_HIP(hipMemset(ctx->d_abort, 0, 2 * sizeof(int)));   // the abort flag and the singular flag behind it
+    LDU_CHECK_HIP(ldu_memset_sync(ctx->d_abort, 0, 2 * sizeof(int)));   // the abort flag and the singular flag behind it
     ctx->h_abort[0] = ctx->h_abort[1] = 0;
     ctx->dualActive = 0;
     ctx->sb = 0;

@@ -65,6 +65,18 @@ def test_real_motorbike_mesh_four_ranks():
     assert not any(out["mismatches"]), out
 
 
+def test_short_multirank_fuzz():
+    """tools/fuzz_peer.py for 25 s on 3 ranks (random matrices, random decompositions, every operator bit for bit, GAMG and
+    Krylov histories): the run that found the set-up memset race of round 4 (interfaceIntCoeffs zeroed again by a late
+    null-stream hipMemset, one case in ~100) must stay clean"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "fuzz_peer.py"), "25", "7"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("fuzz ") or ln.startswith("rank ")]
+    assert r.returncode == 0 and any(ln.startswith("fuzz ok") for ln in lines), "\n".join(lines) + r.stderr[-2000:]
+
+
 def _self_coupled(oracle, asym):
     from test_gpu_multidomain import _self_coupled_problem
     return _self_coupled_problem(asym)
