@@ -339,17 +339,50 @@ def main():
 
     ctx = capi.Context(device_index)
     # carriers: RCCL (one GPU per rank only) and / or the peer-store backend; with both on the context RCCL carries the
-    # set-up messages and whatever ctx.comm_select leaves to it
+    # set-up messages and whatever ctx.comm_select leaves to it.  In `auto` a carrier that cannot be set up on EVERY rank (an
+    # image whose RCCL cannot bootstrap, a node whose GPUs cannot map each other's memory) is dropped by all ranks together
+    # and said so in the line; the other one carries the run.
     backends = []
+    carrier_notes = {}
     if world > 1:
-        if not shared_gpus and args.comm in ("auto", "rccl"):
-            uid = [capi.Context.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(rank, world, uid[0])
-            backends.append("rccl")
-        if args.comm in ("auto", "peer"):
-            ctx.comm_init_peer(rank, world, capi.oob_torch(oob_group))
-            backends.append("peer")
+        def everywhere(ok):
+            t = torch.tensor([1 if ok else 0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=oob_group)
+            return bool(t.item())
+        want_rccl = not shared_gpus and args.comm in ("auto", "rccl")
+        want_peer = args.comm in ("auto", "peer")
+        for attempt in range(3):
+            ok_r = ok_p = True
+            try:
+                if want_rccl:
+                    uid = [capi.Context.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(uid, src=0)
+                    ctx.comm_init(rank, world, uid[0])
+            except Exception as e:  # pragma: no cover
+                ok_r = False
+                carrier_notes["rccl"] = str(e)[:200]
+            if want_rccl and not everywhere(ok_r):
+                if args.comm == "rccl":
+                    raise SystemExit("bench.py: the RCCL communicator could not be created: %s" % carrier_notes.get("rccl"))
+                carrier_notes.setdefault("rccl", "not available on every rank")
+                want_rccl = False
+                ctx.close(); ctx = capi.Context(device_index)
+                continue
+            try:
+                if want_peer:
+                    ctx.comm_init_peer(rank, world, capi.oob_torch(oob_group))
+            except Exception as e:  # pragma: no cover
+                ok_p = False
+                carrier_notes["peer"] = str(e)[:200]
+            if want_peer and not everywhere(ok_p):
+                if args.comm == "peer" or not want_rccl:
+                    raise SystemExit("bench.py: the peer windows could not be mapped: %s" % carrier_notes.get("peer"))
+                carrier_notes.setdefault("peer", "not available on every rank")
+                want_peer = False
+                ctx.close(); ctx = capi.Context(device_index)
+                continue
+            break
+        backends = (["rccl"] if want_rccl else []) + (["peer"] if want_peer else [])
     elif args.rank_of > 1:
         if args.comm in ("auto", "rccl"):
             ctx.comm_init(0, 1, capi.Context.unique_id())
@@ -781,6 +814,7 @@ def main():
                        "gpus_visible": ndev,
                        "comm_per_vcycle": comm_per_vcycle if world > 1 else None,
                        "comm_backends": comm_backends or None,
+                       "carriers_dropped": carrier_notes or None,
                        "vcycles_per_solve": perf["nIterations"],
                        "dependency_levels_finest": info["nLevels"],
                        # sweeps that expired a dependency wait and were re-run on the level-kernel engine (0 = the fast

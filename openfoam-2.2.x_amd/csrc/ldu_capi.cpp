@@ -490,7 +490,12 @@ int ldu_matrix_set_coeffs(ldu_matrix* m, const double* diag, const double* upper
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_upperO, upper, sizeof(double) * a->nFaces, hipMemcpyDefault, s));
         if (!sym) LDU_CHECK_HIP(hipMemcpyAsync(m->d_lowerO, lower, sizeof(double) * a->nFaces, hipMemcpyDefault, s));
     }
-    return matrix_refresh_layout(m);
+    const int rc = matrix_refresh_layout(m);
+    // host arrays belong to the caller again when this returns (an asynchronous copy from pageable memory may still be
+    // reading them: the runtime pins the pages and returns); device arrays are only read by work already ordered on the stream
+    if (!is_device_ptr(diag) || (a->nFaces && (!is_device_ptr(upper) || (!sym && !is_device_ptr(lower)))))
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+    return rc;
 }
 
 int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bou, const double* intc)
@@ -503,6 +508,7 @@ int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bou
     {
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_bou + p.offset, bou, sizeof(double) * p.n, hipMemcpyDefault, s));
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_int + p.offset, intc, sizeof(double) * p.n, hipMemcpyDefault, s));
+        if (!is_device_ptr(bou) || !is_device_ptr(intc)) LDU_CHECK_HIP(hipStreamSynchronize(s));   // (as in set_coeffs)
     }
     m->coeffEpoch++;   // coarse-level interface coefficients follow
     return 0;
