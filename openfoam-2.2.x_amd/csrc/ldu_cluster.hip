@@ -21,6 +21,8 @@
 #include <vector>
 
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <string>
 #include <thread>
 
@@ -60,7 +62,7 @@ static inline void cl_advance(ClBase& B, int nChunks, int grid)
     }
 }
 #define CL_MAXSEG 1536  // runs of the pipelined task list kept in LDS (12 KB)
-#define CL_MAXD 12     // dependencies (lower resp. upper neighbours) per row held in registers (variants 3 / 6 / 12)
+#define CL_MAXD LDU_CL_MAXD     // dependencies (lower resp. upper neighbours) per row held in registers (variants 3 / 6 / 12)
 #define CL_SPIN_LIMIT_DEFAULT (1u << 22)
 
 typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
@@ -138,8 +140,18 @@ static int cl_upload(T** dst, const std::vector<T>& src)
     return 0;
 }
 
+static int cl_upload_n(int** dst, const int* src, size_t n)
+{
+    LDU_CHECK_HIP(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(int)));
+    if (n) LDU_CHECK_HIP(hipMemcpy(*dst, src, n * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
 void cluster_free(ldu_addr* a)
 {
+    if (a->greedyThread.joinable()) a->greedyThread.join();
+    delete a->greedyEarly;
+    a->greedyEarly = nullptr;
     ClusterPlan* P = a->cluster;
     if (!P) return;
     void* ptrs[] = {P->d_sliceEnt, P->d_sliceDepth, P->d_rowMeta,
@@ -189,15 +201,21 @@ static int cluster_build(ldu_addr* a)
     if (nC < 64) return 0;
 
     // ---- greedy clustering in a topological order (ldu_cluster_greedy.hpp)
-    ClGreedy GR;
-    cluster_greedy(nC, nF, l.data(), u.data(), a->losort.data(), a->losortStart.data(), a->ownerStart.data(),
-                   a->level.data(), LDU_WAVE, GR);
+    if (a->greedyThread.joinable()) a->greedyThread.join();   // started by plan_build (large addressings)
+    std::unique_ptr<ClGreedy> early(a->greedyEarly);
+    a->greedyEarly = nullptr;
+    ClGreedy GRlocal;
+    if (!early)
+        cluster_greedy(nC, nF, l.data(), u.data(), a->losort.data(), a->losortStart.data(), a->ownerStart.data(),
+                       a->level.data(), LDU_WAVE, GRlocal);
+    const ClGreedy& GR = early ? *early : GRlocal;
     const std::vector<int>& cluster = GR.cluster;
     const std::vector<int>& intra = GR.intra;
-    const std::vector<std::vector<int>>& members = GR.members;
+    const std::vector<int>& memberStart = GR.memberStart;
+    const std::vector<int>& memberCells = GR.memberCells;
     const std::vector<int>& cLevel = GR.cLevel;
     const std::vector<int>& cDepth = GR.cDepth;
-    const int nCl = (int)members.size();
+    const int nCl = (int)GR.nClusters();
     const auto tGreedy = std::chrono::steady_clock::now();
     // ---- schedule order: by cluster level (ties: creation order) = a topological order of the quotient
     std::vector<int> order(nCl);
@@ -211,29 +229,43 @@ static int cluster_build(ldu_addr* a)
 
     std::vector<int> sliceEnt(nCl, 0), crowOf(nC);
     std::vector<unsigned char> sliceDepth(nCl);
-    std::vector<int2> rowMeta((size_t)nCl * LDU_WAVE, make_int2(0, 255 << 16));
+    std::vector<int2> rowMeta((size_t)nCl * LDU_WAVE);
     long ent = 0;
     std::vector<int> sliceW(nCl);
     int Wmax = 0;
-    for (int s = 0; s < nCl; s++)
+    // the clusters write disjoint ranges of every table: host threads over cluster ranges
+    const int nT = nCl >= 4096 ? (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    auto overClusters = [&](const std::function<void(int, int)>& fn) {
+        if (nT == 1) { fn(0, nCl); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nT; t++) th.emplace_back(fn, (int)((long)nCl * t / nT), (int)((long)nCl * (t + 1) / nT));
+        for (auto& t : th) t.join();
+    };
+    overClusters([&](int s0, int s1) {
+    for (int s = s0; s < s1; s++)
     {
         const int id = order[s];
         sliceDepth[s] = (unsigned char)cDepth[id];
         int W = 0;
         int row = s * LDU_WAVE;
-        // every lane of the cluster carries its depth (bits 24..31): the wave needs no sliceDepth load
-        for (int i = 0; i < LDU_WAVE; i++) rowMeta[(size_t)row + i].y = (255 << 16) | (cDepth[id] << 24);
-        for (int c : members[id])
+        for (int q = memberStart[id]; q < memberStart[id + 1]; q++)
         {
+            const int c = memberCells[q];
             crowOf[c] = row;
             const int cl_ = a->losortStart[c + 1] - a->losortStart[c], cu = a->ownerStart[c + 1] - a->ownerStart[c];
             rowMeta[row] = make_int2(a->iperm[c], cl_ | (cu << 8) | (intra[c] << 16) | (cDepth[id] << 24));
             W = std::max(W, cl_ + cu);
             row++;
         }
+        // every lane of the cluster carries its depth (bits 24..31): the wave needs no sliceDepth load
+        for (; row < (s + 1) * LDU_WAVE; row++) rowMeta[row] = make_int2(0, (255 << 16) | (cDepth[id] << 24));
         sliceW[s] = W;
-        Wmax = std::max(Wmax, W);
-        ent += (long)W * LDU_WAVE;
+    }
+    });
+    for (int s = 0; s < nCl; s++)
+    {
+        Wmax = std::max(Wmax, sliceW[s]);
+        ent += (long)sliceW[s] * LDU_WAVE;
     }
     // fixed stride when the padding it costs is small (a hex mesh tiled by cubes: none)
     if (nCl && (double)Wmax * LDU_WAVE * nCl <= 1.15 * (double)ent && !getenv("LDU_CLUSTER_VARW")) P->fixedW = Wmax;
@@ -253,10 +285,26 @@ static int cluster_build(ldu_addr* a)
         for (int s = 0; s < nCl; s++) P->levelStart[cLevel[order[s]] + 1]++;
         for (int L = 0; L < P->nClusterLevels; L++) P->levelStart[L + 1] += P->levelStart[L];
         P->upLevel.assign(P->nClusterLevels, 0);
-        for (int f = 0; f < nF; f++)
         {
-            const int La = cLevel[cluster[l[f]]], Lb = cLevel[cluster[u[f]]];
-            if (Lb > P->upLevel[La]) P->upLevel[La] = Lb;
+            const int nTf = nT > 1 ? nT : 1;
+            std::vector<std::vector<int>> part(nTf, std::vector<int>(P->nClusterLevels, 0));
+            auto job = [&](int t) {
+                std::vector<int>& up = part[t];
+                for (long f = (long)nF * t / nTf; f < (long)nF * (t + 1) / nTf; f++)
+                {
+                    const int La = cLevel[cluster[l[f]]], Lb = cLevel[cluster[u[f]]];
+                    if (Lb > up[La]) up[La] = Lb;
+                }
+            };
+            if (nTf == 1) job(0);
+            else
+            {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nTf; t++) th.emplace_back(job, t);
+                for (auto& t : th) t.join();
+            }
+            for (int t = 0; t < nTf; t++)
+                for (int L = 0; L < P->nClusterLevels; L++) P->upLevel[L] = std::max(P->upLevel[L], part[t][L]);
         }
         for (int L = 0; L < P->nClusterLevels; L++)
         {
@@ -270,20 +318,37 @@ static int cluster_build(ldu_addr* a)
         lvlSliceRow.resize(a->nSlices + 1); lvlSliceEnt.resize(a->nSlices);
         LDU_CHECK_HIP(hipMemcpy(lvlSliceRow.data(), a->d_sliceRow, sizeof(int) * (a->nSlices + 1), hipMemcpyDeviceToHost));
         LDU_CHECK_HIP(hipMemcpy(lvlSliceEnt.data(), a->d_sliceEnt, sizeof(int) * a->nSlices, hipMemcpyDeviceToHost));
-        for (int s = 0; s < a->nSlices; s++)
-            for (int r = lvlSliceRow[s]; r < lvlSliceRow[s + 1]; r++) lvlSliceOfRow[r] = s;
+        const int nS = a->nSlices;
+        auto job = [&](int t, int n) {
+            for (int s = (int)((long)nS * t / n); s < (int)((long)nS * (t + 1) / n); s++)
+                for (int r = lvlSliceRow[s]; r < lvlSliceRow[s + 1]; r++) lvlSliceOfRow[r] = s;
+        };
+        if (nT == 1) job(0, 1);
+        else
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nT; t++) th.emplace_back(job, t, nT);
+            for (auto& t : th) t.join();
+        }
     }
-    std::vector<int> colF((size_t)P->nEntries, 0), colB((size_t)P->nEntries, 0), src((size_t)P->nEntries, 0);
-    std::vector<int> srcFace((size_t)P->nEntries, -1);
-    // the clusters write disjoint ranges of the tables: host threads over cluster ranges
+    // (every entry is written below - the tables are not value-initialised first: 4 x 0.24 GB at 216^3)
+    const size_t nEnt = (size_t)P->nEntries;
+    std::unique_ptr<int[]> colF(new int[nEnt]), colB(new int[nEnt]), src(new int[nEnt]), srcFace(new int[nEnt]);
+    for (size_t e = (size_t)ent; e < nEnt; e++) { colF[e] = 0; colB[e] = 0; src[e] = 0; srcFace[e] = -1; }
     auto fillRange = [&](int s0, int s1) {
     for (int s = s0; s < s1; s++)
     {
         const int id = order[s];
-        for (size_t i = 0; i < members[id].size(); i++)
+        for (int i = memberStart[id + 1] - memberStart[id]; i < LDU_WAVE; i++)   // lanes without a cell
+            for (int k = 0; k < sliceW[s]; k++)
+            {
+                const long e = (long)sliceEnt[s] + i + (long)k * LDU_WAVE;
+                colF[e] = 0; colB[e] = 0; src[e] = 0; srcFace[e] = -1;
+            }
+        for (int i = 0; i < memberStart[id + 1] - memberStart[id]; i++)
         {
-            const int c = members[id][i];
-            const int r = s * LDU_WAVE + (int)i;
+            const int c = memberCells[memberStart[id] + i];
+            const int r = s * LDU_WAVE + i;
             const int lr = a->iperm[c];
             const int ls = lvlSliceOfRow[lr];
             const long lbase = (long)lvlSliceEnt[ls] + (lr - lvlSliceRow[ls]);
@@ -309,26 +374,17 @@ static int cluster_build(ldu_addr* a)
             {
                 colF[base + (long)k * LDU_WAVE] = r; colB[base + (long)k * LDU_WAVE] = r;
                 src[base + (long)k * LDU_WAVE] = (int)lbase;
+                srcFace[base + (long)k * LDU_WAVE] = -1;
             }
             (void)r;
         }
     }
     };
-    {
-        const int nT = nCl >= 4096 ? (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-        if (nT == 1) fillRange(0, nCl);
-        else
-        {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nT; t++)
-                th.emplace_back(fillRange, (int)((long)nCl * t / nT), (int)((long)nCl * (t + 1) / nT));
-            for (auto& t : th) t.join();
-        }
-    }
+    overClusters(fillRange);
     const auto tTables = std::chrono::steady_clock::now();
     if (cl_upload(&P->d_sliceEnt, sliceEnt) || cl_upload(&P->d_sliceDepth, sliceDepth) || cl_upload(&P->d_rowMeta, rowMeta)
-        || cl_upload(&P->d_colF, colF) || cl_upload(&P->d_colB, colB) || cl_upload(&P->d_src, src)
-        || (a->nFaces < (1 << 30) && cl_upload(&P->d_srcFace, srcFace)))
+        || cl_upload_n(&P->d_colF, colF.get(), nEnt) || cl_upload_n(&P->d_colB, colB.get(), nEnt)
+        || cl_upload_n(&P->d_src, src.get(), nEnt) || (a->nFaces < (1 << 30) && cl_upload_n(&P->d_srcFace, srcFace.get(), nEnt)))
         return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(P->nRows + 1)));
     LDU_CHECK_HIP(ldu_memset_sync(P->d_granule, 0, sizeof(uint4) * (size_t)(P->nRows + 1)));

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -323,72 +324,98 @@ static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fine
 
 // ---------------------------------------------------------------- hierarchy construction
 
-static int build_level_maps(GamgLevel& L, const ldu_addr* fineA)
+// restriction / prolongation maps (cells) and coefficient-agglomeration lists (faces) of one level: the two halves are
+// independent and run side by side on large levels.  Needs this level's and the finer level's plan (perm / iperm).
+static int build_level_maps(GamgLevel& L, const ldu_addr* cA, const ldu_addr* fineA, const std::vector<int>& restrictAddr,
+                            const std::vector<int>& faceRestrictAddr)
 {
-    const ldu_addr* cA = L.addr;
-    const int nFC = L.nFineCells, nFF = L.nFineFaces, nCC = cA->nCells, nCF = cA->nFaces;
-    // children per coarse cell, ascending original fine index
-    std::vector<int> childStartO(nCC + 1, 0), childO(nFC);
-    for (int i = 0; i < nFC; i++) childStartO[L.restrictAddr[i] + 1]++;
-    for (int c = 0; c < nCC; c++) childStartO[c + 1] += childStartO[c];
-    {
-        std::vector<int> pos(childStartO.begin(), childStartO.end() - 1);
-        for (int i = 0; i < nFC; i++) childO[pos[L.restrictAddr[i]]++] = i;
-    }
-    // the same in NEW numbering of both levels (order of summation unchanged)
-    std::vector<int> childStart(nCC + 1, 0), child(nFC), mapNew(nFC);
-    for (int cn = 0; cn < nCC; cn++)
-    {
-        int co = cA->perm[cn];
-        childStart[cn + 1] = childStart[cn] + (childStartO[co + 1] - childStartO[co]);
-    }
-    for (int cn = 0; cn < nCC; cn++)
-    {
-        int co = cA->perm[cn];
-        int k = childStart[cn];
-        for (int t = childStartO[co]; t < childStartO[co + 1]; t++) child[k++] = fineA->iperm[childO[t]];
-    }
-    for (int fn = 0; fn < nFC; fn++) mapNew[fn] = cA->iperm[L.restrictAddr[fineA->perm[fn]]];
-
-    // coefficient agglomeration lists (ascending fine face): GAMGSolverAgglomerateMatrix.C:148-205
-    std::vector<int> cfStart(nCF + 1, 0), cfFine, ccStart(nCC + 1, 0), ccFine;
-    std::vector<unsigned char> cfFlip;
-    for (int f = 0; f < nFF; f++)
-    {
-        int v = L.faceRestrictAddr[f];
-        if (v >= 0) cfStart[v + 1]++;
-        else ccStart[-1 - v + 1]++;
-    }
-    for (int c = 0; c < nCF; c++) cfStart[c + 1] += cfStart[c];
-    for (int c = 0; c < nCC; c++) ccStart[c + 1] += ccStart[c];
-    cfFine.resize(cfStart[nCF]);
-    cfFlip.resize(cfStart[nCF] ? cfStart[nCF] : 1);
-    ccFine.resize(ccStart[nCC]);
-    {
-        std::vector<int> p1(cfStart.begin(), cfStart.end() - 1), p2(ccStart.begin(), ccStart.end() - 1);
+    const int nFC = fineA->nCells, nFF = fineA->nFaces, nCC = cA->nCells, nCF = cA->nFaces;
+    const int dev = cA->ctx->device;
+    int rcCells = 0, rcFaces = 0;
+    std::string errCells, errFaces;
+    auto cells = [&]() {
+        if (hipSetDevice(dev) != hipSuccess) { rcCells = -1; errCells = "hipSetDevice failed"; return; }
+        // children per coarse cell, ascending original fine index
+        std::vector<int> childStartO(nCC + 1, 0), childO(nFC);
+        for (int i = 0; i < nFC; i++) childStartO[restrictAddr[i] + 1]++;
+        for (int c = 0; c < nCC; c++) childStartO[c + 1] += childStartO[c];
+        {
+            std::vector<int> pos(childStartO.begin(), childStartO.end() - 1);
+            for (int i = 0; i < nFC; i++) childO[pos[restrictAddr[i]]++] = i;
+        }
+        // the same in NEW numbering of both levels (order of summation unchanged)
+        std::vector<int> childStart(nCC + 1, 0), child(nFC), mapNew(nFC);
+        for (int cn = 0; cn < nCC; cn++)
+        {
+            int co = cA->perm[cn];
+            childStart[cn + 1] = childStart[cn] + (childStartO[co + 1] - childStartO[co]);
+        }
+        for (int cn = 0; cn < nCC; cn++)
+        {
+            int co = cA->perm[cn];
+            int k = childStart[cn];
+            for (int t = childStartO[co]; t < childStartO[co + 1]; t++) child[k++] = fineA->iperm[childO[t]];
+        }
+        for (int fn = 0; fn < nFC; fn++) mapNew[fn] = cA->iperm[restrictAddr[fineA->perm[fn]]];
+        if (up(&L.d_childStart, childStart) || up(&L.d_child, child) || up(&L.d_mapNew, mapNew)
+            || up(&L.d_childStartO, childStartO) || up(&L.d_childO, childO)
+            || hipMalloc((void**)&L.d_corr, sizeof(double) * (size_t)(nCC + 1)) != hipSuccess
+            || hipMalloc((void**)&L.d_src, sizeof(double) * (size_t)(nCC + 1)) != hipSuccess)
+        {
+            rcCells = -1;
+            errCells = ldu_last_error_string();
+            if (errCells.empty()) errCells = "device allocation of the level vectors failed";
+        }
+    };
+    auto faces = [&]() {
+        // coefficient agglomeration lists (ascending fine face): GAMGSolverAgglomerateMatrix.C:148-205
+        std::vector<int> cfStart(nCF + 1, 0), cfFine, ccStart(nCC + 1, 0), ccFine;
+        std::vector<unsigned char> cfFlip;
         for (int f = 0; f < nFF; f++)
         {
-            int v = L.faceRestrictAddr[f];
-            if (v >= 0)
-            {
-                int k = p1[v]++;
-                cfFine[k] = f;
-                // orientation test against restrictAddr[l[f]] (:158-171)
-                int rl = L.restrictAddr[fineA->l[f]];
-                if (cA->l[v] == rl) cfFlip[k] = 0;
-                else if (cA->u[v] == rl) cfFlip[k] = 1;
-                else { ldu_set_error("GAMG: inconsistent addressing between fine and coarse grids"); return -5; }
-            }
-            else ccFine[p2[-1 - v]++] = f;
+            int v = faceRestrictAddr[f];
+            if (v >= 0) cfStart[v + 1]++;
+            else ccStart[-1 - v + 1]++;
         }
+        for (int c = 0; c < nCF; c++) cfStart[c + 1] += cfStart[c];
+        for (int c = 0; c < nCC; c++) ccStart[c + 1] += ccStart[c];
+        cfFine.resize(cfStart[nCF]);
+        cfFlip.resize(cfStart[nCF] ? cfStart[nCF] : 1);
+        ccFine.resize(ccStart[nCC]);
+        {
+            std::vector<int> p1(cfStart.begin(), cfStart.end() - 1), p2(ccStart.begin(), ccStart.end() - 1);
+            for (int f = 0; f < nFF; f++)
+            {
+                int v = faceRestrictAddr[f];
+                if (v >= 0)
+                {
+                    int k = p1[v]++;
+                    cfFine[k] = f;
+                    // orientation test against restrictAddr[l[f]] (:158-171)
+                    int rl = restrictAddr[fineA->l[f]];
+                    if (cA->l[v] == rl) cfFlip[k] = 0;
+                    else if (cA->u[v] == rl) cfFlip[k] = 1;
+                    else { rcFaces = -5; errFaces = "GAMG: inconsistent addressing between fine and coarse grids"; return; }
+                }
+                else ccFine[p2[-1 - v]++] = f;
+            }
+        }
+        if (up(&L.d_cfStart, cfStart) || up(&L.d_cfFine, cfFine) || up(&L.d_cfFlip, cfFlip)
+            || up(&L.d_ccStart, ccStart) || up(&L.d_ccFine, ccFine))
+        {
+            rcFaces = -1;
+            errFaces = ldu_last_error_string();
+        }
+    };
+    if (nFC >= 200000)
+    {
+        std::thread t(cells);
+        faces();
+        t.join();
     }
-    if (up(&L.d_childStart, childStart) || up(&L.d_child, child) || up(&L.d_mapNew, mapNew)
-        || up(&L.d_cfStart, cfStart) || up(&L.d_cfFine, cfFine) || up(&L.d_cfFlip, cfFlip)
-        || up(&L.d_ccStart, ccStart) || up(&L.d_ccFine, ccFine) || up(&L.d_childStartO, childStartO)
-        || up(&L.d_childO, childO))
-        return -1;
-    LDU_CHECK_HIP(hipMalloc((void**)&L.d_corr, sizeof(double) * (size_t)(nCC + 1)));
-    LDU_CHECK_HIP(hipMalloc((void**)&L.d_src, sizeof(double) * (size_t)(nCC + 1)));
+    else { cells(); faces(); }
+    if (rcCells) { ldu_set_error(errCells); return rcCells; }
+    if (rcFaces) { ldu_set_error(errFaces); return rcFaces; }
     return 0;
 }
 
@@ -454,13 +481,28 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 rcFinest = k_cluster_build_one(a);
                 if (rcFinest) errFinest = ldu_last_error_string();
             });
+        // per level: 0 = plan pending, 1 = plan there, -1 = failed.  The maps of level i (restriction / prolongation /
+        // coefficient agglomeration) need the plans of levels i and i - 1 only: they start on level i's thread as soon as
+        // both are there, not after the last level's plan (216^3: level 1's maps, 0.4 s, used to start at 1.07 s)
+        std::vector<int> planState(kMaxLevels, 0);
+        std::vector<int> mrc(kMaxLevels, 0);
+        std::vector<std::string> merr(kMaxLevels);
+        std::mutex planMu;
+        std::condition_variable planCv;
         auto levelReady = [&](size_t i) {
             if (!parallelPlans) return;
-            th.emplace_back([&, i]() {
-                if (hipSetDevice(a->ctx->device) != hipSuccess) { rcs[i] = -1; errs[i] = "hipSetDevice failed"; return; }
+            const double tAnnounced = since();
+            th.emplace_back([&, i, tAnnounced]() {
+                auto publish = [&](int v) {
+                    { std::lock_guard<std::mutex> lk(planMu); planState[i] = v; }
+                    planCv.notify_all();
+                };
+                if (hipSetDevice(a->ctx->device) != hipSuccess) { rcs[i] = -1; errs[i] = "hipSetDevice failed"; publish(-1); return; }
                 rcs[i] = addr_create_internal(a->ctx, &g->levels[i].addr, hl[i].nCells, (int)hl[i].lower.size(),
                                               hl[i].lower.data(), hl[i].upper.data());
-                if (rcs[i]) { errs[i] = ldu_last_error_string(); return; }
+                if (rcs[i]) { errs[i] = ldu_last_error_string(); publish(-1); return; }
+                publish(1);
+                const double tPlanDone = since();
                 // the cluster plan of the level right behind its level plan, on a thread of its own
                 if (prebuild && hl[i].patches.empty())
                 {
@@ -471,6 +513,20 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                         if (crc[i]) cerr[i] = ldu_last_error_string();
                     });
                 }
+                const ldu_addr* fa = a;
+                if (i > 0)
+                {
+                    std::unique_lock<std::mutex> lk(planMu);
+                    planCv.wait(lk, [&]() { return planState[i - 1] != 0; });
+                    if (planState[i - 1] < 0) return;      // (reported by that level)
+                    fa = g->levels[i - 1].addr;
+                }
+                const double tMapsStart = since();
+                mrc[i] = build_level_maps(g->levels[i], g->levels[i].addr, fa, hl[i].restrictAddr, hl[i].faceRestrictAddr);
+                if (mrc[i]) merr[i] = ldu_last_error_string();
+                if (verbose && hl[i].nCells >= 100000)
+                    fprintf(stderr, "[ldugpu] set-up of level %zu (%d cells): announced at %.3f s, plan done at %.3f s, maps %.3f - %.3f s\n",
+                            i + 1, hl[i].nCells, tAnnounced, tPlanDone, tMapsStart, since());
             });
         };
         const int rcAgg = agglomerate_all(a, w, c->nCellsInCoarsestLevel, std::max(1, c->mergeLevels), hl, levelReady);
@@ -531,26 +587,13 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                         i + 1, L.addr->nCells, L.addr->nFaces, L.addr->nLevels, L.addr->nSlices);
             fineA = L.addr;
         }
-        {
-            // restriction / prolongation / coefficient-agglomeration maps: independent per level (each needs its own and the
-            // finer level's plan only), one host thread each (0.6 s one after the other at 216^3)
-            std::vector<int> mrc(hl.size(), 0);
-            std::vector<std::string> merr(hl.size());
-            std::vector<std::thread> mth;
+        if (!parallelPlans)
             for (size_t i = 0; i < hl.size(); i++)
-            {
-                const ldu_addr* fa = i == 0 ? a : g->levels[i - 1].addr;
-                auto job = [&, i, fa]() {
-                    if (hipSetDevice(a->ctx->device) != hipSuccess) { mrc[i] = -1; merr[i] = "hipSetDevice failed"; return; }
-                    mrc[i] = build_level_maps(g->levels[i], fa);
-                    if (mrc[i]) merr[i] = ldu_last_error_string();
-                };
-                if (parallelPlans) mth.emplace_back(job); else job();
-            }
-            for (auto& t : mth) t.join();
-            for (size_t i = 0; i < hl.size(); i++)
-                if (mrc[i]) { ldu_set_error("GAMG level maps: " + merr[i]); return -1; }
-        }
+                if (build_level_maps(g->levels[i], g->levels[i].addr, i == 0 ? a : g->levels[i - 1].addr, g->levels[i].restrictAddr,
+                                     g->levels[i].faceRestrictAddr))
+                    return -1;
+        for (size_t i = 0; i < hl.size(); i++)
+            if (mrc[i]) { ldu_set_error("GAMG level maps: " + merr[i]); return -1; }
         const double tMaps = since();
         {
             std::lock_guard<std::mutex> lk(cthMu);     // (no plan thread is alive any more: the list is complete)
@@ -832,7 +875,21 @@ static bool check_convergence(ldu_perf* p, double tol, double relTol)
 int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, ldu_perf* perf,
                double* hist)
 {
+    const bool firstSolve = !m->gamg && getenv("LDU_VERBOSE");
+    const auto tSolve0 = std::chrono::steady_clock::now();
     if (ensure_hierarchy(m, c)) return -1;
+    const auto tSolve1 = std::chrono::steady_clock::now();
+    struct FirstSolveNote {
+        bool on; std::chrono::steady_clock::time_point t0, t1; hipStream_t s;
+        ~FirstSolveNote()
+        {
+            if (!on) return;
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "[ldugpu] first GAMG solve: hierarchy and level coefficients %.3f s, V-cycles (lazy engine plans "
+                            "included) %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+        }
+    } firstSolveNote{firstSolve, tSolve0, tSolve1, m->a->ctx->stream};
     GamgHierarchy* g = m->gamg;
     ldu_ctx* ctx = m->a->ctx;
     hipStream_t s = ctx->stream;

@@ -19,6 +19,7 @@
 
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ldugpu.h"
@@ -49,6 +50,8 @@ static inline hipError_t ldu_memset_sync(void* p, int v, size_t n)
 
 struct ldu_comm_impl;  // RCCL wrapper (ldu_comm.cpp)
 struct ClusterPlan;    // ldu_cluster.hip
+struct ClGreedy;       // ldu_cluster_greedy.hpp
+#define LDU_CL_MAXD 12  // ldu_cluster.hip: dependencies per row the cluster kernels hold in registers
 #define LDU_PROF_NCAT 8
 
 // scalar slots on the device
@@ -272,6 +275,10 @@ struct ldu_addr {
     unsigned char* d_xflag = nullptr;      // [nCells] 1 = has a neighbour in another slab
 
     ClusterPlan* cluster = nullptr;        // secondary structure of the cluster sweep engine (lazy)
+    // the greedy clustering of a large addressing starts on a host thread of its own as soon as plan_build knows the
+    // dependency levels (it needs nothing else) and runs beside the rest of the level plan; cluster_build joins it
+    ClGreedy* greedyEarly = nullptr;
+    std::thread greedyThread;
     // single-workgroup pipelined GaussSeidel sweeps of small matrices (gs_small_pipe_kernel): per slice, how many
     // slices the PREVIOUS sweep must have finished before this slice may run (all its upper neighbours done)
     int* d_smallNeed = nullptr;            // [nSlices] (lazy)

@@ -2,8 +2,11 @@
 // sliced-ELL entry layout and the sweep schedule.  Built once per addressing
 // (the reference builds losort/ownerStart lazily once per mesh: lduAddressing.C:31-169).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <thread>
 
 #include "ldu_internal.hpp"
 #include "ldu_cluster_greedy.hpp"
@@ -136,9 +139,30 @@ static int choose_slabs(const ldu_addr* a, std::vector<int>& slabCell)
     return S;
 }
 
+// host threads over [0, n) in contiguous ranges (the big table fills write disjoint ranges)
+static void par_ranges(long n, long grain, const std::function<void(long, long)>& fn)
+{
+    const int nT = n >= grain ? (int)std::min<long>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / grain) : 1;
+    if (nT <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nT; t++) th.emplace_back(fn, n * t / nT, n * (t + 1) / nT);
+    for (auto& t : th) t.join();
+}
+
 int plan_build(ldu_addr* a)
 {
     const int nC = a->nCells, nF = a->nFaces;
+    // LDU_VERBOSE: where the plan of a large addressing spends its time
+    struct Phases {
+        bool on; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); std::string txt;
+        void mark(const char* name)
+        {
+            if (!on) return;
+            char b[64];
+            snprintf(b, sizeof(b), " %s %.3f", name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            txt += b;
+        }
+    } ph{getenv("LDU_VERBOSE") != nullptr && nC >= 1000000};
     const std::vector<int>& l = a->l;
     const std::vector<int>& u = a->u;
 
@@ -173,6 +197,7 @@ int plan_build(ldu_addr* a)
         a->ownerStart = oc;
     }
 
+    ph.mark("losort");
     // dependency levels of the lower-triangular DAG: one pass in face order is enough
     // because every face into cell k (owner < k) precedes the faces owned by k.
     a->level.assign(nC, 0);
@@ -181,6 +206,25 @@ int plan_build(ldu_addr* a)
     int nLevels = 0;
     for (int c = 0; c < nC; c++) nLevels = std::max(nLevels, a->level[c] + 1);
     a->nLevels = nLevels;
+    {
+        // the cluster engine's greedy clustering needs the graph and the levels only: on large addressings it starts now,
+        // on a thread of its own, beside the rest of this plan (216^3: 1.0 s next to the 1.0 s that follow here)
+        const ldu_ctx* ctx = a->ctx;
+        int maxDep = 0;
+        for (int c = 0; c < nC; c++)
+            maxDep = std::max(maxDep, std::max(a->losortStart[c + 1] - a->losortStart[c], a->ownerStart[c + 1] - a->ownerStart[c]));
+        static const bool early = !getenv("LDU_NO_EARLY_GREEDY");
+        if (early && ctx->clusterEngine && ctx->sweepP2P && nC >= std::max(ctx->clusterMinCells, 200000) && maxDep <= LDU_CL_MAXD
+            && !a->greedyThread.joinable() && !a->greedyEarly && !a->cluster)
+        {
+            a->greedyEarly = new ClGreedy();
+            a->greedyThread = std::thread([a, nC, nF]() {
+                cluster_greedy(nC, nF, a->l.data(), a->u.data(), a->losort.data(), a->losortStart.data(), a->ownerStart.data(),
+                               a->level.data(), LDU_WAVE, *a->greedyEarly);
+            });
+        }
+    }
+    ph.mark("levels");
     a->levelStart.assign(nLevels + 1, 0);
     for (int c = 0; c < nC; c++) a->levelStart[a->level[c] + 1]++;
     for (int L = 0; L < nLevels; L++) a->levelStart[L + 1] += a->levelStart[L];
@@ -262,6 +306,7 @@ int plan_build(ldu_addr* a)
     // (width class, lag bucket) first and by original index only within such a group, so rowSlab is non-decreasing inside a
     // (level, class, bucket) group, not inside the level: slices are cut wherever it changes (below), and on multi-slab
     // levels every group fragments at the slab boundaries
+    ph.mark("perm");
     std::vector<int> slabCell;
     const int S = choose_slabs(a, slabCell);
     a->nSlabs = S;
@@ -335,8 +380,10 @@ int plan_build(ldu_addr* a)
     a->nEntries = entPad;
     sliceRow.push_back(nC);
 
+    ph.mark("slices");
     std::vector<int> col((size_t)entPad, 0), face((size_t)entPad, -1);
-    for (int s = 0; s < a->nSlices; s++)
+    par_ranges(a->nSlices, 4096, [&](long s0, long s1) {
+    for (long s = s0; s < s1; s++)
     {
         for (int i = 0; i < sliceCnt[s]; i++)
         {
@@ -362,6 +409,8 @@ int plan_build(ldu_addr* a)
             for (int k = 0; k < sliceW[s]; k++)
                 col[(long)sliceEnt[s] + i + (long)k * LDU_WAVE] = sliceRow[s];
     }
+    });
+    ph.mark("col/face");
 
     // slab engine tables
     std::vector<int> slabList, colX;
@@ -392,7 +441,8 @@ int plan_build(ldu_addr* a)
         colX = col;
         xflag.assign(nC, 0);
         if (S > 1)
-            for (int s = 0; s < a->nSlices; s++)
+            par_ranges(a->nSlices, 4096, [&](long s0, long s1) {
+            for (long s = s0; s < s1; s++)
                 for (int i = 0; i < sliceCnt[s]; i++)
                 {
                     const int r = sliceRow[s] + i;
@@ -403,16 +453,21 @@ int plan_build(ldu_addr* a)
                         if (rowSlab[q] != rowSlab[r])
                         {
                             colX[e] = (int)((unsigned)q | 0x80000000u);
-                            xflag[r] = 1;
-                            xflag[q] = 1;
+                            // (several threads may flag the same row: relaxed atomic stores of the same value)
+                            __atomic_store_n(&xflag[r], (unsigned char)1, __ATOMIC_RELAXED);
+                            __atomic_store_n(&xflag[q], (unsigned char)1, __ATOMIC_RELAXED);
                         }
                     }
                 }
+            });
     }
+    ph.mark("slabs");
 
     // polling gates of the point-to-point sweeps: the slice one dependency level before the
     // latest-scheduled slice this one depends on (forward: lower neighbours; backward: upper)
+    // (LDU_P2P_GATE experiment only: nothing reads them otherwise)
     std::vector<int> gateF(a->nSlices, -1), gateB(a->nSlices, -1);
+    if (a->ctx->p2pGate)
     {
         std::vector<int> rowSlice(nC), sliceLevel(a->nSlices);
         for (int L = 0; L < nLevels; L++)
@@ -477,6 +532,7 @@ int plan_build(ldu_addr* a)
         }
     }
 
+    ph.mark("gates/segments");
     if (upload(&a->d_perm, a->perm)) return -1;
     if (upload(&a->d_iperm, a->iperm)) return -1;
     if (upload(&a->d_sliceRow, sliceRow)) return -1;
@@ -506,6 +562,8 @@ int plan_build(ldu_addr* a)
     if (upload(&a->d_gateB, gateB)) return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&a->d_sliceDone, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
     LDU_CHECK_HIP(ldu_memset_sync(a->d_sliceDone, 0, sizeof(unsigned) * (size_t)(a->nSlices + 1)));
+    ph.mark("upload");
+    if (ph.on) fprintf(stderr, "[ldugpu] level plan of %d cells, cumulative seconds:%s\n", nC, ph.txt.c_str());
     return 0;
 }
 
@@ -650,15 +708,15 @@ extern "C" int ldu_debug_dag_stats(int32_t nCells, int32_t nFaces, const int32_t
                    maxCells > 0 ? maxCells : LDU_WAVE, G);
     for (int i = 0; i < 16; i++) out[i] = 0;
     out[0] = nLevels;
-    out[1] = (int64_t)G.members.size();
+    out[1] = (int64_t)G.nClusters();
     int maxCl = 0;
-    for (size_t i = 0; i < G.members.size(); i++)
+    for (size_t i = 0; i < G.nClusters(); i++)
     {
         maxCl = std::max(maxCl, G.cLevel[i]);
         out[3] += G.cDepth[i];
         out[4] = std::max<int64_t>(out[4], G.cDepth[i]);
     }
-    out[2] = G.members.empty() ? 0 : maxCl + 1;
+    out[2] = (G.nClusters() == 0) ? 0 : maxCl + 1;
     for (int c = 0; c < nC; c++)
     {
         const int nl = losortStart[c + 1] - losortStart[c], nu = ownerStart[c + 1] - ownerStart[c];
@@ -671,12 +729,12 @@ extern "C" int ldu_debug_dag_stats(int32_t nCells, int32_t nFaces, const int32_t
     {
         std::vector<int> w(nLevels + 1, 0), wc(out[2] + 1, 0);
         for (int c = 0; c < nC; c++) w[level[c]]++;
-        for (size_t i = 0; i < G.members.size(); i++) wc[G.cLevel[i]]++;
+        for (size_t i = 0; i < G.nClusters(); i++) wc[G.cLevel[i]]++;
         for (int x : w) out[10] = std::max<int64_t>(out[10], x);
         for (int x : wc) out[11] = std::max<int64_t>(out[11], x);
     }
     if (cellLevel) for (int c = 0; c < nC; c++) cellLevel[c] = level[c];
     if (cellCluster) for (int c = 0; c < nC; c++) cellCluster[c] = G.cluster[c];
-    if (clusterLevel) for (size_t i = 0; i < G.members.size(); i++) clusterLevel[i] = G.cLevel[i];
+    if (clusterLevel) for (size_t i = 0; i < G.nClusters(); i++) clusterLevel[i] = G.cLevel[i];
     return 0;
 }
