@@ -617,6 +617,15 @@ fv_gaussGradFull_kernel(int nCells, const int* __restrict__ cs, const int* __res
 // and those neighbour-side faces that the tile owns too - from there.  Only the neighbour-side faces owned by other
 // tiles are gathered per lane from global memory (216^3 box: 2 of a cell's 6 faces instead of 6).  Same products, same
 // order of additions per cell and component as fv_gaussGradFull_kernel.
+// Workgroups go to the eight XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2: with tile =
+// workgroup index, neighbouring tiles - which read each other's faces - never share an L2.  Here XCD x walks the x-th
+// eighth of the tiles in order, so the faces a tile gathers from its predecessors were staged by the same XCD moments ago.
+__device__ __forceinline__ int xcd_tile(int nTiles)
+{
+    const int per = (nTiles + 7) >> 3;
+    return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+}
+static inline int xcd_tile_grid(int nCells) { const int nT = (nCells + GLUE_BLK - 1) / GLUE_BLK; return 8 * ((nT + 7) / 8); }
 #define GG_MAXF 768   // staged faces per tile (x 3*NC doubles of LDS); a tile owning more stages the first GG_MAXF
 template <int NC>
 __global__ void __launch_bounds__(GLUE_BLK)
@@ -628,7 +637,10 @@ fv_gaussGradTile_kernel(int nCells, const int* __restrict__ cs, const int* __res
 {
     constexpr int K = 3 * NC;
     __shared__ double prod[GG_MAXF * K];
-    const int c0 = blockIdx.x * GLUE_BLK;
+    const int nTiles = (nCells + GLUE_BLK - 1) / GLUE_BLK;
+    const int tile = xcd_tile(nTiles);
+    if (tile >= nTiles) return;
+    const int c0 = tile * GLUE_BLK;
     const int cEnd = c0 + GLUE_BLK < nCells ? c0 + GLUE_BLK : nCells;
     const int fA = ownerStart[c0];
     int nOwn = ownerStart[cEnd] - fA;
@@ -691,6 +703,120 @@ fv_gaussGradTile_kernel(int nCells, const int* __restrict__ cs, const int* __res
     const double v = V[c];
 #pragma unroll
     for (int q = 0; q < K; q++) grad[K * (size_t)c + q] = acc[q] / v;
+}
+
+// Vector field (tensor gradient): the tile's owned faces are staged RAW - Sf and ssf, 6 doubles per face, copied from the
+// two contiguous global ranges by coalesced loads (the per-lane loads of fv_gaussGradFull_kernel<3> walk 24-byte records:
+// nine load instructions of 64 x 8 bytes spread over 4.6 KB each, the texture path of the CU is the bound, not HBM) -
+// and every cell forms its products from LDS; 9 products per face in LDS (fv_gaussGradTile_kernel<3>) cost 55 KB per
+// workgroup and measured slower.  The gradient leaves through LDS as well: 72-byte records per lane become coalesced
+// rows.  Same products, same order of additions per cell and component as fv_gaussGradFull_kernel.
+__global__ void __launch_bounds__(GLUE_BLK)
+fv_gaussGradTile3_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                         const int* __restrict__ losortStart, const int* __restrict__ losort,
+                         const int* __restrict__ ownerStart, const double* __restrict__ Sf3,
+                         const double* __restrict__ ssf, const double* __restrict__ bSf3,
+                         const double* __restrict__ bssf, const double* __restrict__ V, double* __restrict__ grad)
+{
+    static_assert(GG_MAXF * 3 >= GLUE_BLK * 9, "the staging buffer of Sf doubles as the output tile");
+    __shared__ double sS[GG_MAXF * 3];
+    __shared__ double sV[GG_MAXF * 3];
+    const int nTiles = (nCells + GLUE_BLK - 1) / GLUE_BLK;
+    const int tile = xcd_tile(nTiles);
+    if (tile >= nTiles) return;
+    const int c0 = tile * GLUE_BLK;
+    const int cEnd = c0 + GLUE_BLK < nCells ? c0 + GLUE_BLK : nCells;
+    const int fA = ownerStart[c0];
+    int nOwn = ownerStart[cEnd] - fA;
+    if (nOwn > GG_MAXF) nOwn = GG_MAXF;
+    for (int e = threadIdx.x; e < nOwn * 3; e += GLUE_BLK)
+    {
+        sS[e] = Sf3[3 * (size_t)fA + e];
+        sV[e] = ssf[3 * (size_t)fA + e];
+    }
+    __syncthreads();
+    const int c = c0 + threadIdx.x;
+    const bool have = c < nCells;
+    double acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) acc[q] = 0.0;
+    if (have)
+    {
+        // faces four at a time: their indices, then their six values each (LDS or global), in flight together; the sums
+        // stay in face order
+        const int t1 = losortStart[c + 1];
+        for (int t = losortStart[c]; t < t1; t += 4)
+        {
+            int f[4];
+            double S[4][3], v[4][3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) f[k] = losort[t + k < t1 ? t + k : t1 - 1];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const unsigned fl = (unsigned)(f[k] - fA);
+                if (fl < (unsigned)nOwn)
+                {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { S[k][i] = sS[3 * fl + i]; v[k][i] = sV[3 * fl + i]; }
+                }
+                else
+                {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { S[k][i] = Sf3[3 * (size_t)f[k] + i]; v[k][i] = ssf[3 * (size_t)f[k] + i]; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (t + k < t1)
+                {
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) acc[3 * i + j] -= S[k][i] * v[k][j];
+                }
+        }
+        for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+        {
+            const unsigned fl = (unsigned)(f - fA);
+            double S[3], v[3];
+            if (fl < (unsigned)nOwn)
+            {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { S[i] = sS[3 * fl + i]; v[i] = sV[3 * fl + i]; }
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { S[i] = Sf3[3 * (size_t)f + i]; v[i] = ssf[3 * (size_t)f + i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc[3 * i + j] += S[i] * v[j];
+        }
+        if (cs)
+            for (int q = cs[c]; q < cs[c + 1]; q++)
+            {
+                const int f = cf[q];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) acc[3 * i + j] += bSf3[3 * (size_t)f + i] * bssf[3 * (size_t)f + j];
+            }
+        const double vol = V[c];
+#pragma unroll
+        for (int q = 0; q < 9; q++) acc[q] = acc[q] / vol;
+    }
+    __syncthreads();      // every lane is done with the staged faces: sS becomes the output tile
+    if (have)
+    {
+#pragma unroll
+        for (int q = 0; q < 9; q++) sS[9 * threadIdx.x + q] = acc[q];
+    }
+    __syncthreads();
+    const int nOut = (cEnd - c0) * 9;
+    for (int e = threadIdx.x; e < nOut; e += GLUE_BLK) grad[9 * (size_t)c0 + e] = sS[e];
 }
 
 // the `bounded` convection wrapper (boundedConvectionScheme.C:60-77): diag -= V * surfaceIntegrate(phi),
@@ -1035,11 +1161,10 @@ int ldu_fvc_gaussGradFull(ldu_addr* a, ldu_fv_boundary* b, int32_t nComp, const 
     const double* v = B.in(V, a->nCells);
     double* g = B.inout(grad, 3 * (size_t)nComp * a->nCells, false);
     if (nComp == 1)
-        fv_gaussGradTile_kernel<1><<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b ? b->d_cellStart : nullptr,
+        fv_gaussGradTile_kernel<1><<<xcd_tile_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b ? b->d_cellStart : nullptr,
             b ? b->d_cellFace : nullptr, a->d_losortStart, a->d_losort, a->d_ownerStart, sf, f, bsf, bf, v, g);
     else
-        // (the tile kernel with 9 products per face in LDS: 55 KB per workgroup, 1.7 ms instead of 0.9 on the 216^3 box)
-        fv_gaussGradFull_kernel<3><<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b ? b->d_cellStart : nullptr,
+        fv_gaussGradTile3_kernel<<<xcd_tile_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b ? b->d_cellStart : nullptr,
             b ? b->d_cellFace : nullptr, a->d_losortStart, a->d_losort, a->d_ownerStart, sf, f, bsf, bf, v, g);
     LDU_CHECK_HIP(hipGetLastError());
     return B.finish(grad, g, 3 * (size_t)nComp * a->nCells);

@@ -3678,14 +3678,26 @@ __global__ void fv_interpolate_kernel(long n, const int* __restrict__ P, const i
                                       const double* __restrict__ lambda, const double* __restrict__ vf,
                                       double* __restrict__ sf)
 {
-    for (long e = (long)blockIdx.x * BLK + threadIdx.x; e < n; e += (long)gridDim.x * BLK)
+    // four elements per lane and trip: the two dependent loads (face -> cells -> values) of all four are in flight together
+    const long stride = (long)gridDim.x * BLK;
+    for (long e0 = (long)blockIdx.x * BLK + threadIdx.x; e0 < n; e0 += 4 * stride)
     {
-        const long f = e / NC;
-        const int c = (int)(e - f * NC);
-        const long p = P[f], q = N[f];
-        const double lam = lambda[f];
-        const double a = vf[p * NC + c], b = vf[q * NC + c];
-        sf[e] = lam * (a - b) + b;
+        long p[4], q[4];
+        double lam[4], a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const long e = e0 + k * stride < n ? e0 + k * stride : e0;
+            const long f = e / NC;
+            const int c = (int)(e - f * NC);
+            p[k] = (long)P[f] * NC + c; q[k] = (long)N[f] * NC + c;
+            lam[k] = lambda[f];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = vf[p[k]]; b[k] = vf[q[k]]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (e0 + k * stride < n) sf[e0 + k * stride] = lam[k] * (a[k] - b[k]) + b[k];
     }
 }
 __global__ void fv_interpolate_any_kernel(long n, int nComp, const int* __restrict__ P, const int* __restrict__ N,
@@ -3707,7 +3719,8 @@ int k_fv_interpolate(ldu_addr* a, int nComp, const double* lambdas, const double
 {
     if (a->nFaces == 0) return 0;
     const long n = (long)a->nFaces * nComp;
-    const int grid = (int)std::min<long>((n + BLK - 1) / BLK, 1 << 20);
+    int grid = (int)std::min<long>((n + BLK - 1) / BLK, 1 << 20);
+    if (nComp == 1 || nComp == 3 || nComp == 6 || nComp == 9) grid = std::max(1, (grid + 3) / 4);   // (four elements per lane)
     switch (nComp)
     {
     case 1: fv_interpolate_kernel<1><<<grid, BLK, 0, s>>>(n, a->d_l, a->d_u, lambdas, vf, sf); break;
