@@ -1,3 +1,4 @@
+# (round-4 experiment: LDU_WAVE_TICKETS was a knob of a patch that was measured and removed again - DESIGN.md section 7c, "measured and buried" (b); kept for the record of what was run)
 mkdir -p gpurun_out/wt
 for mesh in motorbike_rcm motorbike; do
 i=0
