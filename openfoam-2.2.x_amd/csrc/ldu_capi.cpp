@@ -975,8 +975,14 @@ int ldu_fvm_laplacian(ldu_addr* a, const double* deltaCoeffs, const double* gamm
     const double* g = B.in(gammaMagSf, a->nFaces);
     double* up = B.outBuf(upper, a->nFaces);
     double* dg = B.outBuf(diag, a->nCells);
-    if (k_fv_laplacian_coeffs(a->nFaces, d, g, up, B.s)) return -1;
-    if (k_fv_negSumDiag(a, up, up, dg, B.s)) return -1;
+    // coefficients and negSumDiag in one pass (in-place arguments: the two-kernel path)
+    const int fused = k_fv_coeffs_diag(a, 0, d, g, nullptr, up, dg, B.s);
+    if (fused < 0) return -1;
+    if (fused > 0)
+    {
+        if (k_fv_laplacian_coeffs(a->nFaces, d, g, up, B.s)) return -1;
+        if (k_fv_negSumDiag(a, up, up, dg, B.s)) return -1;
+    }
     if (B.finish(upper, up, a->nFaces)) return -1;
     return B.finish(diag, dg, a->nCells);
 }
@@ -990,8 +996,13 @@ int ldu_fvm_div(ldu_addr* a, const double* weights, const double* faceFlux, doub
     double* up = B.outBuf(upper, a->nFaces);
     double* lo = B.outBuf(lower, a->nFaces);
     double* dg = B.outBuf(diag, a->nCells);
-    if (k_fv_div_coeffs(a->nFaces, w, phi, lo, up, B.s)) return -1;
-    if (k_fv_negSumDiag(a, lo, up, dg, B.s)) return -1;
+    const int fused = k_fv_coeffs_diag(a, 1, w, phi, lo, up, dg, B.s);
+    if (fused < 0) return -1;
+    if (fused > 0)
+    {
+        if (k_fv_div_coeffs(a->nFaces, w, phi, lo, up, B.s)) return -1;
+        if (k_fv_negSumDiag(a, lo, up, dg, B.s)) return -1;
+    }
     if (B.finish(upper, up, a->nFaces)) return -1;
     if (B.finish(lower, lo, a->nFaces)) return -1;
     return B.finish(diag, dg, a->nCells);

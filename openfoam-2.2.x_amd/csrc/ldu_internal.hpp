@@ -479,6 +479,8 @@ int k_fv_interpolate(ldu_addr* a, int nComp, const double* lambdas, const double
 int k_fv_surfaceIntegrate(ldu_addr* a, int nComp, const double* ssf, const double* sfVec, const double* V,
                           double* out, hipStream_t s);
 int k_fv_snGrad(ldu_addr* a, const double* delta, const double* vf, double* ssf, hipStream_t s);
+int k_fv_coeffs_diag(ldu_addr* a, int mode, const double* A, const double* B, double* lower, double* upper, double* diag,
+                     hipStream_t s);   // 1 = not applicable
 int k_fv_negSumDiag(ldu_addr* a, const double* lower, const double* upper, double* diag, hipStream_t s);
 int k_fv_laplacian_coeffs(int nFaces, const double* delta, const double* gammaMagSf, double* upper, hipStream_t s);
 int k_fv_div_coeffs(int nFaces, const double* w, const double* phi, double* lower, double* upper, hipStream_t s);

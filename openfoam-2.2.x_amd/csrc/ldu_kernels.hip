@@ -3867,6 +3867,94 @@ int k_fv_div_coeffs(int nFaces, const double* w, const double* phi, double* lowe
     return 0;
 }
 
+// gaussLaplacianScheme.C:63 / gaussConvectionScheme.C:87-88 AND lduMatrix::negSumDiag in one pass: a tile of BLK consecutive
+// cells owns one contiguous face range (faces are ordered by owner); its two input arrays are read once by coalesced
+// loads, the coefficients are written from there and kept in LDS, and every cell sums its owned faces - and the
+// neighbour-side faces the tile owns too - from LDS.  Neighbour-side faces of other tiles: the same coefficient formed
+// again from its two inputs (same arithmetic, no contraction: bit-identical to what the owning tile wrote).  Same order
+// of subtractions per cell as fv_negSumDiag_kernel.  MODE 0: upper = delta*gamma (symmetric); MODE 1: lower = -w*phi,
+// upper = lower + phi.
+#define FVC_MAXF 1024
+template <int MODE>
+__global__ void __launch_bounds__(BLK)
+fv_coeffs_diag_tile_kernel(int nCells, const int* __restrict__ losortStart, const int* __restrict__ losort,
+                           const int* __restrict__ ownerStart, const double* __restrict__ A, const double* __restrict__ B,
+                           double* __restrict__ lower, double* __restrict__ upper, double* __restrict__ diag)
+{
+    __shared__ double sUp[FVC_MAXF];
+    __shared__ double sLo[MODE == 1 ? FVC_MAXF : 1];
+    const int nTiles = (nCells + BLK - 1) / BLK;
+    const int per = (nTiles + 7) >> 3;                      // XCD x walks the x-th eighth of the tiles in order
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= nTiles) return;
+    const int c0 = tile * BLK;
+    const int cEnd = c0 + BLK < nCells ? c0 + BLK : nCells;
+    const int fA = ownerStart[c0];
+    const int nOwnAll = ownerStart[cEnd] - fA;
+    const int nOwn = nOwnAll < FVC_MAXF ? nOwnAll : FVC_MAXF;
+    for (int e = threadIdx.x; e < nOwnAll; e += BLK)
+    {
+        const size_t f = (size_t)fA + e;
+        double lo, up;
+        if (MODE == 0) { up = A[f] * B[f]; lo = up; }
+        else { const double ph = B[f]; lo = -A[f] * ph; up = lo + ph; lower[f] = lo; }
+        upper[f] = up;
+        if (e < nOwn) { sUp[e] = up; if (MODE == 1) sLo[e] = lo; }
+    }
+    __syncthreads();
+    const int c = c0 + threadIdx.x;
+    if (c >= nCells) return;
+    double acc = 0.0;
+    const int t1 = losortStart[c + 1];
+    for (int t = losortStart[c]; t < t1; t += 4)
+    {
+        int f[4];
+        double v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) f[i] = losort[t + i < t1 ? t + i : t1 - 1];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const unsigned fl = (unsigned)(f[i] - fA);
+            if (fl < (unsigned)nOwn) v[i] = sUp[fl];
+            else if (MODE == 0) v[i] = A[f[i]] * B[f[i]];
+            else { const double ph = B[f[i]]; const double lo = -A[f[i]] * ph; v[i] = lo + ph; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (t + i < t1) acc -= v[i];
+    }
+    const int f1 = ownerStart[c + 1];
+    for (int f = ownerStart[c]; f < f1; f++)
+    {
+        const unsigned fl = (unsigned)(f - fA);
+        double v;
+        if (fl < (unsigned)nOwn) v = MODE == 1 ? sLo[fl] : sUp[fl];
+        else if (MODE == 0) v = A[f] * B[f];
+        else v = -A[f] * B[f];
+        acc -= v;
+    }
+    diag[c] = acc;
+}
+
+// 0 = done; 1 = not applicable (in-place arguments)
+int k_fv_coeffs_diag(ldu_addr* a, int mode, const double* A, const double* B, double* lower, double* upper, double* diag,
+                     hipStream_t s)
+{
+    if (a->nCells == 0) return 0;
+    if (A == upper || B == upper || A == lower || B == lower) return 1;   // (the tiles re-read inputs other tiles write beside)
+    const int nTiles = (a->nCells + BLK - 1) / BLK;
+    const int grid = 8 * ((nTiles + 7) / 8);
+    if (mode == 0)
+        fv_coeffs_diag_tile_kernel<0><<<grid, BLK, 0, s>>>(a->nCells, a->d_losortStart, a->d_losort, a->d_ownerStart, A, B,
+                                                           nullptr, upper, diag);
+    else
+        fv_coeffs_diag_tile_kernel<1><<<grid, BLK, 0, s>>>(a->nCells, a->d_losortStart, a->d_losort, a->d_ownerStart, A, B,
+                                                           lower, upper, diag);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int k_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks)
 {
     const unsigned long long v[2] = {budgetTicks, stallTicks};
