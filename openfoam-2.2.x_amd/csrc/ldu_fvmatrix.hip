@@ -139,21 +139,44 @@ glue_A_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf
 }
 
 // fvMatrix<scalar>::H = the scalar specialisation fvScalarMatrix.C:209-237 (no boundary-diagonal term);
-// lduMatrix::H = lduMatrixTemplates.C:32-69
+// lduMatrix::H = lduMatrixTemplates.C:32-69: H = (source - sum_nbr lower*psi[l] - sum_own upper*psi[u] + boundary source)/V,
+// per cell the neighbour-side faces (ascending face index) before the owned ones, four faces at a time (index ->
+// coefficient, column -> psi, each stage's loads in flight together).
+// The owned faces of a tile of GLUE_BLK consecutive cells are staged through LDS (one contiguous face range:
+// upper, lower, neighbour label by coalesced loads): a face's coefficient and column come from LDS, only psi is gathered -
+// two dependent global round trips per face instead of three (216^3: 0.324 -> 0.305 ms).  Neighbour-side faces owned by
+// other tiles read their coefficient from global memory.  XCD-aware tile order (see xcd_tile).
+#define GH_MAXF 1024
 __global__ void __launch_bounds__(GLUE_BLK)
-glue_H_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
-              const unsigned char* __restrict__ coupled, const double* __restrict__ iC,
-              const double* __restrict__ bC, const double* __restrict__ pnf,
-              const int* __restrict__ losortStart, const int* __restrict__ losort,
-              const int* __restrict__ ownerStart, const int* __restrict__ l, const int* __restrict__ u,
-              const double* __restrict__ upper, const double* __restrict__ lower,
-              const double* __restrict__ psi, const double* __restrict__ source, const double* __restrict__ V,
-              double* __restrict__ H)
+glue_H_tile_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
+                   const unsigned char* __restrict__ coupled, const double* __restrict__ bC, const double* __restrict__ pnf,
+                   const int* __restrict__ losortStart, const int* __restrict__ losort,
+                   const int* __restrict__ ownerStart, const int* __restrict__ l, const int* __restrict__ u,
+                   const double* __restrict__ upper, const double* __restrict__ lower,
+                   const double* __restrict__ psi, const double* __restrict__ source, const double* __restrict__ V,
+                   double* __restrict__ H)
 {
-    const int c = blockIdx.x * GLUE_BLK + threadIdx.x;
+    __shared__ double sUp[GH_MAXF];
+    __shared__ double sLo[GH_MAXF];
+    __shared__ int sU[GH_MAXF];
+    const int nTiles = (nCells + GLUE_BLK - 1) / GLUE_BLK;
+    const int per = (nTiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= nTiles) return;
+    const int c0 = tile * GLUE_BLK;
+    const int cEnd = c0 + GLUE_BLK < nCells ? c0 + GLUE_BLK : nCells;
+    const int fA = ownerStart[c0];
+    int nOwn = ownerStart[cEnd] - fA;
+    if (nOwn > GH_MAXF) nOwn = GH_MAXF;
+    for (int e = threadIdx.x; e < nOwn; e += GLUE_BLK)
+    {
+        sUp[e] = upper[(size_t)fA + e];
+        sLo[e] = lower[(size_t)fA + e];
+        sU[e] = u[(size_t)fA + e];
+    }
+    __syncthreads();
+    const int c = c0 + threadIdx.x;
     if (c >= nCells) return;
-    const int b = cs[c], e = cs[c + 1];
-    // lduMatrix::H(psi); four faces at a time: index -> (coefficient, column) -> psi, each stage's loads in flight together
     double hl = 0.0;
     const int t1 = losortStart[c + 1];
     for (int t = losortStart[c]; t < t1; t += 4)
@@ -163,7 +186,12 @@ glue_H_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf
 #pragma unroll
         for (int i = 0; i < 4; i++) f[i] = losort[t + i < t1 ? t + i : t1 - 1];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { co[i] = lower[f[i]]; col[i] = l[f[i]]; }
+        for (int i = 0; i < 4; i++)
+        {
+            const unsigned fl = (unsigned)(f[i] - fA);
+            co[i] = fl < (unsigned)nOwn ? sLo[fl] : lower[f[i]];
+            col[i] = l[f[i]];
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) ps[i] = psi[col[i]];
 #pragma unroll
@@ -176,7 +204,13 @@ glue_H_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf
         int col[4];
         double co[4], ps[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int g = f + i < f1 ? f + i : f1 - 1; co[i] = upper[g]; col[i] = u[g]; }
+        for (int i = 0; i < 4; i++)
+        {
+            const int g = f + i < f1 ? f + i : f1 - 1;
+            const unsigned fl = (unsigned)(g - fA);
+            if (fl < (unsigned)nOwn) { co[i] = sUp[fl]; col[i] = sU[fl]; }
+            else { co[i] = upper[g]; col[i] = u[g]; }
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) ps[i] = psi[col[i]];
 #pragma unroll
@@ -184,8 +218,7 @@ glue_H_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf
             if (f + i < f1) hl -= co[i] * ps[i];
     }
     double h = hl + source[c];
-    // addBoundarySource (couples = true)
-    for (int j = b; j < e; j++)
+    for (int j = cs[c]; j < cs[c + 1]; j++)
     {
         const int f = cf[j];
         h += coupled[f] ? bC[f] * pnf[f] : bC[f];
@@ -1000,8 +1033,11 @@ int ldu_fvm_H(ldu_fv_boundary* b, const double* internalCoeffs, const double* bo
     const double* v = B.in(V, a->nCells);
     double* o = B.inout(H, a->nCells, false);
     if (!pnf) pnf = bC;   // never dereferenced without coupled patches
-    glue_H_kernel<<<glue_grid(a->nCells), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace, b->d_coupled,
-        iC, bC, pnf, a->d_losortStart, a->d_losort, a->d_ownerStart, a->d_l, a->d_u, up, lo, x, s, v, o);
+    {
+        const int nTiles = (a->nCells + GLUE_BLK - 1) / GLUE_BLK;
+        glue_H_tile_kernel<<<8 * ((nTiles + 7) / 8), GLUE_BLK, 0, B.s>>>(a->nCells, b->d_cellStart, b->d_cellFace, b->d_coupled,
+            bC, pnf, a->d_losortStart, a->d_losort, a->d_ownerStart, a->d_l, a->d_u, up, lo, x, s, v, o);
+    }
     LDU_CHECK_HIP(hipGetLastError());
     return B.finish(H, o, a->nCells);
 }
