@@ -666,13 +666,15 @@ def main():
                                       nCellsInCoarsestLevel=10, mergeLevels=1, cacheAgglomeration="on",
                                       tolerance=1e-7, relTol=0.01)
             res, _ = oracle_py.run_ref("time", dict(cp, psi=np.zeros(cp["nCells"])), d)
-            t_first, t_second, it_first, it_second = [float(v) for v in res["time"]]
+            # (own names: `t_first` is the GPU's first solve, reported as extra.first_solve_s - until round 4 this line
+            #  overwrote it, and full bench lines carried the REFERENCE's first-solve time there)
+            t_ref_first, t_second, it_first, it_second = [float(v) for v in res["time"]]
             cpu = dict(value=round(it_second / t_second * scale, 4), unit="V-cycles/s", cores=1, kind="reference",
                        sample="oracle/_ref/ref_driver = the reference's own lduMatrix::solver (GAMG, GaussSeidel, "
                               "faceAreaPair weights supplied) on %s: second solve %d V-cycles in %.2f s "
                               "(first solve incl. agglomeration %.2f s)%s"
                               % ("the same %s matrix (%d cells)" % (args.mesh, cp["nCells"]) if (is_octree or args.mesh == "jump2d")
-                                 else "the %d^3 box" % cn, int(it_second), t_second, t_first, note))
+                                 else "the %d^3 box" % cn, int(it_second), t_second, t_ref_first, note))
         else:
             S = oracle_py.System(cp)
             okw = dict(smoother="GaussSeidel", nCellsInCoarsestLevel=10, mergeLevels=1,
