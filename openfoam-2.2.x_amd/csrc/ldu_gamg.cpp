@@ -153,51 +153,97 @@ static void pair_level(int nCells, int nFaces, const int* lower, const int* uppe
 }
 
 // Coarse addressing (GAMGAgglomerateLduAddressing.C:91-198): coarse faces de-duplicated per
-// (owner, neighbour) pair, numbered owner by owner in order of first discovery.
+// (owner, neighbour) pair, numbered owner by owner, inside an owner in the order in which the fine faces (ascending)
+// discover its neighbours; and restrictFaceField of the face weights (GAMGAgglomerationTemplates.C:63-83: the fine
+// weights added to their coarse face in ascending fine-face order).
+// Host threads, same result as the reference's sequential loop: a coarse face belongs to ONE coarse owner, so the owners are
+// cut into contiguous ranges of equal face counts and every thread walks ALL fine faces in order but only handles those
+// whose coarse owner lies in its range - the discovery order inside an owner and the order of the weight sums are the
+// sequential ones.  (12.7 M-cell motorBike mesh: 0.55 s of every 0.81 s pairing step were this function, one thread.)
 static void coarse_addressing(int nFineFaces, const int* lower, const int* upper,
                               const std::vector<int>& rmap, int nCoarse, std::vector<int>& faceRestrict,
-                              std::vector<int>& cLower, std::vector<int>& cUpper)
+                              std::vector<int>& cLower, std::vector<int>& cUpper, const std::vector<double>& w,
+                              std::vector<double>& cw)
 {
+    const int nT = nFineFaces >= 400000 ? (int)std::min(12u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    auto par = [&](long n, const std::function<void(int, long, long)>& fn) {
+        if (nT == 1) { fn(0, 0, n); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nT; t++) th.emplace_back(fn, t, n * t / nT, n * (t + 1) / nT);
+        for (auto& t : th) t.join();
+    };
     faceRestrict.assign(nFineFaces, 0);
+    // coarse owner of every fine face (-1: both cells in one coarse cell) and the faces per owner (an upper bound of its
+    // neighbour count)
+    std::vector<int> ownOf(nFineFaces), neiOf(nFineFaces);
     std::vector<int> cap(nCoarse + 1, 0);
-    for (int f = 0; f < nFineFaces; f++)
-    {
-        int a = rmap[upper[f]], b = rmap[lower[f]];
-        if (a != b) cap[std::min(a, b) + 1]++;
-    }
+    par(nFineFaces, [&](int, long f0, long f1) {
+        for (long f = f0; f < f1; f++)
+        {
+            const int a = rmap[upper[f]], b = rmap[lower[f]];
+            if (a == b) { faceRestrict[f] = -(a + 1); ownOf[f] = -1; neiOf[f] = -1; continue; }
+            ownOf[f] = std::min(a, b);
+            neiOf[f] = std::max(a, b);
+            __atomic_fetch_add(&cap[ownOf[f] + 1], 1, __ATOMIC_RELAXED);
+        }
+    });
     for (int c = 0; c < nCoarse; c++) cap[c + 1] += cap[c];
-    std::vector<int> nbrOf(cap[nCoarse]), idOf(cap[nCoarse]), cnt(nCoarse, 0);
-    int nTmp = 0;
-    for (int f = 0; f < nFineFaces; f++)
+    const long nSlots = cap[nCoarse];
+    std::vector<int> nbrOf(nSlots), cnt(nCoarse, 0), local(nFineFaces);
+    std::vector<double> wSlot(nSlots, 0.0);
+    // owner ranges of equal slot counts
+    std::vector<int> cut(nT + 1, nCoarse);
+    cut[0] = 0;
+    for (int t = 1; t < nT; t++)
+        cut[t] = (int)(std::lower_bound(cap.begin(), cap.end(), (int)(nSlots * t / nT)) - cap.begin());
+    for (int t = 1; t <= nT; t++) cut[t] = std::max(cut[t], cut[t - 1]);
+    cut[nT] = nCoarse;
     {
-        int a = rmap[upper[f]], b = rmap[lower[f]];
-        if (a == b) { faceRestrict[f] = -(a + 1); continue; }
-        int own = std::min(a, b), nei = std::max(a, b);
-        int base = cap[own], found = -1;
-        for (int i = 0; i < cnt[own]; i++)
-            if (nbrOf[base + i] == nei) { found = idOf[base + i]; break; }
-        if (found < 0)
+        auto job = [&](int t) {
+            const int c0 = cut[t], c1 = cut[t + 1];
+            if (c0 >= c1) return;
+            for (int f = 0; f < nFineFaces; f++)
+            {
+                const int own = ownOf[f];
+                if (own < c0 || own >= c1) continue;
+                const int nei = neiOf[f];
+                const int base = cap[own];
+                int found = -1;
+                for (int i = 0; i < cnt[own]; i++)
+                    if (nbrOf[base + i] == nei) { found = i; break; }
+                if (found < 0) { found = cnt[own]++; nbrOf[base + found] = nei; }
+                local[f] = found;
+                wSlot[base + found] += w[f];
+            }
+        };
+        if (nT == 1) job(0);
+        else
         {
-            nbrOf[base + cnt[own]] = nei;
-            idOf[base + cnt[own]] = nTmp;
-            cnt[own]++;
-            found = nTmp++;
+            std::vector<std::thread> th;
+            for (int t = 0; t < nT; t++) th.emplace_back(job, t);
+            for (auto& t : th) t.join();
         }
-        faceRestrict[f] = found;
     }
-    std::vector<int> renum(nTmp);
-    cLower.resize(nTmp);
-    cUpper.resize(nTmp);
-    int k = 0;
-    for (int c = 0; c < nCoarse; c++)
-        for (int i = 0; i < cnt[c]; i++)
-        {
-            cLower[k] = c;
-            cUpper[k] = nbrOf[cap[c] + i];
-            renum[idOf[cap[c] + i]] = k++;
-        }
-    for (int f = 0; f < nFineFaces; f++)
-        if (faceRestrict[f] >= 0) faceRestrict[f] = renum[faceRestrict[f]];
+    std::vector<int> start(nCoarse + 1, 0);
+    for (int c = 0; c < nCoarse; c++) start[c + 1] = start[c] + cnt[c];
+    const int nCF = start[nCoarse];
+    cLower.resize(nCF);
+    cUpper.resize(nCF);
+    cw.assign(nCF, 0.0);
+    par(nCoarse, [&](int, long c0, long c1) {
+        for (long c = c0; c < c1; c++)
+            for (int i = 0; i < cnt[c]; i++)
+            {
+                const int k = start[c] + i;
+                cLower[k] = (int)c;
+                cUpper[k] = nbrOf[cap[c] + i];
+                cw[k] = wSlot[cap[c] + i];
+            }
+    });
+    par(nFineFaces, [&](int, long f0, long f1) {
+        for (long f = f0; f < f1; f++)
+            if (ownOf[f] >= 0) faceRestrict[f] = start[ownOf[f]] + local[f];
+    });
 }
 
 // coarse image of one processor patch (processorGAMGInterface.C:47-126)
@@ -237,18 +283,21 @@ static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fine
         const std::vector<int>& up_ = top ? fine->u : out.back().upper;
         const int nF = (int)lo.size();
         HostLevel L;
+        const auto tp0 = std::chrono::steady_clock::now();
         pair_level(nC, nF, lo.data(), up_.data(), w, L.restrictAddr, L.nCells);
+        const auto tp1 = std::chrono::steady_clock::now();
         // continueAgglomerating (GAMGAgglomeration.C:53-62): and-reduce over the ranks
         int cont = (L.nCells >= nCellsInCoarsestLevel) ? 1 : 0;
         if (comm_allreduce_min_int(ctx, &cont)) return -1;
         if (!cont) break;
+        std::vector<double> cw;
         coarse_addressing(nF, lo.data(), up_.data(), L.restrictAddr, L.nCells, L.faceRestrictAddr,
-                          L.lower, L.upper);
-        // restrictFaceField of the weights (GAMGAgglomerationTemplates.C:63-83)
-        std::vector<double> cw(L.lower.size(), 0.0);
-        for (int f = 0; f < nF; f++)
-            if (L.faceRestrictAddr[f] >= 0) cw[L.faceRestrictAddr[f]] += w[f];
+                          L.lower, L.upper, w, cw);
         w.swap(cw);
+        if (getenv("LDU_VERBOSE") && nC >= 1000000)
+            fprintf(stderr, "[ldugpu] pairing of %d cells: pairs %.3f s, coarse addressing and weights %.3f s\n", nC,
+                    std::chrono::duration<double>(tp1 - tp0).count(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count());
 
         // coarse processor interfaces: coarse faces = unique (master cell, slave cell) pairs in
         // order of first occurrence - both ranks scan the same faces in the same order
@@ -475,11 +524,19 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
         std::vector<int> crc(kMaxLevels, 0);
         std::vector<std::string> cerr(kMaxLevels);
         struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } joinClusters{cth};
+        // the task orders of the pipelined GaussSeidel sweeps a level will be asked for (lazily built at the first smoothing
+        // call otherwise: 2.3 s of the first solve on the 12.7 M-cell motorBike mesh, one level after the other)
+        auto sweepPlans = [&](ldu_addr* A, int nPost, int nPre) {
+            if (c->smoother != LDU_SM_GAUSSSEIDEL && c->smoother != LDU_SM_NONBLOCKINGGAUSSSEIDEL) return;
+            for (int n : {nPost, nPre})
+                if (n >= 2) (void)k_gs_prebuild(A, n > 4 ? 4 : n);   // (errors: the smoothing call builds again and says)
+        };
         if (prebuild)   // the finest level's cluster plan (the longest single piece, 1.4 s at 216^3) beside everything else
             cth.emplace_back([&]() {
                 if (hipSetDevice(a->ctx->device) != hipSuccess) { rcFinest = -1; errFinest = "hipSetDevice failed"; return; }
                 rcFinest = k_cluster_build_one(a);
                 if (rcFinest) errFinest = ldu_last_error_string();
+                else sweepPlans(a, c->nFinestSweeps, 0);
             });
         // per level: 0 = plan pending, 1 = plan there, -1 = failed.  The maps of level i (restriction / prolongation /
         // coefficient agglomeration) need the plans of levels i and i - 1 only: they start on level i's thread as soon as
@@ -511,6 +568,9 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                         if (hipSetDevice(a->ctx->device) != hipSuccess) { crc[i] = -1; cerr[i] = "hipSetDevice failed"; return; }
                         crc[i] = k_cluster_build_one(g->levels[i].addr);
                         if (crc[i]) cerr[i] = ldu_last_error_string();
+                        else
+                            sweepPlans(g->levels[i].addr, std::min(c->nPostSweeps + c->postSweepsLevelMultiplier * (int)i, c->maxPostSweeps),
+                                       c->nPreSweeps ? std::min(c->nPreSweeps + c->preSweepsLevelMultiplier * (int)i, c->maxPreSweeps) : 0);
                     });
                 }
                 const ldu_addr* fa = a;

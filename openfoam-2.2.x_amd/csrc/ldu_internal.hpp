@@ -394,6 +394,7 @@ int k_sweep_cluster_vec3(ldu_addr* a, int mode, double* w, const double* rhs, si
 bool k_cluster_active(ldu_addr* a);
 bool k_cluster_kind_active(ldu_addr* a, int kind);
 int k_engine_of(ldu_addr* a, int kind);
+int k_gs_prebuild(ldu_addr* a, int k);   // the host plan of k pipelined GaussSeidel sweeps on the level engines, ahead of the first call
 int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* valA);
 void cluster_free(ldu_addr* a);
 void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converted copy of a value array

@@ -2917,18 +2917,15 @@ int k_set_peer_timeout_kernels(unsigned long long ticks)
     return 0;
 }
 
-// Host side: topological task order for k pipelined sweeps (cached per k in the addressing).
-int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
-                     const double* val)
+// Host side: topological task order for k pipelined sweeps (cached per k in the addressing; an entry with n < 0 = this
+// addressing does not pipeline).  Built at the first smoothing call that needs it - or ahead of it, on the set-up threads of
+// a GAMG hierarchy (k_gs_prebuild): on the 12.7 M-cell motorBike mesh the orders of all levels were 2.3 s of the first solve.
+static int gs_tasks_ensure(ldu_addr* a, int k)
 {
     ldu_ctx* ctx = a->ctx;
-    ldu_addr::P2PLane& P = *a->lane(0);
-    hipStream_t s = ctx->stream;
-    if (a->nCells == 0 || k <= 0) return 0;
-    auto it = a->gsTasks.find(k);
-    if (it != a->gsTasks.end() && it->second.n < 0) return 1;   // not pipelinable (see below)
-    if (it == a->gsTasks.end())
+    if (a->gsTasks.find(k) != a->gsTasks.end()) return 0;
     {
+
         // M[L] = running max over levels <= L of the highest level holding an upper neighbour
         const int nLev = a->nLevels;
         std::vector<int> M(nLev, 0);
@@ -2956,8 +2953,8 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
         {
             ldu_addr::GsTasks none;
             none.n = -1;
-            it = a->gsTasks.emplace(k, none).first;
-            return 1;
+            a->gsTasks.emplace(k, none);
+            return 0;
         }
         // Task order = (sweep, slice) pairs sorted by their time in the slice-level DAG of the k sweeps:
         //   T(0, s) = dependency level of s;   T(j, s) = 1 + max( T(j, slices holding lower neighbours of s's rows),
@@ -3017,8 +3014,30 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
             LDU_CHECK_HIP(hipMemcpy(gt.d_slabTasks, slabTasks.data(), sizeof(int) * slabTasks.size(),
                                     hipMemcpyHostToDevice));
         }
-        it = a->gsTasks.emplace(k, gt).first;
+        a->gsTasks.emplace(k, gt);
     }
+    return 0;
+}
+
+int k_gs_prebuild(ldu_addr* a, int k)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (k < 2 || k > 4 || a->nCells == 0 || a->nPatchFaces || !ctx->sweepP2P || !ctx->gsPipeline) return 0;
+    const int e = k_engine_of(a, 2);
+    if (e != 0 && e != 1) return 0;      // one workgroup / single wavefront / clusters: their own (cheap) plans
+    return gs_tasks_ensure(a, k);
+}
+
+int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag,
+                     const double* val)
+{
+    ldu_ctx* ctx = a->ctx;
+    ldu_addr::P2PLane& P = *a->lane(0);
+    hipStream_t s = ctx->stream;
+    if (a->nCells == 0 || k <= 0) return 0;
+    if (gs_tasks_ensure(a, k)) return -1;
+    auto it = a->gsTasks.find(k);
+    if (it->second.n < 0) return 1;   // not pipelinable
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
     if (a->nCoopSlices) T.sliceT = a->d_sliceT;
     if (ctx->p2pGate)
