@@ -117,6 +117,9 @@ static int ctx_init(ldu_ctx* c, int device)
     LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evAggFork, hipEventDisableTiming));
+    LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evAggJoin, hipEventDisableTiming));
     LDU_CHECK_HIP(hipStreamCreateWithFlags(&c->streamComm, hipStreamNonBlocking));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evPacked, hipEventDisableTiming));
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming));
@@ -198,6 +201,8 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e) c->p2pSlabs = atoi(e);
     e = getenv("LDU_P2P_WINDOW");
     if (e) c->p2pWindowLevels = atof(e);
+    e = getenv("LDU_AGG_OVERLAP");
+    if (e) c->aggOverlap = atoi(e);
     e = getenv("LDU_HALO_OVERLAP");
     if (e) c->haloOverlap = atoi(e);
     e = getenv("LDU_WATCHDOG_MS");
@@ -227,6 +232,10 @@ int ldu_ctx_destroy(ldu_ctx* c)
     (void)hipHostFree(c->h_scalars);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+    if (c->evAggFork) (void)hipEventDestroy(c->evAggFork);
+    if (c->evAggJoin) (void)hipEventDestroy(c->evAggJoin);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->streamComm) (void)hipStreamSynchronize(c->streamComm);
     if (c->evPacked) (void)hipEventDestroy(c->evPacked);
     if (c->evHalo) (void)hipEventDestroy(c->evHalo);
@@ -270,6 +279,7 @@ int64_t ldu_ctx_overlapped_halo_count(const ldu_ctx* c) { return c ? (int64_t)c-
 int ldu_ctx_sync(ldu_ctx* c)
 {
     LDU_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (c->stream3) LDU_CHECK_HIP(hipStreamSynchronize(c->stream3));
     return 0;
 }
 
@@ -425,10 +435,10 @@ void matrix_free(ldu_matrix* m)
 }
 
 // LDU-space device coefficients (original order) -> level-ordered diag + sliced-ELL values.
-int matrix_refresh_layout(ldu_matrix* m)
+int matrix_refresh_layout(ldu_matrix* m, hipStream_t onStream)
 {
     ldu_addr* a = m->a;
-    hipStream_t s = a->ctx->stream;
+    hipStream_t s = onStream ? onStream : a->ctx->stream;
     const size_t nE = (size_t)(a->nEntries > 0 ? a->nEntries : 1);
     if (k_permute_in(a, m->d_diag, m->d_diagO, s)) return -1;
     if (k_fill_sell(a, m->d_lowerO, m->d_upperO, m->d_valA, s)) return -1;
@@ -476,6 +486,9 @@ int ldu_matrix_set_coeffs(ldu_matrix* m, const double* diag, const double* upper
     hipStream_t s = a->ctx->stream;
     LDU_CHECK_HIP(hipSetDevice(a->ctx->device));
     const bool sym = (lower == nullptr) || (lower == upper);
+    // (a coefficient agglomeration of the previous coefficients that nobody joined yet - a hierarchy built for a query, a
+    //  solve that failed - still reads the LDU arrays on ctx->stream3: the copies below wait for it; no-op otherwise)
+    if (a->ctx->evAggJoin) LDU_CHECK_HIP(hipStreamWaitEvent(s, a->ctx->evAggJoin, 0));
     if (!sym && m->d_lowerO == m->d_upperO)
         LDU_CHECK_HIP(hipMalloc((void**)&m->d_lowerO, sizeof(double) * ((size_t)a->nFaces + 1)));
     if (sym && m->d_lowerO != m->d_upperO)
@@ -490,7 +503,11 @@ int ldu_matrix_set_coeffs(ldu_matrix* m, const double* diag, const double* upper
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_upperO, upper, sizeof(double) * a->nFaces, hipMemcpyDefault, s));
         if (!sym) LDU_CHECK_HIP(hipMemcpyAsync(m->d_lowerO, lower, sizeof(double) * a->nFaces, hipMemcpyDefault, s));
     }
+    // (the LDU arrays are in place: what the coefficient agglomeration of a GAMG hierarchy waits for, gamg.cpp)
+    const bool forked = a->ctx->evAggFork && hipEventRecord(a->ctx->evAggFork, s) == hipSuccess;
     const int rc = matrix_refresh_layout(m);
+    a->ctx->aggForkOf = forked ? m : nullptr;
+    a->ctx->aggForkEpoch = m->coeffEpoch;
     // host arrays belong to the caller again when this returns (an asynchronous copy from pageable memory may still be
     // reading them: the runtime pins the pages and returns); device arrays are only read by work already ordered on the stream
     if (!is_device_ptr(diag) || (a->nFaces && (!is_device_ptr(upper) || (!sym && !is_device_ptr(lower)))))
@@ -506,6 +523,7 @@ int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bou
     hipStream_t s = a->ctx->stream;
     if (p.n)
     {
+        if (a->ctx->evAggJoin) LDU_CHECK_HIP(hipStreamWaitEvent(s, a->ctx->evAggJoin, 0));   // (as in set_coeffs)
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_bou + p.offset, bou, sizeof(double) * p.n, hipMemcpyDefault, s));
         LDU_CHECK_HIP(hipMemcpyAsync(m->d_int + p.offset, intc, sizeof(double) * p.n, hipMemcpyDefault, s));
         if (!is_device_ptr(bou) || !is_device_ptr(intc)) LDU_CHECK_HIP(hipStreamSynchronize(s));   // (as in set_coeffs)

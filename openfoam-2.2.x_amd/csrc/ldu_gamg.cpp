@@ -61,6 +61,7 @@ struct GamgHierarchy {
     int coarsestPeerEpoch = -1;
     int peerWgEpoch = -1;                // carrier epoch the levels' one-launch smoother decisions (ldu_addr::peerWg) belong to          // ctx->commEpoch the decision belongs to (ldu_ctx_comm_select changes the carriers)
     int* d_cycPair = nullptr;
+    bool aggPending = false;             // level coefficients still being built on ctx->stream3: the main stream joins before it reads them
 };
 
 template <class T>
@@ -76,6 +77,8 @@ static int up(T** dst, const std::vector<T>& src)
 void gamg_free(GamgHierarchy* g)
 {
     if (!g) return;
+    if (g->aggPending && !g->levels.empty() && g->levels[0].addr && g->levels[0].addr->ctx->stream3)
+        (void)hipStreamSynchronize(g->levels[0].addr->ctx->stream3);   // the level matrices are still being written
     for (auto& L : g->levels)
     {
         void* ptrs[] = {L.d_childStart, L.d_child, L.d_mapNew, L.d_cfStart, L.d_cfFine, L.d_cfFlip,
@@ -683,7 +686,21 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
     // (GAMGSolver.C:86-89 runs agglomerateMatrix for every level in every solver construction)
     if (g->coeffEpoch != m->coeffEpoch)
     {
-        hipStream_t s = a->ctx->stream;
+        // On a stream of its own, beside the finest level's own work of this solve (its level layout, the initial residual,
+        // the normalisation factor, the restrictions): the chain below - two gathers, a permutation and a layout fill per
+        // level, every level from the one above it - is a few large launches and ~80 small ones.  It starts when the finest
+        // LDU arrays are in place (event of ldu_matrix_set_coeffs; otherwise: now) and vcycle() joins before the first level
+        // matrix is read.
+        ldu_ctx* ctx = a->ctx;
+        hipStream_t s = ctx->stream;
+        if (ctx->aggOverlap && ctx->stream3)
+        {
+            if (g->aggPending) LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evAggJoin, 0));   // (an unfinished earlier chain)
+            if (!(ctx->aggForkOf == m && ctx->aggForkEpoch == m->coeffEpoch))
+                LDU_CHECK_HIP(hipEventRecord(ctx->evAggFork, ctx->stream));
+            LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evAggFork, 0));
+            s = ctx->stream3;
+        }
         const ldu_matrix* fm = m;
         for (auto& L : g->levels)
         {
@@ -702,8 +719,13 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 if (k_patch_agglomerate(L.addr->nPatchFaces, L.d_pcStart, L.d_pcFine, fm->d_bou, fm->d_int,
                                         cm->d_bou, cm->d_int, s))
                     return -1;
-            if (matrix_refresh_layout(cm)) return -1;
+            if (matrix_refresh_layout(cm, s)) return -1;
             fm = cm;
+        }
+        if (s != ctx->stream)
+        {
+            LDU_CHECK_HIP(hipEventRecord(ctx->evAggJoin, s));
+            g->aggPending = true;
         }
         g->coeffEpoch = m->coeffEpoch;
     }
@@ -826,6 +848,15 @@ static int gamg_decide_peer_smoothers(ldu_matrix* m)
     return 0;
 }
 
+// the level matrices are being built on ctx->stream3 (ensure_hierarchy): the main stream waits here, before it reads one
+static int gamg_join_levels(GamgHierarchy* g, ldu_ctx* ctx)
+{
+    if (!g->aggPending) return 0;
+    LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evAggJoin, 0));
+    g->aggPending = false;
+    return 0;
+}
+
 // GAMGSolverSolve.C:120-364
 static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const double* source, double* Apsi,
                   double* finestCorrection, double* finestResidual)
@@ -837,6 +868,8 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
     const int scaleCorrection = c->scaleCorrection < 0 ? (m->sym ? 1 : 0) : c->scaleCorrection;
     auto& Lv = g->levels;
     if (gamg_decide_peer_smoothers(m)) return -1;
+    // (without pre-smoothing the way down is restrictions only: the level matrices are first read at the coarsest level)
+    if (c->nPreSweeps && gamg_join_levels(g, ctx)) return -1;
 
     if (k_restrict(Lv[0].addr->nCells, Lv[0].d_childStart, Lv[0].d_child, finestResidual, Lv[0].d_src, s))
         return -1;
@@ -865,6 +898,7 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
         static const bool timeCoarsest = getenv("LDU_GAMG_TIME") != nullptr;
         std::chrono::steady_clock::time_point t0;
         if (timeCoarsest) { (void)hipStreamSynchronize(s); t0 = std::chrono::steady_clock::now(); }
+        if (gamg_join_levels(g, ctx)) return -1;
         if (solve_coarsest(g, Lv[coarsestLevel].mat, c, Lv[coarsestLevel].d_corr, Lv[coarsestLevel].d_src)) return -1;
         if (timeCoarsest)
         {
@@ -1061,6 +1095,7 @@ int gamg_level_data(ldu_matrix* m, int level, int32_t* restrictAddr, double* dia
     GamgHierarchy* g = m->gamg;
     if (!g || level < 0 || level >= (int)g->levels.size()) { ldu_set_error("bad GAMG level"); return -9; }
     GamgLevel& L = g->levels[level];
+    if (gamg_join_levels(g, m->a->ctx)) return -1;
     LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
     if (restrictAddr) memcpy(restrictAddr, L.restrictAddr.data(), sizeof(int) * L.restrictAddr.size());
     if (diag) LDU_CHECK_HIP(hipMemcpy(diag, L.mat->d_diagO, sizeof(double) * L.addr->nCells, hipMemcpyDeviceToHost));

@@ -65,6 +65,14 @@ struct ldu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second stream (PBiCG transpose system)
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // third stream: the coefficient agglomeration of a GAMG hierarchy (levels 1 ...) runs beside the finest level's own work
+    // of a solve (its level layout, the initial residual, the restrictions); evAggFork = the finest LDU arrays are in place
+    // (recorded by ldu_matrix_set_coeffs for matrix aggForkOf at epoch aggForkEpoch), evAggJoin = the level matrices are ready
+    hipStream_t stream3 = nullptr;
+    hipEvent_t evAggFork = nullptr, evAggJoin = nullptr;
+    const void* aggForkOf = nullptr;
+    uint64_t aggForkEpoch = 0;
+    int aggOverlap = 1;              // LDU_AGG_OVERLAP=0: everything on the main stream
     // halo exchange overlapped with the interior rows: the send/recv of an operator application runs on its own
     // stream between pack (initMatrixInterfaces) and apply (updateMatrixInterfaces) - the window the reference
     // itself leaves for the interior loops (lduMatrixUpdateMatrixInterfaces.C:30-93, 127-160; lduMatrixATmul.C:62-89)
@@ -585,7 +593,7 @@ int gamg_level_data(ldu_matrix* m, int level, int32_t* restrictAddr, double* dia
 
 // matrix helpers (ldu_capi.cpp)
 int matrix_alloc(ldu_addr* a, ldu_matrix** out);
-int matrix_refresh_layout(ldu_matrix* m);   // LDU-space device coefficients -> compute layout
+int matrix_refresh_layout(ldu_matrix* m, hipStream_t onStream = nullptr);   // LDU-space device coefficients -> compute layout
 void matrix_free(ldu_matrix* m);
 int addr_create_internal(ldu_ctx* ctx, ldu_addr** out, int nCells, int nFaces, const int* l, const int* u);
 
