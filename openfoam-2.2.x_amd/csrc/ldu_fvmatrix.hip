@@ -687,68 +687,55 @@ fv_gaussGradTile_kernel(int nCells, const int* __restrict__ cs, const int* __res
     }
     __syncthreads();
     const int c = c0 + threadIdx.x;
-    const bool have = c < nCells;
+    if (c >= nCells) return;
     double acc[K];
 #pragma unroll
     for (int q = 0; q < K; q++) acc[q] = 0.0;
-    if (have)
+    for (int t = losortStart[c]; t < losortStart[c + 1]; t++)
     {
-        for (int t = losortStart[c]; t < losortStart[c + 1]; t++)
+        const int f = losort[t];
+        const unsigned fl = (unsigned)(f - fA);
+        if (fl < (unsigned)nOwn)
         {
-            const int f = losort[t];
-            const unsigned fl = (unsigned)(f - fA);
-            if (fl < (unsigned)nOwn)
-            {
 #pragma unroll
-                for (int q = 0; q < K; q++) acc[q] -= prod[fl * K + q];
-            }
-            else
-            {
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = 0; j < NC; j++) acc[NC * i + j] -= Sf3[3 * (size_t)f + i] * ssf[NC * (size_t)f + j];
-            }
+            for (int q = 0; q < K; q++) acc[q] -= prod[fl * K + q];
         }
-        for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
+        else
         {
-            const unsigned fl = (unsigned)(f - fA);
-            if (fl < (unsigned)nOwn)
-            {
 #pragma unroll
-                for (int q = 0; q < K; q++) acc[q] += prod[fl * K + q];
-            }
-            else
-            {
+            for (int i = 0; i < 3; i++)
 #pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = 0; j < NC; j++) acc[NC * i + j] += Sf3[3 * (size_t)f + i] * ssf[NC * (size_t)f + j];
-            }
+                for (int j = 0; j < NC; j++) acc[NC * i + j] -= Sf3[3 * (size_t)f + i] * ssf[NC * (size_t)f + j];
         }
-        if (cs)
-            for (int q = cs[c]; q < cs[c + 1]; q++)
-            {
-                const int f = cf[q];
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = 0; j < NC; j++) acc[NC * i + j] += bSf3[3 * (size_t)f + i] * bssf[NC * (size_t)f + j];
-            }
-        const double v = V[c];
-#pragma unroll
-        for (int q = 0; q < K; q++) acc[q] = acc[q] / v;
     }
-    // the gradient leaves through LDS: K-double records per lane become coalesced rows (the staged products are no longer read)
-    __syncthreads();
-    if (have)
+    for (int f = ownerStart[c]; f < ownerStart[c + 1]; f++)
     {
+        const unsigned fl = (unsigned)(f - fA);
+        if (fl < (unsigned)nOwn)
+        {
 #pragma unroll
-        for (int q = 0; q < K; q++) prod[K * threadIdx.x + q] = acc[q];
+            for (int q = 0; q < K; q++) acc[q] += prod[fl * K + q];
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < NC; j++) acc[NC * i + j] += Sf3[3 * (size_t)f + i] * ssf[NC * (size_t)f + j];
+        }
     }
-    __syncthreads();
-    const int nOut = (cEnd - c0) * K;
-    for (int e = threadIdx.x; e < nOut; e += GLUE_BLK) grad[K * (size_t)c0 + e] = prod[e];
+    if (cs)
+        for (int q = cs[c]; q < cs[c + 1]; q++)
+        {
+            const int f = cf[q];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < NC; j++) acc[NC * i + j] += bSf3[3 * (size_t)f + i] * bssf[NC * (size_t)f + j];
+        }
+    const double v = V[c];
+#pragma unroll
+    for (int q = 0; q < K; q++) grad[K * (size_t)c + q] = acc[q] / v;
 }
 
 // Vector field (tensor gradient): the tile's owned faces are staged RAW - Sf and ssf, 6 doubles per face, copied from the

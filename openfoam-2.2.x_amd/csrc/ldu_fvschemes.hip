@@ -342,64 +342,6 @@ fs_surfaceIntegrate_kernel(int nCells, const int* __restrict__ cs, const int* __
   }
 }
 
-// Scalar fields: the same sums with the owned faces of a tile of FS_BLK consecutive cells staged through LDS (faces are
-// ordered by owner: ONE contiguous range, copied by coalesced loads; a cell's owned faces - and the neighbour-side faces
-// the tile owns too - come from there, only the neighbour-side faces of other tiles are gathered from global memory).
-// XCD-aware tile order: XCD x walks the x-th eighth of the tiles, so the faces gathered from the previous tiles were
-// staged by the same XCD moments ago (its own L2).  Same order of additions per cell.
-#define FS_MAXF 1024
-template <int MODE>
-__global__ void __launch_bounds__(FS_BLK)
-fs_surfaceIntegrateTile1_kernel(int nCells, const int* __restrict__ cs, const int* __restrict__ cf,
-                                const int* __restrict__ losortStart, const int* __restrict__ losort,
-                                const int* __restrict__ ownerStart, const double* __restrict__ ssf,
-                                const double* __restrict__ bssf, const double* __restrict__ V, double* __restrict__ out)
-{
-    __shared__ double sV[FS_MAXF];
-    const int nTiles = (nCells + FS_BLK - 1) / FS_BLK;
-    const int per = (nTiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (tile >= nTiles) return;
-    const int c0 = tile * FS_BLK;
-    const int cEnd = c0 + FS_BLK < nCells ? c0 + FS_BLK : nCells;
-    const int fA = ownerStart[c0];
-    int nOwn = ownerStart[cEnd] - fA;
-    if (nOwn > FS_MAXF) nOwn = FS_MAXF;
-    for (int e = threadIdx.x; e < nOwn; e += FS_BLK) sV[e] = ssf[(size_t)fA + e];
-    __syncthreads();
-    const int c = c0 + threadIdx.x;
-    if (c >= nCells) return;
-    double acc = 0.0;
-    const int t1 = losortStart[c + 1];
-    for (int t = losortStart[c]; t < t1; t += 4)
-    {
-        int f[4];
-        double v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) f[k] = losort[t + k < t1 ? t + k : t1 - 1];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            const unsigned fl = (unsigned)(f[k] - fA);
-            v[k] = fl < (unsigned)nOwn ? sV[fl] : ssf[f[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (t + k < t1) acc -= v[k];
-    }
-    const int f1 = ownerStart[c + 1];
-    for (int f = ownerStart[c]; f < f1; f++)
-    {
-        const unsigned fl = (unsigned)(f - fA);
-        acc += fl < (unsigned)nOwn ? sV[fl] : ssf[f];
-    }
-    if (cs)
-        for (int j = cs[c]; j < cs[c + 1]; j++) acc += bssf[cf[j]];
-    const double v = V[c];
-    if (MODE == 0) out[c] = acc / v;
-    else out[c] -= v * (acc / v);
-}
-
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -615,11 +557,10 @@ static int fs_integrate(ldu_addr* a, ldu_fv_boundary* b, int nComp, const double
     const int grid = fs_grid(a->nCells);
     if (a->nCells)
     {
-        const int tgrid = 8 * (((a->nCells + FS_BLK - 1) / FS_BLK + 7) / 8);
         if (nComp == 1 && mode == 0)
-            fs_surfaceIntegrateTile1_kernel<0><<<tgrid, FS_BLK, 0, B.s>>>(a->nCells, cs, cf, a->d_losortStart, a->d_losort, a->d_ownerStart, f, bf, v, o);
+            fs_surfaceIntegrate_kernel<1, 0><<<grid, FS_BLK, 0, B.s>>>(a->nCells, cs, cf, a->d_losortStart, a->d_losort, a->d_ownerStart, f, bf, v, o);
         else if (nComp == 1)
-            fs_surfaceIntegrateTile1_kernel<1><<<tgrid, FS_BLK, 0, B.s>>>(a->nCells, cs, cf, a->d_losortStart, a->d_losort, a->d_ownerStart, f, bf, v, o);
+            fs_surfaceIntegrate_kernel<1, 1><<<grid, FS_BLK, 0, B.s>>>(a->nCells, cs, cf, a->d_losortStart, a->d_losort, a->d_ownerStart, f, bf, v, o);
         else if (mode == 0)
             fs_surfaceIntegrate_kernel<3, 0><<<grid, FS_BLK, 0, B.s>>>(a->nCells, cs, cf, a->d_losortStart, a->d_losort, a->d_ownerStart, f, bf, v, o);
         else
