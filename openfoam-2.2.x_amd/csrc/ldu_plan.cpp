@@ -257,8 +257,11 @@ int plan_build(ldu_addr* a)
         // (nor for the levels of the one-workgroup engine: every slice is a task there, full slices are what it wants.
         //  LDU_WG_WIDE=1 lets it take rows of any width - measured on the octree twin's coarse levels it loses to the slab
         //  engine with cooperative rows and lag buckets there, 1.2-2.3 against 0.6-1.1 ms for four sweeps)
+        //  Below ~400 cells it wins with rows of any width - there a level is a chain of one-slice steps and the hand-off is
+        //  everything: levels of 77 / 152 / 303 cells of the real motorBike mesh 0.138 / 0.179 / 0.298 -> 0.089 / 0.111 / 0.231 ms
+        //  for four sweeps, the 1200-cell level 0.41 -> 0.49 ms)
         a->wgLevel = a->ctx->wgEngine && nC <= std::min(a->ctx->wgMaxCells, 18000) && nC >= a->ctx->wgMinCells
-                     && (widestRow <= 16 || a->ctx->wgWide);
+                     && (widestRow <= 16 || a->ctx->wgWide || nC <= 400);
         const bool smallKernels = (nC <= a->ctx->smallMaxCells && widestRow <= 16) || a->wgLevel;
         const int lagW = (sortRows && a->ctx->lagBucketWidth > 0 && !smallKernels && nC >= 512) ? a->ctx->lagBucketWidth : 0;
         int NLAG = 1;
