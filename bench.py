@@ -613,6 +613,18 @@ def main():
         extra["pcg_dic_GBs_algorithmic"] = round((160.0 * nC + 48.0 * nF) * nit / tp / 1e9, 1)
         if "tri_sweep" in pprof:
             extra["dic_sweep_avg_ms"] = round(pprof["tri_sweep"]["ms"] / pprof["tri_sweep"]["count"], 4)
+        # DIC preconditioner calls back to back (two half sweeps + the permutations of a C-ABI call each, no host read-back
+        # between them as inside the PCG loop; 1.28 ms per call on a box with 0.46 ms half sweeps): on the boxes where the
+        # PCG leg runs at ~540 instead of ~735 it/s (profiles/r04_pcg_variance.md) this tells the kernel from the loop
+        d_w = torch.zeros_like(d_source)
+        Lb = capi.lib()
+        capi._chk(Lb.ldu_precondition(mat.h, capi.PRECONDITIONERS["DIC"], capi._ptr(d_w), capi._ptr(d_source), 0))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            capi._chk(Lb.ldu_precondition(mat.h, capi.PRECONDITIONERS["DIC"], capi._ptr(d_w), capi._ptr(d_source), 0))
+        barrier()
+        extra["dic_precondition_call_back_to_back_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
     except Exception as e:  # pragma: no cover
         extra["pcg_error"] = str(e)
     # config C3's other half: the U-equation solvers of the motorBike case on the ASYMMETRIC matrix of the same box
