@@ -520,6 +520,7 @@ def main():
                    "clusters": ("sweep_cluster_gs_multi_kernel", "sweep_cluster_kernel<SW_GS_FWD>"),
                    "single wavefront": ("gs_small_kernel", "gs_small_kernel"),
                    "one workgroup": ("gs_wg_kernel", "gs_wg_kernel"),
+                   "blocks": ("gs_blk_kernel", "gs_blk_kernel"),
                    "level kernels": ("sweep_level_kernel", "sweep_level_kernel")}[eng]
         kname = ("%s (%s engine): %d pipelined GaussSeidel sweeps of the finest level per launch"
                  % (kernels[0], eng, per_launch)) if key == "gs_multi" else \

@@ -239,6 +239,12 @@ int ldu_debug_cluster_trace(ldu_matrix* m, void* buf);
  * memory or NULL.  ldu_debug_slice_levels: out[0] = dependency levels, out[1..] = first slice of every level. */
 int ldu_debug_gs_multi_trace(ldu_matrix* m, void* buf);
 int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap);
+/* The block engine (ldu_blocks.hip): per (sweep, group) task 8 x u64 - start, loads issued, dependencies seen, stored
+ * [100 MHz wall clock], wavefront, sweep, block, lanes per row; buf = (tasks of k sweeps) * 64 bytes or NULL.
+ * ldu_debug_blocks_info: out[0..5] = blocks, compute wavefronts per block, LDS bytes per block, ghosts, groupings, tasks
+ * of k sweeps (all 0: the addressing is not on the block engine). */
+int ldu_debug_blocks_trace(ldu_matrix* m, void* buf);
+int ldu_debug_blocks_info(ldu_matrix* m, int32_t k, int64_t* out);
 int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap);
 /* ldu_debug_slices: per slice of the level-ordered layout {first row, rows, entries per row, most lower, most upper
  * neighbours of a row}; out holds 5 * cap values, cap >= slices */

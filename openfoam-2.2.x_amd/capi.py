@@ -20,7 +20,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
-    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_slice_levels",
+    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_blocks_trace", "ldu_debug_blocks_info", "ldu_debug_slice_levels",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_ctx_comm_init_peer", "ldu_ctx_comm_select", "ldu_ctx_comm_info", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
@@ -372,7 +372,7 @@ class Addressing:
         _chk(lib().ldu_addr_get_face_weights(self.h, _ptr(w)))
         return w
 
-    ENGINES = ("chip-wide point-to-point", "XCD slabs", "clusters", "single wavefront", "level kernels", "one workgroup")
+    ENGINES = ("chip-wide point-to-point", "XCD slabs", "clusters", "single wavefront", "level kernels", "one workgroup", "blocks")
 
     def sweep_engine(self, kind):
         rc = lib().ldu_addr_sweep_engine(self.h, int(kind))

@@ -1,0 +1,939 @@
+// Block engine: k pipelined GaussSeidel sweeps of a mid-size matrix (GAMG levels of ~6 000 ... ~2.5 M cells on unstructured
+// meshes) with the dependency hand-offs INSIDE a workgroup's LDS.
+//
+// Why.  The sequential GaussSeidel recurrence (GaussSeidelSmoother.C:147-176) is executed in the reference's order, row by
+// row, so a sweep costs (depth of the dependency DAG) x (time of one hand-off).  The chip-wide / slab engines hand over
+// through L2 (2.5-3 us per dependency level on the agglomerated levels of the motorBike mesh: 12-15 neighbours per row,
+// 400-900 levels deep); the one-workgroup engine (gs_wg_kernel) hands over through LDS but holds the whole matrix in ONE
+// workgroup (<= 6 000 cells).  Here the matrix is cut into compact BLOCKS of a few thousand cells; every block is one
+// workgroup that keeps the solution values AND a sweep stamp per row of its block in LDS and runs the k sweeps as
+// (sweep, group of rows) tasks of its wavefronts.  Only dependencies that cross a block boundary travel through memory: a row
+// with a neighbour in another block publishes {value, tag} as a 16-byte granule (the engines' common hand-off format); the
+// consuming block has a GHOST slot for that row in its LDS, filled by a dedicated importer wavefront that polls the
+// granules in the order in which they become due.
+//
+// Groups.  A task is a group of rows of one block that can run at the same time.  For sweep j the rows are grouped by their
+// time T_j in the ROW-level dependency DAG of the k sweeps (T_0 = dependency level; T_j(r) = 1 + max(T_j of the lower
+// neighbours, T_j-1 of the upper neighbours, T_j-1(r))): every sweep has its own grouping and its own copy of the row and
+// entry tables.  Grouping every sweep by the dependency level (what the level engines' slices do) makes sweep j + 1 trail
+// sweep j by the WORST upper-neighbour reach inside a group - on the agglomerated levels four sweeps then cost 3.7 x one
+// (1247 steps against 518 on the 93 k-cell level of the 12.7 M-cell motorBike mesh, tools/block_probe2.cpp).
+// Rows of more than 16 entries are spread over 2 / 4 / 8 lanes (16 entries per lane in registers, the partial sums handed
+// from lane to lane in entry order), so a wide row costs no memory round trip on the dependency chain.
+//
+// Exactness.  Per row: acc = b; acc -= coeff * value in the reference's accumulation order (lower-neighbour faces ascending,
+// then owned faces ascending); ldu_div - the arithmetic of every other engine, bit-identical to the sequential loop.
+// The readiness rule is the exact dependency of that loop: a row of sweep j needs its lower neighbours with stamp j + 1 and
+// its upper neighbours with stamp j; a stamp can never be AHEAD of what a row needs (the neighbour's next sweep needs this
+// row's current one), so one value slot per row suffices - in LDS and in the granule array.
+//
+// Progress.  Within a sweep a group holds rows of ONE value of a strict potential of the row DAG, so the (sweep, group)
+// tasks of all blocks form an acyclic graph; Phi (the group-level version of T) orders them.  Every worker - a compute
+// wavefront's task list, a lane of the importer - walks its items in non-decreasing Phi: the unfinished item of smallest
+// Phi has all its inputs and is its worker's current item.  What this needs from the hardware is that all blocks are
+// RESIDENT at the same time (the quotient graph of the blocks is cyclic): the grid is limited to what the occupancy API
+// promises for this kernel, and every wait is bounded like in the other engines (abort flag -> the operation is re-run on
+// the level kernels), so a launch that does not get its residency fails loudly instead of hanging.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "ldu_internal.hpp"
+
+#define BK_MAX_LDS (160 * 1024)
+#define BK_NLAY 4
+
+typedef unsigned int bk_u32x4 __attribute__((ext_vector_type(4)));
+
+struct BlockPlan {
+    bool built = false;
+    bool eligible = false;
+    int nBlocks = 0;
+    int maxSlots = 0;              // max over blocks of local rows + ghosts
+    int nGhostTotal = 0;
+    int nw = 7;                    // compute wavefronts per block (+ 1 importer): 7 = one workgroup of 512 threads per CU, 3 = two of 256
+    int nLayouts = BK_NLAY;        // sweep j uses the grouping of layout min(j, nLayouts - 1)
+    size_t ldsBytes = 0;
+    // device tables
+    int4* d_blk = nullptr;         // [nBlocks] {first local row in d_localRow, nLocal, ghostBase, nGhost}
+    int* d_localRow = nullptr;     // [nCells] slot order of every block: level-ordered row
+    int* d_ghostRow = nullptr;     // [nGhostTotal] level-ordered row of a ghost
+    struct Layout {
+        int nGroups = 0;
+        long nLanes = 0, nEntries = 0;
+        int2* d_meta = nullptr;            // [nLanes + 64] {level-ordered row | exported << 31 | last lane of the row << 30,
+                                           //                 LDS slot | lower entries of this lane << 16 | entries of this lane << 24}
+        unsigned short* d_col = nullptr;   // [nEntries] LDS slot of the column
+        int* d_srcFace = nullptr;          // [nEntries] face << 1 | (1: upper-triangle coefficient), -1 padding
+        // host
+        std::vector<int> grpBlk, grpLane0, grpCnt, grpT, grpEnt, grpStride, Phi, grpOfCell;
+    } lay[BK_NLAY];
+    uint4* d_granule = nullptr;    // [nCells + 1]
+    unsigned* d_start = nullptr;   // blocks that have loaded their initial values (monotonic)
+    unsigned startBase = 0;
+    unsigned epoch = 0;
+    int gen = 0;
+    struct Tasks { int4* d_tasks = nullptr; int* d_taskStart = nullptr; int4* d_imps = nullptr; int* d_impStart = nullptr; long nTasks = 0; };
+    std::map<int, Tasks> tasks;    // per k
+    struct Conv { double* d[BK_NLAY] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long stamp = 0; };
+    std::map<const double*, Conv> conv;
+    // host copies the per-k lists are made from
+    std::vector<int> ghostBase;            // [nBlocks + 1]
+    std::vector<int> ghostCell;            // [nGhostTotal] old cell label
+    std::vector<unsigned char> ghostLower; // [nGhostTotal] 1 = lower neighbour of a local row (needs stamps 1 ... k)
+    std::vector<int> ghostRowH;            // [nGhostTotal] level-ordered row
+    std::vector<int> blkNLocal;            // [nBlocks]
+};
+
+template <class T>
+static int bk_upload(T** dst, const std::vector<T>& src, size_t extra = 0)
+{
+    const size_t n = src.size() + extra ? src.size() + extra : 1;
+    LDU_CHECK_HIP(hipMalloc((void**)dst, n * sizeof(T)));
+    if (extra || !src.size()) LDU_CHECK_HIP(ldu_memset_sync(*dst, 0, n * sizeof(T)));
+    if (src.size()) LDU_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void blocks_free(ldu_addr* a)
+{
+    BlockPlan* P = a->blocks;
+    if (!P) return;
+    void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_start};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& L : P->lay)
+        for (void* p : {(void*)L.d_meta, (void*)L.d_col, (void*)L.d_srcFace}) if (p) (void)hipFree(p);
+    for (auto& kv : P->conv) for (double* d : kv.second.d) if (d) (void)hipFree(d);
+    for (auto& kv : P->tasks)
+        for (void* p : {(void*)kv.second.d_tasks, (void*)kv.second.d_taskStart, (void*)kv.second.d_imps, (void*)kv.second.d_impStart})
+            if (p) (void)hipFree(p);
+    delete P;
+    a->blocks = nullptr;
+}
+
+void blocks_forget(ldu_addr* a, const double* levelVal)
+{
+    if (!a || !a->blocks) return;
+    auto it = a->blocks->conv.find(levelVal);
+    if (it == a->blocks->conv.end()) return;
+    (void)hipStreamSynchronize(a->ctx->stream);
+    for (double* d : it->second.d) if (d) (void)hipFree(d);
+    a->blocks->conv.erase(it);
+}
+
+// ---------------------------------------------------------------- kernels
+
+static __device__ unsigned long long* g_bk_trace = nullptr;
+
+int k_blocks_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks)
+{
+    unsigned long long v[2] = {budgetTicks, stallTicks};
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wait_budget), v, sizeof(v)));
+    return 0;
+}
+
+__global__ void __launch_bounds__(256)
+bk_fill_kernel(long n, const int* __restrict__ srcFace, const double* __restrict__ lowerO, const double* __restrict__ upperO,
+               double* __restrict__ out)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    {
+        const int code = srcFace[i];
+        double v = 0.0;
+        if (code >= 0) v = (code & 1) ? upperO[code >> 1] : lowerO[code >> 1];
+        out[i] = v;
+    }
+}
+
+__device__ __forceinline__ void bk_store(uint4* G, int row, double v, unsigned tag)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    bk_u32x4 d;
+    d.x = (unsigned)b; d.y = tag; d.z = (unsigned)(b >> 32); d.w = tag;
+    uint4* p = G + row;
+    // (s_nop 1: the two wait states a VMEM store of more than 64 bits needs before its data registers are rewritten -
+    //  the hazard recognizer does not look inside inline asm, DESIGN.md "A hardware hazard worth recording")
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+}
+
+__device__ __forceinline__ bk_u32x4 bk_load(const uint4* p)
+{
+    bk_u32x4 g;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory");
+    return g;
+}
+
+// the value of the previous lane (row_shr:1 inside a row of 16 lanes; groups of 2 / 4 / 8 lanes never straddle one)
+__device__ __forceinline__ double bk_from_prev_lane(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x111, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+struct BkTab {
+    const int4* blk; const int* localRow; const int* ghostRow;
+    const int2* meta[BK_NLAY]; const unsigned short* col[BK_NLAY]; const double* val[BK_NLAY];
+    int nLayouts;
+    const int4* tasks; const int* taskStart; const int4* imps; const int* impStart;
+};
+
+// a task's rows in flight: one lane = one row (T = 1) or one sixteen-entry part of a row (T = 2 / 4 / 8 lanes per row)
+struct BkRow { int rg, slot, nl, nn, T, j; bool have; unsigned short c[16]; double v[16]; double b, d; };
+
+// stage B of a task's prefetch: everything that depends on the task record alone
+__device__ __forceinline__ void bk_row_load(const int4& Q, int lane, const BkTab& T, BkRow& R)
+{
+    const int cnt = Q.y & 255, stride = (Q.y >> 16) & 255, j = Q.w;
+    const int L = j < T.nLayouts ? j : T.nLayouts - 1;
+    const int2* __restrict__ meta = T.meta[L];
+    const unsigned short* __restrict__ col = T.col[L];
+    const double* __restrict__ val = T.val[L];
+    const bool have = lane < cnt;
+    const int2 M = meta[Q.x + (have ? lane : 0)];
+    const long ent = (long)Q.z + (have ? lane : 0);
+    R.rg = M.x;
+    R.slot = M.y & 0xffff;
+    R.nl = (M.y >> 16) & 255;
+    R.nn = (M.y >> 24) & 255;
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+    {
+        const long e = ent + (long)q * stride;   // (a group's entries: 16 x stride, stride >= its lanes)
+        R.c[q] = col[e];
+        R.v[q] = val[e];
+    }
+    R.have = have;
+    R.T = (Q.y >> 8) & 255;
+    R.j = j;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(LDU_WAVE * (NW + 1))
+gs_blk_kernel(BkTab T, int nBlocks, uint4* __restrict__ G, unsigned tagBase, unsigned* startCtr, unsigned startBase,
+              int* abortFlag, double* __restrict__ psi, const double* __restrict__ rhs, const double* __restrict__ diag)
+{
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    const int4 B = T.blk[b];
+    const int rowBase = B.x, nLocal = B.y, ghostBase = B.z, nGhost = B.w;
+    const int nSlots = nLocal + nGhost;
+    double* x = smem;
+    unsigned char* stamp = (unsigned char*)(x + nSlots);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int t0 = T.taskStart[b], nTasks = T.taskStart[b + 1] - t0;
+    const int4* tasks = T.tasks + t0;
+    BkRow R0, R1, R2;
+    int4 Q = make_int4(0, 0, 0, 0);
+    int iNext = wave;
+#define BK_REC() do { Q = (iNext < nTasks && wave < NW) ? tasks[iNext] : make_int4(0, 0, 0, 0); iNext += NW; } while (0)
+#define BK_FILLB(R) do { bk_row_load(Q, lane, T, (R)); BK_REC(); } while (0)
+#define BK_FILLC(R) do { const int g_ = (R).rg & 0x3fffffff; (R).b = rhs[g_]; (R).d = diag[g_]; } while (0)
+    if (wave < NW)
+    {
+        BK_REC();
+        BK_FILLB(R0);
+        BK_FILLB(R1);
+    }
+    for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) { x[i] = psi[T.localRow[rowBase + i]]; stamp[i] = 0; }
+    for (int i = tid; i < nGhost; i += LDU_WAVE * (NW + 1)) { x[nLocal + i] = psi[T.ghostRow[ghostBase + i]]; stamp[nLocal + i] = 0; }
+    __syncthreads();
+    // every block reads psi before any block may overwrite it (the write-back at the end waits for this count)
+    if (tid == 0) __hip_atomic_fetch_add(startCtr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    bool alive = true;
+    if (wave == NW)
+    {
+        // ---- importer: lane L walks the block's import records L, L + 64, ... (sorted by the time they become due); a
+        // record = {ghost slot, level-ordered row, stamp}; the granule of the row carries tag tagBase + stamp once the
+        // producing block has finished that sweep of the row
+        const int i0 = T.impStart[b], nImp = T.impStart[b + 1] - i0;
+        const int4* I = T.imps + i0;
+        int i = lane;
+        int4 e = i < nImp ? I[i] : make_int4(0, 0, 0, 0);
+        int4 en = i + LDU_WAVE < nImp ? I[i + LDU_WAVE] : make_int4(0, 0, 0, 0);
+        unsigned spins = 0;
+        unsigned long long tw0 = 0;
+        while (true)
+        {
+            const bool have = i < nImp;
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+            bool ok = false;
+            if (have)
+            {
+                const bk_u32x4 g = bk_load(G + e.y);
+                const unsigned want = tagBase + (unsigned)e.z;
+                ok = g.y == want && g.w == want;
+                if (ok)
+                {
+                    x[e.x] = __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
+                    LDU_LDS_RELEASE();
+                    stamp[e.x] = (unsigned char)e.z;
+                    i += LDU_WAVE;
+                    e = en;
+                    en = i + LDU_WAVE < nImp ? I[i + LDU_WAVE] : make_int4(0, 0, 0, 0);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(ok) != 0ull) { spins = 0; tw0 = 0; }
+            else
+            {
+                __builtin_amdgcn_s_sleep(2);
+                if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; break; }
+            }
+        }
+    }
+    else
+    {
+        BK_FILLC(R0);
+        int left = (nTasks - wave + NW - 1) / NW;      // this wavefront's tasks
+        if (left < 0) left = 0;
+        unsigned long long* trc = g_bk_trace ? g_bk_trace + ((size_t)t0 + wave) * 8 : nullptr;
+#define BK_TRC(k) do { if (trc && lane == 0) trc[k] = wall_clock64(); } while (0)
+#define BK_STEP(CUR, NXT, FILL)                                                           \
+    do {                                                                                  \
+        BK_TRC(0);                                                                        \
+        BK_FILLC(NXT);                                                                    \
+        BK_FILLB(FILL);                                                                   \
+        BK_TRC(1);                                                                        \
+        const double rd_ = ldu_div_prepare((CUR).d);                                      \
+        {                                                                                 \
+            const bool have = (CUR).have;                                                 \
+            const int self = have ? (CUR).slot : 0;                                       \
+            const int nl = (CUR).nl, nn = have ? (CUR).nn : 0, j = (CUR).j;               \
+            int cc[16];                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) cc[q] = q < nn ? (int)(CUR).c[q] : self; \
+            /* lower entries need stamp j + 1, upper entries and the padding (the row itself) stamp j; a lane without a row \
+               reads stamp[0] sixteen times over and does not vote */                     \
+            const int want = 16 * j + nl;                                                 \
+            double xv[16], pr[16];                                                        \
+            {                                                                             \
+                unsigned spins = 0;                                                       \
+                unsigned long long tw0 = 0;                                               \
+                while (alive)                                                             \
+                {                                                                         \
+                    int st[16];                                                           \
+                    _Pragma("unroll") for (int q = 0; q < 16; q++) st[q] = stamp[cc[q]];  \
+                    int sum = 0;                                                          \
+                    _Pragma("unroll") for (int q = 0; q < 16; q++) sum += st[q];          \
+                    if (__builtin_amdgcn_ballot_w64(have && sum != want) == 0ull) break;  \
+                    if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; alive = false; } \
+                }                                                                         \
+                LDU_LDS_ACQUIRE();                                                        \
+                _Pragma("unroll") for (int q = 0; q < 16; q++) xv[q] = x[cc[q]];          \
+            }                                                                             \
+            BK_TRC(2);                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 16; q++) asm volatile("" : "+v"(xv[q])); \
+            _Pragma("unroll") for (int q = 0; q < 16; q++)                                \
+                pr[q] = q < nn ? (CUR).v[q] * xv[q] : 0.0;                                \
+            double acc = (CUR).b;                                                         \
+            const int Tl = (CUR).T;                                                       \
+            if (Tl == 1)                                                                  \
+            {                                                                             \
+                _Pragma("unroll") for (int q = 0; q < 16; q++) acc -= pr[q];              \
+            }                                                                             \
+            else                                                                          \
+            {                                                                             \
+                /* a row of more than 16 entries: lane t of its Tl lanes holds entries 16 t ... 16 t + 15; the partial sum \
+                   travels from lane to lane, every lane subtracting its products in entry order */ \
+                const int t = lane & (Tl - 1);                                            \
+                for (int s_ = 0; s_ < Tl; s_++)                                           \
+                {                                                                         \
+                    const double up = bk_from_prev_lane(acc);                             \
+                    double a2 = s_ ? up : acc;                                            \
+                    _Pragma("unroll") for (int q = 0; q < 16; q++) a2 -= pr[q];           \
+                    acc = t == s_ ? a2 : acc;                                             \
+                }                                                                         \
+            }                                                                             \
+            if (have && ((CUR).rg & 0x40000000))                                          \
+            {                                                                             \
+                const double xn_ = ldu_div(acc, (CUR).d, rd_);                            \
+                x[self] = xn_;                                                            \
+                /* a row with a neighbour in another block publishes its granule (first: the longer way) */ \
+                if ((CUR).rg < 0) bk_store(G, (CUR).rg & 0x3fffffff, xn_, tagBase + (unsigned)j + 1u); \
+                LDU_LDS_RELEASE();                                                        \
+                stamp[self] = (unsigned char)(j + 1);                                     \
+            }                                                                             \
+        }                                                                                 \
+        LDU_STEP_FENCE();                                                                 \
+        if (trc && lane == 0) { trc[3] = wall_clock64(); trc[4] = wave; trc[5] = (CUR).j; trc[6] = b; trc[7] = (CUR).T; trc += (size_t)NW * 8; } \
+        --left;                                                                           \
+    } while (0)
+        while (left > 0)
+        {
+            BK_STEP(R0, R1, R2);
+            if (left == 0) break;
+            BK_STEP(R1, R2, R0);
+            if (left == 0) break;
+            BK_STEP(R2, R0, R1);
+        }
+#undef BK_STEP
+#undef BK_TRC
+    }
+#undef BK_FILLB
+#undef BK_FILLC
+#undef BK_REC
+    __syncthreads();
+    // psi may be overwritten once EVERY block has read its initial values (a block that has no lower neighbour in another
+    // block can be done before a late block has even started)
+    if (tid == 0)
+    {
+        unsigned spins = 0;
+        unsigned long long tw0 = 0;
+        while (__hip_atomic_load(startCtr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - startBase < (unsigned)nBlocks)
+        {
+            __builtin_amdgcn_s_sleep(8);
+            if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; break; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) psi[T.localRow[rowBase + i]] = x[i];
+}
+
+// ---------------------------------------------------------------- host: the plan
+
+// compact blocks: breadth-first blobs of <= target cells grown from the lowest unassigned cell (under a bandwidth-reducing
+// numbering the blobs tile the shells of the numbering), fragments merged into their smallest neighbour
+static int bk_partition(const ldu_addr* a, int target, std::vector<int>& blk)
+{
+    const int nC = a->nCells;
+    blk.assign(nC, -1);
+    int nB = 0;
+    std::vector<int> q;
+    q.reserve((size_t)target + 64);
+    auto visit = [&](int c, auto&& fn) {
+        for (int t = a->losortStart[c]; t < a->losortStart[c + 1]; t++) fn(a->l[a->losort[t]]);
+        for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) fn(a->u[f]);
+    };
+    for (int s = 0; s < nC; s++)
+    {
+        if (blk[s] >= 0) continue;
+        q.clear();
+        q.push_back(s);
+        blk[s] = nB;
+        size_t h = 0;
+        while (h < q.size() && (int)q.size() < target)
+        {
+            const int c = q[h++];
+            visit(c, [&](int n) { if (blk[n] < 0 && (int)q.size() < target) { blk[n] = nB; q.push_back(n); } });
+        }
+        nB++;
+    }
+    // merge fragments
+    std::vector<int> sz(nB, 0);
+    for (int c = 0; c < nC; c++) sz[blk[c]]++;
+    const int small = target / 4, cap = target + target / 3;
+    std::vector<int> best(nB, -1);
+    for (int c = 0; c < nC; c++)
+    {
+        const int bc = blk[c];
+        if (sz[bc] >= small) continue;
+        visit(c, [&](int n) {
+            const int bn = blk[n];
+            if (bn != bc && sz[bn] >= small && (best[bc] < 0 || sz[bn] < sz[best[bc]])) best[bc] = bn;
+        });
+    }
+    std::vector<int> tgt(nB);
+    for (int b = 0; b < nB; b++) tgt[b] = b;
+    for (int b = 0; b < nB; b++)
+        if (sz[b] < small && best[b] >= 0 && sz[best[b]] + sz[b] <= cap) { tgt[b] = best[b]; sz[best[b]] += sz[b]; sz[b] = 0; }
+    // compact the labels in order of first occurrence
+    std::vector<int> lab(nB, -1);
+    int n2 = 0;
+    for (int c = 0; c < nC; c++)
+    {
+        const int b = tgt[blk[c]];
+        if (lab[b] < 0) lab[b] = n2++;
+        blk[c] = lab[b];
+    }
+    return n2;
+}
+
+template <int NW>
+static int bk_occupancy(size_t lds, int* perCU)
+{
+    LDU_CHECK_HIP(hipFuncSetAttribute((const void*)gs_blk_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, BK_MAX_LDS));
+    int n = 0;
+    LDU_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gs_blk_kernel<NW>, LDU_WAVE * (NW + 1), lds));
+    *perCU = n;
+    return 0;
+}
+
+static inline int bk_width(const ldu_addr* a, int c)
+{
+    return a->losortStart[c + 1] - a->losortStart[c] + a->ownerStart[c + 1] - a->ownerStart[c];
+}
+
+static int bk_build(ldu_addr* a)
+{
+    if (a->blocks) return 0;
+    ldu_ctx* ctx = a->ctx;
+    BlockPlan* P = new BlockPlan();
+    a->blocks = P;
+    P->built = true;
+    const int nC = a->nCells, nF = a->nFaces;
+    if (!ctx->blkEngine || a->nPatchFaces || nC < ctx->blkMinCells || nC > ctx->blkMaxCells || nF == 0) return 0;
+    const auto tB0 = std::chrono::steady_clock::now();
+    const bool verbose = getenv("LDU_VERBOSE") != nullptr;
+    for (int c = 0; c < nC; c++)
+        if (bk_width(a, c) > 128) return 0;       // (8 lanes x 16 entries per row)
+    const int nw = ctx->blkWaves == 3 ? 3 : 7;
+    P->nw = nw;
+    P->nLayouts = std::min(BK_NLAY, std::max(1, ctx->blkLayouts));
+    // how many workgroups of this kernel a CU holds (registers; LDS is checked per candidate below)
+    int perCUregs = 0;
+    if (nw == 7 ? bk_occupancy<7>(1024, &perCUregs) : bk_occupancy<3>(1024, &perCUregs)) return -1;
+    if (perCUregs < 1) return 0;
+    if (perCUregs > ctx->blkMaxPerCU) perCUregs = ctx->blkMaxPerCU;
+    const long capacityMax = (long)ctx->numCUs * perCUregs;
+    // block size: as many blocks as the chip holds at once (with a margin for fragments), at least blkCellsMin cells
+    int target = ctx->blkCells;
+    if (target <= 0)
+    {
+        target = (int)((double)nC / (0.85 * (double)capacityMax)) + 1;
+        if (target < ctx->blkCellsMin) target = ctx->blkCellsMin;
+        if (target > ctx->blkCellsMax) return 0;
+    }
+    std::vector<int> blk;
+    int nB = 0;
+    std::vector<int> nLocal, slot(nC), rowBase;
+    std::vector<int>& ghostBase = P->ghostBase;
+    std::vector<int>& ghostCell = P->ghostCell;
+    std::vector<unsigned char>& ghostLower = P->ghostLower;
+    int maxSlots = 0, perCU = 0;
+    for (int attempt = 0; attempt < 4; attempt++, target += target / 6)
+    {
+        nB = bk_partition(a, target, blk);
+        // LDS slots of a block's rows: the order of the level-ordered numbering restricted to the block
+        nLocal.assign(nB, 0);
+        for (int r = 0; r < nC; r++) { const int c = a->perm[r]; slot[c] = nLocal[blk[c]]++; }
+        // ghosts
+        ghostBase.assign(nB + 1, 0);
+        ghostCell.clear();
+        ghostLower.clear();
+        {
+            std::vector<int> cellsOf(nC), start(nB + 1, 0);
+            for (int c = 0; c < nC; c++) start[blk[c] + 1]++;
+            for (int b = 0; b < nB; b++) start[b + 1] += start[b];
+            { std::vector<int> pos(start.begin(), start.end() - 1); for (int c = 0; c < nC; c++) cellsOf[pos[blk[c]]++] = c; }
+            std::vector<int> mark(nC, -1), gidx(nC, 0);
+            for (int b = 0; b < nB; b++)
+            {
+                ghostBase[b] = (int)ghostCell.size();
+                for (int t = start[b]; t < start[b + 1]; t++)
+                {
+                    const int c = cellsOf[t];
+                    for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++)
+                    {
+                        const int n = a->l[a->losort[s]];
+                        if (blk[n] == b) continue;
+                        if (mark[n] != b) { mark[n] = b; gidx[n] = (int)ghostCell.size(); ghostCell.push_back(n); ghostLower.push_back(0); }
+                        ghostLower[gidx[n]] = 1;
+                    }
+                    for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++)
+                    {
+                        const int n = a->u[f];
+                        if (blk[n] == b) continue;
+                        if (mark[n] != b) { mark[n] = b; gidx[n] = (int)ghostCell.size(); ghostCell.push_back(n); ghostLower.push_back(0); }
+                    }
+                }
+            }
+            ghostBase[nB] = (int)ghostCell.size();
+        }
+        maxSlots = 0;
+        for (int b = 0; b < nB; b++) maxSlots = std::max(maxSlots, nLocal[b] + ghostBase[b + 1] - ghostBase[b]);
+        const size_t lds = ((size_t)9 * maxSlots + 64 + 15) & ~(size_t)15;
+        perCU = 0;
+        if (lds <= BK_MAX_LDS && maxSlots < 65536)
+        {
+            if (nw == 7 ? bk_occupancy<7>(lds, &perCU) : bk_occupancy<3>(lds, &perCU)) return -1;
+            if (perCU > ctx->blkMaxPerCU) perCU = ctx->blkMaxPerCU;
+        }
+        P->ldsBytes = lds;
+        if (verbose)
+            fprintf(stderr, "[ldugpu] block engine: %d cells, target %d cells per block -> %d blocks, largest %d slots (%zu B of LDS), "
+                            "%d ghosts in all, %d workgroups per CU -> %ld resident\n", nC, target, nB, maxSlots, lds,
+                    (int)ghostCell.size(), perCU, (long)perCU * ctx->numCUs);
+        if (perCU < 1) break;                                   // a block does not fit into LDS: larger blocks will not either
+        if ((long)nB <= (long)perCU * ctx->numCUs) break;       // every block resident
+        perCU = 0;
+        if (ctx->blkCells > 0) break;
+    }
+    if (perCU < 1) return 0;
+    P->nBlocks = nB;
+    P->maxSlots = maxSlots;
+    P->blkNLocal = nLocal;
+    P->nGhostTotal = (int)ghostCell.size();
+    rowBase.assign(nB + 1, 0);
+    for (int b = 0; b < nB; b++) rowBase[b + 1] = rowBase[b] + nLocal[b];
+    std::vector<int> localRow(nC);
+    for (int c = 0; c < nC; c++) localRow[rowBase[blk[c]] + slot[c]] = a->iperm[c];
+    P->ghostRowH.resize(ghostCell.size());
+    for (size_t g = 0; g < ghostCell.size(); g++) P->ghostRowH[g] = a->iperm[ghostCell[g]];
+    // ghost slot of (block, cell): filled block by block below
+    std::vector<char> exported(nC, 0);
+    for (int f = 0; f < nF; f++)
+        if (blk[a->l[f]] != blk[a->u[f]]) exported[a->l[f]] = exported[a->u[f]] = 1;
+
+    // ---- per sweep: times in the row-level DAG, groups, tables, group-level times
+    std::vector<int> RTprev, RT(nC);
+    std::vector<int> gslot(nC, -1);
+    for (int L = 0; L < P->nLayouts; L++)
+    {
+        BlockPlan::Layout& Y = P->lay[L];
+        // T_L of every row (cells in ascending label order: lower neighbours first)
+        for (int c = 0; c < nC; c++)
+        {
+            int t = L ? RTprev[c] : 0;
+            if (L) for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) t = std::max(t, RTprev[a->u[f]]);
+            for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++) t = std::max(t, RT[a->l[a->losort[s]]]);
+            RT[c] = t + 1;
+        }
+        const int maxRT = *std::max_element(RT.begin(), RT.end());
+        // rows sorted by (block, T, lanes per row, level-ordered row): counting sort by T of the level-ordered rows, then by block
+        std::vector<int> order(nC);
+        {
+            std::vector<long> st((size_t)maxRT + 2, 0);
+            for (int c = 0; c < nC; c++) st[(size_t)RT[c] + 1]++;
+            for (size_t i = 0; i + 1 < st.size(); i++) st[i + 1] += st[i];
+            std::vector<int> byT(nC);
+            for (int r = 0; r < nC; r++) { const int c = a->perm[r]; byT[(size_t)st[RT[c]]++] = c; }
+            std::vector<int> pos(rowBase.begin(), rowBase.end() - 1);
+            for (int i = 0; i < nC; i++) { const int c = byT[i]; order[pos[blk[c]]++] = c; }
+        }
+        auto lanesOf = [&](int c) { const int w = bk_width(a, c); return w <= 16 ? 1 : w <= 32 ? 2 : w <= 64 ? 4 : 8; };
+        Y.grpOfCell.assign(nC, 0);
+        long nLanes = 0, nEnt = 0;
+        for (int b = 0; b < nB; b++)
+        {
+            int i = rowBase[b];
+            while (i < rowBase[b + 1])
+            {
+                // rows of one T; inside it one group per lanes-per-row class (1, 2, 4, 8), at most 64 lanes each
+                int iEnd = i;
+                while (iEnd < rowBase[b + 1] && RT[order[iEnd]] == RT[order[i]]) iEnd++;
+                for (int Tc = 1; Tc <= 8; Tc *= 2)
+                {
+                    int cnt = 0;
+                    auto flush = [&]() {
+                        if (!cnt) return;
+                        const int stride = std::max(8, (cnt + 7) & ~7);
+                        Y.grpBlk.push_back(b); Y.grpLane0.push_back((int)nLanes); Y.grpCnt.push_back(cnt); Y.grpT.push_back(Tc);
+                        Y.grpEnt.push_back((int)nEnt); Y.grpStride.push_back(stride);
+                        nLanes += cnt;
+                        nEnt += 16L * stride;
+                        cnt = 0;
+                    };
+                    for (int t = i; t < iEnd; t++)
+                    {
+                        const int c = order[t];
+                        if (lanesOf(c) != Tc) continue;
+                        if (cnt + Tc > LDU_WAVE) flush();
+                        Y.grpOfCell[c] = (int)Y.grpBlk.size();
+                        cnt += Tc;
+                    }
+                    flush();
+                }
+                i = iEnd;
+            }
+            if (nEnt > 0x7ff00000L) return 0;     // (entry offsets are 32-bit in the task records)
+        }
+        Y.nGroups = (int)Y.grpBlk.size();
+        Y.nLanes = nLanes;
+        Y.nEntries = nEnt + 16 * LDU_WAVE;
+        // tables
+        std::vector<int2> meta((size_t)nLanes);
+        std::vector<unsigned short> col((size_t)Y.nEntries, 0);
+        std::vector<int> srcFace((size_t)Y.nEntries, -1);
+        {
+            std::vector<int> fill(Y.nGroups, 0);     // lanes placed so far per group
+            int bCur = -1;
+            for (int t = 0; t < nC; t++)
+            {
+                const int c = order[t], b = blk[c];
+                if (b != bCur)
+                {
+                    for (int g = ghostBase[b]; g < ghostBase[b + 1]; g++) gslot[ghostCell[g]] = nLocal[b] + (g - ghostBase[b]);
+                    bCur = b;
+                }
+                const int g = Y.grpOfCell[c], Tc = Y.grpT[g], stride = Y.grpStride[g];
+                const int lane0 = fill[g];
+                fill[g] += Tc;
+                const int nl = a->losortStart[c + 1] - a->losortStart[c], nn = nl + a->ownerStart[c + 1] - a->ownerStart[c];
+                for (int tl = 0; tl < Tc; tl++)
+                {
+                    const int lo = std::min(16, std::max(0, nl - 16 * tl)), en = std::min(16, std::max(0, nn - 16 * tl));
+                    int2 M;
+                    M.x = a->iperm[c] | (exported[c] ? (int)0x80000000 : 0) | (tl == Tc - 1 ? 0x40000000 : 0);
+                    M.y = slot[c] | (lo << 16) | (en << 24);
+                    meta[(size_t)Y.grpLane0[g] + lane0 + tl] = M;
+                }
+                int q = 0;
+                auto put = [&](int n, int code) {
+                    const int tl = q >> 4, qq = q & 15;
+                    const size_t e = (size_t)Y.grpEnt[g] + (size_t)qq * stride + (size_t)(lane0 + tl);
+                    col[e] = (unsigned short)(blk[n] == b ? slot[n] : gslot[n]);
+                    srcFace[e] = code;
+                    q++;
+                };
+                for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++) { const int f = a->losort[s]; put(a->l[f], f << 1); }
+                for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) put(a->u[f], (f << 1) | 1);
+            }
+        }
+        // group-level times Phi: groups in ascending T (a group holds one T): all inputs of lower T are final
+        Y.Phi.assign(Y.nGroups, 0);
+        {
+            const BlockPlan::Layout* Yp = L ? &P->lay[L - 1] : nullptr;
+            std::vector<long> st((size_t)maxRT + 2, 0);
+            for (int c = 0; c < nC; c++) st[(size_t)RT[c] + 1]++;
+            for (size_t i = 0; i + 1 < st.size(); i++) st[i + 1] += st[i];
+            std::vector<int> byT(nC);
+            { std::vector<long> pos(st.begin(), st.end() - 1); for (int c = 0; c < nC; c++) byT[(size_t)pos[RT[c]]++] = c; }
+            for (int tv = 0; tv <= maxRT; tv++)
+            {
+                for (long i = st[tv]; i < st[tv + 1]; i++)
+                {
+                    const int c = byT[(size_t)i], g = Y.grpOfCell[c];
+                    int ph = Y.Phi[g];
+                    if (Yp)
+                    {
+                        ph = std::max(ph, Yp->Phi[Yp->grpOfCell[c]] + 1);
+                        for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) ph = std::max(ph, Yp->Phi[Yp->grpOfCell[a->u[f]]] + 1);
+                    }
+                    for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++)
+                        ph = std::max(ph, Y.Phi[Y.grpOfCell[a->l[a->losort[s]]]] + 1);
+                    Y.Phi[g] = ph;
+                }
+            }
+        }
+        if (bk_upload(&Y.d_meta, meta, 64) || bk_upload(&Y.d_col, col) || bk_upload(&Y.d_srcFace, srcFace)) return -1;
+        if (verbose)
+            fprintf(stderr, "[ldugpu] block engine plan: sweep %d: row-level DAG %d steps; %d groups (%.1f lanes each), group-level DAG %d steps, "
+                            "%.1f M entries (%.2f x the coefficients)\n", L, maxRT, Y.nGroups, (double)nLanes / std::max(1, Y.nGroups),
+                    *std::max_element(Y.Phi.begin(), Y.Phi.end()) + 1, Y.nEntries / 1e6, (double)Y.nEntries / std::max(1, 2 * nF));
+        RTprev = RT;
+    }
+    // ---- upload
+    std::vector<int4> blkInfo(nB);
+    for (int b = 0; b < nB; b++) blkInfo[b] = make_int4(rowBase[b], nLocal[b], ghostBase[b], ghostBase[b + 1] - ghostBase[b]);
+    if (bk_upload(&P->d_blk, blkInfo) || bk_upload(&P->d_localRow, localRow) || bk_upload(&P->d_ghostRow, P->ghostRowH)) return -1;
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
+    LDU_CHECK_HIP(ldu_memset_sync(P->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_start, sizeof(unsigned) * 64));
+    LDU_CHECK_HIP(ldu_memset_sync(P->d_start, 0, sizeof(unsigned) * 64));
+    P->gen = ctx->p2pGen;
+    P->eligible = true;
+    if (verbose)
+    {
+        long cut = 0;
+        for (int f = 0; f < nF; f++) cut += blk[a->l[f]] != blk[a->u[f]];
+        fprintf(stderr, "[ldugpu] block engine plan: %d cells in %d blocks (%d wavefronts + importer each, %zu B of LDS), "
+                        "%.1f %% of the faces cut, %d ghosts, %d dependency levels; %.3f s\n",
+                nC, nB, nw, P->ldsBytes, 100.0 * cut / std::max(1, nF), P->nGhostTotal, a->nLevels,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tB0).count());
+    }
+    return 0;
+}
+
+// the task and import lists of k sweeps
+static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
+{
+    BlockPlan* P = a->blocks;
+    auto it = P->tasks.find(k);
+    if (it == P->tasks.end())
+    {
+        const int nB = P->nBlocks;
+        auto layOf = [&](int j) -> const BlockPlan::Layout& { return P->lay[std::min(j, P->nLayouts - 1)]; };
+        // (with fewer layouts than sweeps the later sweeps reuse the last grouping: their Phi = the last layout's + a shift that
+        //  keeps every dependency ascending - computed here by running the group recurrence once more per extra sweep)
+        std::vector<std::vector<int>> Phi(k);
+        for (int j = 0; j < k; j++)
+        {
+            if (j < P->nLayouts) { Phi[j] = P->lay[j].Phi; continue; }
+            const BlockPlan::Layout& Y = layOf(j);
+            // the same grouping as sweep j - 1: Phi_j(g) = 1 + max(Phi_j(lower groups), Phi_j-1(upper groups), Phi_j-1(g)); groups
+            // of one T are independent, and the group ids ascend with (block, T) only - so iterate to the fixed point in T order
+            // via the cells in ascending T order of that layout: its Phi is itself a valid ascending key
+            std::vector<int> ord(Y.nGroups);
+            for (int g = 0; g < Y.nGroups; g++) ord[g] = g;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return Y.Phi[x] < Y.Phi[y]; });
+            std::vector<int> rank(Y.nGroups);
+            for (int i = 0; i < Y.nGroups; i++) rank[ord[i]] = i;
+            Phi[j].assign(Y.nGroups, 0);
+            // cells grouped per group
+            std::vector<int> gs(Y.nGroups + 1, 0), gc(a->nCells);
+            for (int c = 0; c < a->nCells; c++) gs[Y.grpOfCell[c] + 1]++;
+            for (int g = 0; g < Y.nGroups; g++) gs[g + 1] += gs[g];
+            { std::vector<int> pos(gs.begin(), gs.end() - 1); for (int c = 0; c < a->nCells; c++) gc[pos[Y.grpOfCell[c]]++] = c; }
+            for (int i = 0; i < Y.nGroups; i++)
+            {
+                const int g = ord[i];
+                int ph = Phi[j - 1][g] + 1;
+                for (int t = gs[g]; t < gs[g + 1]; t++)
+                {
+                    const int c = gc[t];
+                    for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) ph = std::max(ph, Phi[j - 1][Y.grpOfCell[a->u[f]]] + 1);
+                    for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++) ph = std::max(ph, Phi[j][Y.grpOfCell[a->l[a->losort[s]]]] + 1);
+                }
+                Phi[j][g] = ph;
+            }
+        }
+        int maxT = 0;
+        long nTasks = 0;
+        for (int j = 0; j < k; j++) { maxT = std::max(maxT, *std::max_element(Phi[j].begin(), Phi[j].end())); nTasks += layOf(j).nGroups; }
+        // tasks: counting sort by Phi (inside one Phi the sweeps ascend), then dealt to the blocks in that order
+        std::vector<long> start((size_t)maxT + 2, 0);
+        for (int j = 0; j < k; j++) for (int v : Phi[j]) start[(size_t)v + 1]++;
+        for (size_t i = 0; i + 1 < start.size(); i++) start[i + 1] += start[i];
+        std::vector<std::pair<int, int>> order((size_t)nTasks);
+        for (int j = 0; j < k; j++)
+            for (int g = 0; g < layOf(j).nGroups; g++) order[(size_t)start[Phi[j][g]]++] = std::make_pair(j, g);
+        std::vector<int> taskStart(nB + 1, 0);
+        for (int j = 0; j < k; j++) for (int b : layOf(j).grpBlk) taskStart[b + 1]++;
+        for (int b = 0; b < nB; b++) taskStart[b + 1] += taskStart[b];
+        std::vector<int4> tasks((size_t)nTasks);
+        {
+            std::vector<int> pos(taskStart.begin(), taskStart.end() - 1);
+            for (auto& t : order)
+            {
+                const BlockPlan::Layout& Y = layOf(t.first);
+                const int g = t.second;
+                tasks[(size_t)pos[Y.grpBlk[g]]++] = make_int4(Y.grpLane0[g], Y.grpCnt[g] | (Y.grpT[g] << 8) | (Y.grpStride[g] << 16), Y.grpEnt[g], t.first);
+            }
+        }
+        // imports: a ghost that is a lower neighbour of a local row is needed with stamps 1 ... k, one that is only an
+        // upper neighbour with stamps 1 ... k - 1 (sweep 0 reads the initial value); due when the producing task is done
+        std::vector<int> impStart(nB + 1, 0);
+        std::vector<int4> imps;
+        {
+            std::vector<std::pair<long, int4>> tmp;
+            for (int b = 0; b < nB; b++)
+            {
+                tmp.clear();
+                for (int g = P->ghostBase[b]; g < P->ghostBase[b + 1]; g++)
+                {
+                    const int top = P->ghostLower[g] ? k : k - 1;
+                    for (int s = 1; s <= top; s++)
+                        tmp.emplace_back(((long)Phi[s - 1][layOf(s - 1).grpOfCell[P->ghostCell[g]]] << 3) | s,
+                                         make_int4(P->blkNLocal[b] + (g - P->ghostBase[b]), P->ghostRowH[g], s, 0));
+                }
+                std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<long, int4>& x, const std::pair<long, int4>& y) { return x.first < y.first; });
+                for (auto& t : tmp) imps.push_back(t.second);
+                impStart[b + 1] = (int)imps.size();
+            }
+        }
+        BlockPlan::Tasks W;
+        W.nTasks = nTasks;
+        if (bk_upload(&W.d_tasks, tasks, 1) || bk_upload(&W.d_taskStart, taskStart) || bk_upload(&W.d_imps, imps, 1) ||
+            bk_upload(&W.d_impStart, impStart))
+            return -1;
+        if (getenv("LDU_VERBOSE"))
+            fprintf(stderr, "[ldugpu] block engine: %d cells, k = %d: %ld tasks, %zu imports, %d steps in the group-level DAG\n",
+                    a->nCells, k, nTasks, imps.size(), maxT + 1);
+        it = P->tasks.emplace(k, W).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+static int bk_values(ldu_addr* a, const double* levelVal, hipStream_t s, const double* out[BK_NLAY])
+{
+    BlockPlan* P = a->blocks;
+    auto org = a->valOrigin.find(levelVal);
+    if (org == a->valOrigin.end()) return 1;
+    BlockPlan::Conv& C = P->conv[levelVal];
+    for (int L = 0; L < P->nLayouts; L++)
+        if (!C.d[L]) LDU_CHECK_HIP(hipMalloc((void**)&C.d[L], sizeof(double) * (size_t)P->lay[L].nEntries));
+    if (C.stamp != a->ctx->valStamp)
+    {
+        for (int L = 0; L < P->nLayouts; L++)
+        {
+            const int grid = (int)std::min<long>((P->lay[L].nEntries + 255) / 256, 8192);
+            bk_fill_kernel<<<grid, 256, 0, s>>>(P->lay[L].nEntries, P->lay[L].d_srcFace, org->second.first, org->second.second, C.d[L]);
+        }
+        C.stamp = a->ctx->valStamp;
+    }
+    for (int L = 0; L < BK_NLAY; L++) out[L] = C.d[std::min(L, P->nLayouts - 1)];
+    return 0;
+}
+
+bool k_blocks_active(ldu_addr* a)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (!ctx->blkEngine || !ctx->sweepP2P || a->nPatchFaces || a->nCells < ctx->blkMinCells || a->nCells > ctx->blkMaxCells) return false;
+    if (!a->blocks && bk_build(a)) return false;
+    return a->blocks && a->blocks->eligible;
+}
+
+int k_blocks_prebuild(ldu_addr* a, int k)
+{
+    if (!k_blocks_active(a)) return 1;
+    const BlockPlan::Tasks* W = nullptr;
+    return bk_tasks(a, k, &W) ? -1 : 0;
+}
+
+int k_blocks_set_trace(unsigned long long* buf)
+{
+    LDU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bk_trace), &buf, sizeof(buf)));
+    return 0;
+}
+
+// introspection (tools): {blocks, compute wavefronts per block, LDS bytes, ghosts, layouts, tasks of k sweeps (0 = not built)}
+int k_blocks_info(ldu_addr* a, int k, long out[8])
+{
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!k_blocks_active(a)) return 1;
+    BlockPlan& P = *a->blocks;
+    out[0] = P.nBlocks; out[1] = P.nw; out[2] = (long)P.ldsBytes; out[3] = P.nGhostTotal; out[4] = P.nLayouts;
+    const BlockPlan::Tasks* W = nullptr;
+    if (k >= 1 && k <= 4 && !bk_tasks(a, k, &W)) out[5] = W->nTasks;
+    return 0;
+}
+
+// k pipelined GaussSeidel sweeps (k = 1 ... 4); 1 = not taken
+int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (k <= 0 || k > 4) return 1;
+    if (!k_blocks_active(a)) return 1;
+    BlockPlan& P = *a->blocks;
+    hipStream_t s = ctx->stream;
+    BkTab T;
+    {
+        const int rc = bk_values(a, val, s, T.val);
+        if (rc) return rc;     // (1: a value array that was not filled from face-ordered coefficients)
+    }
+    const BlockPlan::Tasks* W = nullptr;
+    if (bk_tasks(a, k, &W)) return -1;
+    if (P.gen != ctx->p2pGen)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_start, 0, sizeof(unsigned) * 64, s));
+        P.startBase = 0;
+        P.gen = ctx->p2pGen;
+    }
+    if (P.epoch > 0xffffff00u)
+    {
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
+        P.epoch = 0;
+    }
+    const unsigned tagBase = P.epoch;
+    P.epoch += (unsigned)k;
+    T.blk = P.d_blk; T.localRow = P.d_localRow; T.ghostRow = P.d_ghostRow;
+    for (int L = 0; L < BK_NLAY; L++) { const BlockPlan::Layout& Y = P.lay[std::min(L, P.nLayouts - 1)]; T.meta[L] = Y.d_meta; T.col[L] = Y.d_col; }
+    T.nLayouts = P.nLayouts;
+    T.tasks = W->d_tasks; T.taskStart = W->d_taskStart; T.imps = W->d_imps; T.impStart = W->d_impStart;
+    ctx->profStart(a, 4);
+    if (P.nw == 7)
+        gs_blk_kernel<7><<<P.nBlocks, LDU_WAVE * 8, P.ldsBytes, s>>>(T, P.nBlocks, P.d_granule, tagBase, P.d_start, P.startBase,
+                                                                     ctx->d_abort, psi, rhs, diag);
+    else
+        gs_blk_kernel<3><<<P.nBlocks, LDU_WAVE * 4, P.ldsBytes, s>>>(T, P.nBlocks, P.d_granule, tagBase, P.d_start, P.startBase,
+                                                                     ctx->d_abort, psi, rhs, diag);
+    ctx->profStop(a, 4);
+    P.startBase += (unsigned)P.nBlocks;
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}

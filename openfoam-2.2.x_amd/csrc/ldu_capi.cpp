@@ -189,6 +189,24 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e) c->wgWide = atoi(e);
     e = getenv("LDU_WG_WAVES");
     if (e) c->wgWaves = atoi(e);
+    e = getenv("LDU_BLK");
+    if (e) c->blkEngine = atoi(e);
+    e = getenv("LDU_BLK_MIN");
+    if (e) c->blkMinCells = atoi(e);
+    e = getenv("LDU_BLK_MAX");
+    if (e) c->blkMaxCells = atoi(e);
+    e = getenv("LDU_BLK_CELLS");
+    if (e) c->blkCells = atoi(e);
+    e = getenv("LDU_BLK_CELLS_MIN");
+    if (e && atoi(e) > 0) c->blkCellsMin = atoi(e);
+    e = getenv("LDU_BLK_CELLS_MAX");
+    if (e && atoi(e) > 0) c->blkCellsMax = atoi(e);
+    e = getenv("LDU_BLK_WAVES");
+    if (e) c->blkWaves = atoi(e);
+    e = getenv("LDU_BLK_LAYOUTS");
+    if (e && atoi(e) > 0) c->blkLayouts = atoi(e);
+    e = getenv("LDU_BLK_PER_CU");
+    if (e && atoi(e) > 0) c->blkMaxPerCU = atoi(e);
     e = getenv("LDU_SMALL_MAX");
     if (e) c->smallMaxCells = std::min(atoi(e), 16384);
     e = getenv("LDU_P2P_WIDE");
@@ -206,7 +224,8 @@ static int ctx_init(ldu_ctx* c, int device)
     e = getenv("LDU_HALO_OVERLAP");
     if (e) c->haloOverlap = atoi(e);
     e = getenv("LDU_WATCHDOG_MS");
-    if (e && (k_set_watchdog((unsigned long long)(atof(e) * 1e5), 0) || k_cluster_set_watchdog((unsigned long long)(atof(e) * 1e5), 0)))
+    if (e && (k_set_watchdog((unsigned long long)(atof(e) * 1e5), 0) || k_cluster_set_watchdog((unsigned long long)(atof(e) * 1e5), 0) ||
+              k_blocks_set_watchdog((unsigned long long)(atof(e) * 1e5), 0)))
         return -1;
     e = getenv("LDU_LAG_BUCKETS");
     if (e) c->lagBucketWidth = atoi(e);
@@ -262,7 +281,7 @@ int ldu_ctx_set_watchdog(ldu_ctx* c, double budgetMs, double debugStallMs)
     LDU_CHECK_HIP(hipStreamSynchronize(c->stream2));
     // wall_clock64() ticks at 100 MHz on gfx950 (s_memrealtime)
     const unsigned long long b = (unsigned long long)(budgetMs * 1e5), st = (unsigned long long)(debugStallMs * 1e5);
-    if (k_set_watchdog(b, st) || k_cluster_set_watchdog(b, st)) return -1;
+    if (k_set_watchdog(b, st) || k_cluster_set_watchdog(b, st) || k_blocks_set_watchdog(b, st)) return -1;
     return 0;
 }
 
@@ -424,7 +443,7 @@ void matrix_free(ldu_matrix* m)
     // the cluster engine keeps converted copies of this matrix's value arrays, keyed by their addresses
     for (const double* v : {(const double*)m->d_valA, (const double*)m->d_valT, (const double*)m->d_valP,
                             (const double*)m->d_valPT})
-        if (v) { cluster_forget(m->a, v); m->a->valOrigin.erase(v); }
+        if (v) { cluster_forget(m->a, v); blocks_forget(m->a, v); m->a->valOrigin.erase(v); }
     if (m->d_lowerO && m->d_lowerO != m->d_upperO) (void)hipFree(m->d_lowerO);
     if (m->d_valT && m->d_valT != m->d_valA) (void)hipFree(m->d_valT);
     void* ptrs[] = {m->d_diagO, m->d_upperO, m->d_diag, m->d_valA, m->d_bou, m->d_int, m->d_rD,
@@ -452,6 +471,7 @@ int matrix_refresh_layout(ldu_matrix* m, hipStream_t onStream)
     else if (m->d_valT != m->d_valA)
     {
         cluster_forget(a, m->d_valT);
+        blocks_forget(a, m->d_valT);
         a->valOrigin.erase(m->d_valT);
         (void)hipFree(m->d_valT);
         m->d_valT = m->d_valA;
@@ -799,6 +819,20 @@ int ldu_debug_gs_multi_trace(ldu_matrix* m, void* buf)
 {
     LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
     return k_set_gs_multi_trace((unsigned long long*)buf, m->a->nSlices);
+}
+
+int ldu_debug_blocks_trace(ldu_matrix* m, void* buf)
+{
+    LDU_CHECK_HIP(hipStreamSynchronize(m->a->ctx->stream));
+    return k_blocks_set_trace((unsigned long long*)buf);
+}
+
+int ldu_debug_blocks_info(ldu_matrix* m, int32_t k, int64_t* out)
+{
+    long o[8];
+    const int rc = k_blocks_info(m->a, k, o);
+    for (int i = 0; i < 8; i++) out[i] = o[i];
+    return rc < 0 ? -1 : 0;
 }
 
 int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap)

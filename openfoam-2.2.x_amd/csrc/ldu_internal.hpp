@@ -51,6 +51,7 @@ static inline hipError_t ldu_memset_sync(void* p, int v, size_t n)
 struct ldu_comm_impl;  // RCCL wrapper (ldu_comm.cpp)
 struct ClusterPlan;    // ldu_cluster.hip
 struct ClGreedy;       // ldu_cluster_greedy.hpp
+struct BlockPlan;      // ldu_blocks.hip
 #define LDU_CL_MAXD 12  // ldu_cluster.hip: dependencies per row the cluster kernels hold in registers
 #define LDU_PROF_NCAT 8
 
@@ -122,6 +123,17 @@ struct ldu_ctx {
     int wgMinCells = 0;              // LDU_WG_MIN
     int wgWaves = 8;                 // LDU_WG_WAVES (4 / 8)
     int wgWide = 0;                  // LDU_WG_WIDE=1: also levels with rows wider than 16 entries
+    // block engine (ldu_blocks.hip): k pipelined GaussSeidel sweeps with the hand-offs inside a workgroup's LDS, blocks of a few
+    // thousand cells, granules only between blocks
+    int blkEngine = 1;               // LDU_BLK=0: off
+    int blkMinCells = 6001;          // LDU_BLK_MIN (below: the one-workgroup engine)
+    int blkMaxCells = 4000000;       // LDU_BLK_MAX
+    int blkCells = 0;                // LDU_BLK_CELLS: cells per block (0 = sized so that all blocks are resident at once)
+    int blkCellsMin = 1024;          // LDU_BLK_CELLS_MIN
+    int blkCellsMax = 12000;         // LDU_BLK_CELLS_MAX (LDS: 9 bytes per local row and per ghost)
+    int blkWaves = 7;                // LDU_BLK_WAVES (7 / 3 compute wavefronts per block, + 1 importer)
+    int blkMaxPerCU = 4;             // LDU_BLK_PER_CU: workgroups per CU the grid may count on
+    int blkLayouts = 4;              // LDU_BLK_LAYOUTS: own grouping (by the row's time in the DAG of the k sweeps) for the first n sweeps
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
@@ -283,6 +295,7 @@ struct ldu_addr {
     unsigned char* d_xflag = nullptr;      // [nCells] 1 = has a neighbour in another slab
 
     ClusterPlan* cluster = nullptr;        // secondary structure of the cluster sweep engine (lazy)
+    BlockPlan* blocks = nullptr;           // secondary structure of the block engine (lazy, ldu_blocks.hip)
     // the greedy clustering of a large addressing starts on a host thread of its own as soon as plan_build knows the
     // dependency levels (it needs nothing else) and runs beside the rest of the level plan; cluster_build joins it
     ClGreedy* greedyEarly = nullptr;
@@ -405,6 +418,15 @@ int k_engine_of(ldu_addr* a, int kind);
 int k_gs_prebuild(ldu_addr* a, int k);   // the host plan of k pipelined GaussSeidel sweeps on the level engines, ahead of the first call
 int k_sweep_cluster_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* valA);
 void cluster_free(ldu_addr* a);
+// block engine (ldu_blocks.hip)
+int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);   // 1 = not taken
+bool k_blocks_active(ldu_addr* a);
+int k_blocks_prebuild(ldu_addr* a, int k);
+int k_blocks_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks);
+int k_blocks_set_trace(unsigned long long* buf);
+int k_blocks_info(ldu_addr* a, int k, long out[8]);
+void blocks_free(ldu_addr* a);
+void blocks_forget(ldu_addr* a, const double* levelVal);
 void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converted copy of a value array
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);

@@ -1521,7 +1521,8 @@ static bool use_slab(const ldu_addr* a, int kind, int k = 1)
 }
 
 // which engine serves a sweep kind on this addressing (introspection for bench.py / tests):
-// 0 chip-wide point-to-point, 1 XCD slabs, 2 clusters, 3 single wavefront (tiny), 4 level kernels, 5 one workgroup (LDS)
+// 0 chip-wide point-to-point, 1 XCD slabs, 2 clusters, 3 single wavefront (tiny), 4 level kernels, 5 one workgroup (LDS),
+// 6 blocks (LDS-resident blocks of a few thousand cells, ldu_blocks.hip; pipelined GaussSeidel sweeps only)
 int k_engine_of(ldu_addr* a, int kind /* 0 triangular, 1 one GaussSeidel sweep, 2 two pipelined sweeps */)
 {
     ldu_ctx* ctx = a->ctx;
@@ -1530,6 +1531,7 @@ int k_engine_of(ldu_addr* a, int kind /* 0 triangular, 1 one GaussSeidel sweep, 
     if (kind >= 1 && ctx->smallKernels && a->maxRowWidth <= 16 && !a->nPatchFaces
         && a->nCells <= ((kind == 2 && ctx->smallPipe) ? ctx->smallMaxCells : std::min(ctx->smallMaxCells, 3000)))
         return 3;
+    if (kind == 2 && k_blocks_active(a)) return 6;
     if (kind == 2 ? (ctx->clusterMulti && k_cluster_active(a)) : k_cluster_kind_active(a, kind)) return 2;
     return use_slab(a, kind, 2) ? 1 : 0;
 }
@@ -3024,6 +3026,7 @@ int k_gs_prebuild(ldu_addr* a, int k)
     ldu_ctx* ctx = a->ctx;
     if (k < 2 || k > 4 || a->nCells == 0 || a->nPatchFaces || !ctx->sweepP2P || !ctx->gsPipeline) return 0;
     const int e = k_engine_of(a, 2);
+    if (e == 6) return k_blocks_prebuild(a, k) < 0 ? -1 : 0;
     if (e != 0 && e != 1) return 0;      // one workgroup / single wavefront / clusters: their own (cheap) plans
     return gs_tasks_ensure(a, k);
 }

@@ -248,6 +248,11 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         if (rc > 0) rc = k_sweep_gs_small(a, nSweeps, psi, source, m->d_diag, m->d_valA);
         if (rc <= 0) return rc;
     }
+    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && nSweeps == 1)
+    {
+        const int rc = k_sweep_gs_blocks(a, 1, psi, source, m->d_diag, m->d_valA);   // (LDS-resident blocks: ldu_blocks.hip)
+        if (rc <= 0) return rc;
+    }
     if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && a->ctx->gsPipeline && nSweeps >= 2)
     {
         // consecutive sweeps pipelined inside one launch (bit-identical to separate sweeps)
@@ -256,8 +261,10 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         while (left > 0)
         {
             const int k = left > 4 ? 4 : left;
-            if (k == 1) break;   // a single remaining sweep: the plain engine below
-            int rc = a->ctx->clusterMulti ? k_sweep_cluster_gs_multi(a, k, psi, source, m->d_diag, m->d_valA) : 1;
+            // LDS-resident blocks (ldu_blocks.hip), clusters, then the level engines
+            int rc = k_sweep_gs_blocks(a, k, psi, source, m->d_diag, m->d_valA);
+            if (k == 1 && rc > 0) break;   // a single remaining sweep: the plain engine below
+            if (rc > 0) rc = a->ctx->clusterMulti ? k_sweep_cluster_gs_multi(a, k, psi, source, m->d_diag, m->d_valA) : 1;
             if (rc > 0) rc = k_sweep_gs_multi(a, k, psi, source, m->d_diag, m->d_valA);
             if (rc < 0) return -1;
             if (rc > 0) { pipelined = false; break; }   // DAG too skewed: sweep by sweep

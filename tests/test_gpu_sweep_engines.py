@@ -35,10 +35,17 @@ ENGINES = {
     "nowg_small16384": {"LDU_WG": "0", "LDU_SMALL_MAX": "16384"},
     "wg_wide18000": {"LDU_WG_MAX": "18000", "LDU_WG_WIDE": "1"},
     "cluster_via_level_layout": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1", "LDU_CLUSTER_DIRECT": "0"},
+    # LDS-resident blocks (ldu_blocks.hip) forced onto the small test matrices: many small blocks / a few large ones,
+    # seven or three compute wavefronts per block
+    "blocks": {"LDU_BLK_MIN": "1", "LDU_BLK_CELLS": "400", "LDU_WG": "0", "LDU_SMALL": "0"},
+    "blocks_w3": {"LDU_BLK_MIN": "1", "LDU_BLK_CELLS": "1500", "LDU_BLK_WAVES": "3", "LDU_WG": "0", "LDU_SMALL": "0"},
+    "blocks_auto": {"LDU_BLK_MIN": "1", "LDU_WG": "0", "LDU_SMALL": "0"},
+    "noblocks": {"LDU_BLK": "0"},
 }
 KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
         "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS", "LDU_LAG_BUCKETS", "LDU_WG", "LDU_WG_WAVES",
-        "LDU_WG_MAX", "LDU_WG_MIN", "LDU_WG_WIDE", "LDU_CLUSTER_DIRECT")
+        "LDU_WG_MAX", "LDU_WG_MIN", "LDU_WG_WIDE", "LDU_CLUSTER_DIRECT", "LDU_BLK", "LDU_BLK_MIN", "LDU_BLK_MAX",
+        "LDU_BLK_CELLS", "LDU_BLK_WAVES", "LDU_BLK_CELLS_MIN", "LDU_BLK_CELLS_MAX", "LDU_BLK_PER_CU")
 
 
 def _problems():
@@ -186,6 +193,41 @@ def test_workgroup_engine_bitexact(oracle, waves):
             for k in (1, 2, 3, 4, 5, 6, 7, 8):
                 for rep in range(2):
                     assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k)
+            assert ctx.fallback_count() == 0
+            m.close(); a.close()
+        ctx.close()
+    finally:
+        for k in KEYS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("waves,cells", [("7", "0"), ("7", "300"), ("3", "900"), ("7", "5000")])
+def test_block_engine_bitexact(oracle, waves, cells):
+    """gs_blk_kernel (ldu_blocks.hip): k = 1 ... 8 GaussSeidel sweeps with the matrix cut into blocks that live in the LDS of
+    one workgroup each (values + sweep stamps; granules and an importer wavefront between blocks); hex / random / chain /
+    wide-row graphs (rows of up to ~60 entries: the chunked tail), one block ... a few hundred blocks; bit-exact against
+    the sequential sweeps, no engine fallback."""
+    saved = {k: os.environ.pop(k, None) for k in KEYS}
+    os.environ.update({"LDU_BLK_MIN": "1", "LDU_BLK_WAVES": waves, "LDU_BLK_CELLS": cells, "LDU_WG": "0", "LDU_SMALL": "0"})
+    try:
+        ctx = capi.Context(0)
+        rng = np.random.RandomState(6)
+        probs = [cases.box3d(3, 4, 3), cases.box3d(11, 12, 13), cases.box3d(26, 26, 26), cases.box3d(40, 37, 41),
+                 cases.random_graph(2999, 9, 200), cases.random_graph(5900, 5, 150, asym=True), cases.random_graph(700, 13, 60),
+                 cases.laplacian2d(1, 50), cases.laplacian2d(100, 100), cases.irregular_box(25), cases.irregular_box(40),
+                 cases.random_graph(12000, 30, 500, asym=True), cases.random_graph(17900, 12, 3000),
+                 cases.random_graph(60000, 7, 900)]
+        for p in probs:
+            a, m = capi.from_problem(ctx, p)
+            S = oracle.System(p)
+            psi, src = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+            for k in (1, 2, 3, 4, 5, 6, 7, 8):
+                for rep in range(2):
+                    assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k)
+            if p["nCells"] > 100 and not (cells == "300" and p["nCells"] > 60000):
+                assert a.sweep_engine(2) == "blocks", p["nCells"]
             assert ctx.fallback_count() == 0
             m.close(); a.close()
         ctx.close()

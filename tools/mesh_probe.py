@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 
 entry.load_package()
-from openfoam_amd import capi, cases, octree
+from openfoam_amd import capi, cases, octree, motorbike
 import torch
 
 
@@ -26,6 +26,11 @@ def make(spec):
         return cases.box3d(int(f[1]))
     if f[0] == "irregular":
         p = cases.irregular_box(int(f[1]))
+    elif f[0] == "motorbike":      # motorbike:<stored mesh>[:snappy]  (renumbered by Foam::bandCompression unless :snappy)
+        p = motorbike.problem(f[1])
+        p.pop("cellLevel"); p.pop("meta")
+        if len(f) > 2 and f[2] == "snappy":
+            return p
     elif f[0] == "octree":
         q = int(f[1])
         p = octree.problem(base=(5 * q, 2 * q, 2 * q), surface_levels=(int(f[2]), int(f[3])))
@@ -100,7 +105,38 @@ for spec, p in problems:
               % (name, info["nLevels"], "%.2fM entries" % (info["nEntriesPadded"] / 1e6), "/".join(e.split()[0] for e in eng), res["gs1"],
                  res["gs1"] * 1e3 / info["nLevels"], NS, res["gs%d" % NS], res["dic"], res["amul"], ctx.fallback_count(), setup),
               flush=True)
-        if os.environ.get("PROBE_TRACE") and eng[2].startswith("one"):
+        if os.environ.get("PROBE_TRACE") and eng[2] == "blocks":
+            bi = np.zeros(8, dtype=np.int64)
+            L.ldu_debug_blocks_info.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+            capi._chk(L.ldu_debug_blocks_info(m.h, NS, bi.ctypes.data))
+            nT = int(bi[5])
+            buf = torch.zeros(nT * 8, dtype=torch.int64, device="cuda")
+            L.ldu_debug_blocks_trace.argtypes = [C.c_void_p, C.c_void_p]
+            capi._chk(L.ldu_debug_blocks_trace(m.h, C.c_void_p(buf.data_ptr())))
+            capi._chk(L.ldu_smooth(m.h, 0, capi._ptr(d_psi), capi._ptr(d_src), NS)); ctx.sync()
+            capi._chk(L.ldu_debug_blocks_trace(m.h, None))
+            T = buf.cpu().numpy().reshape(nT, 8).astype(np.float64)
+            T = T[T[:, 3] > 0]
+            T[:, :4] = (T[:, :4] - T[:, 0].min()) * 0.01
+            print("   block engine: %d blocks x %d wavefronts, %d B of LDS, %d ghosts, %d tasks: first start %.1f, last stored %.1f us"
+                  % (bi[0], bi[1], bi[2], bi[3], nT, T[:, 0].min(), T[:, 3].max()))
+            for nm, d in (("loads issued", T[:, 1] - T[:, 0]), ("waiting", T[:, 2] - T[:, 1]), ("compute+store", T[:, 3] - T[:, 2])):
+                print("      %-14s median %.2f  mean %.2f  p90 %.2f  max %.2f us  (sum %.0f us)" % (nm, np.median(d), d.mean(), np.percentile(d, 90), d.max(), d.sum()))
+            for tl in (1, 2, 4, 8):
+                sel = T[:, 7] == tl
+                if sel.any():
+                    print("      %d lane(s) per row: %d tasks, compute+store median %.2f mean %.2f us" % (tl, sel.sum(), np.median((T[:, 3] - T[:, 2])[sel]), (T[:, 3] - T[:, 2])[sel].mean()))
+            for j in range(NS):
+                sel = T[:, 5] == j
+                print("      sweep %d: first task starts %.1f us, first stored %.1f, last stored %.1f us (%d tasks)"
+                      % (j, T[sel, 0].min(), T[sel, 3].min(), T[sel, 3].max(), sel.sum()))
+            # busiest wavefront: what its time is made of
+            key = T[:, 6] * 16 + T[:, 4]
+            ks, inv = np.unique(key, return_inverse=True)
+            busy = np.bincount(inv, weights=T[:, 3] - T[:, 0])
+            cnt = np.bincount(inv)
+            print("      per wavefront: tasks median %d max %d; time in tasks median %.0f max %.0f us" % (np.median(cnt), cnt.max(), np.median(busy), busy.max()))
+        elif os.environ.get("PROBE_TRACE") and eng[2].startswith("one"):
             nT = NS * info["nSlices"]
             buf = torch.zeros(nT * 8, dtype=torch.int64, device="cuda")
             L.ldu_debug_gs_multi_trace.argtypes = [C.c_void_p, C.c_void_p]
