@@ -66,7 +66,7 @@ struct BlockPlan {
         long nLanes = 0, nEntries = 0;
         int2* d_meta = nullptr;            // [nLanes + 64] {level-ordered row | exported << 31 | last lane of the row << 30,
                                            //                 LDS slot | lower entries of this lane << 16 | entries of this lane << 24}
-        unsigned short* d_col = nullptr;   // [nEntries] LDS slot of the column
+        unsigned* d_col = nullptr;         // [nEntries / 2] LDS slots of the columns of entries 2 p, 2 p + 1 (low, high half)
         int* d_srcFace = nullptr;          // [nEntries] face << 1 | (1: upper-triangle coefficient), -1 padding
         // host
         std::vector<int> grpBlk, grpLane0, grpCnt, grpT, grpEnt, grpStride, Phi, grpOfCell;
@@ -177,36 +177,35 @@ __device__ __forceinline__ double bk_from_prev_lane(double v)
 
 struct BkTab {
     const int4* blk; const int* localRow; const int* ghostRow;
-    const int2* meta[BK_NLAY]; const unsigned short* col[BK_NLAY]; const double* val[BK_NLAY];
+    const int2* meta[BK_NLAY]; const unsigned* col[BK_NLAY]; const double* val[BK_NLAY];
     int nLayouts;
     const int4* tasks; const int* taskStart; const int4* imps; const int* impStart;
 };
 
 // a task's rows in flight: one lane = one row (T = 1) or one sixteen-entry part of a row (T = 2 / 4 / 8 lanes per row)
-struct BkRow { int rg, slot, nl, nn, T, j; bool have; unsigned short c[16]; double v[16]; double b, d; };
+struct BkRow { int4 Q; int rg, slot, nl, nn, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
 
-// stage B of a task's prefetch: everything that depends on the task record alone
-__device__ __forceinline__ void bk_row_load(const int4& Q, int lane, const BkTab& T, BkRow& R)
+// stage B of a task's prefetch: everything that depends on the task record (R.Q, loaded a step earlier) alone
+__device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
 {
+    const int4 Q = R.Q;
     const int cnt = Q.y & 255, stride = (Q.y >> 16) & 255, j = Q.w;
     const int L = j < T.nLayouts ? j : T.nLayouts - 1;
     const int2* __restrict__ meta = T.meta[L];
-    const unsigned short* __restrict__ col = T.col[L];
+    const unsigned* __restrict__ col = T.col[L];
     const double* __restrict__ val = T.val[L];
     const bool have = lane < cnt;
     const int2 M = meta[Q.x + (have ? lane : 0)];
     const long ent = (long)Q.z + (have ? lane : 0);
+    const long ent2 = (long)(Q.z >> 1) + (have ? lane : 0);
     R.rg = M.x;
     R.slot = M.y & 0xffff;
     R.nl = (M.y >> 16) & 255;
     R.nn = (M.y >> 24) & 255;
 #pragma unroll
-    for (int q = 0; q < 16; q++)
-    {
-        const long e = ent + (long)q * stride;   // (a group's entries: 16 x stride, stride >= its lanes)
-        R.c[q] = col[e];
-        R.v[q] = val[e];
-    }
+    for (int q = 0; q < 8; q++) R.c2[q] = col[ent2 + (long)q * stride];
+#pragma unroll
+    for (int q = 0; q < 16; q++) R.v[q] = val[ent + (long)q * stride];   // (a group's entries: 16 x stride, stride >= its lanes)
     R.have = have;
     R.T = (Q.y >> 8) & 255;
     R.j = j;
@@ -214,11 +213,19 @@ __device__ __forceinline__ void bk_row_load(const int4& Q, int lane, const BkTab
 
 template <int NW>
 __global__ void __launch_bounds__(LDU_WAVE * (NW + 1))
-gs_blk_kernel(BkTab T, int nBlocks, uint4* __restrict__ G, unsigned tagBase, unsigned* startCtr, unsigned startBase,
+gs_blk_kernel(BkTab T, int nBlocks, int xcdMap, uint4* __restrict__ G, unsigned tagBase, unsigned* startCtr, unsigned startBase,
               int* abortFlag, double* __restrict__ psi, const double* __restrict__ rhs, const double* __restrict__ diag)
 {
     extern __shared__ double smem[];
-    const int b = blockIdx.x;
+    // workgroups are dealt to the XCDs round-robin: physical workgroup p runs on XCD p % 8.  Blocks are numbered in the order of
+    // the (bandwidth-reducing) cell numbering, so consecutive blocks are neighbours in space: XCD x takes a contiguous range
+    // of blocks and most granules travel inside one XCD's L2.
+    int b = blockIdx.x;
+    if (xcdMap)
+    {
+        const int x = b & 7, i = b >> 3, q = nBlocks >> 3, r = nBlocks & 7;
+        b = x * q + (x < r ? x : r) + i;
+    }
     const int4 B = T.blk[b];
     const int rowBase = B.x, nLocal = B.y, ghostBase = B.z, nGhost = B.w;
     const int nSlots = nLocal + nGhost;
@@ -226,17 +233,25 @@ gs_blk_kernel(BkTab T, int nBlocks, uint4* __restrict__ G, unsigned tagBase, uns
     unsigned char* stamp = (unsigned char*)(x + nSlots);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int t0 = T.taskStart[b], nTasks = T.taskStart[b + 1] - t0;
+    // every compute wavefront has its own task list (taskStart[b * NW + wave]): the tasks of ONE sweep - inside a block a sweep is
+    // nearly a chain of dependent groups, and a wavefront sees its own LDS writes in program order: no hand-off between
+    // wavefronts along the chain, only between the sweeps
+    const int t0 = wave < NW ? T.taskStart[b * NW + wave] : 0;
+    const int nTasks = wave < NW ? T.taskStart[b * NW + wave + 1] - t0 : 0;
     const int4* tasks = T.tasks + t0;
     BkRow R0, R1, R2;
-    int4 Q = make_int4(0, 0, 0, 0);
-    int iNext = wave;
-#define BK_REC() do { Q = (iNext < nTasks && wave < NW) ? tasks[iNext] : make_int4(0, 0, 0, 0); iNext += NW; } while (0)
-#define BK_FILLB(R) do { bk_row_load(Q, lane, T, (R)); BK_REC(); } while (0)
+    int iNext = 0;
+    // a task's data arrive in three stages, each a step (= one task of this wavefront) ahead of the next: its record; its rows'
+    // meta data, columns and coefficients (they depend on the record only); rhs and diagonal (they depend on the row).  The
+    // record of a buffer's NEXT task is requested at the start of the step that computes its current one.
+#define BK_REC(R) do { (R).Q = iNext < nTasks ? tasks[iNext] : make_int4(0, 0, 0, 0); iNext++; } while (0)
+#define BK_FILLB(R) bk_row_load(lane, T, (R))
 #define BK_FILLC(R) do { const int g_ = (R).rg & 0x3fffffff; (R).b = rhs[g_]; (R).d = diag[g_]; } while (0)
     if (wave < NW)
     {
-        BK_REC();
+        BK_REC(R0);
+        BK_REC(R1);
+        BK_REC(R2);
         BK_FILLB(R0);
         BK_FILLB(R1);
     }
@@ -281,7 +296,7 @@ gs_blk_kernel(BkTab T, int nBlocks, uint4* __restrict__ G, unsigned tagBase, uns
             if (__builtin_amdgcn_ballot_w64(ok) != 0ull) { spins = 0; tw0 = 0; }
             else
             {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
                 if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; break; }
             }
         }
@@ -289,13 +304,13 @@ gs_blk_kernel(BkTab T, int nBlocks, uint4* __restrict__ G, unsigned tagBase, uns
     else
     {
         BK_FILLC(R0);
-        int left = (nTasks - wave + NW - 1) / NW;      // this wavefront's tasks
-        if (left < 0) left = 0;
-        unsigned long long* trc = g_bk_trace ? g_bk_trace + ((size_t)t0 + wave) * 8 : nullptr;
+        int left = nTasks;      // this wavefront's tasks
+        unsigned long long* trc = g_bk_trace ? g_bk_trace + (size_t)t0 * 8 : nullptr;
 #define BK_TRC(k) do { if (trc && lane == 0) trc[k] = wall_clock64(); } while (0)
 #define BK_STEP(CUR, NXT, FILL)                                                           \
     do {                                                                                  \
         BK_TRC(0);                                                                        \
+        BK_REC(CUR);                                                                      \
         BK_FILLC(NXT);                                                                    \
         BK_FILLB(FILL);                                                                   \
         BK_TRC(1);                                                                        \
@@ -305,7 +320,8 @@ gs_blk_kernel(BkTab T, int nBlocks, uint4* __restrict__ G, unsigned tagBase, uns
             const int self = have ? (CUR).slot : 0;                                       \
             const int nl = (CUR).nl, nn = have ? (CUR).nn : 0, j = (CUR).j;               \
             int cc[16];                                                                   \
-            _Pragma("unroll") for (int q = 0; q < 16; q++) cc[q] = q < nn ? (int)(CUR).c[q] : self; \
+            _Pragma("unroll") for (int q = 0; q < 16; q++)                                \
+                cc[q] = q < nn ? (int)((q & 1) ? (CUR).c2[q >> 1] >> 16 : (CUR).c2[q >> 1] & 0xffffu) : self; \
             /* lower entries need stamp j + 1, upper entries and the padding (the row itself) stamp j; a lane without a row \
                reads stamp[0] sixteen times over and does not vote */                     \
             const int want = 16 * j + nl;                                                 \
@@ -359,7 +375,7 @@ gs_blk_kernel(BkTab T, int nBlocks, uint4* __restrict__ G, unsigned tagBase, uns
             }                                                                             \
         }                                                                                 \
         LDU_STEP_FENCE();                                                                 \
-        if (trc && lane == 0) { trc[3] = wall_clock64(); trc[4] = wave; trc[5] = (CUR).j; trc[6] = b; trc[7] = (CUR).T; trc += (size_t)NW * 8; } \
+        if (trc && lane == 0) { trc[3] = wall_clock64(); trc[4] = wave; trc[5] = (CUR).j; trc[6] = b; trc[7] = (CUR).T; trc += 8; } \
         --left;                                                                           \
     } while (0)
         while (left > 0)
@@ -480,7 +496,11 @@ static int bk_build(ldu_addr* a)
     const bool verbose = getenv("LDU_VERBOSE") != nullptr;
     for (int c = 0; c < nC; c++)
         if (bk_width(a, c) > 128) return 0;       // (8 lanes x 16 entries per row)
-    const int nw = ctx->blkWaves == 3 ? 3 : 7;
+    // seven compute wavefronts per block (one workgroup of 512 threads per CU, up to 256 blocks of up to ~11 000 cells) on the
+    // large levels, three (two workgroups of 256 threads per CU: twice as many, smaller blocks) below - measured on the GAMG
+    // levels of the 12.7 M-cell motorBike mesh (profiles/r05_block_engine_probe.log): 769 k cells 1.57 / 1.77 ms per four
+    // sweeps with 7 / 3 wavefronts, 189 k equal, 46 k 0.85 / 0.75, 11 k 0.65 / 0.57
+    const int nw = ctx->blkWaves == 3 || ctx->blkWaves == 7 ? ctx->blkWaves : (nC >= ctx->blkWideFrom ? 7 : 3);
     P->nw = nw;
     P->nLayouts = std::min(BK_NLAY, std::max(1, ctx->blkLayouts));
     // how many workgroups of this kernel a CU holds (registers; LDS is checked per candidate below)
@@ -494,7 +514,8 @@ static int bk_build(ldu_addr* a)
     if (target <= 0)
     {
         target = (int)((double)nC / (0.85 * (double)capacityMax)) + 1;
-        if (target < ctx->blkCellsMin) target = ctx->blkCellsMin;
+        const int cmin = nw == 3 ? std::min(ctx->blkCellsMin, 256) : ctx->blkCellsMin;
+        if (target < cmin) target = cmin;
         if (target > ctx->blkCellsMax) return 0;
     }
     std::vector<int> blk;
@@ -615,7 +636,12 @@ static int bk_build(ldu_addr* a)
                 // rows of one T; inside it one group per lanes-per-row class (1, 2, 4, 8), at most 64 lanes each
                 int iEnd = i;
                 while (iEnd < rowBase[b + 1] && RT[order[iEnd]] == RT[order[i]]) iEnd++;
-                for (int Tc = 1; Tc <= 8; Tc *= 2)
+                // one group with the lanes-per-row of its widest row when that fits a wavefront (half as many tasks on the
+                // agglomerated levels, where a third of the rows have more than 16 entries); otherwise one group per class
+                int Tmax = 1;
+                for (int t = i; t < iEnd; t++) Tmax = std::max(Tmax, lanesOf(order[t]));
+                const bool uniform = (iEnd - i) * Tmax <= LDU_WAVE;
+                for (int Tc = uniform ? Tmax : 1; Tc <= 8; Tc *= 2)
                 {
                     int cnt = 0;
                     auto flush = [&]() {
@@ -630,12 +656,13 @@ static int bk_build(ldu_addr* a)
                     for (int t = i; t < iEnd; t++)
                     {
                         const int c = order[t];
-                        if (lanesOf(c) != Tc) continue;
+                        if (!uniform && lanesOf(c) != Tc) continue;
                         if (cnt + Tc > LDU_WAVE) flush();
                         Y.grpOfCell[c] = (int)Y.grpBlk.size();
                         cnt += Tc;
                     }
                     flush();
+                    if (uniform) break;
                 }
                 i = iEnd;
             }
@@ -646,7 +673,7 @@ static int bk_build(ldu_addr* a)
         Y.nEntries = nEnt + 16 * LDU_WAVE;
         // tables
         std::vector<int2> meta((size_t)nLanes);
-        std::vector<unsigned short> col((size_t)Y.nEntries, 0);
+        std::vector<unsigned> col((size_t)(Y.nEntries / 2), 0);
         std::vector<int> srcFace((size_t)Y.nEntries, -1);
         {
             std::vector<int> fill(Y.nGroups, 0);     // lanes placed so far per group
@@ -675,7 +702,9 @@ static int bk_build(ldu_addr* a)
                 auto put = [&](int n, int code) {
                     const int tl = q >> 4, qq = q & 15;
                     const size_t e = (size_t)Y.grpEnt[g] + (size_t)qq * stride + (size_t)(lane0 + tl);
-                    col[e] = (unsigned short)(blk[n] == b ? slot[n] : gslot[n]);
+                    const unsigned sl = (unsigned)(blk[n] == b ? slot[n] : gslot[n]);
+                    const size_t e2 = (size_t)(Y.grpEnt[g] / 2) + (size_t)(qq >> 1) * stride + (size_t)(lane0 + tl);
+                    col[e2] |= (qq & 1) ? sl << 16 : sl;
                     srcFace[e] = code;
                     q++;
                 };
@@ -791,17 +820,32 @@ static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
         std::vector<std::pair<int, int>> order((size_t)nTasks);
         for (int j = 0; j < k; j++)
             for (int g = 0; g < layOf(j).nGroups; g++) order[(size_t)start[Phi[j][g]]++] = std::make_pair(j, g);
-        std::vector<int> taskStart(nB + 1, 0);
-        for (int j = 0; j < k; j++) for (int b : layOf(j).grpBlk) taskStart[b + 1]++;
-        for (int b = 0; b < nB; b++) taskStart[b + 1] += taskStart[b];
+        // wavefront of a task: sweep j runs on wavefronts j * wps ... j * wps + wps - 1 of its block (round-robin inside the sweep)
+        const int NW = P->nw;
+        // (blkWavesPerSweep = 0: all tasks of a block round-robin over its wavefronts, whatever their sweep - measured best: a
+        //  wavefront spends ~1.5 us per task even when nothing has to be waited for, and the other wavefronts hide that)
+        int wps = a->ctx->blkWavesPerSweep;
+        if (wps * k > NW) wps = std::max(1, NW / k);
+        std::vector<int> seq((size_t)nB * k, 0), seqB(nB, 0);
+        std::vector<int> waveOf((size_t)nTasks);
+        std::vector<int> taskStart((size_t)nB * NW + 1, 0);
+        for (size_t i = 0; i < order.size(); i++)
+        {
+            const int j = order[i].first, b = layOf(j).grpBlk[order[i].second];
+            const int w = wps > 0 ? (j * wps + (seq[(size_t)b * k + j]++ % wps)) % NW : seqB[b]++ % NW;
+            waveOf[i] = w;
+            taskStart[(size_t)b * NW + w + 1]++;
+        }
+        for (size_t i = 0; i + 1 < taskStart.size(); i++) taskStart[i + 1] += taskStart[i];
         std::vector<int4> tasks((size_t)nTasks);
         {
             std::vector<int> pos(taskStart.begin(), taskStart.end() - 1);
-            for (auto& t : order)
+            for (size_t i = 0; i < order.size(); i++)
             {
-                const BlockPlan::Layout& Y = layOf(t.first);
-                const int g = t.second;
-                tasks[(size_t)pos[Y.grpBlk[g]]++] = make_int4(Y.grpLane0[g], Y.grpCnt[g] | (Y.grpT[g] << 8) | (Y.grpStride[g] << 16), Y.grpEnt[g], t.first);
+                const BlockPlan::Layout& Y = layOf(order[i].first);
+                const int g = order[i].second;
+                tasks[(size_t)pos[(size_t)Y.grpBlk[g] * NW + waveOf[i]]++] =
+                    make_int4(Y.grpLane0[g], Y.grpCnt[g] | (Y.grpT[g] << 8) | (Y.grpStride[g] << 16), Y.grpEnt[g], order[i].first);
             }
         }
         // imports: a ghost that is a lower neighbour of a local row is needed with stamps 1 ... k, one that is only an
@@ -925,12 +969,13 @@ int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const 
     for (int L = 0; L < BK_NLAY; L++) { const BlockPlan::Layout& Y = P.lay[std::min(L, P.nLayouts - 1)]; T.meta[L] = Y.d_meta; T.col[L] = Y.d_col; }
     T.nLayouts = P.nLayouts;
     T.tasks = W->d_tasks; T.taskStart = W->d_taskStart; T.imps = W->d_imps; T.impStart = W->d_impStart;
+    const int xcdMap = ctx->blkXcdMap && ctx->nXcd == 8 && P.nBlocks >= 16;
     ctx->profStart(a, 4);
     if (P.nw == 7)
-        gs_blk_kernel<7><<<P.nBlocks, LDU_WAVE * 8, P.ldsBytes, s>>>(T, P.nBlocks, P.d_granule, tagBase, P.d_start, P.startBase,
+        gs_blk_kernel<7><<<P.nBlocks, LDU_WAVE * 8, P.ldsBytes, s>>>(T, P.nBlocks, xcdMap, P.d_granule, tagBase, P.d_start, P.startBase,
                                                                      ctx->d_abort, psi, rhs, diag);
     else
-        gs_blk_kernel<3><<<P.nBlocks, LDU_WAVE * 4, P.ldsBytes, s>>>(T, P.nBlocks, P.d_granule, tagBase, P.d_start, P.startBase,
+        gs_blk_kernel<3><<<P.nBlocks, LDU_WAVE * 4, P.ldsBytes, s>>>(T, P.nBlocks, xcdMap, P.d_granule, tagBase, P.d_start, P.startBase,
                                                                      ctx->d_abort, psi, rhs, diag);
     ctx->profStop(a, 4);
     P.startBase += (unsigned)P.nBlocks;

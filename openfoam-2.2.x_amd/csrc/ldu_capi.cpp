@@ -203,6 +203,12 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e && atoi(e) > 0) c->blkCellsMax = atoi(e);
     e = getenv("LDU_BLK_WAVES");
     if (e) c->blkWaves = atoi(e);
+    e = getenv("LDU_BLK_WIDE_FROM");
+    if (e) c->blkWideFrom = atoi(e);
+    e = getenv("LDU_BLK_WPS");
+    if (e) c->blkWavesPerSweep = atoi(e);
+    e = getenv("LDU_BLK_XCD");
+    if (e) c->blkXcdMap = atoi(e);
     e = getenv("LDU_BLK_LAYOUTS");
     if (e && atoi(e) > 0) c->blkLayouts = atoi(e);
     e = getenv("LDU_BLK_PER_CU");

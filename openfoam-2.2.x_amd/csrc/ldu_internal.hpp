@@ -126,13 +126,16 @@ struct ldu_ctx {
     // block engine (ldu_blocks.hip): k pipelined GaussSeidel sweeps with the hand-offs inside a workgroup's LDS, blocks of a few
     // thousand cells, granules only between blocks
     int blkEngine = 1;               // LDU_BLK=0: off
-    int blkMinCells = 6001;          // LDU_BLK_MIN (below: the one-workgroup engine)
+    int blkMinCells = 2000;          // LDU_BLK_MIN (below: the one-workgroup engine)
+    int blkWideFrom = 400000;        // LDU_BLK_WIDE_FROM: seven compute wavefronts per block from this many cells, three below
     int blkMaxCells = 4000000;       // LDU_BLK_MAX
     int blkCells = 0;                // LDU_BLK_CELLS: cells per block (0 = sized so that all blocks are resident at once)
     int blkCellsMin = 1024;          // LDU_BLK_CELLS_MIN
     int blkCellsMax = 12000;         // LDU_BLK_CELLS_MAX (LDS: 9 bytes per local row and per ghost)
-    int blkWaves = 7;                // LDU_BLK_WAVES (7 / 3 compute wavefronts per block, + 1 importer)
+    int blkWaves = 0;                // LDU_BLK_WAVES (7 / 3 compute wavefronts per block, + 1 importer; 0 = by size)
     int blkMaxPerCU = 4;             // LDU_BLK_PER_CU: workgroups per CU the grid may count on
+    int blkWavesPerSweep = 0;        // LDU_BLK_WPS: wavefronts a sweep's tasks of one block are dealt to (0 = all tasks round-robin over all wavefronts)
+    int blkXcdMap = 1;               // LDU_BLK_XCD=0: blocks in launch order instead of contiguous ranges per XCD
     int blkLayouts = 4;              // LDU_BLK_LAYOUTS: own grouping (by the row's time in the DAG of the k sweeps) for the first n sweeps
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid

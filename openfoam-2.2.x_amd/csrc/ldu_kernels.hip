@@ -1527,11 +1527,11 @@ int k_engine_of(ldu_addr* a, int kind /* 0 triangular, 1 one GaussSeidel sweep, 
 {
     ldu_ctx* ctx = a->ctx;
     if (!ctx->sweepP2P) return 4;
+    if (kind == 2 && !(ctx->clusterMulti && k_cluster_active(a)) && k_blocks_active(a)) return 6;
     if (kind >= 1 && !a->nPatchFaces && ctx->wgEngine && a->wgLevel && 9 * (size_t)a->nCells + 64 <= 160 * 1024) return 5;
     if (kind >= 1 && ctx->smallKernels && a->maxRowWidth <= 16 && !a->nPatchFaces
         && a->nCells <= ((kind == 2 && ctx->smallPipe) ? ctx->smallMaxCells : std::min(ctx->smallMaxCells, 3000)))
         return 3;
-    if (kind == 2 && k_blocks_active(a)) return 6;
     if (kind == 2 ? (ctx->clusterMulti && k_cluster_active(a)) : k_cluster_kind_active(a, kind)) return 2;
     return use_slab(a, kind, 2) ? 1 : 0;
 }

@@ -227,7 +227,9 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     hipStream_t s = a->ctx->stream;
     double* bPrime = nullptr;
     if (a->nPatchFaces || sym) bPrime = m->workVec(12);
-    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P)
+    // LDS-resident blocks (ldu_blocks.hip) wherever the cluster engine (structured numberings, <= 6 + 6 neighbours) does not apply
+    const bool blk = !sym && !a->nPatchFaces && a->ctx->sweepP2P && !(a->ctx->clusterMulti && k_cluster_active(a)) && k_blocks_active(a);
+    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && !blk)
     {
         // small matrix: every sweep inside one workgroup, solution vector in LDS
         int rc = 1;
@@ -248,7 +250,7 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         if (rc > 0) rc = k_sweep_gs_small(a, nSweeps, psi, source, m->d_diag, m->d_valA);
         if (rc <= 0) return rc;
     }
-    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && nSweeps == 1)
+    if (blk && nSweeps == 1)
     {
         const int rc = k_sweep_gs_blocks(a, 1, psi, source, m->d_diag, m->d_valA);   // (LDS-resident blocks: ldu_blocks.hip)
         if (rc <= 0) return rc;
@@ -262,7 +264,7 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         {
             const int k = left > 4 ? 4 : left;
             // LDS-resident blocks (ldu_blocks.hip), clusters, then the level engines
-            int rc = k_sweep_gs_blocks(a, k, psi, source, m->d_diag, m->d_valA);
+            int rc = blk ? k_sweep_gs_blocks(a, k, psi, source, m->d_diag, m->d_valA) : 1;
             if (k == 1 && rc > 0) break;   // a single remaining sweep: the plain engine below
             if (rc > 0) rc = a->ctx->clusterMulti ? k_sweep_cluster_gs_multi(a, k, psi, source, m->d_diag, m->d_valA) : 1;
             if (rc > 0) rc = k_sweep_gs_multi(a, k, psi, source, m->d_diag, m->d_valA);

@@ -13,39 +13,40 @@ from openfoam_amd import capi, cases
 pytestmark = pytest.mark.gpu
 
 ENGINES = {
-    "chip": {"LDU_P2P_SLABS": "0"},
-    "slab1": {"LDU_P2P_SLABS": "1"},
-    "slab3": {"LDU_P2P_SLABS": "3"},
-    "slab8": {"LDU_P2P_SLABS": "8"},
-    "slab8_bpc3": {"LDU_P2P_SLABS": "8", "LDU_P2P_BPC": "3"},
+    "chip": {"LDU_BLK": "0", "LDU_P2P_SLABS": "0"},
+    "slab1": {"LDU_BLK": "0", "LDU_P2P_SLABS": "1"},
+    "slab3": {"LDU_BLK": "0", "LDU_P2P_SLABS": "3"},
+    "slab8": {"LDU_BLK": "0", "LDU_P2P_SLABS": "8"},
+    "slab8_bpc3": {"LDU_BLK": "0", "LDU_P2P_SLABS": "8", "LDU_P2P_BPC": "3"},
     "auto": {},
     "levels": {"LDU_SWEEP": "levels"},
-    "nosmall": {"LDU_SMALL": "0"},
+    "nosmall": {"LDU_BLK": "0", "LDU_SMALL": "0"},
     "cluster": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1"},
     "cluster_bpc1": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1", "LDU_CLUSTER_BPC": "1"},
-    "nocluster": {"LDU_CLUSTER": "0"},
-    "small8192": {"LDU_SMALL_MAX": "8192"},
-    "small16384": {"LDU_SMALL_MAX": "16384"},
-    "small_nopipe": {"LDU_SMALL_PIPE": "0"},
-    "nocoop": {"LDU_COOP_ROWS": "0"},
-    "nolag": {"LDU_LAG_BUCKETS": "0"},
-    "nosort": {"LDU_SORT_ROWS": "0"},
-    "nowg": {"LDU_WG": "0"},
-    "wg4": {"LDU_WG_WAVES": "4"},
-    "nowg_small16384": {"LDU_WG": "0", "LDU_SMALL_MAX": "16384"},
-    "wg_wide18000": {"LDU_WG_MAX": "18000", "LDU_WG_WIDE": "1"},
+    "nocluster": {"LDU_BLK": "0", "LDU_CLUSTER": "0"},
+    "small8192": {"LDU_BLK": "0", "LDU_SMALL_MAX": "8192"},
+    "small16384": {"LDU_BLK": "0", "LDU_SMALL_MAX": "16384"},
+    "small_nopipe": {"LDU_BLK": "0", "LDU_SMALL_PIPE": "0"},
+    "nocoop": {"LDU_BLK": "0", "LDU_COOP_ROWS": "0"},
+    "nolag": {"LDU_BLK": "0", "LDU_LAG_BUCKETS": "0"},
+    "nosort": {"LDU_BLK": "0", "LDU_SORT_ROWS": "0"},
+    "nowg": {"LDU_BLK": "0", "LDU_WG": "0"},
+    "wg4": {"LDU_BLK": "0", "LDU_WG_WAVES": "4"},
+    "nowg_small16384": {"LDU_BLK": "0", "LDU_WG": "0", "LDU_SMALL_MAX": "16384"},
+    "wg_wide18000": {"LDU_BLK": "0", "LDU_WG_MAX": "18000", "LDU_WG_WIDE": "1"},
     "cluster_via_level_layout": {"LDU_CLUSTER": "2", "LDU_CLUSTER_MIN": "1", "LDU_CLUSTER_DIRECT": "0"},
     # LDS-resident blocks (ldu_blocks.hip) forced onto the small test matrices: many small blocks / a few large ones,
     # seven or three compute wavefronts per block
-    "blocks": {"LDU_BLK_MIN": "1", "LDU_BLK_CELLS": "400", "LDU_WG": "0", "LDU_SMALL": "0"},
-    "blocks_w3": {"LDU_BLK_MIN": "1", "LDU_BLK_CELLS": "1500", "LDU_BLK_WAVES": "3", "LDU_WG": "0", "LDU_SMALL": "0"},
-    "blocks_auto": {"LDU_BLK_MIN": "1", "LDU_WG": "0", "LDU_SMALL": "0"},
+    "blocks": {"LDU_CLUSTER": "0", "LDU_BLK_MIN": "1", "LDU_BLK_CELLS": "400", "LDU_WG": "0", "LDU_SMALL": "0"},
+    "blocks_w3": {"LDU_CLUSTER": "0", "LDU_BLK_MIN": "1", "LDU_BLK_CELLS": "1500", "LDU_BLK_WAVES": "3", "LDU_WG": "0", "LDU_SMALL": "0"},
+    "blocks_auto": {"LDU_CLUSTER": "0", "LDU_BLK_MIN": "1", "LDU_WG": "0", "LDU_SMALL": "0"},
     "noblocks": {"LDU_BLK": "0"},
 }
 KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX", "LDU_CLUSTER", "LDU_CLUSTER_MIN",
         "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS", "LDU_LAG_BUCKETS", "LDU_WG", "LDU_WG_WAVES",
         "LDU_WG_MAX", "LDU_WG_MIN", "LDU_WG_WIDE", "LDU_CLUSTER_DIRECT", "LDU_BLK", "LDU_BLK_MIN", "LDU_BLK_MAX",
-        "LDU_BLK_CELLS", "LDU_BLK_WAVES", "LDU_BLK_CELLS_MIN", "LDU_BLK_CELLS_MAX", "LDU_BLK_PER_CU")
+        "LDU_BLK_CELLS", "LDU_BLK_WAVES", "LDU_BLK_CELLS_MIN", "LDU_BLK_CELLS_MAX", "LDU_BLK_PER_CU", "LDU_BLK_WPS",
+        "LDU_BLK_XCD", "LDU_BLK_LAYOUTS")
 
 
 def _problems():
@@ -144,6 +145,7 @@ def test_small_pipelined_sweeps_bitexact(oracle, pipe):
     saved = {k: os.environ.pop(k, None) for k in KEYS}
     os.environ["LDU_SMALL_PIPE"] = pipe
     os.environ["LDU_WG"] = "0"
+    os.environ["LDU_BLK"] = "0"
     try:
         ctx = capi.Context(0)
         rng = np.random.RandomState(4)
@@ -178,6 +180,7 @@ def test_workgroup_engine_bitexact(oracle, waves):
     os.environ["LDU_WG_WAVES"] = waves
     os.environ["LDU_WG_MAX"] = "18000"
     os.environ["LDU_WG_WIDE"] = "1"
+    os.environ["LDU_BLK"] = "0"
     try:
         ctx = capi.Context(0)
         rng = np.random.RandomState(5)
@@ -203,14 +206,18 @@ def test_workgroup_engine_bitexact(oracle, waves):
                 os.environ[k] = saved[k]
 
 
-@pytest.mark.parametrize("waves,cells", [("7", "0"), ("7", "300"), ("3", "900"), ("7", "5000")])
-def test_block_engine_bitexact(oracle, waves, cells):
+@pytest.mark.parametrize("waves,cells,extra", [("7", "0", {}), ("7", "300", {}), ("3", "900", {}), ("7", "5000", {}),
+                                               ("7", "700", {"LDU_BLK_WPS": "2", "LDU_BLK_XCD": "0"}),
+                                               ("7", "500", {"LDU_BLK_LAYOUTS": "2"})])
+def test_block_engine_bitexact(oracle, waves, cells, extra):
     """gs_blk_kernel (ldu_blocks.hip): k = 1 ... 8 GaussSeidel sweeps with the matrix cut into blocks that live in the LDS of
     one workgroup each (values + sweep stamps; granules and an importer wavefront between blocks); hex / random / chain /
     wide-row graphs (rows of up to ~60 entries: the chunked tail), one block ... a few hundred blocks; bit-exact against
     the sequential sweeps, no engine fallback."""
     saved = {k: os.environ.pop(k, None) for k in KEYS}
-    os.environ.update({"LDU_BLK_MIN": "1", "LDU_BLK_WAVES": waves, "LDU_BLK_CELLS": cells, "LDU_WG": "0", "LDU_SMALL": "0"})
+    os.environ.update({"LDU_BLK_MIN": "1", "LDU_BLK_WAVES": waves, "LDU_BLK_CELLS": cells, "LDU_WG": "0", "LDU_SMALL": "0",
+                       "LDU_CLUSTER": "0"})
+    os.environ.update(extra)
     try:
         ctx = capi.Context(0)
         rng = np.random.RandomState(6)
@@ -356,6 +363,7 @@ def test_pipelined_sweeps_on_level_following_numbering_bitexact(oracle):
     for env in ({}, {"LDU_P2P_SLABS": "0"}):
         saved = {k: os.environ.pop(k, None) for k in KEYS}
         os.environ.update(env)
+        os.environ["LDU_BLK"] = "0"    # (the level engines are the subject here; the block engine: test_block_engine_bitexact)
         try:
             ctx = capi.Context(0)
             a, m = capi.from_problem(ctx, p)
