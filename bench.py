@@ -166,10 +166,10 @@ def main():
     ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
     ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random", "octree", "octree_hexref", "jump2d",
                                        "motorbike", "motorbike_rcm"],
-                    default="box",
+                    default="motorbike_rcm",
                     help="motorbike: the REAL mesh of the metric's workload - the reference's own blockMesh + snappyHexMesh "
                          "(castellatedMesh) on the reference's motorBike.obj, refined to ~10 M cells "
-                         "(oracle/_ref/motorbike/<--motorbike-name>.npz, made by tools/make_motorbike.py), in the cell numbering "
+                         "(data/motorbike/<--motorbike-name>.npz, made by tools/make_motorbike.py), in the cell numbering "
                          "snappyHexMesh produced; motorbike_rcm: the same renumbered by Foam::bandCompression (renumberMesh); "
                          "box: the SURVEY 8d C3 stand-in in blockMesh's natural ordering; "
                          "renumbered: the same matrix under Foam::bandCompression (what renumberMesh applies); "
@@ -181,7 +181,7 @@ def main():
                          "octree_hexref: the same in hexRef8's own numbering (what the tutorial's Allrun solves on); "
                          "jump2d: BASELINE config C5's twin at its size - n x n 2-D 5-point matrix with the coefficient "
                          "jumping 1 <-> 1000 across the diagonal (damBreak p_rgh, --n 2000 = 4.0 M cells)")
-    ap.add_argument("--motorbike-name", default="mb12", help="which stored motorBike mesh (oracle/_ref/motorbike/<name>.npz)")
+    ap.add_argument("--motorbike-name", default="mb12", help="which stored motorBike mesh (data/motorbike/<name>.npz)")
     ap.add_argument("--octree-q", type=int, default=14, help="octree background mesh 5q x 2q x 2q (14 -> ~10 M cells)")
     ap.add_argument("--octree-levels", type=int, nargs=2, default=[6, 7], help="octree surface refinement levels")
     ap.add_argument("--rank-of", type=int, default=0, metavar="N",
@@ -202,6 +202,8 @@ def main():
                     help="allow more ranks than visible GPUs (ranks share GPUs round-robin; peer backend only - RCCL "
                          "refuses two ranks on one device): executes the N-rank path on a 1-GPU box, NOT a scaling number")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCG / asymmetric / host-path legs")
+    ap.add_argument("--no-sublegs", action="store_true", help="skip the sub-legs of the default line (the 216^3 box stand-in and the "
+                                                                "mesh in snappyHexMesh's own numbering, each in its own process)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=0, help="box edge of the CPU sample (0 = same)")
     # (ranks spawned by this script receive the command line through the environment: torch.distributed.run's own
@@ -258,6 +260,15 @@ def main():
     from openfoam_amd import capi, cases, decompose
 
     n = args.n
+    mesh_fallback = None
+    if args.mesh.startswith("motorbike"):
+        from openfoam_amd import motorbike as _mbchk
+        if not _mbchk.available(args.motorbike_name):
+            # the metric's own mesh is data outside git (data/motorbike/, 73 MB): say so loudly and measure the stand-in
+            mesh_fallback = ("data/motorbike/%s.npz is not on this machine (tools/make_motorbike.py makes it where the reference "
+                             "exists): the 216^3 box stand-in was measured instead" % args.motorbike_name)
+            sys.stderr.write("bench.py: WARNING: %s\n" % mesh_fallback)
+            args.mesh = "box"
     t_gen = time.perf_counter()
     if args.mesh == "random":
         p = cases.random_graph_fast(n ** 3, 7.0, 600)
@@ -718,41 +729,43 @@ def main():
         except Exception as e:  # pragma: no cover
             cpu_all = dict(error=str(e)[:300], cores=cores)
 
-    # the REAL motorBike mesh next to the headline (the 216^3 box is C3's primary input, the real
-    # snappyHexMesh mesh its "next"): its own processes (own context, own memory), in snappyHexMesh's cell numbering and
-    # renumbered by Foam::bandCompression.  Where the stored mesh is absent the analytic octree twin runs instead.
-    motorbike_leg = None
+    # Sub-legs of the default line, each in its own process (own context, own memory): the 216^3 box stand-in of SURVEY 8d
+    # (rounds 1-4's headline; with its PCG / asymmetric / resident-pipeline / host-pointer legs) and the same real mesh in the
+    # cell numbering snappyHexMesh wrote (the headline is renumbered by Foam::bandCompression = renumberMesh).
+    box_leg = None
+    snappy_leg = None
     octree_leg = None
     fallbacks_main = ctx.fallback_count()
     mem_in_use_gb = round((lambda fr, tot: (tot - fr) / 1e9)(*torch.cuda.mem_get_info()), 2)
-    if rank == 0 and world == 1 and args.mesh == "box" and not args.no_extras and args.rank_of <= 1:
+    if rank == 0 and world == 1 and args.mesh == "motorbike_rcm" and not args.no_extras and not args.no_sublegs and args.rank_of <= 1:
         import subprocess
-        from openfoam_amd import motorbike as _mb
         mat.close(); addr.close(); ctx.close()
         mat = addr = ctx = None
         torch.cuda.empty_cache()
 
-        def leg(mesh, extra=()):
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mesh", mesh, "--no-extras", "--steps", "3",
-                                "--warmup", "1"] + list(extra), capture_output=True, text=True, timeout=900)
-            oj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            return dict(vcycles_per_s=oj["value"], ms_per_step=oj["ms_per_step"], workload=oj["config"]["workload"],
-                        vcycles_per_solve=oj["config"]["vcycles_per_solve"],
-                        dependency_levels_finest=oj["config"]["dependency_levels_finest"],
-                        finest_launch_ms=oj["roofline"]["avg_launch_ms"], roofline_frac=oj["roofline"]["frac"],
-                        roofline_kernel=oj["roofline"]["kernel"], roofline_vcycle_frac=oj["roofline_vcycle"]["frac"],
-                        amul_frac=(oj.get("amul") or {}).get("frac"),
-                        engine_fallbacks=oj["config"]["engine_fallbacks"], cpu_baseline=oj.get("cpu_baseline"),
-                        first_solve_s=oj["extra"]["first_solve_s"], residual_history=oj["extra"]["residual_history"])
+        def run_leg(mesh, extra=()):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mesh", mesh, "--no-sublegs", "--no-cpu"] + list(extra),
+                               capture_output=True, text=True, timeout=900)
+            return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         try:
-            if _mb.available(args.motorbike_name):
-                motorbike_leg = dict(snappyHexMesh_numbering=leg("motorbike", ["--motorbike-name", args.motorbike_name]),
-                                     bandCompression_numbering=leg("motorbike_rcm", ["--motorbike-name", args.motorbike_name,
-                                                                                     "--no-cpu"]))
-            else:
-                octree_leg = leg("octree", ["--no-cpu"])
+            oj = run_leg("motorbike", ["--motorbike-name", args.motorbike_name, "--no-extras", "--steps", "3", "--warmup", "1"])
+            snappy_leg = dict(vcycles_per_s=oj["value"], ms_per_step=oj["ms_per_step"], workload=oj["config"]["workload"],
+                              vcycles_per_solve=oj["config"]["vcycles_per_solve"],
+                              dependency_levels_finest=oj["config"]["dependency_levels_finest"],
+                              finest_launch_ms=oj["roofline"]["avg_launch_ms"], roofline_frac=oj["roofline"]["frac"],
+                              roofline_kernel=oj["roofline"]["kernel"], roofline_vcycle_frac=oj["roofline_vcycle"]["frac"],
+                              amul_frac=(oj.get("amul") or {}).get("frac"), engine_fallbacks=oj["config"]["engine_fallbacks"],
+                              first_solve_s=oj["extra"]["first_solve_s"], residual_history=oj["extra"]["residual_history"])
         except Exception as e:  # pragma: no cover
-            motorbike_leg = dict(error=str(e)[:300])
+            snappy_leg = dict(error=str(e)[:300])
+        try:
+            oj = run_leg("box", ["--steps", "10", "--warmup", "2"])
+            box_leg = dict(vcycles_per_s=oj["value"], ms_per_step=oj["ms_per_step"], workload=oj["config"]["workload"],
+                           vcycles_per_solve=oj["config"]["vcycles_per_solve"], roofline=oj["roofline"],
+                           roofline_vcycle={k: v for k, v in (oj.get("roofline_vcycle") or {}).items() if k != "levels"},
+                           amul=oj.get("amul"), extra=oj.get("extra"), engine_fallbacks=oj["config"]["engine_fallbacks"])
+        except Exception as e:  # pragma: no cover
+            box_leg = dict(error=str(e)[:300])
 
     if rank == 0 and args.rank_of > 1:
         # a projection, not a measurement of N GPUs: its own line shape so that nobody mistakes it for the metric
@@ -772,7 +785,8 @@ def main():
             "residual_history": [float("%.6e" % h) for h in perf["history"]]}))
     elif rank == 0:
         out = {
-            "metric": "GAMG p-solve iterations/sec (V-cycles/s) + achieved HBM GB/s, 10M-cell motorBike stand-in",
+            "metric": "GAMG p-solve iterations/sec (V-cycles/s) + achieved HBM GB/s, motorBike 10M-cell p-solve" + (
+                "" if is_mb else " (stand-in workload, see config.workload)"),
             "value": round(iters / elapsed, 3),
             "unit": "V-cycles/s",
             "n_gpus": world,
@@ -783,7 +797,8 @@ def main():
             "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" coefficients and right-hand side on the REAL mesh (the reference's blockMesh + snappyHexMesh "
+                                   "on its motorBike.obj)" if is_mb else ""),
             "config": {"workload": (("simpleFoam motorBike p-solve on the REAL mesh: the reference's blockMesh + snappyHexMesh "
                                      "(castellatedMesh) on motorBike.obj, background %dx%dx%d, refinementBox level %d, surface "
                                      "levels %d-%d, cells per refinement level %s; %d cells, %d faces; laplacian coefficients "
@@ -815,6 +830,7 @@ def main():
                                        "octree": "; hexRef8 cell numbering renumbered by Foam::bandCompression",
                                        "octree_hexref": "; hexRef8 cell numbering (parent keeps its label, 7 children appended)"}[args.mesh]),
                        "mesh": args.mesh,
+                       "mesh_fallback": mesh_fallback,
                        "parallelism": ("domain decomposition x%d" % world) + (
                            "" if world == 1 else " (%s, %s scaling: %s; halo exchanges and global sums by %s%s)" % (
                                mb_decomp if is_mb else
@@ -841,8 +857,8 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "amul": amul,
-            "motorbike": motorbike_leg,
-            "octree_twin": octree_leg,
+            "box216": box_leg,
+            "motorbike_snappy_numbering": snappy_leg,
             "extra": dict(extra, device_memory_in_use_GB=mem_in_use_gb,
                           first_solve_s=round(t_first, 3), addressing_setup_s=round(t_addr, 3),
                           problem_generation_s=round(t_gen, 3),

@@ -128,6 +128,11 @@ static int ctx_init(ldu_ctx* c, int device)
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * (S_NSLOTS + 1)));
     LDU_CHECK_HIP(ldu_memset_sync(c->d_scalars, 0, sizeof(double) * (S_NSLOTS + 1)));
     LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * (S_NSLOTS + 1), hipHostMallocDefault));
+    for (int i = 0; i < 2; i++)
+    {
+        LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_ring[i], sizeof(double) * (S_NSLOTS + 1), hipHostMallocDefault));
+        LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evRing[i], hipEventDisableTiming));
+    }
     c->d_abort = (int*)(c->d_scalars + S_NSLOTS);
     c->h_abort = (int*)(c->h_scalars + S_NSLOTS);
     *c->h_abort = 0;
@@ -203,6 +208,8 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e && atoi(e) > 0) c->blkCellsMax = atoi(e);
     e = getenv("LDU_BLK_WAVES");
     if (e) c->blkWaves = atoi(e);
+    e = getenv("LDU_KRYLOV_SPECULATE");
+    if (e) c->krylovSpeculate = atoi(e);
     e = getenv("LDU_BLK_WIDE_FROM");
     if (e) c->blkWideFrom = atoi(e);
     e = getenv("LDU_BLK_WPS");
@@ -255,6 +262,11 @@ int ldu_ctx_destroy(ldu_ctx* c)
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_scalars);
     (void)hipHostFree(c->h_scalars);
+    for (int i = 0; i < 2; i++)
+    {
+        if (c->h_ring[i]) (void)hipHostFree(c->h_ring[i]);
+        if (c->evRing[i]) (void)hipEventDestroy(c->evRing[i]);
+    }
     if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     if (c->stream3) (void)hipStreamSynchronize(c->stream3);

@@ -58,7 +58,10 @@ struct BlockPlan;      // ldu_blocks.hip
 // scalar slots on the device
 enum {
     S_WARA0 = 0, S_WARA1 = 1, S_WAPA = 2, S_RES = 3, S_NORM = 4, S_SINGULAR = 5, S_SUMPSI = 6,
-    S_TMP0 = 7, S_TMP1 = 8, S_SCALE_NUM = 9, S_SCALE_DEN = 10, S_COUNT = 11, S_BANK = 16, S_NSLOTS = 128
+    S_TMP0 = 7, S_TMP1 = 8, S_SCALE_NUM = 9, S_SCALE_DEN = 10, S_COUNT = 11,
+    S_STOP = 12,   // Krylov loops: 1 = the iteration whose residual was just formed is the last one (decided on the device)
+    S_INIT = 13,   // ... their initial residual (for the relTol test on the device)
+    S_BANK = 16, S_NSLOTS = 128
 };
 
 struct ldu_ctx {
@@ -86,6 +89,11 @@ struct ldu_ctx {
     int maxRedBlocks = 1024;
     double* d_scalars = nullptr;     // [S_NSLOTS] = banks of S_BANK slots
     double* h_scalars = nullptr;     // pinned mirror
+    // PCG / PBiCG with the convergence read-back off the critical path (ldu_solvers.cpp: solve_krylov): two more pinned
+    // mirrors and the events behind their copies - iteration k + 1 is queued before the residual of iteration k is read
+    double* h_ring[2] = {nullptr, nullptr};
+    hipEvent_t evRing[2] = {nullptr, nullptr};
+    int krylovSpeculate = 1;         // LDU_KRYLOV_SPECULATE=0: read the residual before queueing the next iteration (round 1-4)
     int sb = 0;                      // current bank offset (nested solves push a new bank)
     double* S() const { return d_scalars + sb; }
     bool useGraphs = true;
@@ -488,6 +496,8 @@ int k_pbicg_update_p(int n, double* pA, const double* wA, double* pT, const doub
 // psi += alpha pA ; rA -= alpha wA ; (rT -= alpha wT) ; partial sum |rA| ; singular test on device
 int k_pcg_update_xr(ldu_ctx* ctx, int n, double* psi, double* rA, const double* pA, const double* wA,
                     double* rT, const double* wT, int cur, hipStream_t s);
+// S_STOP := singular || converged || !(it < maxIter)  (PCG.C:174-181's loop condition, evaluated on the device)
+int k_krylov_decide(ldu_ctx* ctx, double tolerance, double relTol, int it, int maxIter, hipStream_t s);
 int k_gamg_scale_update(int n, double* field, const double* source, const double* Acf,
                         const double* diag, const double* scalars, hipStream_t s);
 int k_neg_div(int n, double* psi, const double* Apsi, const double* diag, hipStream_t s);

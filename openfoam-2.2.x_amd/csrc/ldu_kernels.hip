@@ -3500,6 +3500,8 @@ pcg_update_xr_kernel(int n, double* __restrict__ psi, double* __restrict__ rA,
     const double wApA = S[S_WAPA];
     const bool singular = fabs(wApA) / S[S_NORM] < 1e-300;   // solverPerformance::vsmall_
     double acc = 0.0;
+    // a speculatively queued iteration behind the last one of the solve: nothing is touched (k_krylov_decide)
+    if (S[S_STOP] != 0.0) { block_partial(acc, partials); return; }
     if (singular)
     {
         if (blockIdx.x == 0 && threadIdx.x == 0) S[S_SINGULAR] = 1.0;
@@ -3528,6 +3530,24 @@ int k_pcg_update_xr(ldu_ctx* ctx, int n, double* psi, double* rA, const double* 
                                            ctx->d_partials);
     reduce_final_kernel<<<1, BLK, 0, s>>>(ctx->d_partials, g, ctx->S(), S_RES, 0.0, 1,
                                          ctx->maxRedBlocks);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// The loop condition of PCG.C:174-181 / PBiCG.C:181-188 on the device, after the residual of iteration `it` was formed:
+// finalResidual = sum|rA| / normFactor; converged = finalResidual < Tolerance || (RelTolerance > small &&
+// finalResidual < RelTolerance*initialResidual) (lduMatrixSolver.C / SolverPerformance.C:37-70); the same IEEE operations the
+// host performs on the same doubles, so both sides take the same decision.  A set flag stays set.
+__global__ void krylov_decide_kernel(double* __restrict__ S, double tolerance, double relTol, int it, int maxIter)
+{
+    if (S[S_STOP] != 0.0) return;
+    const double fin = S[S_RES] / S[S_NORM];
+    const bool conv = fin < tolerance || (relTol > 1e-20 && fin < relTol * S[S_INIT]);
+    S[S_STOP] = (S[S_SINGULAR] != 0.0 || conv || !(it < maxIter)) ? 1.0 : 0.0;
+}
+int k_krylov_decide(ldu_ctx* ctx, double tolerance, double relTol, int it, int maxIter, hipStream_t s)
+{
+    krylov_decide_kernel<<<1, 1, 0, s>>>(ctx->S(), tolerance, relTol, it, maxIter);
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }

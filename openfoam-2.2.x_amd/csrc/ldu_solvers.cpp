@@ -475,6 +475,7 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
     {
         double z = 0.0;
         LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_SINGULAR, &z, sizeof(double), hipMemcpyHostToDevice, s));
+        LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_STOP, &z, sizeof(double), hipMemcpyHostToDevice, s));
         double g[2] = {kGreat, kGreat};   // wArA = great_ (PCG.C:89)
         LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_WARA0, g, 2 * sizeof(double), hipMemcpyHostToDevice, s));
         LDU_CHECK_HIP(hipStreamSynchronize(s));
@@ -486,6 +487,19 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
     perf->initialResidual = v[0] / normFactor;
     perf->finalResidual = perf->initialResidual;
     hist_push(perf, c, hist);
+    // The convergence read-back off the critical path: iteration k + 1 is queued BEFORE the residual of iteration k is read.
+    // Everything an iteration writes before its last kernel is work space (wA, pA, the scalar slots); psi and rA change in
+    // k_pcg_update_xr only, and that kernel does nothing once the device itself has found the loop condition of
+    // PCG.C:174-181 false (k_krylov_decide: the host's own test on the same doubles).  Iterations, psi and the residual
+    // history are those of the sequential loop; the price is one iteration of discarded work per solve.  Not with the GAMG
+    // preconditioner (it reads scalars back itself).
+    const bool speculate = ctx->krylovSpeculate && c->preconditioner != LDU_PRE_GAMG && c->maxIter > 0;
+    if (speculate)
+    {
+        const double ir = perf->initialResidual;
+        LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_INIT, &ir, sizeof(double), hipMemcpyHostToDevice, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+    }
 
     if (!check_convergence(perf, c->tolerance, c->relTol))
     {
@@ -500,8 +514,8 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
         }
         int cur = S_WARA0, prev = S_WARA1;
         const bool dual = bi && !a->nPatchFaces && ctx->dualStream && pre != LDU_PRE_GAMG;
-        do
-        {
+        // one iteration, queued: PCG.C:123-172 / PBiCG.C:130-179 up to the residual sum (S_RES)
+        auto iteration = [&](int it) -> int {
             // wArAold = wArA (slot swap)
             { int t = cur; cur = prev; prev = t; }
             // --- precondition (PCG.C:129 / PBiCG.C:138-139)
@@ -531,7 +545,7 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
             if (k_reduce(ctx, n, RED_DOT, wA, bi ? rT : rA, nullptr, nullptr, cur, s)) return -1;
             if (comm_allreduce_scalars(ctx, cur, 1, s)) return -1;
             // --- search directions
-            const int first = perf->nIterations == 0;
+            const int first = it == 0;
             if (bi)
             {
                 if (k_pbicg_update_p(n, pA, wA, pT, wT, ctx->S(), cur, prev, first, s)) return -1;
@@ -554,12 +568,68 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
             // --- singularity test + psi/rA update + |rA| partial sums, one pass
             if (k_pcg_update_xr(ctx, n, psi, rA, pA, wA, rT, wT, cur, s)) return -1;
             if (comm_allreduce_scalars(ctx, S_RES, 1, s)) return -1;
-            double rs[3];
-            if (dev_read_scalars(ctx, S_RES, 3, rs)) return -1;   // S_RES, S_NORM, S_SINGULAR
-            if (rs[2] != 0.0) { perf->singular = 1; break; }
-            perf->finalResidual = rs[0] / normFactor;
-            hist_push(perf, c, hist);
-        } while (perf->nIterations++ < c->maxIter && !check_convergence(perf, c->tolerance, c->relTol));
+            return 0;
+        };
+        if (!speculate)
+        {
+            do
+            {
+                if (iteration(perf->nIterations)) return -1;
+                double rs[3];
+                if (dev_read_scalars(ctx, S_RES, 3, rs)) return -1;   // S_RES, S_NORM, S_SINGULAR
+                if (rs[2] != 0.0) { perf->singular = 1; break; }
+                perf->finalResidual = rs[0] / normFactor;
+                hist_push(perf, c, hist);
+            } while (perf->nIterations++ < c->maxIter && !check_convergence(perf, c->tolerance, c->relTol));
+        }
+        else
+        {
+            // queue(it): iteration it, the device-side loop condition, the scalars on their way to the host
+            auto queue = [&](int it) -> int {
+                if (iteration(it)) return -1;
+                if (k_krylov_decide(ctx, c->tolerance, c->relTol, it, c->maxIter, s)) return -1;
+                if (comm_allreduce_abort(ctx, s)) return -1;
+                ctx->nScalarReadbacks++;
+                LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_ring[it & 1], ctx->d_scalars, sizeof(double) * (S_NSLOTS + 1),
+                                             hipMemcpyDeviceToHost, s));
+                LDU_CHECK_HIP(hipEventRecord(ctx->evRing[it & 1], s));
+                return 0;
+            };
+            int it = 0;
+            if (queue(0)) return -1;
+            for (;;)
+            {
+                // iteration it + 1 goes into the queue while iteration it runs (the reference's loop condition allows it
+                // for it < maxIter; whether it takes effect is the device's decision)
+                const bool more = it < c->maxIter;
+                if (more && queue(it + 1)) return -1;
+                LDU_CHECK_HIP(hipEventSynchronize(ctx->evRing[it & 1]));
+                const double* H = ctx->h_ring[it & 1];
+                const int* habort = (const int*)(H + S_NSLOTS);
+                if (habort[1])
+                {
+                    LDU_CHECK_HIP(hipStreamSynchronize(s));
+                    (void)hipMemsetAsync(ctx->d_abort + 1, 0, sizeof(int), s);
+                    ldu_set_error("directSolveCoarsest: singular coarsest-level matrix");
+                    return -17;
+                }
+                if (habort[0])
+                {
+                    LDU_CHECK_HIP(hipStreamSynchronize(s));
+                    (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), s);
+                    ctx->p2pGen++;
+                    ctx->abortSeen = 1;
+                    ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
+                    return -20;
+                }
+                const double* rs = H + ctx->sb + S_RES;              // S_RES, S_NORM, S_SINGULAR
+                if (rs[2] != 0.0) { perf->singular = 1; break; }
+                perf->finalResidual = rs[0] / normFactor;
+                hist_push(perf, c, hist);
+                if (!(perf->nIterations++ < c->maxIter && !check_convergence(perf, c->tolerance, c->relTol))) break;
+                it++;
+            }
+        }
     }
     return 0;
 }

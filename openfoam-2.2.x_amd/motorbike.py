@@ -3,7 +3,7 @@ SURVEY.md 8f rank 3).
 
 The mesh is made by the reference's own blockMesh + snappyHexMesh (castellatedMesh only) from the reference's own
 motorBike.obj (oracle/motorbike_case.py, oracle/build_ref_mesh.sh, tools/make_motorbike.py - where /root/reference
-exists) and stored in a compact form under oracle/_ref/motorbike/<name>.npz: lduAddressing of the internal faces
+exists) and stored in a compact form under data/motorbike/<name>.npz (not in git): lduAddressing of the internal faces
 (owner counts + neighbour labels, the cell numbering hexRef8 / snappyHexMesh produced), the face normal direction, the
 refinement level of every cell and the cells of the outlet patch.  tools/make_motorbike.py verified against the mesh's own
 geometry (the reference's face / cell formulas) that every cell is a cube of its level and every internal face an
@@ -23,7 +23,7 @@ import numpy as np
 from . import cases as _cases
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STORE = os.path.join(ROOT, "oracle", "_ref", "motorbike")
+STORE = os.path.join(ROOT, "data", "motorbike")
 
 
 def path(name):

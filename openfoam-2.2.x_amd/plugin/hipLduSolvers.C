@@ -268,6 +268,12 @@ static ldu_ctx* hipContext()
     return hipCtx_;
 }
 
+// the process's one device context, for the scheme plug-in (hipFvSchemes.C) that shares it
+ldu_ctx* hipLduSharedContext()
+{
+    return hipContext();
+}
+
 // Device image of (lduAddressing, coupled patches), built once per addressing like the
 // reference's lazily built losort/ownerStart.
 template<class InterfaceList>

@@ -219,7 +219,10 @@ if [ -f "$SIM/simpleFoam.C" ] && [ -z "$NO_SIMPLEFOAM" ]; then
     done
     if [ "$FORCE_SIM" != "MISSING" ]; then
         g++ $SFLAGS -I"$SIM" -c "$SIM/simpleFoam.C" -o "$W/simpleFoam.o"
-        g++ -o "$OUT/simpleFoam" "$W/simpleFoam.o" "$W"/sfobj/*.o $FORCE_SIM "$W/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm -Wl,-rpath,'$ORIGIN' \
+        # (-rdynamic: the executable exports its symbols - the run-time selection tables of the statically linked finiteVolume
+        #  units among them - so that a library loaded through `libs (...)` registers into THOSE tables, as it would with
+        #  the reference's shared libfiniteVolume.so; a link flag, simpleFoam.C is compiled unchanged)
+        g++ -rdynamic -o "$OUT/simpleFoam" "$W/simpleFoam.o" "$W"/sfobj/*.o $FORCE_SIM "$W/libfiniteVolume.a" -L"$OUT" -lOpenFOAM -ldl -lm -Wl,-rpath,'$ORIGIN' \
             && echo "build_ref_fv.sh: OK -> $OUT/simpleFoam (the reference's simpleFoam.C, unchanged)"
     fi
 fi

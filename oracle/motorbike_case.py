@@ -18,7 +18,7 @@ Runs serially (no MPI in this image): `decomposePar` + `runParallel snappyHexMes
 
 A mesh generator is an input producer, not an oracle: nothing here is compared against; the matrix built on
 the mesh is checked HIP-vs-oracle like every other (tests/test_motorbike.py).  Only runs where /root/reference
-(the .obj) and oracle/_ref exist; the result is stored compressed under oracle/_ref/motorbike/ (git-ignored,
+(the .obj) and oracle/_ref exist; the result is stored compressed under data/motorbike/ (git-ignored,
 travels to the GPU box like the rest of oracle/_ref) by tools/make_motorbike.py.
 """
 import gzip

@@ -40,7 +40,9 @@ def _w(path, cls, obj, body):
         f.write(HEAD % (cls, obj) + body)
 
 
-def write(case, steps=30, libs=None, p_solver=None):
+def write(case, steps=30, libs=None, p_solver=None, gauss="Gauss"):
+    """gauss: the name the gradient / convection / laplacian schemes are selected under - "Gauss" (the reference's classes) or
+    "hipGauss" (libhipFvSchemes.so: the same schemes with their face loops on the device; needs that library in `libs`)"""
     g = np.load(GOLDEN, allow_pickle=True)
     pm = os.path.join(case, "constant", "polyMesh")
     pts, fs, fp = g["points"], g["faceStart"], g["facePoints"]
@@ -61,27 +63,27 @@ def write(case, steps=30, libs=None, p_solver=None):
        % (steps, ("libs (%s);" % " ".join('"%s"' % l for l in libs)) if libs else ""))
     _w(os.path.join(case, "system", "fvSchemes"), "dictionary", "fvSchemes", """
 ddtSchemes { default steadyState; }
-gradSchemes { default Gauss linear; grad(p) Gauss linear; grad(U) Gauss linear; }
+gradSchemes { default GAUSS linear; grad(p) GAUSS linear; grad(U) GAUSS linear; }
 divSchemes
 {
     default none;
-    div(phi,U) bounded Gauss upwind;
-    div(phi,k) bounded Gauss upwind;
-    div(phi,epsilon) bounded Gauss upwind;
+    div(phi,U) bounded GAUSS upwind;
+    div(phi,k) bounded GAUSS upwind;
+    div(phi,epsilon) bounded GAUSS upwind;
     div((nuEff*dev(T(grad(U))))) Gauss linear;
 }
 laplacianSchemes
 {
     default none;
-    laplacian(nuEff,U) Gauss linear corrected;
-    laplacian((1|A(U)),p) Gauss linear corrected;
-    laplacian(DkEff,k) Gauss linear corrected;
-    laplacian(DepsilonEff,epsilon) Gauss linear corrected;
+    laplacian(nuEff,U) GAUSS linear corrected;
+    laplacian((1|A(U)),p) GAUSS linear corrected;
+    laplacian(DkEff,k) GAUSS linear corrected;
+    laplacian(DepsilonEff,epsilon) GAUSS linear corrected;
 }
 interpolationSchemes { default linear; interpolate(U) linear; }
 snGradSchemes { default corrected; }
 fluxRequired { default no; p ; }
-""")
+""".replace("GAUSS", gauss))
     bicg = "{ solver PBiCG; preconditioner DILU; tolerance 1e-05; relTol 0.1; }"
     _w(os.path.join(case, "system", "fvSolution"), "dictionary", "fvSolution", """
 solvers

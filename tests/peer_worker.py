@@ -31,7 +31,7 @@ def main():
     import oracle_py
     oracle_py.build()
     if size.startswith("mb"):
-        # a REAL snappyHexMesh motorBike mesh (oracle/_ref/motorbike/<name>.npz), cut into n contiguous ranges of its cell
+        # a REAL snappyHexMesh motorBike mesh (data/motorbike/<name>.npz), cut into n contiguous ranges of its cell
         # numbering: unstructured processor patches, several neighbours per rank
         from openfoam_amd import motorbike
         p = motorbike.problem(size)

@@ -60,7 +60,7 @@ def test_real_motorbike_mesh_four_ranks():
     patches (hanging faces, several neighbours per rank), GAMG / PCG / smoothSolver against the multi-domain oracle"""
     from openfoam_amd import motorbike
     if not motorbike.available("mbtut"):
-        pytest.skip("oracle/_ref/motorbike/mbtut.npz not present")
+        pytest.skip("data/motorbike/mbtut.npz not present")
     out = run_worker(4, False, size="mbtut", timeout=1200)
     assert not any(out["mismatches"]), out
 

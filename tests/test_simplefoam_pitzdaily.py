@@ -20,6 +20,7 @@ import cavity_case as cc
 import pitzdaily_case as pc
 
 PLUGIN = os.path.abspath(os.path.join(HERE, "..", "openfoam-2.2.x_amd", "lib", "libhipLduSolvers.so"))
+FV_PLUGIN = os.path.abspath(os.path.join(HERE, "..", "openfoam-2.2.x_amd", "lib", "libhipFvSchemes.so"))
 STEPS = 40
 needs_ref = pytest.mark.skipif(not pc.available(), reason="needs oracle/_ref/simpleFoam (oracle/build_ref_fv.sh)")
 CASES = [("", None), ("_gamg", pc.GAMG)]
@@ -65,3 +66,37 @@ def test_simplefoam_through_the_plugin(tag, psolver, tmp_path):
     print("simpleFoam pitzDaily through the plugin (%s): %d solver lines, %d with a different iteration count, worst relative "
           "difference of an initial residual %.2e" % (tag or "pcg", len(lines), off, worst))
     assert off <= len(lines) // 50
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.skipif(not (os.path.exists(PLUGIN) and os.path.exists(FV_PLUGIN)), reason="needs the prebuilt plugins")
+def test_simplefoam_with_hipgauss_schemes(tmp_path):
+    """SURVEY 8a a33-a39 reachable from an unchanged application: the same simpleFoam binary and case with
+    `libs ("libhipLduSolvers.so" "libhipFvSchemes.so");` and fvSchemes selecting `hipGauss` for every gradient, convection
+    and laplacian scheme - fv::gradScheme / convectionScheme / laplacianScheme run-time tables (gradScheme.H:87,
+    convectionScheme.H:82-95, laplacianScheme.H:97-104) -> hipGaussGrad / hipGaussConvectionScheme / hipGaussLaplacianScheme ->
+    ldu_fvc_gaussGradFull / ldu_fvm_div / ldu_fvm_laplacian on the device.  The kernels reproduce the reference's face loops
+    bit for bit, so the run must print the SAME solver log as the run with the stock `Gauss` schemes (both through the
+    solver plug-in): every solver line equal, and within the application-level bars of the stock fixture."""
+    import re
+    logs = {}
+    for gauss in ("Gauss", "hipGauss"):
+        case = str(tmp_path / ("pitzDaily_" + gauss))
+        pc.write(case, STEPS, libs=[PLUGIN, FV_PLUGIN], p_solver=pc.GAMG, gauss=gauss)
+        logs[gauss] = pc.run(case, extra_env={"LDU_VERBOSE": "1"})
+    log = logs["hipGauss"]
+    assert "[hipFvSchemes] finite-volume stencils on the device" in log, log[-2000:]
+    m = re.search(r"\[hipFvSchemes\] device calls: fvmLaplacian (\d+), fvmDiv (\d+), gaussGrad (\d+)", log)
+    assert m, log[-2000:]
+    nLap, nDiv, nGrad = (int(v) for v in m.groups())
+    # per SIMPLE iteration: laplacian(nuEff,U), laplacian(rAU,p), laplacian(DkEff,k), laplacian(DepsilonEff,epsilon);
+    # div(phi,U), div(phi,k), div(phi,epsilon); grad(p) twice and grad(U) (UEqn.H, pEqn.H, kEpsilon.C:225-260)
+    assert nLap == 4 * STEPS and nDiv == 3 * STEPS and nGrad >= 3 * STEPS, (nLap, nDiv, nGrad)
+    assert "[hipFvSchemes] device calls: fvmLaplacian 0, fvmDiv 0, gaussGrad 0" in logs["Gauss"]   # (loaded, not selected)
+    lines, base, gold = cc.solve_lines(log), cc.solve_lines(logs["Gauss"]), golden("_gamg")
+    assert len(lines) == len(base) == len(gold) == 5 * STEPS
+    assert lines == base          # device assembly == host assembly, bit for bit: the same printed residuals and counts
+    for got, ref in zip(lines, gold):
+        assert got[0] == ref[0] and got[1] == ref[1] and got[4] == ref[4], (got, ref)
+        assert abs(got[2] - ref[2]) <= 1e-3 * abs(ref[2]) + 1e-9, (got, ref)

@@ -9,7 +9,7 @@
    face size) and CHECKS that the mesh is what the compact form below
    assumes: every internal face an axis-aligned square of the finer cell's size, every cell a cube of its cellLevel,
    |Sf| / (n . d) of the real geometry equal to area / normal distance from the levels to 1e-9;
-3. stores what the p-equation needs, compressed, under oracle/_ref/motorbike/<name>.npz (git-ignored, travels to the GPU
+3. stores what the p-equation needs, compressed, under data/motorbike/<name>.npz (git-ignored, travels to the GPU
    box like the rest of oracle/_ref): owner / neighbour of the internal faces (lduAddressing: `ownerCount` per cell and
    `upper`), the face normal direction (0/1/2), cellLevel, the cells of the `outlet` patch, the background cell size -
    ~4 bytes per face.  The 1.5 GB of points / faces stay here.
@@ -107,7 +107,7 @@ def main():
     entry.load_package()
     from openfoam_amd import polymesh
     import motorbike_case as mb
-    out_dir = os.path.join(ROOT, "oracle", "_ref", "motorbike")
+    out_dir = os.path.join(ROOT, "data", "motorbike")
     os.makedirs(out_dir, exist_ok=True)
     case = args.case
     secs = {}
