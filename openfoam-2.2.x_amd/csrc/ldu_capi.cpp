@@ -125,12 +125,12 @@ static int ctx_init(ldu_ctx* c, int device)
     LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming));
     LDU_CHECK_HIP(hipMalloc((void**)&c->d_partials, sizeof(double) * 2 * (size_t)c->maxRedBlocks));
     // the abort flag lives behind the scalar slots so that ONE device-to-host copy brings both
-    LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * (S_NSLOTS + 1)));
-    LDU_CHECK_HIP(ldu_memset_sync(c->d_scalars, 0, sizeof(double) * (S_NSLOTS + 1)));
-    LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * (S_NSLOTS + 1), hipHostMallocDefault));
+    LDU_CHECK_HIP(hipMalloc((void**)&c->d_scalars, sizeof(double) * (S_NSLOTS + 2)));
+    LDU_CHECK_HIP(ldu_memset_sync(c->d_scalars, 0, sizeof(double) * (S_NSLOTS + 2)));
+    LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_scalars, sizeof(double) * (S_NSLOTS + 2), hipHostMallocDefault));
     for (int i = 0; i < 2; i++)
     {
-        LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_ring[i], sizeof(double) * (S_NSLOTS + 1), hipHostMallocDefault));
+        LDU_CHECK_HIP(hipHostMalloc((void**)&c->h_ring[i], sizeof(double) * (S_NSLOTS + 2), hipHostMallocDefault));
         LDU_CHECK_HIP(hipEventCreateWithFlags(&c->evRing[i], hipEventDisableTiming));
     }
     c->d_abort = (int*)(c->d_scalars + S_NSLOTS);

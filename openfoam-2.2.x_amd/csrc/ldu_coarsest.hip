@@ -211,7 +211,7 @@ __device__ __forceinline__ double co_allreduce(const CoarsePeer& C, unsigned& rs
         const uint4* src = C.K.P.win[C.K.me] + C.K.redOff + par + (size_t)r * 16 + i;
         while (!peer_load(src, rseq, x))
         {
-            if (peer_wait_expired(spins, tw0, C.abortFlag)) { *C.abortFlag = 1; x = 0.0; break; }
+            if (peer_wait_expired(spins, tw0, C.abortFlag)) { C.abortFlag[LDU_PEER_FLAG] = 1; x = 0.0; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         stage[r][i] = x;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void co_halo(const CoarsePeer& C, unsigned& hseq, con
             unsigned long long tw0 = 0;
             while (!peer_load(s, hseq, x))
             {
-                if (peer_wait_expired(spins, tw0, C.abortFlag)) { *C.abortFlag = 1; x = 0.0; break; }
+                if (peer_wait_expired(spins, tw0, C.abortFlag)) { C.abortFlag[LDU_PEER_FLAG] = 1; x = 0.0; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -443,10 +443,12 @@ coarsest_krylov_peer_kernel(CoarsePeer C, int n, int nF, const int* __restrict__
                 sh[0] = res;
             }
             __syncthreads();
-            g = co_allreduce(C, rseq, lane < 1 ? sh[0] : 0.0, 1, stage);
+            // (second value: this rank's peer-timeout word - summed over the ranks, so that every rank leaves the loop in the
+            //  SAME iteration when a wait gave up anywhere: the sequence numbers of the kernel-private exchanges stay equal)
+            g = co_allreduce(C, rseq, lane < 1 ? sh[0] : (lane == 1 ? (double)C.abortFlag[LDU_PEER_FLAG] : 0.0), 2, stage);
             final_ = __shfl(g, 0) / nf;
             converged = final_ < tolerance || (relTol > small_ && final_ < relTol * initial);
-            if (lane == 0) shStop = *C.abortFlag;   // a wait that gave up: leave instead of iterating on garbage
+            if (lane == 0) shStop = __shfl(g, 1) != 0.0 ? 1 : 0;
             __syncthreads();
             if (shStop) break;
         } while (nIterations++ < maxIter && !converged);

@@ -131,9 +131,20 @@ extern "C" int ldu_ctx_comm_init(ldu_ctx* ctx, int rank, int nRanks, const uint8
         ldu_set_error("ldu_ctx_comm_init: rank / size differ from the peer windows'");
         return -2;
     }
+    if (ctx->comm->comm) { ldu_set_error("ldu_ctx_comm_init: the context already has an RCCL communicator"); return -2; }
     LDU_CHECK_NCCL(ncclCommInitRank(&ctx->comm->comm, nRanks, u, rank));
     ctx->rank = rank;
     ctx->nRanks = nRanks;
+    if (ctx->comm->peer)
+    {
+        // peer windows first, communicator second: RCCL becomes the default carrier, as ldugpu.h promises for either order
+        // (LDU_HALO=p2p / LDU_REDUCE=p2p keep the halo exchanges / the global sums on peer stores)
+        const char* eh = getenv("LDU_HALO");
+        const char* er = getenv("LDU_REDUCE");
+        ctx->comm->peerHalo = eh && !strcmp(eh, "p2p");
+        ctx->comm->peerReduce = er && !strcmp(er, "p2p");
+        ctx->commEpoch++;
+    }
     return 0;
 }
 
@@ -192,8 +203,9 @@ extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oo
         ldu_set_error("ldu_ctx_comm_init_peer: rank / size differ from the RCCL communicator's");
         return -2;
     }
+    if (ctx->comm->peer) { ldu_set_error("ldu_ctx_comm_init_peer: the context already has peer windows"); return -2; }
     PeerWindow* W = new PeerWindow();
-    ctx->comm->peer = W;
+    ctx->comm->peer = W;     // (comm_destroy releases whatever of it exists, also after an error return below)
     W->oob = oob;
     W->oobUser = user;
     size_t mb = 256;
@@ -207,6 +219,11 @@ extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oo
     W->freeList[0] = W->bytes;
     W->redOff = W->alloc(sizeof(uint4) * 2 * LDU_MAX_PEERS * 16);
     W->redOffK = W->alloc(sizeof(uint4) * 2 * LDU_MAX_PEERS * 16);
+    if (W->redOff == (size_t)-1 || W->redOffK == (size_t)-1)
+    {
+        ldu_set_error("ldu_ctx_comm_init_peer: the window is too small for the reduction regions (LDU_PEER_WINDOW_MB)");
+        return -1;
+    }
     LDU_CHECK_HIP(hipMalloc((void**)&W->d_redSeqK, sizeof(unsigned)));
     LDU_CHECK_HIP(ldu_memset_sync(W->d_redSeqK, 0, sizeof(unsigned)));
     W->peer.assign(nRanks, nullptr);
@@ -507,24 +524,28 @@ int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s)
         PeerWindow* W = ctx->comm->peer;
         PeerRed P;
         for (int r = 0; r < LDU_MAX_PEERS; r++) P.win[r] = r < ctx->nRanks ? W->peer[r] : nullptr;
-        return k_peer_allreduce(ctx, P, W->redOff / sizeof(uint4), ctx->rank, ctx->nRanks, 1, ++W->redSeq, nullptr,
+        // (both words: the sweep engines' abort flag and the singular-matrix flag of directSolveCoarsest - every rank takes
+        //  the same error path, none runs on into the next collective alone)
+        return k_peer_allreduce(ctx, P, W->redOff / sizeof(uint4), ctx->rank, ctx->nRanks, 2, ++W->redSeq, nullptr,
                                 ctx->d_abort, s);
     }
     if (ctx->comm->local)
     {
         LocalGroup* G = ctx->comm->local;
-        int mine = 0;
+        int mine[2] = {0, 0};
         LDU_CHECK_HIP(hipStreamSynchronize(s));
-        LDU_CHECK_HIP(hipMemcpy(&mine, ctx->d_abort, sizeof(int), hipMemcpyDeviceToHost));
-        G->dbuf[ctx->rank][0] = (double)mine;
+        LDU_CHECK_HIP(hipMemcpy(mine, ctx->d_abort, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        G->dbuf[ctx->rank][0] = (double)mine[0];
+        G->dbuf[ctx->rank][1] = (double)mine[1];
         G->barrier();
-        int any = 0;
-        for (int r = 0; r < G->n; r++) any |= G->dbuf[r][0] != 0.0;
+        int any[2] = {0, 0};
+        for (int r = 0; r < G->n; r++) { any[0] |= G->dbuf[r][0] != 0.0; any[1] |= G->dbuf[r][1] != 0.0; }
         G->barrier();
-        if (any && !mine) LDU_CHECK_HIP(hipMemcpy(ctx->d_abort, &any, sizeof(int), hipMemcpyHostToDevice));
+        if ((any[0] && !mine[0]) || (any[1] && !mine[1]))
+            LDU_CHECK_HIP(hipMemcpy(ctx->d_abort, any, 2 * sizeof(int), hipMemcpyHostToDevice));
         return 0;
     }
-    LDU_CHECK_NCCL(ncclAllReduce(ctx->d_abort, ctx->d_abort, 1, ncclInt, ncclMax, ctx->comm->comm, s));
+    LDU_CHECK_NCCL(ncclAllReduce(ctx->d_abort, ctx->d_abort, 2, ncclInt, ncclMax, ctx->comm->comm, s));
     return 0;
 }
 

@@ -98,7 +98,10 @@ void gamg_free(GamgHierarchy* g)
 void gamg_invalidate_factors(GamgHierarchy* g)
 {
     for (auto& L : g->levels)
+    {
         if (L.mat) { L.mat->rDKind = -1; coupled_invalidate(L.mat); }
+        if (L.addr && L.addr->peer) L.addr->peer->pending = false;   // (fallback_prepare: an exchange left half-way)
+    }
 }
 
 // ---------------------------------------------------------------- pair agglomeration (host)
@@ -784,7 +787,7 @@ static int solve_coarsest(GamgHierarchy* g, ldu_matrix* A, const ldu_controls* c
                 fprintf(stderr, "[ldugpu] coarsest level (%d cells, %d coupled faces): %s\n", A->a->nCells, A->a->nPatchFaces,
                         ok ? "distributed Krylov solve in one kernel per rank (peer stores)" : "host-driven Krylov loop");
         }
-        if (g->coarsestPeer)
+        if (g->coarsestPeer && A->a->ctx->sweepP2P)     // (an engine-fallback re-run takes the host-driven loop below)
         {
             const int rc = k_coarsest_solve_peer(A, c->tolerance, c->relTol, 1000, corr, src, g->d_cycPair);
             if (rc <= 0) return rc;

@@ -2668,7 +2668,7 @@ gs_wg_peer_kernel(WgPeer PS, const unsigned char* __restrict__ nLv, const unsign
                     unsigned long long tw0 = 0;
                     while (!peer_load(sp, hseq, pn))
                     {
-                        if (peer_wait_expired(spins, tw0, abortFlag)) { *abortFlag = 1; pn = 0.0; break; }
+                        if (peer_wait_expired(spins, tw0, abortFlag)) { abortFlag[LDU_PEER_FLAG] = 1; pn = 0.0; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
@@ -2873,7 +2873,9 @@ int k_sweep_gs_wg_peer(ldu_addr* a, int k, double* psi, const double* source, co
                        const double* bou, const int* d_cycPair)
 {
     ldu_ctx* ctx = a->ctx;
-    if (!wg_qualifies(a) || k <= 0) return 1;
+    // (the sweep stamps of a row are bytes - stamp = sweeps done, want = 16 sweep + lower entries: beyond 15 sweeps per launch the
+    //  sums no longer fit; a smoothing call with more sweeps goes sweep by sweep on the caller's path)
+    if (!wg_qualifies(a) || k <= 0 || k > 15) return 1;
     const ldu_addr::WgTasks* W = nullptr;
     if (wg_tasks(a, 1, &W)) return -1;
 

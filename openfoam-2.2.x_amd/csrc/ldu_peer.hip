@@ -50,7 +50,7 @@ __global__ void peer_unpack_kernel(int n, const uint4* const* __restrict__ src, 
             if (peer_wait_expired(spins, tw0, abortFlag)) { ok = false; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (!ok) { *abortFlag = 1; v = 0.0; }
+        if (!ok) { abortFlag[LDU_PEER_FLAG] = 1; v = 0.0; }
         recv[i] = v;
     }
 }
@@ -78,7 +78,8 @@ int k_peer_unpack(ldu_addr* a, unsigned seq, hipStream_t s)
 // rank alike (deterministic, identical on all ranks - what the convergence decisions need; the reference's
 // reduce() adds in a tree of ranks, Pstream/gatherScatter: ~1e-16 apart).
 // Region layout in every window: [parity][source rank][16] granules.
-// abortWord != nullptr: the integer there is max-reduced instead (the collective engine fallback).
+// abortWord != nullptr: the `count` integers there are max-reduced instead (the collective engine fallback: the sweep
+// engines' abort flag and the singular-matrix flag behind it).
 __global__ void __launch_bounds__(256) peer_allreduce_kernel(PeerRed P, size_t redOff, int me, int n, int count, unsigned seq,
                                                              double* __restrict__ vals, int* abortWord, int* abortFlag)
 {
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256) peer_allreduce_kernel(PeerRed P, size_t r
     const size_t par = (size_t)(seq & 1u) * LDU_MAX_PEERS * 16;
     if (r < n && i < count)
     {
-        const double mine = abortWord ? (double)*abortWord : vals[i];
+        const double mine = abortWord ? (double)abortWord[i] : vals[i];
         peer_store(P.win[r] + redOff + par + (size_t)me * 16 + i, mine, seq);
         double x = 0.0;
         unsigned spins = 0;
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) peer_allreduce_kernel(PeerRed P, size_t r
         const uint4* src = P.win[me] + redOff + par + (size_t)r * 16 + i;
         while (!peer_load(src, seq, x))
         {
-            if (peer_wait_expired(spins, tw0, abortFlag)) { *abortFlag = 1; x = 0.0; break; }
+            if (peer_wait_expired(spins, tw0, abortFlag)) { abortFlag[LDU_PEER_FLAG] = 1; x = 0.0; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         v[r][i] = x;
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(256) peer_allreduce_kernel(PeerRed P, size_t r
         {
             double m = v[0][lane];
             for (int q = 1; q < n; q++) m = m > v[q][lane] ? m : v[q][lane];
-            if (m != 0.0) *abortWord = 1;
+            if (m != 0.0) abortWord[lane] = 1;
         }
         else
         {

@@ -26,13 +26,18 @@ __device__ __forceinline__ bool peer_load(const uint4* p, unsigned tag, double& 
 
 // A wait for ANOTHER RANK is not a wait for another wave of the same launch: the peer may simply be late (its host is
 // still busy), so the 200 ms budget of the sweep engines does not apply.  Bound: LDU_PEER_TIMEOUT_S of wall clock
-// (default 20 s; 100 MHz s_memrealtime read every 256 polls) - past it the wave sets the abort flag, the operation
-// fails loudly (-20) instead of hanging the GPU.
+// (default 20 s; 100 MHz s_memrealtime read every 256 polls) - past it the wave sets the PEER-TIMEOUT word (the third
+// word behind the scalars, abortFlag[LDU_PEER_FLAG]) and the operation fails loudly (-21) instead of hanging the GPU.
+// The word is not the sweep engines' abort flag (abortFlag[0]): a rank whose local watchdog gave up keeps every
+// inter-rank exchange in step (it only skips its own arithmetic) - the engine fallback is collective, and a rank that ran
+// ahead would overwrite receive slots its neighbours have not read yet.  Only a real peer timeout, which is
+// fatal for the operation on every rank, shortens the remaining waits.
+#define LDU_PEER_FLAG 2
 static __device__ unsigned long long g_peer_budget = 2000000000ull;
 __device__ __forceinline__ bool peer_wait_expired(unsigned& spins, unsigned long long& tw0, volatile int* abortFlag)
 {
     if ((++spins & 255u) != 8u) return false;
-    if (*abortFlag) return true;
+    if (abortFlag[LDU_PEER_FLAG]) return true;
     const unsigned long long now = wall_clock64();
     if (!tw0) { tw0 = now; return false; }
     return now - tw0 > g_peer_budget;

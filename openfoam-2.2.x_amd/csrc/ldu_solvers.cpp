@@ -22,27 +22,32 @@ double* ldu_matrix::workVec(int i)
     return work[i];
 }
 
-int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
+// The four flag words behind the scalars (d_abort / h_abort): [0] a point-to-point sweep gave up a dependency wait (->
+// collective engine fallback), [1] singular coarsest-level matrix (directSolveCoarsest), [2] a wait for ANOTHER RANK timed
+// out (peer-store backend, LDU_PEER_FLAG in ldu_peer_dev.hpp; fatal for the operation, no re-run), [3] spare.
+static int abort_words_to_error(ldu_ctx* ctx, const int* h, hipStream_t s)
 {
-    if (comm_allreduce_abort(ctx, ctx->stream)) return -1;
-    ctx->nScalarReadbacks++;
-    // scalars and the abort flag (stored behind them) in one copy: a second small copy costs ~20 us of latency
-    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * (S_NSLOTS + 1), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < count; i++) out[i] = ctx->h_scalars[ctx->sb + slot + i];
-    if (ctx->h_abort[1])
+    if (h[2])
+    {
+        // the neighbour never wrote what this rank waited for: nothing a re-run on this rank alone could repair
+        (void)hipStreamSynchronize(s);
+        (void)hipMemsetAsync(ctx->d_abort, 0, 4 * sizeof(int), s);
+        ctx->p2pGen++;
+        ldu_set_error("peer-store backend: a wait for another rank timed out (LDU_PEER_TIMEOUT_S)");
+        return -21;
+    }
+    if (h[1])
     {
         // LUDecompose's FatalError("Singular matrix") (scalarMatrices.C:52-56): a zero row of the coarsest level
-        (void)hipMemsetAsync(ctx->d_abort + 1, 0, sizeof(int), ctx->stream);
-        ctx->h_abort[1] = 0;
+        (void)hipMemsetAsync(ctx->d_abort, 0, 2 * sizeof(int), s);     // (and a sweep abort of the same operation with it)
+        if (h[0]) ctx->p2pGen++;
         ldu_set_error("directSolveCoarsest: singular coarsest-level matrix");
         return -17;
     }
-    if (*ctx->h_abort)
+    if (h[0])
     {
         // a point-to-point sweep gave up waiting (bounded spin): fail loudly, never hang
-        (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), ctx->stream);
+        (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), s);
         ctx->p2pGen++;
         ctx->abortSeen = 1;
         ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
@@ -51,28 +56,29 @@ int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
     return 0;
 }
 
+int dev_read_scalars(ldu_ctx* ctx, int slot, int count, double* out)
+{
+    if (comm_allreduce_abort(ctx, ctx->stream)) return -1;
+    ctx->nScalarReadbacks++;
+    // scalars and the flag words (stored behind them) in one copy: a second small copy costs ~20 us of latency
+    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double) * (S_NSLOTS + 2), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < count; i++) out[i] = ctx->h_scalars[ctx->sb + slot + i];
+    const int rc = abort_words_to_error(ctx, ctx->h_abort, ctx->stream);
+    ctx->h_abort[0] = ctx->h_abort[1] = ctx->h_abort[2] = 0;
+    return rc;
+}
+
 // Surface an aborted point-to-point sweep to callers that do not read scalars (ldu_smooth, ...).
 int dev_check_abort(ldu_ctx* ctx)
 {
     if (comm_allreduce_abort(ctx, ctx->stream)) return -1;
-    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_abort, ctx->d_abort, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_abort, ctx->d_abort, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->h_abort[1])
-    {
-        (void)hipMemsetAsync(ctx->d_abort + 1, 0, sizeof(int), ctx->stream);
-        ctx->h_abort[1] = 0;
-        ldu_set_error("directSolveCoarsest: singular coarsest-level matrix");
-        return -17;
-    }
-    if (*ctx->h_abort)
-    {
-        (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), ctx->stream);
-        ctx->p2pGen++;
-        ctx->abortSeen = 1;
-        ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
-        return -20;
-    }
-    return 0;
+    const int rc = abort_words_to_error(ctx, ctx->h_abort, ctx->stream);
+    ctx->h_abort[0] = ctx->h_abort[1] = ctx->h_abort[2] = 0;
+    return rc;
 }
 
 int fallback_prepare(ldu_matrix* m)
@@ -83,14 +89,15 @@ int fallback_prepare(ldu_matrix* m)
     if (ctx->streamComm) LDU_CHECK_HIP(hipStreamSynchronize(ctx->streamComm));   // a halo exchange of the failed attempt
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->haloInFlight = false;
-    LDU_CHECK_HIP(ldu_memset_sync(ctx->d_abort, 0, 2 * sizeof(int)));   // the abort flag and the singular flag behind it
-    ctx->h_abort[0] = ctx->h_abort[1] = 0;
+    LDU_CHECK_HIP(ldu_memset_sync(ctx->d_abort, 0, 4 * sizeof(int)));   // the abort flag and the words behind it
+    ctx->h_abort[0] = ctx->h_abort[1] = ctx->h_abort[2] = 0;
     ctx->dualActive = 0;
     ctx->sb = 0;
     ctx->abortSeen = 0;
     // factors a broken sweep may have written (calcReciprocalD runs as a sweep): this matrix, its GAMG levels,
     // the coupled family's rD
     m->rDKind = -1;
+    if (m->a->peer) m->a->peer->pending = false;      // a halo exchange of the failed attempt that was packed, never unpacked
     if (m->gamg) gamg_invalidate_factors(m->gamg);
     coupled_invalidate(m);
     if (ctx->nFallbacks++ == 0 || getenv("LDU_VERBOSE"))
@@ -279,14 +286,18 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     {
         // small GAMG level with coupled patches, peer-store backend: all sweeps of this smoothing AND their boundary
         // exchanges in one launch (collective decision: gamg_decide_peer_smoothers)
-        const int rc = k_sweep_gs_wg_peer(a, nSweeps, psi, source, m->d_diag, m->d_valA, m->d_bou, a->d_cycPair);
-        if (rc <= 0)
+        // (at most 15 sweeps per launch: the row stamps of the kernel are bytes)
+        for (int left = nSweeps; left > 0;)
         {
-            if (rc == 0) { a->ctx->nHaloExchanges += nSweeps; a->ctx->nHaloOverlapped += nSweeps; }
-            return rc;
+            const int kk = left > 15 ? 15 : left;
+            const int rc = k_sweep_gs_wg_peer(a, kk, psi, source, m->d_diag, m->d_valA, m->d_bou, a->d_cycPair);
+            if (rc > 0) { ldu_set_error("one-launch smoother: refused by an addressing that was declared eligible"); return -1; }
+            if (rc < 0) return rc;
+            a->ctx->nHaloExchanges += kk;
+            a->ctx->nHaloOverlapped += kk;
+            left -= kk;
         }
-        ldu_set_error("one-launch smoother: refused by an addressing that was declared eligible");
-        return -1;
+        return 0;
     }
     // bPrime differs from the source in the boundary rows only: one copy per call, then the boundary rows are
     // rewritten from the source before every sweep (one small kernel per sweep instead of copy + apply)
@@ -590,7 +601,7 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
                 if (k_krylov_decide(ctx, c->tolerance, c->relTol, it, c->maxIter, s)) return -1;
                 if (comm_allreduce_abort(ctx, s)) return -1;
                 ctx->nScalarReadbacks++;
-                LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_ring[it & 1], ctx->d_scalars, sizeof(double) * (S_NSLOTS + 1),
+                LDU_CHECK_HIP(hipMemcpyAsync(ctx->h_ring[it & 1], ctx->d_scalars, sizeof(double) * (S_NSLOTS + 2),
                                              hipMemcpyDeviceToHost, s));
                 LDU_CHECK_HIP(hipEventRecord(ctx->evRing[it & 1], s));
                 return 0;
@@ -605,22 +616,9 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
                 if (more && queue(it + 1)) return -1;
                 LDU_CHECK_HIP(hipEventSynchronize(ctx->evRing[it & 1]));
                 const double* H = ctx->h_ring[it & 1];
-                const int* habort = (const int*)(H + S_NSLOTS);
-                if (habort[1])
                 {
-                    LDU_CHECK_HIP(hipStreamSynchronize(s));
-                    (void)hipMemsetAsync(ctx->d_abort + 1, 0, sizeof(int), s);
-                    ldu_set_error("directSolveCoarsest: singular coarsest-level matrix");
-                    return -17;
-                }
-                if (habort[0])
-                {
-                    LDU_CHECK_HIP(hipStreamSynchronize(s));
-                    (void)hipMemsetAsync(ctx->d_abort, 0, sizeof(int), s);
-                    ctx->p2pGen++;
-                    ctx->abortSeen = 1;
-                    ldu_set_error("point-to-point sweep aborted: dependency wait exceeded its spin bound");
-                    return -20;
+                    const int rcA = abort_words_to_error(ctx, (const int*)(H + S_NSLOTS), s);
+                    if (rcA) return rcA;
                 }
                 const double* rs = H + ctx->sb + S_RES;              // S_RES, S_NORM, S_SINGULAR
                 if (rs[2] != 0.0) { perf->singular = 1; break; }
