@@ -201,6 +201,11 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible GPUs (ranks share GPUs round-robin; peer backend only - RCCL "
                          "refuses two ranks on one device): executes the N-rank path on a 1-GPU box, NOT a scaling number")
+    ap.add_argument("--subdomains", type=int, default=0, metavar="K",
+                    help="sub-domain mode (ldu_addr_set_subdomains): the matrix cut into K compact sub-domains that are coupled "
+                         "like K ranks of the reference (processor-patch semantics: GaussSeidelSmoother.C:98-145, rank-local "
+                         "agglomeration) but solved inside ONE context and one set of launches.  A different algorithm from "
+                         "the one-rank solve (more V-cycles per solve): its own leg, never the headline")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCG / asymmetric / host-path legs")
     ap.add_argument("--no-sublegs", action="store_true", help="skip the sub-legs of the default line (the 216^3 box stand-in and the "
                                                                 "mesh in snappyHexMesh's own numbering, each in its own process)")
@@ -347,6 +352,20 @@ def main():
                 q["nbrRank"] = 0
     else:
         lp = p
+    sub_info = None
+    if args.subdomains > 1:
+        if world > 1 or args.rank_of > 1:
+            raise SystemExit("bench.py: --subdomains is a single-GPU mode")
+        t_sd = time.perf_counter()
+        sd_rank = decompose.blob_ranks(p["nCells"], p["lowerAddr"], p["upperAddr"], args.subdomains)
+        nK = int(sd_rank.max()) + 1       # (a seed that finds only enclosed pockets makes no sub-domain: K can come back smaller)
+        lp, sd_order = decompose.concatenated(p, sd_rank, nK)
+        sizes = np.bincount(sd_rank, minlength=nK)
+        sub_info = dict(K=nK, K_requested=args.subdomains, cells_min=int(sizes.min()), cells_max=int(sizes.max()),
+                        interface_faces=int(sum(q["faceCells"].size for q in lp["patches"]) // 2), patches=len(lp["patches"]),
+                        decomposition="compact breadth-first blobs of the cell numbering (ldu_partition_blobs)",
+                        decomposition_s=round(time.perf_counter() - t_sd, 2))
+        args.no_extras = True
 
     ctx = capi.Context(device_index)
     # carriers: RCCL (one GPU per rank only) and / or the peer-store backend; with both on the context RCCL carries the
@@ -404,7 +423,7 @@ def main():
 
     t0 = time.perf_counter()
     addr = capi.Addressing(ctx, lp["nCells"], lp["lowerAddr"], lp["upperAddr"], lp.get("faceWeights"),
-                           patches=lp.get("patches_dev", ()))
+                           patches=lp.get("patches_dev", ()), subdomains=lp.get("subdomains"))
     mat = capi.Matrix(addr)
     t_addr = time.perf_counter() - t0
     info = addr.info()
@@ -734,6 +753,7 @@ def main():
     # cell numbering snappyHexMesh wrote (the headline is renumbered by Foam::bandCompression = renumberMesh).
     box_leg = None
     snappy_leg = None
+    subdomain_leg = None
     octree_leg = None
     fallbacks_main = ctx.fallback_count()
     mem_in_use_gb = round((lambda fr, tot: (tot - fr) / 1e9)(*torch.cuda.mem_get_info()), 2)
@@ -758,6 +778,24 @@ def main():
                               first_solve_s=oj["extra"]["first_solve_s"], residual_history=oj["extra"]["residual_history"])
         except Exception as e:  # pragma: no cover
             snappy_leg = dict(error=str(e)[:300])
+        try:
+            # the reference's own N-rank semantics inside one GPU: the same matrix cut into 8 sub-domains
+            # coupled like 8 ranks.  A different algorithm from the one-rank solve - never compared as V-cycles/s alone:
+            # V-cycles per solve and time per solve (to the same tolerance) stand beside it
+            oj = run_leg("motorbike_rcm", ["--motorbike-name", args.motorbike_name, "--subdomains", "8", "--steps", "3", "--warmup", "1"])
+            subdomain_leg = dict(K=oj["config"]["subdomains"]["K"], subdomains=oj["config"]["subdomains"],
+                                 vcycles_per_s=oj["value"], vcycles_per_solve=oj["config"]["vcycles_per_solve"],
+                                 ms_per_solve=oj["ms_per_step"], one_domain_ms_per_solve=round(elapsed / args.steps * 1e3, 3),
+                                 one_domain_vcycles_per_solve=perf["nIterations"],
+                                 dependency_levels=[oj["config"]["dependency_levels_finest"]] + [L[2] for L in oj["roofline_vcycle"]["levels"]],
+                                 one_domain_dependency_levels=[info["nLevels"]] + [L["nLevels"] for L in (levels or [])],
+                                 engines=[L[3] for L in oj["roofline_vcycle"]["levels"]],
+                                 engine_fallbacks=oj["config"]["engine_fallbacks"], residual_history=oj["extra"]["residual_history"],
+                                 note="K ranks of the reference inside one context (ldu_addr_set_subdomains): processor-patch "
+                                      "coupling between the sub-domains (GaussSeidelSmoother.C:98-145), rank-local agglomeration; "
+                                      "patched levels sweep one by one on the level engines (no block engine, no pipelining yet)")
+        except Exception as e:  # pragma: no cover
+            subdomain_leg = dict(error=str(e)[:300])
         try:
             oj = run_leg("box", ["--steps", "10", "--warmup", "2"])
             box_leg = dict(vcycles_per_s=oj["value"], ms_per_step=oj["ms_per_step"], workload=oj["config"]["workload"],
@@ -831,6 +869,7 @@ def main():
                                        "octree_hexref": "; hexRef8 cell numbering (parent keeps its label, 7 children appended)"}[args.mesh]),
                        "mesh": args.mesh,
                        "mesh_fallback": mesh_fallback,
+                       "subdomains": sub_info,
                        "parallelism": ("domain decomposition x%d" % world) + (
                            "" if world == 1 else " (%s, %s scaling: %s; halo exchanges and global sums by %s%s)" % (
                                mb_decomp if is_mb else
@@ -859,6 +898,7 @@ def main():
             "amul": amul,
             "box216": box_leg,
             "motorbike_snappy_numbering": snappy_leg,
+            "subdomains_8": subdomain_leg,
             "extra": dict(extra, device_memory_in_use_GB=mem_in_use_gb,
                           first_solve_s=round(t_first, 3), addressing_setup_s=round(t_addr, 3),
                           problem_generation_s=round(t_gen, 3),

@@ -156,6 +156,14 @@ int ldu_addr_sweep_engine(ldu_addr* a, int32_t kind);
 /* Face weights for the geometric agglomerator (faceAreaPairGAMGAgglomeration.C:48-73
  * computes them from Sf; the shim passes mag(cmptMultiply(Sf/sqrt(magSf),(1,1.01,1.02)))). */
 int ldu_addr_set_face_weights(ldu_addr* a, const double* faceWeights);
+/* Sub-domain mode: K ranks of the reference inside ONE addressing.  The caller hands over the matrices of the K ranks
+ * concatenated (cells of rank 0, rank 1, ...; processor patch (a -> b) as a cyclic patch paired with (b -> a),
+ * ldu_addr_add_cyclic_patch) and says here which cell belongs to which rank.  Every operator then IS the K-rank operator
+ * (GaussSeidelSmoother.C:98-145: neighbour ranks' values of the previous sweep; lduMatrixUpdateMatrixInterfaces.C:30-160),
+ * computed in one set of launches, and GAMG coarsens rank by rank as the K-rank run does: pairs never cross an interface,
+ * and coarsening stops when ANY sub-domain would fall below nCellsInCoarsestLevel (GAMGAgglomeration.C:53-62, the
+ * and-reduce of continueAgglomerating).  Call before the first solve; nSub = 0 switches it off. */
+int ldu_addr_set_subdomains(ldu_addr* a, int32_t nSub, const int32_t* cellSub);
 /* The same from the face area vectors themselves, as faceAreaPairGAMGAgglomeration.C:48-73 does with
  * fvMesh::Sf() / magSf() (= mag(Sf) + VSMALL, fvMeshGeometry.C:101-114): Sf = nFaces*3 doubles (internal
  * faces = the first nInternalFaces entries of primitiveMesh::faceAreas()), host or device.  The weights are
@@ -497,6 +505,10 @@ int ldu_mesh_interpolation_factors(ldu_ctx* ctx, int32_t nCells, int32_t nIntern
  * internal faces: newOrder[i] = old label of the cell that becomes cell i (what renumberMesh applies) */
 int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
                          int32_t* newOrder);
+/* nParts compact sub-domains of nearly equal size (breadth-first blobs in the order of the numbering; host code): the cut
+ * ldu_addr_set_subdomains' callers use when the case brings no decomposition of its own */
+int ldu_partition_blobs(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr, int32_t nParts,
+                        int32_t* part);
 /* the matrix addressing under such a renumbering, back in upper-triangular order (lduAddressing.C:92-126 needs
  * it): faceMap[newFace] = old face, flip[newFace] = 1 when lower/upper of that face swap (may be NULL) */
 int ldu_renumber_addressing(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,

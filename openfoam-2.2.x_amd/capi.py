@@ -22,7 +22,7 @@ EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
     "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_blocks_trace", "ldu_debug_blocks_info", "ldu_debug_slice_levels",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_ctx_comm_init_peer", "ldu_ctx_comm_select", "ldu_ctx_comm_info", "ldu_addr_create", "ldu_addr_add_patch",
-    "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights",
+    "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights", "ldu_addr_set_subdomains", "ldu_partition_blobs",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
@@ -299,7 +299,7 @@ class Context:
 class Addressing:
     """Device image of one lduAddressing (+ coupled patches)."""
 
-    def __init__(self, ctx, nCells, lowerAddr, upperAddr, faceWeights=None, patches=()):
+    def __init__(self, ctx, nCells, lowerAddr, upperAddr, faceWeights=None, patches=(), subdomains=None):
         self.ctx = ctx
         self.nCells = int(nCells)
         l = np.ascontiguousarray(lowerAddr, dtype=np.int32)
@@ -318,6 +318,9 @@ class Addressing:
         if faceWeights is not None:
             w = np.ascontiguousarray(faceWeights, dtype=np.float64)
             _chk(lib().ldu_addr_set_face_weights(self.h, _ptr(w)))
+        if subdomains is not None:
+            sd = np.ascontiguousarray(subdomains, dtype=np.int32)
+            _chk(lib().ldu_addr_set_subdomains(self.h, int(sd.max()) + 1 if sd.size else 0, _ptr(sd)))
 
     def linearUpwindCorrection(self, phi, C3, Cf3, grad3):
         out = np.zeros(self.nFaces)
@@ -637,9 +640,12 @@ class Matrix:
 def from_problem(ctx, p):
     """cases.py problem dict -> (Addressing, Matrix) with coefficients set."""
     a = Addressing(ctx, p["nCells"], p["lowerAddr"], p["upperAddr"], p.get("faceWeights"),
-                   patches=p.get("patches_dev", ()))
+                   patches=p.get("patches_dev", ()), subdomains=p.get("subdomains"))
     m = Matrix(a)
     m.set_coeffs(p["diag"], p["upper"], p.get("lower"))
+    if p.get("patches_dev") and p.get("patches") and "bouCoeffs" in p["patches"][0]:
+        for i, q in enumerate(p["patches"]):
+            m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
     return a, m
 
 
@@ -876,6 +882,14 @@ def band_compression(nCells, lowerAddr, upperAddr):
     l, u = _i32(lowerAddr), _i32(upperAddr)
     out = np.zeros(int(nCells), dtype=np.int32)
     _chk(lib().ldu_band_compression(int(nCells), l.size, _ptr(l), _ptr(u), _ptr(out)))
+    return out
+
+
+def partition_blobs(nCells, lowerAddr, upperAddr, nParts):
+    """sub-domain of every cell: nParts compact breadth-first blobs of nearly equal size (host code in the library)"""
+    l, u = _i32(lowerAddr), _i32(upperAddr)
+    out = np.zeros(int(nCells), dtype=np.int32)
+    _chk(lib().ldu_partition_blobs(int(nCells), l.size, _ptr(l), _ptr(u), int(nParts), _ptr(out)))
     return out
 
 

@@ -426,6 +426,24 @@ int ldu_addr_set_face_weights(ldu_addr* a, const double* w)
     return 0;
 }
 
+int ldu_addr_set_subdomains(ldu_addr* a, int32_t nSub, const int32_t* cellSub)
+{
+    if (nSub <= 0) { a->subOf.clear(); a->nSub = 0; return 0; }
+    a->subOf.assign(cellSub, cellSub + a->nCells);
+    for (int c = 0; c < a->nCells; c++)
+        if (a->subOf[c] < 0 || a->subOf[c] >= nSub) { a->subOf.clear(); a->nSub = 0; ldu_set_error("ldu_addr_set_subdomains: label out of range"); return -2; }
+    // a sub-domain is a rank: internal faces never cross (what couples two of them is an interface)
+    for (int f = 0; f < a->nFaces; f++)
+        if (a->subOf[a->l[f]] != a->subOf[a->u[f]])
+        {
+            a->subOf.clear(); a->nSub = 0;
+            ldu_set_error("ldu_addr_set_subdomains: an internal face joins two sub-domains (couple them through cyclic patches)");
+            return -2;
+        }
+    a->nSub = nSub;
+    return 0;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- matrix

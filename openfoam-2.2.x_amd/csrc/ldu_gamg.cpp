@@ -281,6 +281,7 @@ static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fine
     size_t announced = 0;
     std::vector<double> w = fineWeights;
     int nPairLevels = 0;
+    std::vector<int> sub = fine->subOf;      // sub-domain of every cell of the level being paired (sub-domain mode)
     while ((int)out.size() < kMaxLevels - 1)
     {
         const bool top = out.empty();
@@ -294,6 +295,15 @@ static int agglomerate_all(const ldu_addr* fine, const std::vector<double>& fine
         const auto tp1 = std::chrono::steady_clock::now();
         // continueAgglomerating (GAMGAgglomeration.C:53-62): and-reduce over the ranks
         int cont = (L.nCells >= nCellsInCoarsestLevel) ? 1 : 0;
+        if (fine->nSub > 0)
+        {
+            // sub-domain mode: every sub-domain is a rank of the reference's run - the and-reduce happens right here
+            std::vector<int> csub(L.nCells, 0), cnt(fine->nSub, 0);
+            for (int c = 0; c < nC; c++) csub[L.restrictAddr[c]] = sub[c];
+            for (int c = 0; c < L.nCells; c++) cnt[csub[c]]++;
+            for (int d = 0; d < fine->nSub; d++) if (cnt[d] < nCellsInCoarsestLevel) cont = 0;
+            sub.swap(csub);
+        }
         if (comm_allreduce_min_int(ctx, &cont)) return -1;
         if (!cont) break;
         std::vector<double> cw;

@@ -226,6 +226,11 @@ struct ldu_addr {
     int maxRowWidth = 0;                   // max over rows of nL + nU
     std::vector<Segment> segs;
     std::vector<double> faceWeights;
+    // sub-domain mode (ldu_addr_set_subdomains): sub-domain of every cell, empty = none.  The cells of a sub-domain are coupled to
+    // the others through (cyclic) interfaces only - K ranks of the reference inside one addressing; GAMG then stops coarsening
+    // as the K-rank run does (every sub-domain keeps nCellsInCoarsestLevel cells, GAMGAgglomeration.C:53-62)
+    std::vector<int> subOf;
+    int nSub = 0;
     bool finalized = false;
 
     // device

@@ -312,6 +312,82 @@ int ldu_device_count(void)
 // picks the unvisited cell with the FEWEST neighbours (first one on ties); the unvisited neighbours of a cell
 // are queued in their cellCells order - the reference sorts an index list by connectivity (:131) but then
 // appends nbrs[i], not nbrs[order[i]] (:134-137).  Host code: it runs once per mesh.
+// nParts compact sub-domains of (nearly) equal size for any numbering (sub-domain mode, ldu_addr_set_subdomains): breadth-first
+// blobs of ceil(nCells / nParts) cells grown from the lowest unassigned cell - under a bandwidth-reducing numbering they tile
+// the shells of the numbering -, pockets a blob leaves behind join the neighbouring part with the fewest cells.  Host code.
+int ldu_partition_blobs(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr, int32_t nParts,
+                        int32_t* part)
+{
+    if (nParts < 1 || nCells < 0) { ldu_set_error("ldu_partition_blobs: nParts >= 1"); return -2; }
+    std::vector<int> start((size_t)nCells + 1, 0), adj(2 * (size_t)nFaces);
+    for (int f = 0; f < nFaces; f++) { start[lowerAddr[f] + 1]++; start[upperAddr[f] + 1]++; }
+    for (int c = 0; c < nCells; c++) start[c + 1] += start[c];
+    {
+        std::vector<int> pos(start.begin(), start.end() - 1);
+        for (int f = 0; f < nFaces; f++) { adj[pos[lowerAddr[f]]++] = upperAddr[f]; adj[pos[upperAddr[f]]++] = lowerAddr[f]; }
+    }
+    for (int c = 0; c < nCells; c++) part[c] = -1;
+    const long target = ((long)nCells + nParts - 1) / nParts;
+    std::vector<long> size(nParts, 0);
+    std::vector<int> q;
+    std::vector<char> pocket((size_t)nCells, 0);   // cells of a blob that got stuck small: left for the pocket pass below
+    int seed = 0;
+    for (int r = 0; r < nParts; r++)
+    {
+        for (;;)
+        {
+            while (seed < nCells && (part[seed] >= 0 || pocket[seed])) seed++;
+            if (seed >= nCells) break;
+            const long lim = r == nParts - 1 ? nCells : target;
+            q.clear();
+            q.push_back(seed);
+            part[seed] = r;
+            size_t h = 0;
+            while (h < q.size() && (long)q.size() < lim)
+            {
+                const int c = q[h++];
+                for (int t = start[c]; t < start[c + 1] && (long)q.size() < lim; t++)
+                    if (part[adj[t]] < 0 && !pocket[adj[t]]) { part[adj[t]] = r; q.push_back(adj[t]); }
+            }
+            if ((long)q.size() >= target / 2 || (long)q.size() == lim) { size[r] = (long)q.size(); break; }
+            // enclosed by earlier blobs before it reached half its size: not a sub-domain of its own
+            for (int c : q) { part[c] = -1; pocket[c] = 1; }
+        }
+    }
+    // pockets: repeatedly the unassigned cells that touch a part join the smallest part they touch
+    for (;;)
+    {
+        long left = 0, moved = 0;
+        for (int c = 0; c < nCells; c++)
+        {
+            if (part[c] >= 0) continue;
+            left++;
+            int best = -1;
+            for (int t = start[c]; t < start[c + 1]; t++)
+            {
+                const int b = part[adj[t]];
+                if (b >= 0 && (best < 0 || size[b] < size[best])) best = b;
+            }
+            if (best >= 0) { part[c] = best; size[best]++; moved++; }
+        }
+        if (!left) break;
+        if (!moved)
+        {
+            // a component no part touches: the smallest part takes it
+            int sm = 0;
+            for (int r = 1; r < nParts; r++) if (size[r] < size[sm]) sm = r;
+            for (int c = 0; c < nCells; c++) if (part[c] < 0) { part[c] = sm; size[sm]++; }
+            break;
+        }
+    }
+    // (the last seeds may have found nothing but pockets: labels are compacted, fewer than nParts parts can come back)
+    std::vector<int> lab(nParts, -1);
+    int used = 0;
+    for (int r = 0; r < nParts; r++) if (size[r] > 0) lab[r] = used++;
+    if (used < nParts) for (int c = 0; c < nCells; c++) part[c] = lab[part[c]];
+    return 0;
+}
+
 int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
                          int32_t* newOrder)
 {

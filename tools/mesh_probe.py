@@ -24,6 +24,10 @@ def make(spec):
     f = spec.split(":")
     if f[0] == "box":
         return cases.box3d(int(f[1]))
+    if f[0] == "chain":            # chain:N - one row per dependency level: the bare hand-off latency of an engine
+        return cases.laplacian2d(1, int(f[1]))
+    if f[0] == "grid2d":           # grid2d:N - N x N five-point matrix
+        return cases.laplacian2d(int(f[1]), int(f[1]))
     if f[0] == "irregular":
         p = cases.irregular_box(int(f[1]))
     elif f[0] == "motorbike":      # motorbike:<stored mesh>[:snappy]  (renumbered by Foam::bandCompression unless :snappy)
