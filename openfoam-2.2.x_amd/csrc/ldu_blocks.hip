@@ -30,10 +30,18 @@
 // Progress.  Within a sweep a group holds rows of ONE value of a strict potential of the row DAG, so the (sweep, group)
 // tasks of all blocks form an acyclic graph; Phi (the group-level version of T) orders them.  Every worker - a compute
 // wavefront's task list, a lane of the importer - walks its items in non-decreasing Phi: the unfinished item of smallest
-// Phi has all its inputs and is its worker's current item.  What this needs from the hardware is that all blocks are
-// RESIDENT at the same time (the quotient graph of the blocks is cyclic): the grid is limited to what the occupancy API
-// promises for this kernel, and every wait is bounded like in the other engines (abort flag -> the operation is re-run on
-// the level kernels), so a launch that does not get its residency fails loudly instead of hanging.
+// Phi has all its inputs and is its worker's current item - PROVIDED its block has been started.  The quotient graph of
+// the blocks is cyclic, so a started block may wait for one that is not.  Workgroups therefore take their block from a
+// ticket counter, in the order of the blocks' smallest Phi: the started blocks are always a prefix of that order.  Let t*
+// be the unfinished task of smallest Phi and b its block: every started, unfinished block before b has a task at or below
+// Phi(t*) and one at or above it - it is OPEN at Phi(t*), and so is b.  If the chip holds at least as many workgroups as
+// blocks are ever open at one value of Phi (openMax, computed from the task lists), b cannot be waiting for a slot: b is
+// started, t* runs.  Levels whose blocks are all resident at once are the special case openMax <= blocks <= capacity;
+// the 6.3 M- and 3.1 M-cell levels of the motorBike hierarchy run with 785 / 390 blocks of which ~150 / ~100 are open at a
+// time.  Nothing is assumed about the order in which the hardware starts workgroups.  Every wait is bounded like in the
+// other engines (abort flag -> the operation is re-run on the level kernels): a launch fails loudly, it never hangs.
+// psi is read at block start and ghosts of late blocks need the OLD values of rows whose block is long done: the sweeps
+// write their result to a scratch vector, copied over psi behind the launch.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -72,13 +80,16 @@ struct BlockPlan {
         std::vector<int> grpBlk, grpLane0, grpCnt, grpT, grpEnt, grpStride, Phi, grpOfCell;
     } lay[BK_NLAY];
     uint4* d_granule = nullptr;    // [nCells + 1]
-    unsigned* d_start = nullptr;   // blocks that have loaded their initial values (monotonic)
-    unsigned startBase = 0;
+    unsigned* d_ticket = nullptr;  // block tickets (monotonic: a launch takes nBlocks of them)
+    unsigned ticketBase = 0;
+    double* d_out = nullptr;       // [nCells] result of a launch before it is copied over psi
+    long capacity = 0;             // workgroups of the kernel the chip holds at once
     unsigned epoch = 0;
     int gen = 0;
-    struct Tasks { int4* d_tasks = nullptr; int* d_taskStart = nullptr; int4* d_imps = nullptr; int* d_impStart = nullptr; long nTasks = 0; };
+    struct Tasks { int4* d_tasks = nullptr; int* d_taskStart = nullptr; int4* d_imps = nullptr; int* d_impStart = nullptr; long nTasks = 0;
+                   int* d_order = nullptr; int openMax = 0; bool usable = true; };
     std::map<int, Tasks> tasks;    // per k
-    struct Conv { double* d[BK_NLAY] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long stamp = 0; };
+    struct Conv { double* d[BK_NLAY] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long stamp[BK_NLAY] = {0, 0, 0, 0}; };
     std::map<const double*, Conv> conv;
     // host copies the per-k lists are made from
     std::vector<int> ghostBase;            // [nBlocks + 1]
@@ -86,6 +97,10 @@ struct BlockPlan {
     std::vector<unsigned char> ghostLower; // [nGhostTotal] 1 = lower neighbour of a local row (needs stamps 1 ... k)
     std::vector<int> ghostRowH;            // [nGhostTotal] level-ordered row
     std::vector<int> blkNLocal;            // [nBlocks]
+    std::vector<int> blk, slot, rowBase;   // [nCells] block / LDS slot of a cell (old labels), [nBlocks + 1]
+    std::vector<char> exported;            // [nCells] has a neighbour in another block
+    std::vector<int> RTlast;               // T of the last grouping built
+    int nBuilt = 0;                        // groupings built so far (sweeps 0 ... nBuilt - 1)
 };
 
 template <class T>
@@ -102,13 +117,13 @@ void blocks_free(ldu_addr* a)
 {
     BlockPlan* P = a->blocks;
     if (!P) return;
-    void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_start};
+    void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_ticket, P->d_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& L : P->lay)
         for (void* p : {(void*)L.d_meta, (void*)L.d_col, (void*)L.d_srcFace}) if (p) (void)hipFree(p);
     for (auto& kv : P->conv) for (double* d : kv.second.d) if (d) (void)hipFree(d);
     for (auto& kv : P->tasks)
-        for (void* p : {(void*)kv.second.d_tasks, (void*)kv.second.d_taskStart, (void*)kv.second.d_imps, (void*)kv.second.d_impStart})
+        for (void* p : {(void*)kv.second.d_tasks, (void*)kv.second.d_taskStart, (void*)kv.second.d_imps, (void*)kv.second.d_impStart, (void*)kv.second.d_order})
             if (p) (void)hipFree(p);
     delete P;
     a->blocks = nullptr;
@@ -213,19 +228,17 @@ __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
 
 template <int NW>
 __global__ void __launch_bounds__(LDU_WAVE * (NW + 1))
-gs_blk_kernel(BkTab T, int nBlocks, int xcdMap, uint4* __restrict__ G, unsigned tagBase, unsigned* startCtr, unsigned startBase,
-              int* abortFlag, double* __restrict__ psi, const double* __restrict__ rhs, const double* __restrict__ diag)
+gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __restrict__ G, unsigned tagBase, unsigned* ticketCtr,
+              unsigned ticketBase, int* abortFlag, const double* __restrict__ psi, double* __restrict__ psiOut,
+              const double* __restrict__ rhs, const double* __restrict__ diag)
 {
     extern __shared__ double smem[];
-    // workgroups are dealt to the XCDs round-robin: physical workgroup p runs on XCD p % 8.  Blocks are numbered in the order of
-    // the (bandwidth-reducing) cell numbering, so consecutive blocks are neighbours in space: XCD x takes a contiguous range
-    // of blocks and most granules travel inside one XCD's L2.
-    int b = blockIdx.x;
-    if (xcdMap)
-    {
-        const int x = b & 7, i = b >> 3, q = nBlocks >> 3, r = nBlocks & 7;
-        b = x * q + (x < r ? x : r) + i;
-    }
+    // the block of this workgroup: the next one in the order of the blocks' first tasks (see "Progress" above) - whatever
+    // order the hardware starts workgroups in, the started blocks are a prefix of that order
+    if (threadIdx.x == 0) *(int*)smem = order[atomicAdd(ticketCtr, 1u) - ticketBase];
+    __syncthreads();
+    const int b = *(const int*)smem;
+    __syncthreads();      // (smem is about to become the block's value slots)
     const int4 B = T.blk[b];
     const int rowBase = B.x, nLocal = B.y, ghostBase = B.z, nGhost = B.w;
     const int nSlots = nLocal + nGhost;
@@ -258,8 +271,6 @@ gs_blk_kernel(BkTab T, int nBlocks, int xcdMap, uint4* __restrict__ G, unsigned 
     for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) { x[i] = psi[T.localRow[rowBase + i]]; stamp[i] = 0; }
     for (int i = tid; i < nGhost; i += LDU_WAVE * (NW + 1)) { x[nLocal + i] = psi[T.ghostRow[ghostBase + i]]; stamp[nLocal + i] = 0; }
     __syncthreads();
-    // every block reads psi before any block may overwrite it (the write-back at the end waits for this count)
-    if (tid == 0) __hip_atomic_fetch_add(startCtr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     bool alive = true;
     if (wave == NW)
     {
@@ -393,20 +404,12 @@ gs_blk_kernel(BkTab T, int nBlocks, int xcdMap, uint4* __restrict__ G, unsigned 
 #undef BK_FILLC
 #undef BK_REC
     __syncthreads();
-    // psi may be overwritten once EVERY block has read its initial values (a block that has no lower neighbour in another
-    // block can be done before a late block has even started)
-    if (tid == 0)
-    {
-        unsigned spins = 0;
-        unsigned long long tw0 = 0;
-        while (__hip_atomic_load(startCtr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - startBase < (unsigned)nBlocks)
-        {
-            __builtin_amdgcn_s_sleep(8);
-            if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; break; }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) psi[T.localRow[rowBase + i]] = x[i];
+    for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) psiOut[T.localRow[rowBase + i]] = x[i];
+}
+
+__global__ void __launch_bounds__(256) bk_copy_kernel(long n, const double* __restrict__ src, double* __restrict__ dst)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------- host: the plan
@@ -483,126 +486,25 @@ static inline int bk_width(const ldu_addr* a, int c)
     return a->losortStart[c + 1] - a->losortStart[c] + a->ownerStart[c + 1] - a->ownerStart[c];
 }
 
-static int bk_build(ldu_addr* a)
+// The grouping of sweep L (rows by their time T_L in the row-level DAG of the sweeps), its row and entry tables and the
+// group-level times Phi.  Built when a smoothing call first asks for L + 1 sweeps (a level that is smoothed twice never pays
+// for four groupings); needs the grouping of sweep L - 1.
+static int bk_build_layout(ldu_addr* a, int L)
 {
-    if (a->blocks) return 0;
-    ldu_ctx* ctx = a->ctx;
-    BlockPlan* P = new BlockPlan();
-    a->blocks = P;
-    P->built = true;
-    const int nC = a->nCells, nF = a->nFaces;
-    if (!ctx->blkEngine || a->nPatchFaces || nC < ctx->blkMinCells || nC > ctx->blkMaxCells || nF == 0) return 0;
-    const auto tB0 = std::chrono::steady_clock::now();
+    BlockPlan* P = a->blocks;
+    const int nC = a->nCells, nF = a->nFaces, nB = P->nBlocks;
     const bool verbose = getenv("LDU_VERBOSE") != nullptr;
-    for (int c = 0; c < nC; c++)
-        if (bk_width(a, c) > 128) return 0;       // (8 lanes x 16 entries per row)
-    // seven compute wavefronts per block (one workgroup of 512 threads per CU, up to 256 blocks of up to ~11 000 cells) on the
-    // large levels, three (two workgroups of 256 threads per CU: twice as many, smaller blocks) below - measured on the GAMG
-    // levels of the 12.7 M-cell motorBike mesh (profiles/r05_block_engine_probe.log): 769 k cells 1.57 / 1.77 ms per four
-    // sweeps with 7 / 3 wavefronts, 189 k equal, 46 k 0.85 / 0.75, 11 k 0.65 / 0.57
-    const int nw = ctx->blkWaves == 3 || ctx->blkWaves == 7 ? ctx->blkWaves : (nC >= ctx->blkWideFrom ? 7 : 3);
-    P->nw = nw;
-    P->nLayouts = std::min(BK_NLAY, std::max(1, ctx->blkLayouts));
-    // how many workgroups of this kernel a CU holds (registers; LDS is checked per candidate below)
-    int perCUregs = 0;
-    if (nw == 7 ? bk_occupancy<7>(1024, &perCUregs) : bk_occupancy<3>(1024, &perCUregs)) return -1;
-    if (perCUregs < 1) return 0;
-    if (perCUregs > ctx->blkMaxPerCU) perCUregs = ctx->blkMaxPerCU;
-    const long capacityMax = (long)ctx->numCUs * perCUregs;
-    // block size: as many blocks as the chip holds at once (with a margin for fragments), at least blkCellsMin cells
-    int target = ctx->blkCells;
-    if (target <= 0)
-    {
-        target = (int)((double)nC / (0.85 * (double)capacityMax)) + 1;
-        const int cmin = nw == 3 ? std::min(ctx->blkCellsMin, 256) : ctx->blkCellsMin;
-        if (target < cmin) target = cmin;
-        if (target > ctx->blkCellsMax) return 0;
-    }
-    std::vector<int> blk;
-    int nB = 0;
-    std::vector<int> nLocal, slot(nC), rowBase;
-    std::vector<int>& ghostBase = P->ghostBase;
-    std::vector<int>& ghostCell = P->ghostCell;
-    std::vector<unsigned char>& ghostLower = P->ghostLower;
-    int maxSlots = 0, perCU = 0;
-    for (int attempt = 0; attempt < 4; attempt++, target += target / 6)
-    {
-        nB = bk_partition(a, target, blk);
-        // LDS slots of a block's rows: the order of the level-ordered numbering restricted to the block
-        nLocal.assign(nB, 0);
-        for (int r = 0; r < nC; r++) { const int c = a->perm[r]; slot[c] = nLocal[blk[c]]++; }
-        // ghosts
-        ghostBase.assign(nB + 1, 0);
-        ghostCell.clear();
-        ghostLower.clear();
-        {
-            std::vector<int> cellsOf(nC), start(nB + 1, 0);
-            for (int c = 0; c < nC; c++) start[blk[c] + 1]++;
-            for (int b = 0; b < nB; b++) start[b + 1] += start[b];
-            { std::vector<int> pos(start.begin(), start.end() - 1); for (int c = 0; c < nC; c++) cellsOf[pos[blk[c]]++] = c; }
-            std::vector<int> mark(nC, -1), gidx(nC, 0);
-            for (int b = 0; b < nB; b++)
-            {
-                ghostBase[b] = (int)ghostCell.size();
-                for (int t = start[b]; t < start[b + 1]; t++)
-                {
-                    const int c = cellsOf[t];
-                    for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++)
-                    {
-                        const int n = a->l[a->losort[s]];
-                        if (blk[n] == b) continue;
-                        if (mark[n] != b) { mark[n] = b; gidx[n] = (int)ghostCell.size(); ghostCell.push_back(n); ghostLower.push_back(0); }
-                        ghostLower[gidx[n]] = 1;
-                    }
-                    for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++)
-                    {
-                        const int n = a->u[f];
-                        if (blk[n] == b) continue;
-                        if (mark[n] != b) { mark[n] = b; gidx[n] = (int)ghostCell.size(); ghostCell.push_back(n); ghostLower.push_back(0); }
-                    }
-                }
-            }
-            ghostBase[nB] = (int)ghostCell.size();
-        }
-        maxSlots = 0;
-        for (int b = 0; b < nB; b++) maxSlots = std::max(maxSlots, nLocal[b] + ghostBase[b + 1] - ghostBase[b]);
-        const size_t lds = ((size_t)9 * maxSlots + 64 + 15) & ~(size_t)15;
-        perCU = 0;
-        if (lds <= BK_MAX_LDS && maxSlots < 65536)
-        {
-            if (nw == 7 ? bk_occupancy<7>(lds, &perCU) : bk_occupancy<3>(lds, &perCU)) return -1;
-            if (perCU > ctx->blkMaxPerCU) perCU = ctx->blkMaxPerCU;
-        }
-        P->ldsBytes = lds;
-        if (verbose)
-            fprintf(stderr, "[ldugpu] block engine: %d cells, target %d cells per block -> %d blocks, largest %d slots (%zu B of LDS), "
-                            "%d ghosts in all, %d workgroups per CU -> %ld resident\n", nC, target, nB, maxSlots, lds,
-                    (int)ghostCell.size(), perCU, (long)perCU * ctx->numCUs);
-        if (perCU < 1) break;                                   // a block does not fit into LDS: larger blocks will not either
-        if ((long)nB <= (long)perCU * ctx->numCUs) break;       // every block resident
-        perCU = 0;
-        if (ctx->blkCells > 0) break;
-    }
-    if (perCU < 1) return 0;
-    P->nBlocks = nB;
-    P->maxSlots = maxSlots;
-    P->blkNLocal = nLocal;
-    P->nGhostTotal = (int)ghostCell.size();
-    rowBase.assign(nB + 1, 0);
-    for (int b = 0; b < nB; b++) rowBase[b + 1] = rowBase[b] + nLocal[b];
-    std::vector<int> localRow(nC);
-    for (int c = 0; c < nC; c++) localRow[rowBase[blk[c]] + slot[c]] = a->iperm[c];
-    P->ghostRowH.resize(ghostCell.size());
-    for (size_t g = 0; g < ghostCell.size(); g++) P->ghostRowH[g] = a->iperm[ghostCell[g]];
-    // ghost slot of (block, cell): filled block by block below
-    std::vector<char> exported(nC, 0);
-    for (int f = 0; f < nF; f++)
-        if (blk[a->l[f]] != blk[a->u[f]]) exported[a->l[f]] = exported[a->u[f]] = 1;
-
-    // ---- per sweep: times in the row-level DAG, groups, tables, group-level times
-    std::vector<int> RTprev, RT(nC);
+    const std::vector<int>& blk = P->blk;
+    const std::vector<int>& slot = P->slot;
+    const std::vector<int>& rowBase = P->rowBase;
+    const std::vector<int>& nLocal = P->blkNLocal;
+    const std::vector<int>& ghostBase = P->ghostBase;
+    const std::vector<int>& ghostCell = P->ghostCell;
+    const std::vector<char>& exported = P->exported;
     std::vector<int> gslot(nC, -1);
-    for (int L = 0; L < P->nLayouts; L++)
+    std::vector<int> RTprev;
+    RTprev.swap(P->RTlast);
+    std::vector<int> RT(nC);
     {
         BlockPlan::Layout& Y = P->lay[L];
         // T_L of every row (cells in ascending label order: lower neighbours first)
@@ -743,25 +645,153 @@ static int bk_build(ldu_addr* a)
             fprintf(stderr, "[ldugpu] block engine plan: sweep %d: row-level DAG %d steps; %d groups (%.1f lanes each), group-level DAG %d steps, "
                             "%.1f M entries (%.2f x the coefficients)\n", L, maxRT, Y.nGroups, (double)nLanes / std::max(1, Y.nGroups),
                     *std::max_element(Y.Phi.begin(), Y.Phi.end()) + 1, Y.nEntries / 1e6, (double)Y.nEntries / std::max(1, 2 * nF));
-        RTprev = RT;
+        P->RTlast.swap(RT);
     }
+    P->nBuilt = L + 1;
+    return 0;
+}
+
+static int bk_build(ldu_addr* a)
+{
+    if (a->blocks) return 0;
+    ldu_ctx* ctx = a->ctx;
+    BlockPlan* P = new BlockPlan();
+    a->blocks = P;
+    P->built = true;
+    const int nC = a->nCells, nF = a->nFaces;
+    if (!ctx->blkEngine || a->nPatchFaces || nC < ctx->blkMinCells || nC > ctx->blkMaxCells || nF == 0) return 0;
+    const auto tB0 = std::chrono::steady_clock::now();
+    const bool verbose = getenv("LDU_VERBOSE") != nullptr;
+    for (int c = 0; c < nC; c++)
+        if (bk_width(a, c) > 128) return 0;       // (8 lanes x 16 entries per row)
+    // seven compute wavefronts per block (one workgroup of 512 threads per CU, up to 256 blocks of up to ~11 000 cells) on the
+    // large levels, three (two workgroups of 256 threads per CU: twice as many, smaller blocks) below - measured on the GAMG
+    // levels of the 12.7 M-cell motorBike mesh (profiles/r05_block_engine_probe.log): 769 k cells 1.57 / 1.77 ms per four
+    // sweeps with 7 / 3 wavefronts, 189 k equal, 46 k 0.85 / 0.75, 11 k 0.65 / 0.57
+    const int nw = ctx->blkWaves == 3 || ctx->blkWaves == 7 ? ctx->blkWaves : (nC >= ctx->blkWideFrom ? 7 : 3);
+    P->nw = nw;
+    P->nLayouts = std::min(BK_NLAY, std::max(1, ctx->blkLayouts));
+    // how many workgroups of this kernel a CU holds (registers; LDS is checked per candidate below)
+    int perCUregs = 0;
+    if (nw == 7 ? bk_occupancy<7>(1024, &perCUregs) : bk_occupancy<3>(1024, &perCUregs)) return -1;
+    if (perCUregs < 1) return 0;
+    if (perCUregs > ctx->blkMaxPerCU) perCUregs = ctx->blkMaxPerCU;
+    const long capacityMax = (long)ctx->numCUs * perCUregs;
+    // block size: as many blocks as the chip holds at once (with a margin for fragments), at least blkCellsMin cells
+    int target = ctx->blkCells;
+    if (target <= 0)
+    {
+        target = (int)((double)nC / (0.85 * (double)capacityMax)) + 1;
+        const int cmin = nw == 3 ? std::min(ctx->blkCellsMin, 256) : ctx->blkCellsMin;
+        if (target < cmin) target = cmin;
+        // more cells than the resident workgroups hold in LDS: blocks of blkCellsMax cells, more blocks than workgroups - fine
+        // as long as few enough of them are OPEN at a time (bk_tasks checks that per k)
+        if (target > ctx->blkCellsMax) target = ctx->blkCellsMax;
+    }
+    std::vector<int> blk;
+    int nB = 0;
+    std::vector<int> nLocal, slot(nC), rowBase;
+    std::vector<int>& ghostBase = P->ghostBase;
+    std::vector<int>& ghostCell = P->ghostCell;
+    std::vector<unsigned char>& ghostLower = P->ghostLower;
+    int maxSlots = 0, perCU = 0;
+    for (int attempt = 0; attempt < 4; attempt++, target += target / 6)
+    {
+        if (target < 64) target = 64;
+        nB = bk_partition(a, target, blk);
+        // LDS slots of a block's rows: the order of the level-ordered numbering restricted to the block
+        nLocal.assign(nB, 0);
+        for (int r = 0; r < nC; r++) { const int c = a->perm[r]; slot[c] = nLocal[blk[c]]++; }
+        // ghosts
+        ghostBase.assign(nB + 1, 0);
+        ghostCell.clear();
+        ghostLower.clear();
+        {
+            std::vector<int> cellsOf(nC), start(nB + 1, 0);
+            for (int c = 0; c < nC; c++) start[blk[c] + 1]++;
+            for (int b = 0; b < nB; b++) start[b + 1] += start[b];
+            { std::vector<int> pos(start.begin(), start.end() - 1); for (int c = 0; c < nC; c++) cellsOf[pos[blk[c]]++] = c; }
+            std::vector<int> mark(nC, -1), gidx(nC, 0);
+            for (int b = 0; b < nB; b++)
+            {
+                ghostBase[b] = (int)ghostCell.size();
+                for (int t = start[b]; t < start[b + 1]; t++)
+                {
+                    const int c = cellsOf[t];
+                    for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++)
+                    {
+                        const int n = a->l[a->losort[s]];
+                        if (blk[n] == b) continue;
+                        if (mark[n] != b) { mark[n] = b; gidx[n] = (int)ghostCell.size(); ghostCell.push_back(n); ghostLower.push_back(0); }
+                        ghostLower[gidx[n]] = 1;
+                    }
+                    for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++)
+                    {
+                        const int n = a->u[f];
+                        if (blk[n] == b) continue;
+                        if (mark[n] != b) { mark[n] = b; gidx[n] = (int)ghostCell.size(); ghostCell.push_back(n); ghostLower.push_back(0); }
+                    }
+                }
+            }
+            ghostBase[nB] = (int)ghostCell.size();
+        }
+        maxSlots = 0;
+        for (int b = 0; b < nB; b++) maxSlots = std::max(maxSlots, nLocal[b] + ghostBase[b + 1] - ghostBase[b]);
+        const size_t lds = ((size_t)9 * maxSlots + 64 + 15) & ~(size_t)15;
+        perCU = 0;
+        if (lds <= BK_MAX_LDS && maxSlots < 65536)
+        {
+            if (nw == 7 ? bk_occupancy<7>(lds, &perCU) : bk_occupancy<3>(lds, &perCU)) return -1;
+            if (perCU > ctx->blkMaxPerCU) perCU = ctx->blkMaxPerCU;
+        }
+        P->ldsBytes = lds;
+        if (verbose)
+            fprintf(stderr, "[ldugpu] block engine: %d cells, target %d cells per block -> %d blocks, largest %d slots (%zu B of LDS), "
+                            "%d ghosts in all, %d workgroups per CU -> %ld resident\n", nC, target, nB, maxSlots, lds,
+                    (int)ghostCell.size(), perCU, (long)perCU * ctx->numCUs);
+        if (perCU < 1 && target > 2048 && ctx->blkCells <= 0) { target = target * 2 / 3 - target / 6; continue; }   // LDS: smaller blocks
+        break;
+    }
+    if (perCU < 1) return 0;
+    P->capacity = (long)perCU * ctx->numCUs;
+    P->nBlocks = nB;
+    P->maxSlots = maxSlots;
+    P->blkNLocal = nLocal;
+    P->nGhostTotal = (int)ghostCell.size();
+    rowBase.assign(nB + 1, 0);
+    for (int b = 0; b < nB; b++) rowBase[b + 1] = rowBase[b] + nLocal[b];
+    std::vector<int> localRow(nC);
+    for (int c = 0; c < nC; c++) localRow[rowBase[blk[c]] + slot[c]] = a->iperm[c];
+    P->ghostRowH.resize(ghostCell.size());
+    for (size_t g = 0; g < ghostCell.size(); g++) P->ghostRowH[g] = a->iperm[ghostCell[g]];
+    // ghost slot of (block, cell): filled block by block below
+    std::vector<char> exported(nC, 0);
+    for (int f = 0; f < nF; f++)
+        if (blk[a->l[f]] != blk[a->u[f]]) exported[a->l[f]] = exported[a->u[f]] = 1;
+
+    P->blk.swap(blk);
+    P->slot.swap(slot);
+    P->rowBase = rowBase;
+    P->exported.swap(exported);
+    P->nBuilt = 0;
     // ---- upload
     std::vector<int4> blkInfo(nB);
     for (int b = 0; b < nB; b++) blkInfo[b] = make_int4(rowBase[b], nLocal[b], ghostBase[b], ghostBase[b + 1] - ghostBase[b]);
     if (bk_upload(&P->d_blk, blkInfo) || bk_upload(&P->d_localRow, localRow) || bk_upload(&P->d_ghostRow, P->ghostRowH)) return -1;
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
     LDU_CHECK_HIP(ldu_memset_sync(P->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
-    LDU_CHECK_HIP(hipMalloc((void**)&P->d_start, sizeof(unsigned) * 64));
-    LDU_CHECK_HIP(ldu_memset_sync(P->d_start, 0, sizeof(unsigned) * 64));
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned) * 64));
+    LDU_CHECK_HIP(ldu_memset_sync(P->d_ticket, 0, sizeof(unsigned) * 64));
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_out, sizeof(double) * (size_t)(nC + 1)));
     P->gen = ctx->p2pGen;
     P->eligible = true;
     if (verbose)
     {
         long cut = 0;
-        for (int f = 0; f < nF; f++) cut += blk[a->l[f]] != blk[a->u[f]];
-        fprintf(stderr, "[ldugpu] block engine plan: %d cells in %d blocks (%d wavefronts + importer each, %zu B of LDS), "
+        for (int f = 0; f < nF; f++) cut += P->blk[a->l[f]] != P->blk[a->u[f]];
+        fprintf(stderr, "[ldugpu] block engine plan: %d cells in %d blocks (%ld resident; %d wavefronts + importer each, %zu B of LDS), "
                         "%.1f %% of the faces cut, %d ghosts, %d dependency levels; %.3f s\n",
-                nC, nB, nw, P->ldsBytes, 100.0 * cut / std::max(1, nF), P->nGhostTotal, a->nLevels,
+                nC, nB, P->capacity, nw, P->ldsBytes, 100.0 * cut / std::max(1, nF), P->nGhostTotal, a->nLevels,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tB0).count());
     }
     return 0;
@@ -775,6 +805,8 @@ static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
     if (it == P->tasks.end())
     {
         const int nB = P->nBlocks;
+        while (P->nBuilt < std::min(k, P->nLayouts))
+            if (bk_build_layout(a, P->nBuilt)) return -1;
         auto layOf = [&](int j) -> const BlockPlan::Layout& { return P->lay[std::min(j, P->nLayouts - 1)]; };
         // (with fewer layouts than sweeps the later sweeps reuse the last grouping: their Phi = the last layout's + a shift that
         //  keeps every dependency ascending - computed here by running the group recurrence once more per extra sweep)
@@ -871,12 +903,38 @@ static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
         }
         BlockPlan::Tasks W;
         W.nTasks = nTasks;
+        // the order in which workgroups take the blocks (ascending first Phi) and the most blocks that are open at one Phi:
+        // what the chip must hold at once (see "Progress" at the top of the file)
+        {
+            std::vector<int> lo(nB, 0x7fffffff), hi(nB, -1);
+            for (int j = 0; j < k; j++)
+            {
+                const BlockPlan::Layout& Y = layOf(j);
+                for (int g = 0; g < Y.nGroups; g++)
+                {
+                    const int b = Y.grpBlk[g], ph = Phi[j][g];
+                    lo[b] = std::min(lo[b], ph);
+                    hi[b] = std::max(hi[b], ph);
+                }
+            }
+            std::vector<int> ord(nB);
+            for (int b = 0; b < nB; b++) ord[b] = b;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return lo[x] < lo[y]; });
+            std::vector<int> delta((size_t)maxT + 3, 0);
+            for (int b = 0; b < nB; b++) if (hi[b] >= 0) { delta[lo[b]]++; delta[hi[b] + 1]--; }
+            int open = 0;
+            for (int t = 0; t <= maxT + 1; t++) { open += delta[t]; W.openMax = std::max(W.openMax, open); }
+            // (a margin: a workgroup that has finished its block holds its slot until its last wavefront has left)
+            W.usable = nB <= P->capacity || (double)W.openMax <= 0.8 * (double)P->capacity;
+            if (bk_upload(&W.d_order, ord)) return -1;
+        }
         if (bk_upload(&W.d_tasks, tasks, 1) || bk_upload(&W.d_taskStart, taskStart) || bk_upload(&W.d_imps, imps, 1) ||
             bk_upload(&W.d_impStart, impStart))
             return -1;
         if (getenv("LDU_VERBOSE"))
-            fprintf(stderr, "[ldugpu] block engine: %d cells, k = %d: %ld tasks, %zu imports, %d steps in the group-level DAG\n",
-                    a->nCells, k, nTasks, imps.size(), maxT + 1);
+            fprintf(stderr, "[ldugpu] block engine: %d cells, k = %d: %ld tasks, %zu imports, %d steps in the group-level DAG; %d blocks, at "
+                            "most %d open at a time, %ld resident%s\n", a->nCells, k, nTasks, imps.size(), maxT + 1, nB, W.openMax, P->capacity,
+                    W.usable ? "" : " - NOT on this engine");
         it = P->tasks.emplace(k, W).first;
     }
     *out = &it->second;
@@ -889,18 +947,17 @@ static int bk_values(ldu_addr* a, const double* levelVal, hipStream_t s, const d
     auto org = a->valOrigin.find(levelVal);
     if (org == a->valOrigin.end()) return 1;
     BlockPlan::Conv& C = P->conv[levelVal];
-    for (int L = 0; L < P->nLayouts; L++)
-        if (!C.d[L]) LDU_CHECK_HIP(hipMalloc((void**)&C.d[L], sizeof(double) * (size_t)P->lay[L].nEntries));
-    if (C.stamp != a->ctx->valStamp)
+    for (int L = 0; L < P->nBuilt; L++)
     {
-        for (int L = 0; L < P->nLayouts; L++)
+        if (!C.d[L]) LDU_CHECK_HIP(hipMalloc((void**)&C.d[L], sizeof(double) * (size_t)P->lay[L].nEntries));
+        if (C.stamp[L] != a->ctx->valStamp)
         {
             const int grid = (int)std::min<long>((P->lay[L].nEntries + 255) / 256, 8192);
             bk_fill_kernel<<<grid, 256, 0, s>>>(P->lay[L].nEntries, P->lay[L].d_srcFace, org->second.first, org->second.second, C.d[L]);
+            C.stamp[L] = a->ctx->valStamp;
         }
-        C.stamp = a->ctx->valStamp;
     }
-    for (int L = 0; L < BK_NLAY; L++) out[L] = C.d[std::min(L, P->nLayouts - 1)];
+    for (int L = 0; L < BK_NLAY; L++) out[L] = C.d[std::min(L, P->nBuilt - 1)];
     return 0;
 }
 
@@ -916,7 +973,8 @@ int k_blocks_prebuild(ldu_addr* a, int k)
 {
     if (!k_blocks_active(a)) return 1;
     const BlockPlan::Tasks* W = nullptr;
-    return bk_tasks(a, k, &W) ? -1 : 0;
+    if (bk_tasks(a, k, &W)) return -1;
+    return W->usable ? 0 : 2;     // 2: k sweeps of this addressing stay on the level engines (too many blocks open at a time)
 }
 
 int k_blocks_set_trace(unsigned long long* buf)
@@ -946,16 +1004,18 @@ int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const 
     BlockPlan& P = *a->blocks;
     hipStream_t s = ctx->stream;
     BkTab T;
-    {
-        const int rc = bk_values(a, val, s, T.val);
-        if (rc) return rc;     // (1: a value array that was not filled from face-ordered coefficients)
-    }
+    if (a->valOrigin.find(val) == a->valOrigin.end()) return 1;   // a value array that was not filled from face-ordered coefficients
     const BlockPlan::Tasks* W = nullptr;
     if (bk_tasks(a, k, &W)) return -1;
+    if (!W->usable) return 1;      // (more blocks open at a time than the chip holds: the level engines)
+    {
+        const int rc = bk_values(a, val, s, T.val);
+        if (rc) return rc;
+    }
     if (P.gen != ctx->p2pGen)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_start, 0, sizeof(unsigned) * 64, s));
-        P.startBase = 0;
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_ticket, 0, sizeof(unsigned) * 64, s));
+        P.ticketBase = 0;
         P.gen = ctx->p2pGen;
     }
     if (P.epoch > 0xffffff00u)
@@ -966,19 +1026,19 @@ int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const 
     const unsigned tagBase = P.epoch;
     P.epoch += (unsigned)k;
     T.blk = P.d_blk; T.localRow = P.d_localRow; T.ghostRow = P.d_ghostRow;
-    for (int L = 0; L < BK_NLAY; L++) { const BlockPlan::Layout& Y = P.lay[std::min(L, P.nLayouts - 1)]; T.meta[L] = Y.d_meta; T.col[L] = Y.d_col; }
+    for (int L = 0; L < BK_NLAY; L++) { const BlockPlan::Layout& Y = P.lay[std::min(L, P.nBuilt - 1)]; T.meta[L] = Y.d_meta; T.col[L] = Y.d_col; }
     T.nLayouts = P.nLayouts;
     T.tasks = W->d_tasks; T.taskStart = W->d_taskStart; T.imps = W->d_imps; T.impStart = W->d_impStart;
-    const int xcdMap = ctx->blkXcdMap && ctx->nXcd == 8 && P.nBlocks >= 16;
     ctx->profStart(a, 4);
     if (P.nw == 7)
-        gs_blk_kernel<7><<<P.nBlocks, LDU_WAVE * 8, P.ldsBytes, s>>>(T, P.nBlocks, xcdMap, P.d_granule, tagBase, P.d_start, P.startBase,
-                                                                     ctx->d_abort, psi, rhs, diag);
+        gs_blk_kernel<7><<<P.nBlocks, LDU_WAVE * 8, P.ldsBytes, s>>>(T, P.nBlocks, W->d_order, P.d_granule, tagBase, P.d_ticket, P.ticketBase,
+                                                                     ctx->d_abort, psi, P.d_out, rhs, diag);
     else
-        gs_blk_kernel<3><<<P.nBlocks, LDU_WAVE * 4, P.ldsBytes, s>>>(T, P.nBlocks, xcdMap, P.d_granule, tagBase, P.d_start, P.startBase,
-                                                                     ctx->d_abort, psi, rhs, diag);
+        gs_blk_kernel<3><<<P.nBlocks, LDU_WAVE * 4, P.ldsBytes, s>>>(T, P.nBlocks, W->d_order, P.d_granule, tagBase, P.d_ticket, P.ticketBase,
+                                                                     ctx->d_abort, psi, P.d_out, rhs, diag);
+    bk_copy_kernel<<<(int)std::min<long>(((long)a->nCells + 255) / 256, 4096), 256, 0, s>>>(a->nCells, P.d_out, psi);
     ctx->profStop(a, 4);
-    P.startBase += (unsigned)P.nBlocks;
+    P.ticketBase += (unsigned)P.nBlocks;
     LDU_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -136,10 +136,11 @@ struct ldu_ctx {
     int blkEngine = 1;               // LDU_BLK=0: off
     int blkMinCells = 2000;          // LDU_BLK_MIN (below: the one-workgroup engine)
     int blkWideFrom = 400000;        // LDU_BLK_WIDE_FROM: seven compute wavefronts per block from this many cells, three below
-    int blkMaxCells = 4000000;       // LDU_BLK_MAX
+    int blkMaxCells = 2600000;       // LDU_BLK_MAX (above: more blocks than resident workgroups, and on the motorBike levels nearly all of
+                                     // them are open at once - 348 of 349 at 3.1 M cells, 678 of 702 at 6.3 M: profiles/r05_block_open_counts.log)
     int blkCells = 0;                // LDU_BLK_CELLS: cells per block (0 = sized so that all blocks are resident at once)
     int blkCellsMin = 1024;          // LDU_BLK_CELLS_MIN
-    int blkCellsMax = 12000;         // LDU_BLK_CELLS_MAX (LDS: 9 bytes per local row and per ghost)
+    int blkCellsMax = 9000;          // LDU_BLK_CELLS_MAX (LDS: 9 bytes per local row and per ghost)
     int blkWaves = 0;                // LDU_BLK_WAVES (7 / 3 compute wavefronts per block, + 1 importer; 0 = by size)
     int blkMaxPerCU = 4;             // LDU_BLK_PER_CU: workgroups per CU the grid may count on
     int blkWavesPerSweep = 0;        // LDU_BLK_WPS: wavefronts a sweep's tasks of one block are dealt to (0 = all tasks round-robin over all wavefronts)

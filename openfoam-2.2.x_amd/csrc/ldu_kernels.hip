@@ -3028,7 +3028,13 @@ int k_gs_prebuild(ldu_addr* a, int k)
     ldu_ctx* ctx = a->ctx;
     if (k < 2 || k > 4 || a->nCells == 0 || a->nPatchFaces || !ctx->sweepP2P || !ctx->gsPipeline) return 0;
     const int e = k_engine_of(a, 2);
-    if (e == 6) return k_blocks_prebuild(a, k) < 0 ? -1 : 0;
+    if (e == 6)
+    {
+        const int rb = k_blocks_prebuild(a, k);
+        if (rb < 0) return -1;
+        if (rb != 2) return 0;
+        return gs_tasks_ensure(a, k);      // this k stays on the level engines
+    }
     if (e != 0 && e != 1) return 0;      // one workgroup / single wavefront / clusters: their own (cheap) plans
     return gs_tasks_ensure(a, k);
 }
