@@ -414,63 +414,6 @@ __global__ void __launch_bounds__(256) bk_copy_kernel(long n, const double* __re
 
 // ---------------------------------------------------------------- host: the plan
 
-// compact blocks: breadth-first blobs of <= target cells grown from the lowest unassigned cell (under a bandwidth-reducing
-// numbering the blobs tile the shells of the numbering), fragments merged into their smallest neighbour
-static int bk_partition(const ldu_addr* a, int target, std::vector<int>& blk)
-{
-    const int nC = a->nCells;
-    blk.assign(nC, -1);
-    int nB = 0;
-    std::vector<int> q;
-    q.reserve((size_t)target + 64);
-    auto visit = [&](int c, auto&& fn) {
-        for (int t = a->losortStart[c]; t < a->losortStart[c + 1]; t++) fn(a->l[a->losort[t]]);
-        for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) fn(a->u[f]);
-    };
-    for (int s = 0; s < nC; s++)
-    {
-        if (blk[s] >= 0) continue;
-        q.clear();
-        q.push_back(s);
-        blk[s] = nB;
-        size_t h = 0;
-        while (h < q.size() && (int)q.size() < target)
-        {
-            const int c = q[h++];
-            visit(c, [&](int n) { if (blk[n] < 0 && (int)q.size() < target) { blk[n] = nB; q.push_back(n); } });
-        }
-        nB++;
-    }
-    // merge fragments
-    std::vector<int> sz(nB, 0);
-    for (int c = 0; c < nC; c++) sz[blk[c]]++;
-    const int small = target / 4, cap = target + target / 3;
-    std::vector<int> best(nB, -1);
-    for (int c = 0; c < nC; c++)
-    {
-        const int bc = blk[c];
-        if (sz[bc] >= small) continue;
-        visit(c, [&](int n) {
-            const int bn = blk[n];
-            if (bn != bc && sz[bn] >= small && (best[bc] < 0 || sz[bn] < sz[best[bc]])) best[bc] = bn;
-        });
-    }
-    std::vector<int> tgt(nB);
-    for (int b = 0; b < nB; b++) tgt[b] = b;
-    for (int b = 0; b < nB; b++)
-        if (sz[b] < small && best[b] >= 0 && sz[best[b]] + sz[b] <= cap) { tgt[b] = best[b]; sz[best[b]] += sz[b]; sz[b] = 0; }
-    // compact the labels in order of first occurrence
-    std::vector<int> lab(nB, -1);
-    int n2 = 0;
-    for (int c = 0; c < nC; c++)
-    {
-        const int b = tgt[blk[c]];
-        if (lab[b] < 0) lab[b] = n2++;
-        blk[c] = lab[b];
-    }
-    return n2;
-}
-
 template <int NW>
 static int bk_occupancy(size_t lds, int* perCU)
 {
@@ -664,41 +607,38 @@ static int bk_build(ldu_addr* a)
     const bool verbose = getenv("LDU_VERBOSE") != nullptr;
     for (int c = 0; c < nC; c++)
         if (bk_width(a, c) > 128) return 0;       // (8 lanes x 16 entries per row)
-    // seven compute wavefronts per block (one workgroup of 512 threads per CU, up to 256 blocks of up to ~11 000 cells) on the
-    // large levels, three (two workgroups of 256 threads per CU: twice as many, smaller blocks) below - measured on the GAMG
-    // levels of the 12.7 M-cell motorBike mesh (profiles/r05_block_engine_probe.log): 769 k cells 1.57 / 1.77 ms per four
-    // sweeps with 7 / 3 wavefronts, 189 k equal, 46 k 0.85 / 0.75, 11 k 0.65 / 0.57
-    const int nw = ctx->blkWaves == 3 || ctx->blkWaves == 7 ? ctx->blkWaves : (nC >= ctx->blkWideFrom ? 7 : 3);
-    P->nw = nw;
+    // How the matrix is cut.  Every block must be resident (see "Progress"), so a configuration is (compute wavefronts per
+    // block, workgroups per CU): 7 + 1 wavefronts = 512 threads, one workgroup per CU, up to 160 KB of LDS = ~18 000 slots per
+    // block, 256 blocks; or 3 + 1 wavefronts = 256 threads, two per CU, 80 KB each, 512 blocks.  Measured on the GAMG levels of
+    // the 12.7 M-cell motorBike mesh (profiles/r05_block_engine_probe.log, ms per four sweeps with 7 / 3 wavefronts): 769 k
+    // cells 1.57 / 1.77, 189 k equal, 46 k 0.85 / 0.75, 11 k 0.65 / 0.57 - seven from blkWideFrom cells, three below; the other
+    // configuration is tried when the preferred one does not fit.  Blocks: nearly equal breadth-first blobs (partition_blobs).
     P->nLayouts = std::min(BK_NLAY, std::max(1, ctx->blkLayouts));
-    // how many workgroups of this kernel a CU holds (registers; LDS is checked per candidate below)
-    int perCUregs = 0;
-    if (nw == 7 ? bk_occupancy<7>(1024, &perCUregs) : bk_occupancy<3>(1024, &perCUregs)) return -1;
-    if (perCUregs < 1) return 0;
-    if (perCUregs > ctx->blkMaxPerCU) perCUregs = ctx->blkMaxPerCU;
-    const long capacityMax = (long)ctx->numCUs * perCUregs;
-    // block size: as many blocks as the chip holds at once (with a margin for fragments), at least blkCellsMin cells
-    int target = ctx->blkCells;
-    if (target <= 0)
-    {
-        target = (int)((double)nC / (0.85 * (double)capacityMax)) + 1;
-        const int cmin = nw == 3 ? std::min(ctx->blkCellsMin, 256) : ctx->blkCellsMin;
-        if (target < cmin) target = cmin;
-        // more cells than the resident workgroups hold in LDS: blocks of blkCellsMax cells, more blocks than workgroups - fine
-        // as long as few enough of them are OPEN at a time (bk_tasks checks that per k)
-        if (target > ctx->blkCellsMax) target = ctx->blkCellsMax;
-    }
-    std::vector<int> blk;
-    int nB = 0;
+    std::vector<int> blk(nC);
+    int nB = 0, nw = 7;
     std::vector<int> nLocal, slot(nC), rowBase;
     std::vector<int>& ghostBase = P->ghostBase;
     std::vector<int>& ghostCell = P->ghostCell;
     std::vector<unsigned char>& ghostLower = P->ghostLower;
     int maxSlots = 0, perCU = 0;
-    for (int attempt = 0; attempt < 4; attempt++, target += target / 6)
+    const int pref = ctx->blkWaves == 3 || ctx->blkWaves == 7 ? ctx->blkWaves : (nC >= ctx->blkWideFrom ? 7 : 3);
+    bool found = false;
+    for (int cand = 0; cand < 2 && !found; cand++)
     {
-        if (target < 64) target = 64;
-        nB = bk_partition(a, target, blk);
+        nw = cand == 0 ? pref : (pref == 7 ? 3 : 7);
+        if (cand == 1 && (ctx->blkWaves == 3 || ctx->blkWaves == 7)) break;      // forced
+        int perCUregs = 0;
+        if (nw == 7 ? bk_occupancy<7>(1024, &perCUregs) : bk_occupancy<3>(1024, &perCUregs)) return -1;
+        if (perCUregs > ctx->blkMaxPerCU) perCUregs = ctx->blkMaxPerCU;
+        if (perCUregs < 1) continue;
+        const long cap = (long)ctx->numCUs * perCUregs;
+        // as many blocks as fit at once (a few spare: the partitioner can come back with fewer), but not smaller than cmin cells
+        const int cmin = nw == 3 ? std::min(ctx->blkCellsMin, 256) : ctx->blkCellsMin;
+        long nParts = ctx->blkCells > 0 ? ((long)nC + ctx->blkCells - 1) / ctx->blkCells : std::min<long>((long)(0.97 * (double)cap), std::max<long>(1, nC / cmin));
+        if (nParts < 1) nParts = 1;
+        if (nParts > cap) { if (ctx->blkCells > 0) continue; nParts = cap; }
+        nB = partition_blobs(nC, nF, a->l.data(), a->u.data(), (int)nParts, blk.data());
+        if (nB < 1) return -1;
         // LDS slots of a block's rows: the order of the level-ordered numbering restricted to the block
         nLocal.assign(nB, 0);
         for (int r = 0; r < nC; r++) { const int c = a->perm[r]; slot[c] = nLocal[blk[c]]++; }
@@ -745,13 +685,14 @@ static int bk_build(ldu_addr* a)
             if (perCU > ctx->blkMaxPerCU) perCU = ctx->blkMaxPerCU;
         }
         P->ldsBytes = lds;
+        found = perCU >= 1 && (long)nB <= (long)perCU * ctx->numCUs;
         if (verbose)
-            fprintf(stderr, "[ldugpu] block engine: %d cells, target %d cells per block -> %d blocks, largest %d slots (%zu B of LDS), "
-                            "%d ghosts in all, %d workgroups per CU -> %ld resident\n", nC, target, nB, maxSlots, lds,
-                    (int)ghostCell.size(), perCU, (long)perCU * ctx->numCUs);
-        if (perCU < 1 && target > 2048 && ctx->blkCells <= 0) { target = target * 2 / 3 - target / 6; continue; }   // LDS: smaller blocks
-        break;
+            fprintf(stderr, "[ldugpu] block engine: %d cells, %d + 1 wavefronts per block: %d blocks (%ld asked for), largest %d slots (%zu B "
+                            "of LDS), %d ghosts in all, %d workgroups per CU -> %ld resident%s\n", nC, nw, nB, nParts, maxSlots, lds,
+                    (int)ghostCell.size(), perCU, (long)perCU * ctx->numCUs, found ? "" : ": does not fit");
     }
+    if (!found) return 0;
+    P->nw = nw;
     if (perCU < 1) return 0;
     P->capacity = (long)perCU * ctx->numCUs;
     P->nBlocks = nB;

@@ -443,6 +443,7 @@ int k_blocks_set_watchdog(unsigned long long budgetTicks, unsigned long long sta
 int k_blocks_set_trace(unsigned long long* buf);
 int k_blocks_info(ldu_addr* a, int k, long out[8]);
 void blocks_free(ldu_addr* a);
+extern "C" int partition_blobs(int nCells, int nFaces, const int* lowerAddr, const int* upperAddr, int nParts, int* part);   // ldu_mesh.hip
 void blocks_forget(ldu_addr* a, const double* levelVal);
 void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converted copy of a value array
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,

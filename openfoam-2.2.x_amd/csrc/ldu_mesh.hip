@@ -318,7 +318,13 @@ int ldu_device_count(void)
 int ldu_partition_blobs(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr, int32_t nParts,
                         int32_t* part)
 {
-    if (nParts < 1 || nCells < 0) { ldu_set_error("ldu_partition_blobs: nParts >= 1"); return -2; }
+    return partition_blobs(nCells, nFaces, lowerAddr, upperAddr, nParts, part) < 0 ? -2 : 0;
+}
+
+// (also the block engine's partitioner, ldu_blocks.hip) -> parts actually made (<= nParts), -1 on bad arguments
+int partition_blobs(int nCells, int nFaces, const int* lowerAddr, const int* upperAddr, int nParts, int* part)
+{
+    if (nParts < 1 || nCells < 0) { ldu_set_error("ldu_partition_blobs: nParts >= 1"); return -1; }
     std::vector<int> start((size_t)nCells + 1, 0), adj(2 * (size_t)nFaces);
     for (int f = 0; f < nFaces; f++) { start[lowerAddr[f] + 1]++; start[upperAddr[f] + 1]++; }
     for (int c = 0; c < nCells; c++) start[c + 1] += start[c];
@@ -385,7 +391,7 @@ int ldu_partition_blobs(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr
     int used = 0;
     for (int r = 0; r < nParts; r++) if (size[r] > 0) lab[r] = used++;
     if (used < nParts) for (int c = 0; c < nCells; c++) part[c] = lab[part[c]];
-    return 0;
+    return used;
 }
 
 int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
