@@ -42,6 +42,15 @@
 // other engines (abort flag -> the operation is re-run on the level kernels): a launch fails loudly, it never hangs.
 // psi is read at block start and ghosts of late blocks need the OLD values of rows whose block is long done: the sweeps
 // write their result to a scratch vector, copied over psi behind the launch.
+//
+// Coupled interfaces (cyclic patches: sub-domain mode, ldu_addr_set_subdomains).  GaussSeidelSmoother.C:98-145 adds the
+// interface terms to bPrime before every sweep, with the neighbour sub-domain's values of the PREVIOUS sweep and negated
+// coefficients, patch by patch, face by face.  Here they are the first entries of a row (coefficient -bouCoeffs, the
+// neighbour cell across the face), ahead of the lower and upper entries: the same subtractions in the same order.  Both
+// sides of an interface want each other's OLD value, so "a stamp is never ahead of what a row needs" does not hold
+// across it: a row can finish sweep j before its interface neighbour has read its value of sweep j - 1.  One sweep
+// ahead is all it can get (its sweep j + 1 needs the neighbour's sweep j, which has read), so interface cells keep TWO
+// values, by sweep parity - in LDS ("hist" slots, for local cells and for ghosts) and in the granule array.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -72,8 +81,9 @@ struct BlockPlan {
     struct Layout {
         int nGroups = 0;
         long nLanes = 0, nEntries = 0;
-        int2* d_meta = nullptr;            // [nLanes + 64] {level-ordered row | exported << 31 | last lane of the row << 30,
-                                           //                 LDS slot | lower entries of this lane << 16 | entries of this lane << 24}
+        int4* d_meta = nullptr;            // [nLanes + 64] {level-ordered row | exported << 31 | last lane of the row << 30,
+                                           //  LDS slot | lower entries of this lane << 16 | entries << 21 | interface entries << 26,
+                                           //  first LDS slot of the row's hist pair (-1: no interface), index of its interface granules}
         unsigned* d_col = nullptr;         // [nEntries / 2] LDS slots of the columns of entries 2 p, 2 p + 1 (low, high half)
         int* d_srcFace = nullptr;          // [nEntries] face << 1 | (1: upper-triangle coefficient), -1 padding
         // host
@@ -101,6 +111,14 @@ struct BlockPlan {
     std::vector<char> exported;            // [nCells] has a neighbour in another block
     std::vector<int> RTlast;               // T of the last grouping built
     int nBuilt = 0;                        // groupings built so far (sweeps 0 ... nBuilt - 1)
+    // coupled (cyclic) interfaces
+    bool iface = false;
+    int nIf = 0;                           // cells with interface faces
+    std::vector<int> ifStart, ifPf, ifNbr; // [nCells + 1] CSR: a cell's patch faces in (patch, face) order: patch-face index, neighbour cell
+    std::vector<int> ifIdx;                // [nCells] index among the interface cells, -1
+    std::vector<int> histBase, histCell;   // [nBlocks + 1]; cells with a hist pair per block: its own interface cells, then interface ghosts
+    int2* d_blk2 = nullptr;                // [nBlocks] {histBase, nHist}
+    int* d_histRow = nullptr;              // [histCell.size()] level-ordered row
 };
 
 template <class T>
@@ -117,7 +135,7 @@ void blocks_free(ldu_addr* a)
 {
     BlockPlan* P = a->blocks;
     if (!P) return;
-    void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_ticket, P->d_out};
+    void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_ticket, P->d_out, P->d_blk2, P->d_histRow};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& L : P->lay)
         for (void* p : {(void*)L.d_meta, (void*)L.d_col, (void*)L.d_srcFace}) if (p) (void)hipFree(p);
@@ -152,13 +170,14 @@ int k_blocks_set_watchdog(unsigned long long budgetTicks, unsigned long long sta
 
 __global__ void __launch_bounds__(256)
 bk_fill_kernel(long n, const int* __restrict__ srcFace, const double* __restrict__ lowerO, const double* __restrict__ upperO,
-               double* __restrict__ out)
+               const double* __restrict__ bou, double* __restrict__ out)
 {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
     {
         const int code = srcFace[i];
         double v = 0.0;
         if (code >= 0) v = (code & 1) ? upperO[code >> 1] : lowerO[code >> 1];
+        else if (code < -1) v = -bou[-2 - code];     // interface face: the negated interfaceBouCoeffs (GaussSeidelSmoother.C:98-107)
         out[i] = v;
     }
 }
@@ -191,14 +210,14 @@ __device__ __forceinline__ double bk_from_prev_lane(double v)
 }
 
 struct BkTab {
-    const int4* blk; const int* localRow; const int* ghostRow;
-    const int2* meta[BK_NLAY]; const unsigned* col[BK_NLAY]; const double* val[BK_NLAY];
+    const int4* blk; const int* localRow; const int* ghostRow; const int2* blk2; const int* histRow; int ifBase;
+    const int4* meta[BK_NLAY]; const unsigned* col[BK_NLAY]; const double* val[BK_NLAY];
     int nLayouts;
     const int4* tasks; const int* taskStart; const int4* imps; const int* impStart;
 };
 
 // a task's rows in flight: one lane = one row (T = 1) or one sixteen-entry part of a row (T = 2 / 4 / 8 lanes per row)
-struct BkRow { int4 Q; int rg, slot, nl, nn, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
+struct BkRow { int4 Q; int rg, slot, nl, nn, ni, hist, ifg, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
 
 // stage B of a task's prefetch: everything that depends on the task record (R.Q, loaded a step earlier) alone
 __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
@@ -206,17 +225,20 @@ __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
     const int4 Q = R.Q;
     const int cnt = Q.y & 255, stride = (Q.y >> 16) & 255, j = Q.w;
     const int L = j < T.nLayouts ? j : T.nLayouts - 1;
-    const int2* __restrict__ meta = T.meta[L];
+    const int4* __restrict__ meta = T.meta[L];
     const unsigned* __restrict__ col = T.col[L];
     const double* __restrict__ val = T.val[L];
     const bool have = lane < cnt;
-    const int2 M = meta[Q.x + (have ? lane : 0)];
+    const int4 M = meta[Q.x + (have ? lane : 0)];
     const long ent = (long)Q.z + (have ? lane : 0);
     const long ent2 = (long)(Q.z >> 1) + (have ? lane : 0);
     R.rg = M.x;
     R.slot = M.y & 0xffff;
-    R.nl = (M.y >> 16) & 255;
-    R.nn = (M.y >> 24) & 255;
+    R.nl = (M.y >> 16) & 31;
+    R.nn = (M.y >> 21) & 31;
+    R.ni = (M.y >> 26) & 31;
+    R.hist = M.z;
+    R.ifg = M.w;
 #pragma unroll
     for (int q = 0; q < 8; q++) R.c2[q] = col[ent2 + (long)q * stride];
 #pragma unroll
@@ -235,13 +257,20 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
     extern __shared__ double smem[];
     // the block of this workgroup: the next one in the order of the blocks' first tasks (see "Progress" above) - whatever
     // order the hardware starts workgroups in, the started blocks are a prefix of that order
-    if (threadIdx.x == 0) *(int*)smem = order[atomicAdd(ticketCtr, 1u) - ticketBase];
+    if (threadIdx.x == 0)
+    {
+        const unsigned t = atomicAdd(ticketCtr, 1u) - ticketBase;
+        ((int*)smem)[0] = order[t];
+        ((int*)smem)[1] = (int)t;
+    }
     __syncthreads();
-    const int b = *(const int*)smem;
+    const int b = ((const int*)smem)[0];
+    const bool firstBlock = ((const int*)smem)[1] == 0;
     __syncthreads();      // (smem is about to become the block's value slots)
     const int4 B = T.blk[b];
     const int rowBase = B.x, nLocal = B.y, ghostBase = B.z, nGhost = B.w;
-    const int nSlots = nLocal + nGhost;
+    const int histBase = T.blk2 ? T.blk2[b].x : 0, nHist = T.blk2 ? T.blk2[b].y : 0;
+    const int nSlots = nLocal + nGhost + 2 * nHist;
     double* x = smem;
     unsigned char* stamp = (unsigned char*)(x + nSlots);
     const int tid = threadIdx.x;
@@ -270,6 +299,13 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
     }
     for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) { x[i] = psi[T.localRow[rowBase + i]]; stamp[i] = 0; }
     for (int i = tid; i < nGhost; i += LDU_WAVE * (NW + 1)) { x[nLocal + i] = psi[T.ghostRow[ghostBase + i]]; stamp[nLocal + i] = 0; }
+    // hist pairs of the interface cells (own and ghosts): slot 0 = the initial value (stamp 0), slot 1 = what sweep 0 leaves
+    for (int i = tid; i < nHist; i += LDU_WAVE * (NW + 1))
+    {
+        const int h = nLocal + nGhost + 2 * i;
+        x[h] = psi[T.histRow[histBase + i]]; x[h + 1] = 0.0;
+        stamp[h] = 0; stamp[h + 1] = 0;
+    }
     __syncthreads();
     bool alive = true;
     if (wave == NW)
@@ -315,6 +351,7 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
     else
     {
         BK_FILLC(R0);
+        ldu_debug_stall(firstBlock && wave == 0);    // (tests: the first task of the launch sits still, ldu_ctx_set_watchdog)
         int left = nTasks;      // this wavefront's tasks
         unsigned long long* trc = g_bk_trace ? g_bk_trace + (size_t)t0 * 8 : nullptr;
 #define BK_TRC(k) do { if (trc && lane == 0) trc[k] = wall_clock64(); } while (0)
@@ -331,8 +368,9 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
             const int self = have ? (CUR).slot : 0;                                       \
             const int nl = (CUR).nl, nn = have ? (CUR).nn : 0, j = (CUR).j;               \
             int cc[16];                                                                   \
+            const int ni = (CUR).ni;                                                      \
             _Pragma("unroll") for (int q = 0; q < 16; q++)                                \
-                cc[q] = q < nn ? (int)((q & 1) ? (CUR).c2[q >> 1] >> 16 : (CUR).c2[q >> 1] & 0xffffu) : self; \
+                cc[q] = q < nn ? (int)((q & 1) ? (CUR).c2[q >> 1] >> 16 : (CUR).c2[q >> 1] & 0xffffu) + (q < ni ? (j & 1) : 0) : self; \
             /* lower entries need stamp j + 1, upper entries and the padding (the row itself) stamp j; a lane without a row \
                reads stamp[0] sixteen times over and does not vote */                     \
             const int want = 16 * j + nl;                                                 \
@@ -381,8 +419,16 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
                 x[self] = xn_;                                                            \
                 /* a row with a neighbour in another block publishes its granule (first: the longer way) */ \
                 if ((CUR).rg < 0) bk_store(G, (CUR).rg & 0x3fffffff, xn_, tagBase + (unsigned)j + 1u); \
+                const int hs_ = (CUR).hist;                                               \
+                if (hs_ >= 0)                                                             \
+                {                                                                         \
+                    /* an interface cell: its value by sweep parity, for the rows across the interface (here and elsewhere) */ \
+                    x[hs_ + ((j + 1) & 1)] = xn_;                                         \
+                    bk_store(G, T.ifBase + 2 * (CUR).ifg + ((j + 1) & 1), xn_, tagBase + (unsigned)j + 1u); \
+                }                                                                         \
                 LDU_LDS_RELEASE();                                                        \
                 stamp[self] = (unsigned char)(j + 1);                                     \
+                if (hs_ >= 0) stamp[hs_ + ((j + 1) & 1)] = (unsigned char)(j + 1);        \
             }                                                                             \
         }                                                                                 \
         LDU_STEP_FENCE();                                                                 \
@@ -426,7 +472,9 @@ static int bk_occupancy(size_t lds, int* perCU)
 
 static inline int bk_width(const ldu_addr* a, int c)
 {
-    return a->losortStart[c + 1] - a->losortStart[c] + a->ownerStart[c + 1] - a->ownerStart[c];
+    const BlockPlan* P = a->blocks;
+    return a->losortStart[c + 1] - a->losortStart[c] + a->ownerStart[c + 1] - a->ownerStart[c]
+           + (P && P->iface ? P->ifStart[c + 1] - P->ifStart[c] : 0);
 }
 
 // The grouping of sweep L (rows by their time T_L in the row-level DAG of the sweeps), its row and entry tables and the
@@ -455,6 +503,7 @@ static int bk_build_layout(ldu_addr* a, int L)
         {
             int t = L ? RTprev[c] : 0;
             if (L) for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) t = std::max(t, RTprev[a->u[f]]);
+            if (L && P->iface) for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++) t = std::max(t, RTprev[P->ifNbr[e]]);
             for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++) t = std::max(t, RT[a->l[a->losort[s]]]);
             RT[c] = t + 1;
         }
@@ -517,7 +566,8 @@ static int bk_build_layout(ldu_addr* a, int L)
         Y.nLanes = nLanes;
         Y.nEntries = nEnt + 16 * LDU_WAVE;
         // tables
-        std::vector<int2> meta((size_t)nLanes);
+        std::vector<int4> meta((size_t)nLanes);
+        std::vector<int> hslot(P->iface ? nC : 0, -1);     // hist pair (first LDS slot) of a cell in the current block
         std::vector<unsigned> col((size_t)(Y.nEntries / 2), 0);
         std::vector<int> srcFace((size_t)Y.nEntries, -1);
         {
@@ -529,30 +579,42 @@ static int bk_build_layout(ldu_addr* a, int L)
                 if (b != bCur)
                 {
                     for (int g = ghostBase[b]; g < ghostBase[b + 1]; g++) gslot[ghostCell[g]] = nLocal[b] + (g - ghostBase[b]);
+                    if (P->iface)
+                    {
+                        const int h0 = nLocal[b] + ghostBase[b + 1] - ghostBase[b];
+                        for (int h = P->histBase[b]; h < P->histBase[b + 1]; h++) hslot[P->histCell[h]] = h0 + 2 * (h - P->histBase[b]);
+                    }
                     bCur = b;
                 }
                 const int g = Y.grpOfCell[c], Tc = Y.grpT[g], stride = Y.grpStride[g];
                 const int lane0 = fill[g];
                 fill[g] += Tc;
-                const int nl = a->losortStart[c + 1] - a->losortStart[c], nn = nl + a->ownerStart[c + 1] - a->ownerStart[c];
+                // entries of a row: interface faces (patch, face order), lower neighbours, upper neighbours
+                const int ni = P->iface ? P->ifStart[c + 1] - P->ifStart[c] : 0;
+                const int nl = a->losortStart[c + 1] - a->losortStart[c], nn = ni + nl + a->ownerStart[c + 1] - a->ownerStart[c];
                 for (int tl = 0; tl < Tc; tl++)
                 {
-                    const int lo = std::min(16, std::max(0, nl - 16 * tl)), en = std::min(16, std::max(0, nn - 16 * tl));
-                    int2 M;
+                    const int fi = std::min(16, std::max(0, ni - 16 * tl));                       // interface entries of this lane
+                    const int lo = std::min(16, std::max(0, ni + nl - 16 * tl)) - fi;             // lower entries of this lane
+                    const int en = std::min(16, std::max(0, nn - 16 * tl));
+                    int4 M;
                     M.x = a->iperm[c] | (exported[c] ? (int)0x80000000 : 0) | (tl == Tc - 1 ? 0x40000000 : 0);
-                    M.y = slot[c] | (lo << 16) | (en << 24);
+                    M.y = slot[c] | (lo << 16) | (en << 21) | (fi << 26);
+                    M.z = ni ? hslot[c] : -1;
+                    M.w = ni ? P->ifIdx[c] : 0;
                     meta[(size_t)Y.grpLane0[g] + lane0 + tl] = M;
                 }
                 int q = 0;
                 auto put = [&](int n, int code) {
                     const int tl = q >> 4, qq = q & 15;
                     const size_t e = (size_t)Y.grpEnt[g] + (size_t)qq * stride + (size_t)(lane0 + tl);
-                    const unsigned sl = (unsigned)(blk[n] == b ? slot[n] : gslot[n]);
+                    const unsigned sl = code < -1 ? (unsigned)hslot[n] : (unsigned)(blk[n] == b ? slot[n] : gslot[n]);
                     const size_t e2 = (size_t)(Y.grpEnt[g] / 2) + (size_t)(qq >> 1) * stride + (size_t)(lane0 + tl);
                     col[e2] |= (qq & 1) ? sl << 16 : sl;
                     srcFace[e] = code;
                     q++;
                 };
+                for (int e = P->iface ? P->ifStart[c] : 0; e < (P->iface ? P->ifStart[c + 1] : 0); e++) put(P->ifNbr[e], -2 - P->ifPf[e]);
                 for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++) { const int f = a->losort[s]; put(a->l[f], f << 1); }
                 for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) put(a->u[f], (f << 1) | 1);
             }
@@ -576,6 +638,7 @@ static int bk_build_layout(ldu_addr* a, int L)
                     {
                         ph = std::max(ph, Yp->Phi[Yp->grpOfCell[c]] + 1);
                         for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) ph = std::max(ph, Yp->Phi[Yp->grpOfCell[a->u[f]]] + 1);
+                        if (P->iface) for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++) ph = std::max(ph, Yp->Phi[Yp->grpOfCell[P->ifNbr[e]]] + 1);
                     }
                     for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++)
                         ph = std::max(ph, Y.Phi[Y.grpOfCell[a->l[a->losort[s]]]] + 1);
@@ -602,9 +665,38 @@ static int bk_build(ldu_addr* a)
     a->blocks = P;
     P->built = true;
     const int nC = a->nCells, nF = a->nFaces;
-    if (!ctx->blkEngine || a->nPatchFaces || nC < ctx->blkMinCells || nC > ctx->blkMaxCells || nF == 0) return 0;
+    // (levels with coupled patches have no one-workgroup engine to fall back on: from 64 cells)
+    if (!ctx->blkEngine || nC < (a->nPatchFaces ? std::min(64, ctx->blkMinCells) : ctx->blkMinCells) || nC > ctx->blkMaxCells || nF == 0) return 0;
     const auto tB0 = std::chrono::steady_clock::now();
     const bool verbose = getenv("LDU_VERBOSE") != nullptr;
+    if (a->nPatchFaces)
+    {
+        // coupled patches: cyclic ones only (the neighbour is a cell of this addressing); a processor patch's neighbour lives on
+        // another rank - those levels stay on the level engines
+        { const char* e = getenv("LDU_BLK_IFACE"); if (e && !atoi(e)) return 0; }      // LDU_BLK_IFACE=0: patched levels on the level engines
+        for (const Patch& q : a->patches) if (q.nbrPatch < 0) return 0;
+        P->ifStart.assign(nC + 1, 0);
+        for (const Patch& q : a->patches) for (int c : q.faceCells) P->ifStart[c + 1]++;
+        for (int c = 0; c < nC; c++) P->ifStart[c + 1] += P->ifStart[c];
+        P->ifPf.resize(a->nPatchFaces); P->ifNbr.resize(a->nPatchFaces);
+        {
+            std::vector<int> pos(P->ifStart.begin(), P->ifStart.end() - 1);
+            for (const Patch& q : a->patches)          // patch order, face order: the order of updateMatrixInterfaces
+            {
+                const Patch& nb = a->patches[q.nbrPatch];
+                if (nb.n != q.n) return 0;
+                for (int i = 0; i < q.n; i++)
+                {
+                    const int c = q.faceCells[i];
+                    P->ifPf[pos[c]] = q.offset + i;
+                    P->ifNbr[pos[c]++] = nb.faceCells[i];
+                }
+            }
+        }
+        P->ifIdx.assign(nC, -1);
+        for (int c = 0; c < nC; c++) if (P->ifStart[c + 1] > P->ifStart[c]) P->ifIdx[c] = P->nIf++;
+        P->iface = true;
+    }
     for (int c = 0; c < nC; c++)
         if (bk_width(a, c) > 128) return 0;       // (8 lanes x 16 entries per row)
     // How the matrix is cut.  Every block must be resident (see "Progress"), so a configuration is (compute wavefronts per
@@ -675,8 +767,36 @@ static int bk_build(ldu_addr* a)
             }
             ghostBase[nB] = (int)ghostCell.size();
         }
+        // hist pairs (interfaces): a block's own interface cells (slot order), then the cells across its interfaces
+        P->histBase.assign(nB + 1, 0);
+        P->histCell.clear();
+        if (P->iface)
+        {
+            std::vector<int> cellsOf(nC), start(nB + 1, 0);
+            for (int c = 0; c < nC; c++) start[blk[c] + 1]++;
+            for (int b = 0; b < nB; b++) start[b + 1] += start[b];
+            { std::vector<int> pos(start.begin(), start.end() - 1); for (int r = 0; r < nC; r++) { const int c = a->perm[r]; cellsOf[pos[blk[c]]++] = c; } }
+            std::vector<int> mark(nC, -1);
+            for (int b = 0; b < nB; b++)
+            {
+                P->histBase[b] = (int)P->histCell.size();
+                for (int t = start[b]; t < start[b + 1]; t++)
+                    if (P->ifIdx[cellsOf[t]] >= 0) { mark[cellsOf[t]] = b; P->histCell.push_back(cellsOf[t]); }
+                for (int t = start[b]; t < start[b + 1]; t++)
+                {
+                    const int c = cellsOf[t];
+                    for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++)
+                    {
+                        const int n = P->ifNbr[e];
+                        if (mark[n] != b) { mark[n] = b; P->histCell.push_back(n); }
+                    }
+                }
+            }
+            P->histBase[nB] = (int)P->histCell.size();
+        }
         maxSlots = 0;
-        for (int b = 0; b < nB; b++) maxSlots = std::max(maxSlots, nLocal[b] + ghostBase[b + 1] - ghostBase[b]);
+        for (int b = 0; b < nB; b++)
+            maxSlots = std::max(maxSlots, nLocal[b] + ghostBase[b + 1] - ghostBase[b] + 2 * (P->histBase[b + 1] - P->histBase[b]));
         const size_t lds = ((size_t)9 * maxSlots + 64 + 15) & ~(size_t)15;
         perCU = 0;
         if (lds <= BK_MAX_LDS && maxSlots < 65536)
@@ -719,8 +839,17 @@ static int bk_build(ldu_addr* a)
     std::vector<int4> blkInfo(nB);
     for (int b = 0; b < nB; b++) blkInfo[b] = make_int4(rowBase[b], nLocal[b], ghostBase[b], ghostBase[b + 1] - ghostBase[b]);
     if (bk_upload(&P->d_blk, blkInfo) || bk_upload(&P->d_localRow, localRow) || bk_upload(&P->d_ghostRow, P->ghostRowH)) return -1;
-    LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(nC + 1)));
-    LDU_CHECK_HIP(ldu_memset_sync(P->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1)));
+    if (P->iface)
+    {
+        std::vector<int2> b2(nB);
+        for (int b = 0; b < nB; b++) b2[b] = make_int2(P->histBase[b], P->histBase[b + 1] - P->histBase[b]);
+        std::vector<int> hr(P->histCell.size());
+        for (size_t i = 0; i < hr.size(); i++) hr[i] = a->iperm[P->histCell[i]];
+        if (bk_upload(&P->d_blk2, b2) || bk_upload(&P->d_histRow, hr)) return -1;
+    }
+    // granules: one per row, then two per interface cell (by sweep parity)
+    LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(nC + 1 + 2 * (size_t)P->nIf)));
+    LDU_CHECK_HIP(ldu_memset_sync(P->d_granule, 0, sizeof(uint4) * (size_t)(nC + 1 + 2 * (size_t)P->nIf)));
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_ticket, sizeof(unsigned) * 64));
     LDU_CHECK_HIP(ldu_memset_sync(P->d_ticket, 0, sizeof(unsigned) * 64));
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_out, sizeof(double) * (size_t)(nC + 1)));
@@ -837,6 +966,20 @@ static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
                         tmp.emplace_back(((long)Phi[s - 1][layOf(s - 1).grpOfCell[P->ghostCell[g]]] << 3) | s,
                                          make_int4(P->blkNLocal[b] + (g - P->ghostBase[b]), P->ghostRowH[g], s, 0));
                 }
+                if (P->iface)
+                {
+                    // the cells across this block's interfaces (hist pairs behind its own interface cells): the value of sweep
+                    // s - 1 (stamp s) for the rows of sweep s, s = 1 ... k - 1, into the slot of parity s & 1
+                    const int h0 = P->blkNLocal[b] + P->ghostBase[b + 1] - P->ghostBase[b];
+                    for (int h = P->histBase[b]; h < P->histBase[b + 1]; h++)
+                    {
+                        const int n = P->histCell[h];
+                        if (P->blk[n] == b) continue;          // (its own cells: written by the producing wavefront itself)
+                        for (int s = 1; s <= k - 1; s++)
+                            tmp.emplace_back(((long)Phi[s - 1][layOf(s - 1).grpOfCell[n]] << 3) | s,
+                                             make_int4(h0 + 2 * (h - P->histBase[b]) + (s & 1), a->nCells + 1 + 2 * P->ifIdx[n] + (s & 1), s, 0));
+                    }
+                }
                 std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<long, int4>& x, const std::pair<long, int4>& y) { return x.first < y.first; });
                 for (auto& t : tmp) imps.push_back(t.second);
                 impStart[b + 1] = (int)imps.size();
@@ -867,6 +1010,7 @@ static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
             for (int t = 0; t <= maxT + 1; t++) { open += delta[t]; W.openMax = std::max(W.openMax, open); }
             // (a margin: a workgroup that has finished its block holds its slot until its last wavefront has left)
             W.usable = nB <= P->capacity || (double)W.openMax <= 0.8 * (double)P->capacity;
+            if (P->iface && k > P->nLayouts) W.usable = false;     // (every sweep needs its own tables: the parity of the hist slots)
             if (bk_upload(&W.d_order, ord)) return -1;
         }
         if (bk_upload(&W.d_tasks, tasks, 1) || bk_upload(&W.d_taskStart, taskStart) || bk_upload(&W.d_imps, imps, 1) ||
@@ -882,7 +1026,7 @@ static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
     return 0;
 }
 
-static int bk_values(ldu_addr* a, const double* levelVal, hipStream_t s, const double* out[BK_NLAY])
+static int bk_values(ldu_addr* a, const double* levelVal, const double* bou, hipStream_t s, const double* out[BK_NLAY])
 {
     BlockPlan* P = a->blocks;
     auto org = a->valOrigin.find(levelVal);
@@ -894,7 +1038,7 @@ static int bk_values(ldu_addr* a, const double* levelVal, hipStream_t s, const d
         if (C.stamp[L] != a->ctx->valStamp)
         {
             const int grid = (int)std::min<long>((P->lay[L].nEntries + 255) / 256, 8192);
-            bk_fill_kernel<<<grid, 256, 0, s>>>(P->lay[L].nEntries, P->lay[L].d_srcFace, org->second.first, org->second.second, C.d[L]);
+            bk_fill_kernel<<<grid, 256, 0, s>>>(P->lay[L].nEntries, P->lay[L].d_srcFace, org->second.first, org->second.second, bou, C.d[L]);
             C.stamp[L] = a->ctx->valStamp;
         }
     }
@@ -905,7 +1049,8 @@ static int bk_values(ldu_addr* a, const double* levelVal, hipStream_t s, const d
 bool k_blocks_active(ldu_addr* a)
 {
     ldu_ctx* ctx = a->ctx;
-    if (!ctx->blkEngine || !ctx->sweepP2P || a->nPatchFaces || a->nCells < ctx->blkMinCells || a->nCells > ctx->blkMaxCells) return false;
+    if (!ctx->blkEngine || !ctx->sweepP2P || a->nCells < (a->nPatchFaces ? std::min(64, ctx->blkMinCells) : ctx->blkMinCells)
+        || a->nCells > ctx->blkMaxCells) return false;
     if (!a->blocks && bk_build(a)) return false;
     return a->blocks && a->blocks->eligible;
 }
@@ -937,7 +1082,15 @@ int k_blocks_info(ldu_addr* a, int k, long out[8])
 }
 
 // k pipelined GaussSeidel sweeps (k = 1 ... 4); 1 = not taken
+int k_sweep_gs_blocks_if(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val, const double* bou);
 int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val)
+{
+    if (a->nPatchFaces) return 1;      // (with coupled patches: k_sweep_gs_blocks_if, which needs the interface coefficients)
+    return k_sweep_gs_blocks_if(a, k, psi, rhs, diag, val, nullptr);
+}
+
+// ... with coupled (cyclic) interfaces: rhs = the SOURCE (the interface terms are entries of the rows), bou = interfaceBouCoeffs
+int k_sweep_gs_blocks_if(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val, const double* bou)
 {
     ldu_ctx* ctx = a->ctx;
     if (k <= 0 || k > 4) return 1;
@@ -950,7 +1103,7 @@ int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const 
     if (bk_tasks(a, k, &W)) return -1;
     if (!W->usable) return 1;      // (more blocks open at a time than the chip holds: the level engines)
     {
-        const int rc = bk_values(a, val, s, T.val);
+        const int rc = bk_values(a, val, bou, s, T.val);
         if (rc) return rc;
     }
     if (P.gen != ctx->p2pGen)
@@ -961,12 +1114,14 @@ int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const 
     }
     if (P.epoch > 0xffffff00u)
     {
-        LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1), s));
+        LDU_CHECK_HIP(hipMemsetAsync(P.d_granule, 0, sizeof(uint4) * (size_t)(a->nCells + 1 + 2 * (size_t)P.nIf), s));
         P.epoch = 0;
     }
     const unsigned tagBase = P.epoch;
     P.epoch += (unsigned)k;
+    if (P.iface && !bou) return 1;
     T.blk = P.d_blk; T.localRow = P.d_localRow; T.ghostRow = P.d_ghostRow;
+    T.blk2 = P.iface ? P.d_blk2 : nullptr; T.histRow = P.d_histRow; T.ifBase = a->nCells + 1;
     for (int L = 0; L < BK_NLAY; L++) { const BlockPlan::Layout& Y = P.lay[std::min(L, P.nBuilt - 1)]; T.meta[L] = Y.d_meta; T.col[L] = Y.d_col; }
     T.nLayouts = P.nLayouts;
     T.tasks = W->d_tasks; T.taskStart = W->d_taskStart; T.imps = W->d_imps; T.impStart = W->d_impStart;

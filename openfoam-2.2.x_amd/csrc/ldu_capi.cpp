@@ -585,6 +585,7 @@ int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bou
         if (!is_device_ptr(bou) || !is_device_ptr(intc)) LDU_CHECK_HIP(hipStreamSynchronize(s));   // (as in set_coeffs)
     }
     m->coeffEpoch++;   // coarse-level interface coefficients follow
+    a->ctx->valStamp++;   // (layouts that hold interface coefficients next to the matrix coefficients: ldu_blocks.hip)
     return 0;
 }
 

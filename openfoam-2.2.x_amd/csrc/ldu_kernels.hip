@@ -1527,7 +1527,8 @@ int k_engine_of(ldu_addr* a, int kind /* 0 triangular, 1 one GaussSeidel sweep, 
 {
     ldu_ctx* ctx = a->ctx;
     if (!ctx->sweepP2P) return 4;
-    if (kind == 2 && !(ctx->clusterMulti && k_cluster_active(a)) && k_blocks_active(a)) return 6;
+    // (with coupled patches the cluster engine sweeps one by one; the block engine pipelines cyclic interfaces: ldu_solvers.cpp smooth_gs)
+    if (kind == 2 && (a->nPatchFaces || !(ctx->clusterMulti && k_cluster_active(a))) && k_blocks_active(a)) return 6;
     if (kind >= 1 && !a->nPatchFaces && ctx->wgEngine && a->wgLevel && 9 * (size_t)a->nCells + 64 <= 160 * 1024) return 5;
     if (kind >= 1 && ctx->smallKernels && a->maxRowWidth <= 16 && !a->nPatchFaces
         && a->nCells <= ((kind == 2 && ctx->smallPipe) ? ctx->smallMaxCells : std::min(ctx->smallMaxCells, 3000)))

@@ -228,6 +228,8 @@ int dev_precondition(ldu_matrix* m, int kind, double* w, const double* r, bool t
 
 // ---------------------------------------------------------------- smoothers
 
+int k_sweep_gs_blocks_if(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val, const double* bou);   // ldu_blocks.hip
+
 static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSweeps, bool sym)
 {
     ldu_addr* a = m->a;
@@ -281,6 +283,25 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         }
         if (pipelined && left == 0) return 0;
         nSweeps = left;
+    }
+    if (a->nPatchFaces && !sym && a->ctx->sweepP2P && nSweeps > 0 && k_blocks_active(a))
+    {
+        // coupled patches that are all cyclic (sub-domain mode: K ranks of the reference inside this addressing): the sweeps
+        // pipelined on the block engine, the interface terms as entries of the rows (ldu_blocks.hip)
+        int left = nSweeps;
+        while (left > 0)
+        {
+            const int k = left > 4 ? 4 : left;
+            const int rc = k_sweep_gs_blocks_if(a, k, psi, source, m->d_diag, m->d_valA, m->d_bou);
+            if (rc < 0) return -1;
+            if (rc > 0)
+            {
+                if (left != nSweeps) { ldu_set_error("block engine: refused after the first launch"); return -1; }
+                break;
+            }
+            left -= k;
+        }
+        if (left == 0) return 0;
     }
     if (a->nPatchFaces && !sym && a->ctx->sweepP2P && a->peerWg == 1 && a->peerWgEpoch == a->ctx->commEpoch && nSweeps > 0)
     {

@@ -101,13 +101,13 @@ def test_forced_abort_falls_back_to_level_engine(ctx, oracle, fuzz8723, what):
     m.close(); a.close()
 
 
-@pytest.mark.parametrize("what", ["GS2_cluster", "DIC_cluster", "GS3_level_engine", "GAMG"])
+@pytest.mark.parametrize("what", ["GS2_cluster", "DIC_cluster", "GS3_level_engine", "GS4_block_engine", "GAMG"])
 def test_crawling_sweep_trips_the_time_watchdog(ctx, oracle, what):
     """the spin bound counts polls, so a launch that merely CRAWLS never reached it.  Every wait is
     now bounded in wall-clock time as well (ldu_ctx_set_watchdog).  Injected here: the wave that runs the first task of
     each sweep launch stalls for 60 ms under a 10 ms budget - every wave behind it gives up, the operation is re-run on
     the level-kernel engine and must still return what the reference computes."""
-    p = cases.box3d(44) if what != "GS3_level_engine" else cases.random_graph(30000, 4, 60)
+    p = cases.box3d(44) if what not in ("GS3_level_engine", "GS4_block_engine") else cases.random_graph(30000, 9 if what == "GS4_block_engine" else 4, 60)
     S = oracle.System(p)
     a, m = capi.from_problem(ctx, p)
     if what.endswith("cluster"):
@@ -124,6 +124,9 @@ def test_crawling_sweep_trips_the_time_watchdog(ctx, oracle, what):
             assert np.array_equal(m.precondition("DIC", v), S.precondition("DIC", v)[0])
         elif what == "GS3_level_engine":
             assert np.array_equal(m.smooth("GaussSeidel", v, w, 3), S.smooth("GaussSeidel", v, w, 3))
+        elif what == "GS4_block_engine":
+            assert a.sweep_engine(2) == "blocks"
+            assert np.array_equal(m.smooth("GaussSeidel", v, w, 4), S.smooth("GaussSeidel", v, w, 4))
         else:
             kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10,
                       mergeLevels=1, tolerance=1e-7, relTol=0.01)

@@ -33,8 +33,14 @@ def _cases():
     return out
 
 
+@pytest.mark.parametrize("env", [{}, {"LDU_BLK_MIN": "1", "LDU_WG": "0", "LDU_SMALL": "0", "LDU_BLK_CELLS": "700"}, {"LDU_BLK_IFACE": "0"}],
+                         ids=["default", "blocks_everywhere", "level_engines"])
 @pytest.mark.parametrize("case", _cases(), ids=lambda c: c[0])
-def test_subdomain_mode_against_the_multidomain_oracle(oracle, case):
+def test_subdomain_mode_against_the_multidomain_oracle(oracle, case, env, monkeypatch):
+    """(env: the levels with interfaces on the block engine - pipelined sweeps, interface values by sweep parity - where it
+    applies / on every level down to the coarsest / nowhere: the level engines sweep by sweep)"""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
     name, p, rank, K = case
     if rank is None:
         rank = decompose.blob_ranks(p["nCells"], p["lowerAddr"], p["upperAddr"], K)
@@ -58,12 +64,17 @@ def test_subdomain_mode_against_the_multidomain_oracle(oracle, case):
     assert np.max(np.abs(xg - xo)) <= 1e-7 * np.max(np.abs(xo))
     # the hierarchy is the K-rank hierarchy: as many levels, as many cells per level as the oracle's K hierarchies together
     lv = m.gamg_level_sizes(**GAMG)
+    engines = [a.sweep_engine(2)] + [L["engine_gs_multi"] for L in lv]
+    if env.get("LDU_BLK_IFACE") == "0":
+        assert "blocks" not in engines, engines
+    elif env or p["nCells"] >= 2000:
+        assert engines[0] == "blocks", engines
     assert ctx.fallback_count() == 0
     # and the one-domain solve of the same matrix needs no more V-cycles than the K-rank algorithm (sanity of the comparison)
     a1, m1 = capi.from_problem(ctx, p)
     x1, p1 = m1.solve(p["psi"], p["source"], **GAMG)
     assert p1["nIterations"] <= pg["nIterations"] + 1
-    print("%s: K = %d, %d levels, %d V-cycles (one domain: %d)" % (name, K, len(lv), pg["nIterations"], p1["nIterations"]))
+    print("%s: K = %d, %d levels, %d V-cycles (one domain: %d), engines %s" % (name, K, len(lv), pg["nIterations"], p1["nIterations"], engines))
     m1.close(); a1.close(); m.close(); a.close(); ctx.close()
 
 

@@ -34,4 +34,5 @@ import json;d=json.loads([l for l in open('$O/bench_mb_rocprof.json') if l.start
 } > $P/${TAG}_dominant_kernel_durations.txt 2>&1
 cp $O/bench_mb_rocprof.json $P/${TAG}_bench_mb12_rcm_under_rocprof.json
 cd $R
+cp $P/${TAG}_* $O/ 2>/dev/null     # (gpurun brings back gpurun_out/ only)
 ls -la $P | grep ${TAG}_
