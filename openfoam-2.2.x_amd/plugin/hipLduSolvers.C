@@ -32,6 +32,8 @@
 #include "ldugpu.h"
 
 #include <map>
+#include <string>
+#include <cstdio>
 #include <vector>
 #include <stdint.h>
 
@@ -528,6 +530,59 @@ static void hipEnsureFaceWeights(hipLduEntry& e, const lduMatrix& matrix)
 }
 
 
+// LDU_DUMP_MATRIX="<field>:<n>:<file>": the n-th (1-based) matrix a solver of this plug-in is handed for <field> is written
+// to <file> before it is solved - int64 {nCells, nFaces, symmetric, hasSf}, lowerAddr, upperAddr (int32), diag, upper,
+// lower (asymmetric only), source, psi (doubles), Sf of the internal faces (3 doubles each, when the mesh is a polyMesh).
+// Matrices without coupled interfaces only.  The test / probe side reads it back (tests/test_simplefoam_motorbike.py):
+// a p-matrix of a real SIMPLE iteration on a real mesh as a stand-alone workload for the C ABI.
+static void hipDumpMatrix
+(
+    const word& fieldName, const lduMatrix& matrix, const lduInterfaceFieldPtrsList& interfaces,
+    const scalarField& psi, const scalarField& source
+)
+{
+    static const char* spec = getenv("LDU_DUMP_MATRIX");
+    if (!spec) return;
+    static std::map<std::string, int> calls;
+    const std::string s(spec);
+    const size_t a = s.find(':'), b = s.find(':', a == std::string::npos ? a : a + 1);
+    if (a == std::string::npos || b == std::string::npos) return;
+    if (s.substr(0, a) != fieldName) return;
+    if (++calls[fieldName] != atoi(s.substr(a + 1, b - a - 1).c_str())) return;
+    forAll(interfaces, i)
+    {
+        if (interfaces.set(i))
+        {
+            WarningIn("hipDumpMatrix") << "matrix with coupled interfaces: not dumped" << endl;
+            return;
+        }
+    }
+    FILE* f = fopen(s.substr(b + 1).c_str(), "wb");
+    if (!f) return;
+    const lduAddressing& ad = matrix.lduAddr();
+    const polyMesh* pm = hipPolyMesh(matrix.mesh());
+    const label nF = ad.lowerAddr().size();
+    const bool sf = pm && pm->nInternalFaces() == nF;
+    long long head[4] = {psi.size(), nF, matrix.symmetric() || matrix.diagonal(), sf};
+    fwrite(head, sizeof(long long), 4, f);
+    std::vector<int> idx(nF);
+    forAll(ad.lowerAddr(), i) idx[i] = ad.lowerAddr()[i];
+    fwrite(idx.data(), sizeof(int), nF, f);
+    forAll(ad.upperAddr(), i) idx[i] = ad.upperAddr()[i];
+    fwrite(idx.data(), sizeof(int), nF, f);
+    fwrite(matrix.diag().begin(), sizeof(double), psi.size(), f);
+    if (matrix.hasUpper()) fwrite(matrix.upper().begin(), sizeof(double), nF, f);
+    else { std::vector<double> z(nF, 0.0); fwrite(z.data(), sizeof(double), nF, f); }
+    if (!head[2]) fwrite(matrix.lower().begin(), sizeof(double), nF, f);
+    fwrite(source.begin(), sizeof(double), psi.size(), f);
+    fwrite(psi.begin(), sizeof(double), psi.size(), f);
+    if (sf) fwrite(pm->faceAreas().begin(), sizeof(double), 3*size_t(nF), f);
+    fclose(f);
+    Info<< "[hipLduSolvers] matrix of " << fieldName << " (call " << calls[fieldName] << ") written to "
+        << s.substr(b + 1).c_str() << endl;
+}
+
+
 // ------------------------------------------------------------------ solvers
 
 template<int SolverKind>
@@ -586,6 +641,7 @@ public:
             hipEnsureFaceWeights(e, matrix_);
         }
 
+        hipDumpMatrix(fieldName_, matrix_, interfaces_, psi, source);
         ldu_perf perf;
         hipCheck(ldu_solve(e.mat, &c, psi.begin(), source.begin(), &perf, NULL), "hipLduSolver::solve");
         if (getenv("LDU_VERBOSE"))

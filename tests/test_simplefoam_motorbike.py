@@ -1,0 +1,140 @@
+"""BASELINE config C3's flow case at the tutorial's mesh size, through an UNCHANGED reference application (VERDICT r4 item 9:
+"the real p-equation on the real mesh"): oracle/_ref/simpleFoam (the reference's own simpleFoam.C, oracle/build_ref_fv.sh) on
+the mesh the reference's blockMesh + snappyHexMesh made of the reference's motorBike.obj - 321 361 cells, 72 patches,
+refinement levels 0..6 (data/motorbike/mbtut_polymesh.npz; the case: oracle/motorbike_simplefoam_case.py).
+ * CPU: the stock run reproduces the committed log fixture (tests/golden/simplefoam_motorbike_tut.json).
+ * GPU (-m gpu): the same binary and case plus `libs ("libhipLduSolvers.so" "libhipFvSchemes.so");` and `hipGauss` schemes:
+   every solve (GAMG for p with the tutorial's block, smoothSolver + GaussSeidel for U, k, epsilon) and every gradient /
+   convection / laplacian assembly on the device, against the reference's residual history; the p-matrix of SIMPLE iteration
+   10 - laplacian((1|A(U)),p) with rAU = 1/UEqn().A() of a developing flow around the bike - is written out by the shim
+   (LDU_DUMP_MATRIX) and solved again through the C ABI against the oracle, beside the synthetic matrix
+   (openfoam_amd/motorbike.py: |Sf|/(n.d) x (1 + 0.5 u01)) the bench uses on the same addressing."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import cavity_case as cc
+import motorbike_simplefoam_case as mc
+
+PLUGIN = os.path.abspath(os.path.join(HERE, "..", "openfoam-2.2.x_amd", "lib", "libhipLduSolvers.so"))
+FV_PLUGIN = os.path.abspath(os.path.join(HERE, "..", "openfoam-2.2.x_amd", "lib", "libhipFvSchemes.so"))
+STEPS = 12
+DUMP_AT = 10
+needs = pytest.mark.skipif(not mc.available(), reason="needs oracle/_ref/simpleFoam and data/motorbike/mbtut_polymesh.npz")
+GAMG = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10, mergeLevels=1,
+            nPreSweeps=0, nPostSweeps=2)
+
+
+def golden():
+    return [tuple(l) for l in json.load(open(os.path.join(HERE, "golden", "simplefoam_motorbike_tut.json")))["lines"]]
+
+
+def read_dump(path):
+    """the shim's LDU_DUMP_MATRIX file (plugin/hipLduSolvers.C: hipDumpMatrix) -> problem dict"""
+    with open(path, "rb") as f:
+        nC, nF, sym, hasSf = (int(v) for v in np.fromfile(f, dtype=np.int64, count=4))
+        p = dict(nCells=nC, lowerAddr=np.fromfile(f, dtype=np.int32, count=nF), upperAddr=np.fromfile(f, dtype=np.int32, count=nF),
+                 diag=np.fromfile(f, dtype=np.float64, count=nC), upper=np.fromfile(f, dtype=np.float64, count=nF))
+        if not sym:
+            p["lower"] = np.fromfile(f, dtype=np.float64, count=nF)
+        p["source"] = np.fromfile(f, dtype=np.float64, count=nC)
+        p["psi"] = np.fromfile(f, dtype=np.float64, count=nC)
+        if hasSf:
+            p["Sf"] = np.fromfile(f, dtype=np.float64, count=3 * nF).reshape(nF, 3)
+    return p
+
+
+@needs
+def test_stock_simplefoam_reproduces_the_fixture(tmp_path):
+    case = str(tmp_path / "motorBike")
+    mc.write(case, STEPS)
+    assert cc.solve_lines(mc.run(case)) == golden()
+
+
+@pytest.mark.gpu
+@needs
+@pytest.mark.skipif(not (os.path.exists(PLUGIN) and os.path.exists(FV_PLUGIN)), reason="needs the prebuilt plugins")
+def test_simplefoam_motorbike_through_the_plugins(tmp_path, oracle):
+    from openfoam_amd import capi, motorbike
+    case = str(tmp_path / "motorBike")
+    dump = str(tmp_path / "p_matrix.bin")
+    mc.write(case, STEPS, libs=[PLUGIN, FV_PLUGIN], gauss="hipGauss")
+    t0 = time.time()
+    log = mc.run(case, extra_env={"LDU_VERBOSE": "1", "LDU_DUMP_MATRIX": "p:%d:%s" % (DUMP_AT, dump)})
+    wall = time.time() - t0
+    assert "[hipLduSolvers]" in log and "[hipFvSchemes] finite-volume stencils on the device" in log, log[-2000:]
+    lines, gold = cc.solve_lines(log), golden()
+    assert len(lines) == len(gold) == 6 * STEPS
+    worst, off = 0.0, 0
+    for got, ref in zip(lines, gold):
+        # the application-level bars of DESIGN section 7b: same solver, field; iteration count within one (a residual landing
+        # on the relTol threshold) on at most 2 % of the lines; initial residuals to 1e-3
+        assert got[0] == ref[0] and got[1] == ref[1], (got, ref)
+        assert abs(got[4] - ref[4]) <= 1, (got, ref)
+        off += int(got[4] != ref[4])
+        assert abs(got[2] - ref[2]) <= 1e-3 * abs(ref[2]) + 1e-9, (got, ref)
+        if ref[2]:
+            worst = max(worst, abs(got[2] - ref[2]) / abs(ref[2]))
+    assert off <= max(1, len(lines) // 50)
+    psecs = [float(l.split(" in ")[1].split()[0]) for l in log.splitlines() if l.startswith("[hipLduSolvers] GAMG for p")]
+    print("simpleFoam on the tutorial-size motorBike mesh through both plug-ins: %d solver lines, %d with a different iteration "
+          "count, worst relative difference of an initial residual %.2e; %d SIMPLE iterations in %.1f s wall (incl. start-up); "
+          "p-solves on the GPU: first %.3f s (agglomeration), then %.4f s mean"
+          % (len(lines), off, worst, STEPS, wall, psecs[0], float(np.mean(psecs[1:]))))
+
+    # the p-matrix of SIMPLE iteration DUMP_AT as a stand-alone workload: HIP path against the oracle, bit for bit
+    assert os.path.exists(dump), log[-1500:]
+    p = read_dump(dump)
+    assert "lower" not in p and "Sf" in p and p["nCells"] > 300000
+    l, u = p["lowerAddr"], p["upperAddr"]
+    assert np.all(p["upper"] < 0) and np.all(p["diag"] > 0)
+    ratio = p["upper"].min() / p["upper"].max()
+    ctx = capi.Context(0)
+    a = capi.Addressing(ctx, p["nCells"], l, u)
+    p["faceWeights"] = a.set_face_areas(p.pop("Sf"))
+    m = capi.Matrix(a)
+    m.set_coeffs(p["diag"], p["upper"], None)
+    S = oracle.System(p)
+    rng = np.random.RandomState(5)
+    x, b = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+    assert np.array_equal(m.Amul(x), S.Amul(x))
+    for k in (1, 2):
+        assert np.array_equal(m.smooth("GaussSeidel", x, b, k), S.smooth("GaussSeidel", x, b, k)), k
+    kw = dict(GAMG, tolerance=1e-7, relTol=0.0, maxIter=60)
+    xg, pg = m.solve(p["psi"], p["source"], **kw)
+    xo, po = S.solve(p["psi"], p["source"], **kw)
+    assert pg["nIterations"] == po["nIterations"] and pg["converged"]
+    np.testing.assert_allclose(pg["history"], po["history"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(xg - xo)) <= 1e-8 * np.max(np.abs(xo))
+
+    # V-cycle cost: the real p-matrix beside the synthetic one of the bench on the same mesh (same addressing, same
+    # faceAreaPair weights -> the same hierarchy: a V-cycle costs the same, the number of V-cycles is what differs)
+    def vcycle_ms(mat, psi, src):
+        mat.solve(psi, src, **dict(GAMG, tolerance=0.0, relTol=0.0, maxIter=3))
+        t = time.time()
+        _, pf = mat.solve(psi, src, **dict(GAMG, tolerance=0.0, relTol=0.0, maxIter=20))
+        return (time.time() - t) * 1e3 / pf["nIterations"]
+    real_ms = vcycle_ms(m, p["psi"], p["source"])
+    q = motorbike.problem("mbtut") if motorbike.available("mbtut") else None
+    if q is not None and q["nCells"] == p["nCells"] and np.array_equal(q["lowerAddr"], l):
+        a2 = capi.Addressing(ctx, q["nCells"], q["lowerAddr"], q["upperAddr"], q["faceWeights"])
+        m2 = capi.Matrix(a2)
+        m2.set_coeffs(q["diag"], q["upper"], None)
+        syn_ms = vcycle_ms(m2, q["psi"], q["source"])
+        _, ps = m2.solve(q["psi"], q["source"], **kw)
+        print("p-matrix of SIMPLE iteration %d (coefficient ratio max/min %.1e): %d V-cycles to 1e-7, %.3f ms per V-cycle; "
+              "the bench's synthetic matrix on the same mesh: %d V-cycles, %.3f ms per V-cycle"
+              % (DUMP_AT, ratio, pg["nIterations"], real_ms, ps["nIterations"], syn_ms))
+        assert abs(real_ms - syn_ms) <= 0.25 * syn_ms
+        m2.close(); a2.close()
+    else:
+        print("p-matrix of SIMPLE iteration %d (coefficient ratio max/min %.1e): %d V-cycles to 1e-7, %.3f ms per V-cycle"
+              % (DUMP_AT, ratio, pg["nIterations"], real_ms))
+    assert ctx.fallback_count() == 0
+    m.close(); a.close(); ctx.close()
