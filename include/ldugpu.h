@@ -253,6 +253,10 @@ int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap);
  * of k sweeps (all 0: the addressing is not on the block engine). */
 int ldu_debug_blocks_trace(ldu_matrix* m, void* buf);
 int ldu_debug_blocks_info(ldu_matrix* m, int32_t k, int64_t* out);
+/* Per-sweep layouts of the chip-wide pipelined GaussSeidel sweeps (ldu_gslayouts.cpp): out[0] = sweeps with a layout of their own
+ * built so far (0: none / not on this addressing), out[1 + j] = slices of sweep j's layout (j = 1 .. 3), out[5] = slices of the
+ * level layout. */
+int ldu_debug_gs_layouts(ldu_matrix* m, int64_t* out);
 int ldu_debug_cluster_levels(ldu_matrix* m, int32_t* out, int32_t cap);
 /* ldu_debug_slices: per slice of the level-ordered layout {first row, rows, entries per row, most lower, most upper
  * neighbours of a row}; out holds 5 * cap values, cap >= slices */

@@ -20,7 +20,7 @@ AGGLOMERATORS = {"faceAreaPair": 0, "algebraicPair": 1}
 
 EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
-    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_blocks_trace", "ldu_debug_blocks_info", "ldu_debug_slice_levels",
+    "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_blocks_trace", "ldu_debug_blocks_info", "ldu_debug_gs_layouts", "ldu_debug_slice_levels",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_ctx_comm_init_peer", "ldu_ctx_comm_select", "ldu_ctx_comm_info", "ldu_addr_create", "ldu_addr_add_patch",
     "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights", "ldu_addr_set_subdomains", "ldu_partition_blobs",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
@@ -596,6 +596,13 @@ class Matrix:
         _chk(lib().ldu_profile_end(self.h, ms, cnt))
         names = ["amul", "gs_sweep", "tri_sweep", "residual", "gs_multi", "c5", "c6", "rd_sweep"]
         return {n: dict(ms=ms[i], count=cnt[i]) for i, n in enumerate(names) if cnt[i]}
+
+    def gs_layouts(self):
+        """per-sweep layouts of the chip-wide pipelined GaussSeidel sweeps: dict(built=sweeps with their own layout, slices=[...])"""
+        o = np.zeros(6, dtype=np.int64)
+        lib().ldu_debug_gs_layouts.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(lib().ldu_debug_gs_layouts(self.h, o.ctypes.data))
+        return dict(built=int(o[0]), slices=[int(v) for v in o[2:5]], level_slices=int(o[5]))
 
     def gamg_level_sizes(self, **controls):
         """[(nCells, nFaces, dependency levels, widest row, engine of one GS sweep, engine of pipelined sweeps)] of the

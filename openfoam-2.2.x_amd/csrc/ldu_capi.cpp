@@ -216,6 +216,10 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e) c->blkWavesPerSweep = atoi(e);
     e = getenv("LDU_BLK_XCD");
     if (e) c->blkXcdMap = atoi(e);
+    e = getenv("LDU_GS_LAYOUTS");
+    if (e) c->gsLayouts = atoi(e) != 0;
+    e = getenv("LDU_GS_LAYOUTS_MIN");
+    if (e) c->gsLayoutsMinCells = atoi(e);
     e = getenv("LDU_BLK_LAYOUTS");
     if (e && atoi(e) > 0) c->blkLayouts = atoi(e);
     e = getenv("LDU_BLK_PER_CU");
@@ -479,7 +483,7 @@ void matrix_free(ldu_matrix* m)
     // the cluster engine keeps converted copies of this matrix's value arrays, keyed by their addresses
     for (const double* v : {(const double*)m->d_valA, (const double*)m->d_valT, (const double*)m->d_valP,
                             (const double*)m->d_valPT})
-        if (v) { cluster_forget(m->a, v); blocks_forget(m->a, v); m->a->valOrigin.erase(v); }
+        if (v) { cluster_forget(m->a, v); blocks_forget(m->a, v); gs_layouts_forget(m->a, v); m->a->valOrigin.erase(v); }
     if (m->d_lowerO && m->d_lowerO != m->d_upperO) (void)hipFree(m->d_lowerO);
     if (m->d_valT && m->d_valT != m->d_valA) (void)hipFree(m->d_valT);
     void* ptrs[] = {m->d_diagO, m->d_upperO, m->d_diag, m->d_valA, m->d_bou, m->d_int, m->d_rD,
@@ -508,6 +512,7 @@ int matrix_refresh_layout(ldu_matrix* m, hipStream_t onStream)
     {
         cluster_forget(a, m->d_valT);
         blocks_forget(a, m->d_valT);
+        gs_layouts_forget(a, m->d_valT);
         a->valOrigin.erase(m->d_valT);
         (void)hipFree(m->d_valT);
         m->d_valT = m->d_valA;
@@ -870,6 +875,16 @@ int ldu_debug_blocks_info(ldu_matrix* m, int32_t k, int64_t* out)
     const int rc = k_blocks_info(m->a, k, o);
     for (int i = 0; i < 8; i++) out[i] = o[i];
     return rc < 0 ? -1 : 0;
+}
+
+int ldu_debug_gs_layouts(ldu_matrix* m, int64_t* out)
+{
+    const ldu_addr* a = m->a;
+    for (int i = 0; i < 6; i++) out[i] = 0;
+    out[0] = a->gsLayState == 1 ? a->gsLayBuilt : 0;
+    for (int j = 1; j < 4; j++) out[1 + j] = a->gsLay[j] ? a->gsLay[j]->nSlices : 0;
+    out[5] = a->nSlices;
+    return 0;
 }
 
 int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap)

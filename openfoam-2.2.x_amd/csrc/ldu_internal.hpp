@@ -134,7 +134,7 @@ struct ldu_ctx {
     // block engine (ldu_blocks.hip): k pipelined GaussSeidel sweeps with the hand-offs inside a workgroup's LDS, blocks of a few
     // thousand cells, granules only between blocks
     int blkEngine = 1;               // LDU_BLK=0: off
-    int blkMinCells = 2000;          // LDU_BLK_MIN (below: the one-workgroup engine)
+    int blkMinCells = 100;           // LDU_BLK_MIN (below: the one-workgroup engine)
     int blkWideFrom = 400000;        // LDU_BLK_WIDE_FROM: seven compute wavefronts per block from this many cells, three below
     int blkMaxCells = 2600000;       // LDU_BLK_MAX (above: more blocks than resident workgroups, and on the motorBike levels nearly all of
                                      // them are open at once - 348 of 349 at 3.1 M cells, 678 of 702 at 6.3 M: profiles/r05_block_open_counts.log)
@@ -145,6 +145,9 @@ struct ldu_ctx {
     int blkMaxPerCU = 4;             // LDU_BLK_PER_CU: workgroups per CU the grid may count on
     int blkWavesPerSweep = 0;        // LDU_BLK_WPS: wavefronts a sweep's tasks of one block are dealt to (0 = all tasks round-robin over all wavefronts)
     int blkXcdMap = 1;               // LDU_BLK_XCD=0: blocks in launch order instead of contiguous ranges per XCD
+    bool gsLayouts = false;          // LDU_GS_LAYOUTS=1: per-sweep layouts for the chip-wide pipelined GaussSeidel sweeps (ldu_gslayouts.cpp);
+                                     // off: measured slower on the levels that would take them (see the file's header)
+    int gsLayoutsMinCells = 200000;  // LDU_GS_LAYOUTS_MIN
     int blkLayouts = 4;              // LDU_BLK_LAYOUTS: own grouping (by the row's time in the DAG of the k sweeps) for the first n sweeps
     int smallPipe = 1;               // LDU_SMALL_PIPE=0: k sweeps one after the other in ONE wavefront (round-1 kernel)
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
@@ -323,7 +326,24 @@ struct ldu_addr {
     double smallLag = 0;                   // average need[s] - s: how far a sweep trails the previous one
 
     // topological (sweep, slice) task lists of k pipelined GaussSeidel sweeps, per k
-    struct GsTasks { int* d_tasks = nullptr; int n = 0; int* d_slabTasks = nullptr; int slabStart[9] = {0}; };
+    struct GsTasks { int* d_tasks = nullptr; int n = 0; int* d_slabTasks = nullptr; int slabStart[9] = {0}; bool layouts = false; };
+    // Per-sweep layouts of the chip-wide pipelined GaussSeidel sweeps (ldu_gslayouts.cpp): sweep j >= 1 of a launch has its OWN
+    // slices - rows grouped by their time T_j in the row-level DAG of the k sweeps (T_0 = dependency level, T_j(r) = 1 + max(T_j of
+    // the lower neighbours, T_j-1 of the upper neighbours, T_j-1(r))) - with its own entry tables; rows are addressed through
+    // rowIdx (slot -> row of the level numbering), granules / psi / rhs / diag stay in the level numbering.
+    struct GsLayout {
+        int nSlices = 0; long nEntries = 0;
+        int* d_sliceRow = nullptr; int* d_sliceCnt = nullptr; int* d_sliceEnt = nullptr; int* d_sliceW = nullptr;
+        unsigned char* d_sliceT = nullptr; unsigned char* d_nL = nullptr; unsigned char* d_nU = nullptr;
+        int* d_col = nullptr; int* d_face = nullptr; int* d_rowIdx = nullptr;
+        std::vector<int> sliceTime;          // host: T_j of the slice's rows
+        bool coop = false;
+    };
+    GsLayout* gsLay[4] = {nullptr, nullptr, nullptr, nullptr};     // [j], j = 1 .. 3 ([0] = the level layout itself)
+    int gsLayState = 0;                    // 0 not decided, 1 built (up to gsLayBuilt sweeps), -1 not on this addressing
+    int gsLayBuilt = 0;
+    struct GsLayVals { double* d[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned long long stamp[4] = {0, 0, 0, 0}; };
+    std::map<const double*, GsLayVals> gsLayVals;     // level value array -> the layouts' value arrays
     // level-layout coefficient arrays filled from face-ordered ones (fill_sell): value array -> (lower-side, upper-side source)
     std::map<const double*, std::pair<const double*, const double*>> valOrigin;
     std::map<int, GsTasks> gsTasks;
@@ -445,6 +465,8 @@ int k_blocks_info(ldu_addr* a, int k, long out[8]);
 void blocks_free(ldu_addr* a);
 extern "C" int partition_blobs(int nCells, int nFaces, const int* lowerAddr, const int* upperAddr, int nParts, int* part);   // ldu_mesh.hip
 void blocks_forget(ldu_addr* a, const double* levelVal);
+void gs_layouts_free(ldu_addr* a);                                    // ldu_gslayouts.cpp
+void gs_layouts_forget(ldu_addr* a, const double* levelVal);
 void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converted copy of a value array
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);

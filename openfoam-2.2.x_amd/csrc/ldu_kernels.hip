@@ -65,6 +65,16 @@ int k_fill_sell(ldu_addr* a, const double* lowerO, const double* upperO, double*
     return 0;
 }
 
+// the coefficient array of a per-sweep layout (ldu_gslayouts.cpp): the same fill, the layout's own tables (nL per slot)
+int k_fill_layout(const ldu_addr::GsLayout* Y, const double* lowerO, const double* upperO, double* val, hipStream_t s)
+{
+    if (Y->nSlices == 0) return 0;
+    fill_sell_kernel<<<cdiv(Y->nSlices, WPB), BLK, 0, s>>>(Y->nSlices, Y->d_sliceRow, Y->d_sliceCnt, Y->d_sliceEnt, Y->d_sliceW,
+                                                           Y->d_nL, Y->d_face, lowerO, upperO, val);
+    LDU_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void scale_rows_kernel(int nSlices, const int* __restrict__ sliceRow,
                                   const int* __restrict__ sliceCnt, const int* __restrict__ sliceEnt,
                                   const int* __restrict__ sliceW, const double* __restrict__ valIn,
@@ -267,6 +277,7 @@ struct SliceTab {
     const unsigned char* sliceT = nullptr;   // per slice: lanes per row (cooperative slices: 2 / 4 / 8), or no table
     const int* gate = nullptr;        // per slice: slice whose completion opens the polling gate (-1: none)
     unsigned* sliceDone = nullptr;    // per slice: tag of the last sweep that completed it (hint only)
+    const int* rowIdx = nullptr;      // per-sweep layouts (ldu_gslayouts.cpp): slot -> row of the level numbering; nL / nU are per slot
 };
 
 template <int MODE>
@@ -931,8 +942,9 @@ __device__ __forceinline__ bool coop_rows(const SliceTab& T, int s, int Tl, int 
     const int i = lane & (R - 1), t = lane / R;  // row, part: lanes of one part read consecutive rows (coalesced)
     const int cnt = T.sliceCnt[s];
     const bool act = i < cnt;
-    const int r = T.sliceRow[s] + (act ? i : 0);
-    const int nl = act ? T.nL[r] : 0, nu = act ? T.nU[r] : 0;
+    const int slot = T.sliceRow[s] + (act ? i : 0);
+    const int r = T.rowIdx ? T.rowIdx[slot] : slot;
+    const int nl = act ? T.nL[slot] : 0, nu = act ? T.nU[slot] : 0;
     const long ent0 = (long)T.sliceEnt[s] + i;
     int first, step, nd, nOld;
     if (B == SW_TRI_FWD || B == SW_RD) { first = 0; step = 1; nd = nl; nOld = 0; }
@@ -1873,9 +1885,10 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
     ldu_debug_stall(s == 0 && j == 0);
     unsigned long long* const trc = g_gsm_trace ? g_gsm_trace + ((size_t)j * (size_t)g_gsm_trace_stride + (size_t)s) * 8 : nullptr;
     if (trc && lane == 0) trc[0] = (unsigned long long)wall_clock64();
-    const int r = T.sliceRow[s] + lane;
-    const int nl = T.nL[r];
-    const int nu = T.nU[r];
+    const int slot = T.sliceRow[s] + lane;
+    const int r = T.rowIdx ? T.rowIdx[slot] : slot;
+    const int nl = T.nL[slot];
+    const int nu = T.nU[slot];
     const long ent = (long)T.sliceEnt[s] + lane;
     const bool exported = SLAB ? xflag[r] != 0 : false;
     double acc = rhs[r];
@@ -1968,11 +1981,14 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
     }
 }
 
+// (per-sweep layouts, ldu_gslayouts.cpp: tables and coefficients of sweeps 1 .. 3; a task's slice index counts in ITS sweep's layout)
+struct GsLays { SliceTab t[3]; const double* val[3]; int on; };
+
 __global__ void __launch_bounds__(P2P_BLK)
 sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
                           unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
                           int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val,
-                          int puSlots)
+                          int puSlots, GsLays L)
 {
     __shared__ int s_chunk[2];
     extern __shared__ double s_pu[];   // [wave][puSlots][64]: parked products of wide upper parts
@@ -1998,12 +2014,20 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
         const int ti = chunk * P2P_CHUNK + wave;
         if (ti < nTasks)
         {
-            const int task = tasks[ti];
+            const int task = __builtin_amdgcn_readfirstlane(tasks[ti]);    // (wave-uniform: ti depends on the wave only)
             if (task >= 0)
             {
-                const int sl = task & 0x0fffffff;
-                p2p_gs_task<false>(T, sl, task >> 28, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst,
-                                   s_pu + (size_t)wave * puSlots * LDU_WAVE, puSlots);
+                const int sl = task & 0x0fffffff, j = task >> 28;
+                if (L.on && j > 0)
+                {
+                    const SliceTab& Tj = j == 1 ? L.t[0] : (j == 2 ? L.t[1] : L.t[2]);
+                    const double* vj = j == 1 ? L.val[0] : (j == 2 ? L.val[1] : L.val[2]);
+                    p2p_gs_task<false>(Tj, sl, j, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, vj, waitEst,
+                                       s_pu + (size_t)wave * puSlots * LDU_WAVE, puSlots);
+                }
+                else
+                    p2p_gs_task<false>(T, sl, j, k, lane, G, nullptr, nullptr, tag0, abortFlag, psi, rhs, diag, val, waitEst,
+                                       s_pu + (size_t)wave * puSlots * LDU_WAVE, puSlots);
             }
         }
         if (window) __syncthreads();
@@ -3024,6 +3048,48 @@ static int gs_tasks_ensure(ldu_addr* a, int k)
     return 0;
 }
 
+// ... and with per-sweep layouts (ldu_gslayouts.cpp): task (j, slice of layout j) at the time T_j of the slice's rows - any order
+// by T is topological; cached under key k + 16.  1 = no layouts on this addressing (the caller takes the list above).
+bool gs_layouts_wanted(const ldu_addr* a);
+int gs_layouts_ensure(ldu_addr* a, int k);
+int gs_layout_values(ldu_addr* a, const double* levelVal, int k, hipStream_t s, const double* out[4]);
+static int gs_layout_tasks_ensure(ldu_addr* a, int k)
+{
+    if (g_wg_trace_on || !gs_layouts_wanted(a) || (a->nSlabs > 0 && use_slab(a, 2, k))) return 1;
+    if (a->gsTasks.find(k + 16) != a->gsTasks.end()) return a->gsTasks[k + 16].n < 0 ? 1 : 0;
+    const int rc = gs_layouts_ensure(a, k);
+    if (rc < 0) return -1;
+    ldu_addr::GsTasks gt;
+    gt.layouts = true;
+    if (rc > 0) { gt.n = -1; a->gsTasks.emplace(k + 16, gt); return 1; }
+    int maxT = a->nLevels - 1;
+    for (int j = 1; j < k; j++)
+        for (int t : a->gsLay[j]->sliceTime) maxT = std::max(maxT, t);
+    std::vector<long> start((size_t)maxT + 2, 0);
+    for (int L = 0; L < a->nLevels; L++) start[(size_t)L + 1] += a->levelSliceStart[L + 1] - a->levelSliceStart[L];
+    for (int j = 1; j < k; j++)
+        for (int t : a->gsLay[j]->sliceTime) start[(size_t)t + 1]++;
+    for (size_t i = 0; i + 1 < start.size(); i++) start[i + 1] += start[i];
+    std::vector<int> tasks((size_t)start.back(), 0);
+    // inside one T the sweeps ascend (the earlier sweep is what everything else waits for) and the slices keep their order
+    for (int L = 0; L < a->nLevels; L++)
+        for (int sl = a->levelSliceStart[L]; sl < a->levelSliceStart[L + 1]; sl++) tasks[(size_t)start[L]++] = sl;
+    for (int j = 1; j < k; j++)
+    {
+        const std::vector<int>& st = a->gsLay[j]->sliceTime;
+        if (st.size() >= (1u << 28)) { ldu_set_error("GS layouts: too many slices"); return -1; }
+        for (size_t sl = 0; sl < st.size(); sl++) tasks[(size_t)start[st[sl]]++] = (j << 28) | (int)sl;
+    }
+    gt.n = (int)tasks.size();
+    LDU_CHECK_HIP(hipMalloc((void**)&gt.d_tasks, sizeof(int) * (tasks.size() + 1)));
+    LDU_CHECK_HIP(hipMemcpy(gt.d_tasks, tasks.data(), sizeof(int) * tasks.size(), hipMemcpyHostToDevice));
+    if (getenv("LDU_VERBOSE"))
+        fprintf(stderr, "[ldugpu] GS pipeline plan with per-sweep layouts: %d cells, k = %d: %d tasks, %d steps in the row-level DAG "
+                        "(one sweep: %d levels)\n", a->nCells, k, gt.n, maxT + 1, a->nLevels);
+    a->gsTasks.emplace(k + 16, gt);
+    return 0;
+}
+
 int k_gs_prebuild(ldu_addr* a, int k)
 {
     ldu_ctx* ctx = a->ctx;
@@ -3034,9 +3100,13 @@ int k_gs_prebuild(ldu_addr* a, int k)
         const int rb = k_blocks_prebuild(a, k);
         if (rb < 0) return -1;
         if (rb != 2) return 0;
-        return gs_tasks_ensure(a, k);      // this k stays on the level engines
+        const int rl = gs_layout_tasks_ensure(a, k);      // this k stays on the level engines
+        if (rl <= 0) return rl;
+        return gs_tasks_ensure(a, k);
     }
     if (e != 0 && e != 1) return 0;      // one workgroup / single wavefront / clusters: their own (cheap) plans
+    const int rl = gs_layout_tasks_ensure(a, k);
+    if (rl <= 0) return rl;
     return gs_tasks_ensure(a, k);
 }
 
@@ -3047,8 +3117,35 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     ldu_addr::P2PLane& P = *a->lane(0);
     hipStream_t s = ctx->stream;
     if (a->nCells == 0 || k <= 0) return 0;
-    if (gs_tasks_ensure(a, k)) return -1;
-    auto it = a->gsTasks.find(k);
+    // per-sweep layouts (ldu_gslayouts.cpp) where they apply and the coefficients' origin is known
+    GsLays LY = GsLays();
+    bool lay = false;
+    if (k >= 2 && k <= 4)
+    {
+        const int rl = gs_layout_tasks_ensure(a, k);
+        if (rl < 0) return -1;
+        if (rl == 0)
+        {
+            const double* lv[4];
+            const int rv = gs_layout_values(a, val, k, s, lv);
+            if (rv < 0) return -1;
+            if (rv == 0)
+            {
+                lay = true;
+                LY.on = 1;
+                for (int j = 1; j < k; j++)
+                {
+                    const ldu_addr::GsLayout* Y = a->gsLay[j];
+                    SliceTab& t = LY.t[j - 1];
+                    t.sliceRow = Y->d_sliceRow; t.sliceCnt = Y->d_sliceCnt; t.sliceEnt = Y->d_sliceEnt; t.nL = Y->d_nL; t.nU = Y->d_nU;
+                    t.col = Y->d_col; t.sliceW = Y->d_sliceW; t.sliceT = Y->coop ? Y->d_sliceT : nullptr; t.rowIdx = Y->d_rowIdx;
+                    LY.val[j - 1] = lv[j];
+                }
+            }
+        }
+    }
+    if (!lay && gs_tasks_ensure(a, k)) return -1;
+    auto it = a->gsTasks.find(lay ? k + 16 : k);
     if (it->second.n < 0) return 1;   // not pipelinable
     SliceTab T{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_col};
     if (a->nCoopSlices) T.sliceT = a->d_sliceT;
@@ -3084,7 +3181,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     P.epoch += (unsigned)k;
     ctx->profStart(a, 4);   // "gs_multi": one launch = k pipelined sweeps
     T.sliceW = a->d_sliceW;
-    if (it->second.d_slabTasks && use_slab(a, 2, k))
+    if (!lay && it->second.d_slabTasks && use_slab(a, 2, k))
     {
         SliceTab TS{a->d_sliceRow, a->d_sliceCnt, a->d_sliceEnt, a->d_nL, a->d_nU, a->d_colX};
         if (a->nCoopSlices) TS.sliceT = a->d_sliceT;
@@ -3110,7 +3207,7 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     const int puSlots = gs_pu_slots(a);
     sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE, s>>>(
             T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
-            P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val, puSlots);
+            P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val, puSlots, LY);
     ctx->profStop(a, 4);
     P.ticketBase += (unsigned)(nChunks + grid);
     if (window) P.doneBase += (unsigned)nChunks;

@@ -653,6 +653,7 @@ void plan_free(ldu_addr* a)
     if (a->d_cycPair) { (void)hipFree(a->d_cycPair); a->d_cycPair = nullptr; }
     cluster_free(a);
     blocks_free(a);
+    gs_layouts_free(a);
     for (auto& kv : a->graphs) (void)hipGraphExecDestroy(kv.second);
     a->graphs.clear();
     if (a->d_smallNeed) { (void)hipFree(a->d_smallNeed); a->d_smallNeed = nullptr; }

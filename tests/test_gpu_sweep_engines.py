@@ -46,7 +46,7 @@ KEYS = ("LDU_P2P_SLABS", "LDU_P2P_BPC", "LDU_SWEEP", "LDU_SMALL", "LDU_SMALL_MAX
         "LDU_CLUSTER_BPC", "LDU_SMALL_PIPE", "LDU_COOP_ROWS", "LDU_SORT_ROWS", "LDU_LAG_BUCKETS", "LDU_WG", "LDU_WG_WAVES",
         "LDU_WG_MAX", "LDU_WG_MIN", "LDU_WG_WIDE", "LDU_CLUSTER_DIRECT", "LDU_BLK", "LDU_BLK_MIN", "LDU_BLK_MAX",
         "LDU_BLK_CELLS", "LDU_BLK_WAVES", "LDU_BLK_CELLS_MIN", "LDU_BLK_CELLS_MAX", "LDU_BLK_PER_CU", "LDU_BLK_WPS",
-        "LDU_BLK_XCD", "LDU_BLK_LAYOUTS")
+        "LDU_BLK_XCD", "LDU_BLK_LAYOUTS", "LDU_GS_LAYOUTS", "LDU_GS_LAYOUTS_MIN")
 
 
 def _problems():
@@ -235,6 +235,53 @@ def test_block_engine_bitexact(oracle, waves, cells, extra):
                     assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k)
             if p["nCells"] > 100 and not (cells == "300" and p["nCells"] > 60000):
                 assert a.sweep_engine(2) == "blocks", p["nCells"]
+            assert ctx.fallback_count() == 0
+            m.close(); a.close()
+        ctx.close()
+    finally:
+        for k in KEYS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("extra", [{}, {"LDU_COOP_ROWS": "0"}, {"LDU_P2P_BPC": "1"}], ids=["default", "nocoop", "bpc1"])
+def test_gs_layouts_bitexact(oracle, extra):
+    """Per-sweep layouts of the chip-wide pipelined GaussSeidel sweeps (ldu_gslayouts.cpp): sweep j >= 1 of a launch runs on its
+    own slices (rows of equal time T_j in the row DAG of the k sweeps, own entry tables, rows addressed through rowIdx); forced
+    onto small matrices (LDU_GS_LAYOUTS_MIN=1, every other engine off); hex / random / chain / wide-row graphs, k = 1 ... 8,
+    coefficient changes on the same matrix; bit-exact against the sequential sweeps, no engine fallback."""
+    saved = {k: os.environ.pop(k, None) for k in KEYS}
+    os.environ.update({"LDU_BLK": "0", "LDU_CLUSTER": "0", "LDU_WG": "0", "LDU_SMALL": "0", "LDU_P2P_SLABS": "0",
+                       "LDU_GS_LAYOUTS": "1", "LDU_GS_LAYOUTS_MIN": "1"})
+    os.environ.update(extra)
+    try:
+        ctx = capi.Context(0)
+        rng = np.random.RandomState(7)
+        probs = [cases.box3d(3, 4, 3), cases.box3d(11, 12, 13), cases.box3d(40, 37, 41), cases.random_graph(2999, 9, 200),
+                 cases.random_graph(5900, 5, 150, asym=True), cases.random_graph(700, 13, 60), cases.laplacian2d(1, 50),
+                 cases.laplacian2d(100, 100), cases.irregular_box(40), cases.random_graph(12000, 30, 500, asym=True),
+                 cases.random_graph(17900, 12, 3000), cases.random_graph(60000, 7, 900), cases.random_graph(200, 90, 150)]
+        for p in probs:
+            a, m = capi.from_problem(ctx, p)
+            S = oracle.System(p)
+            psi, src = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+            for k in (1, 2, 3, 4, 5, 6, 7, 8):
+                for rep in range(2):
+                    assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k)
+            assert a.sweep_engine(2) == "chip-wide point-to-point", p["nCells"]
+            lay = m.gs_layouts()
+            assert lay["built"] == 4 and all(v > 0 for v in lay["slices"]), (p["nCells"], lay)
+            # new coefficients on the same matrix object: the layouts' value arrays follow
+            q = dict(p)
+            q["diag"] = p["diag"] * (1.0 + 0.25 * rng.rand(p["nCells"]))
+            q["upper"] = p["upper"] * (1.0 + 0.25 * rng.rand(p["upper"].size))
+            if "lower" in p:
+                q["lower"] = p["lower"] * (1.0 + 0.25 * rng.rand(p["upper"].size))
+            m.set_coeffs(q["diag"], q["upper"], q.get("lower"))
+            S2 = oracle.System(q)
+            for k in (2, 4):
+                assert np.array_equal(m.smooth("GaussSeidel", psi, src, k), S2.smooth("GaussSeidel", psi, src, k)), (p["nCells"], k, "new")
             assert ctx.fallback_count() == 0
             m.close(); a.close()
         ctx.close()

@@ -93,8 +93,8 @@ def test_simplefoam_motorbike_through_the_plugins(tmp_path, oracle):
     p = read_dump(dump)
     assert "lower" not in p and "Sf" in p and p["nCells"] > 300000
     l, u = p["lowerAddr"], p["upperAddr"]
-    assert np.all(p["upper"] < 0) and np.all(p["diag"] > 0)
-    ratio = p["upper"].min() / p["upper"].max()
+    assert np.all(p["upper"] > 0) and np.all(p["diag"] < 0)      # fvm::laplacian: negative definite (gaussLaplacianScheme.C:57-73)
+    ratio = p["upper"].max() / p["upper"].min()
     ctx = capi.Context(0)
     a = capi.Addressing(ctx, p["nCells"], l, u)
     p["faceWeights"] = a.set_face_areas(p.pop("Sf"))
@@ -106,11 +106,14 @@ def test_simplefoam_motorbike_through_the_plugins(tmp_path, oracle):
     assert np.array_equal(m.Amul(x), S.Amul(x))
     for k in (1, 2):
         assert np.array_equal(m.smooth("GaussSeidel", x, b, k), S.smooth("GaussSeidel", x, b, k)), k
-    kw = dict(GAMG, tolerance=1e-7, relTol=0.0, maxIter=60)
+    # (the V-cycle reduces this matrix's residual by 10 x in the first cycle and by ~0.92 per cycle afterwards - zeroGradient on
+    #  71 of 72 patches, rAU varying over orders of magnitude; the application stops at relTol 0.1 after 1-3 cycles: a fixed
+    #  number of cycles is compared)
+    kw = dict(GAMG, tolerance=0.0, relTol=0.0, maxIter=12)
     xg, pg = m.solve(p["psi"], p["source"], **kw)
     xo, po = S.solve(p["psi"], p["source"], **kw)
-    assert pg["nIterations"] == po["nIterations"] and pg["converged"]
-    np.testing.assert_allclose(pg["history"], po["history"], rtol=1e-6, atol=1e-12)
+    assert pg["nIterations"] == po["nIterations"] == 12
+    np.testing.assert_allclose(pg["history"], po["history"], rtol=1e-6, atol=1e-14)
     assert np.max(np.abs(xg - xo)) <= 1e-8 * np.max(np.abs(xo))
 
     # V-cycle cost: the real p-matrix beside the synthetic one of the bench on the same mesh (same addressing, same
@@ -128,13 +131,14 @@ def test_simplefoam_motorbike_through_the_plugins(tmp_path, oracle):
         m2.set_coeffs(q["diag"], q["upper"], None)
         syn_ms = vcycle_ms(m2, q["psi"], q["source"])
         _, ps = m2.solve(q["psi"], q["source"], **kw)
-        print("p-matrix of SIMPLE iteration %d (coefficient ratio max/min %.1e): %d V-cycles to 1e-7, %.3f ms per V-cycle; "
-              "the bench's synthetic matrix on the same mesh: %d V-cycles, %.3f ms per V-cycle"
-              % (DUMP_AT, ratio, pg["nIterations"], real_ms, ps["nIterations"], syn_ms))
+        print("p-matrix of SIMPLE iteration %d (coefficient ratio max/min %.1e): residual %.2e -> %.2e -> %.2e after 1 / 12 V-cycles, "
+              "%.3f ms per V-cycle; the bench's synthetic matrix on the same mesh: %.2e -> %.2e -> %.2e, %.3f ms per V-cycle"
+              % (DUMP_AT, ratio, pg["history"][0], pg["history"][1], pg["history"][-1], real_ms,
+                 ps["history"][0], ps["history"][1], ps["history"][-1], syn_ms))
         assert abs(real_ms - syn_ms) <= 0.25 * syn_ms
         m2.close(); a2.close()
     else:
-        print("p-matrix of SIMPLE iteration %d (coefficient ratio max/min %.1e): %d V-cycles to 1e-7, %.3f ms per V-cycle"
-              % (DUMP_AT, ratio, pg["nIterations"], real_ms))
+        print("p-matrix of SIMPLE iteration %d (coefficient ratio max/min %.1e): residual %.2e -> %.2e -> %.2e after 1 / 12 V-cycles, "
+              "%.3f ms per V-cycle" % (DUMP_AT, ratio, pg["history"][0], pg["history"][1], pg["history"][-1], real_ms))
     assert ctx.fallback_count() == 0
     m.close(); a.close(); ctx.close()
