@@ -1035,11 +1035,11 @@ static int bk_values(ldu_addr* a, const double* levelVal, const double* bou, hip
     for (int L = 0; L < P->nBuilt; L++)
     {
         if (!C.d[L]) LDU_CHECK_HIP(hipMalloc((void**)&C.d[L], sizeof(double) * (size_t)P->lay[L].nEntries));
-        if (C.stamp[L] != a->ctx->valStamp)
+        if (C.stamp[L] != val_stamp(a, levelVal))
         {
             const int grid = (int)std::min<long>((P->lay[L].nEntries + 255) / 256, 8192);
             bk_fill_kernel<<<grid, 256, 0, s>>>(P->lay[L].nEntries, P->lay[L].d_srcFace, org->second.first, org->second.second, bou, C.d[L]);
-            C.stamp[L] = a->ctx->valStamp;
+            C.stamp[L] = val_stamp(a, levelVal);
         }
     }
     for (int L = 0; L < BK_NLAY; L++) out[L] = C.d[std::min(L, P->nBuilt - 1)];
@@ -1053,6 +1053,18 @@ bool k_blocks_active(ldu_addr* a)
         || a->nCells > ctx->blkMaxCells) return false;
     if (!a->blocks && bk_build(a)) return false;
     return a->blocks && a->blocks->eligible;
+}
+
+// the layouts' copies of the coefficients of `val`, filled on stream s ahead of the first sweep that asks for them (the
+// coefficient chain of a GAMG solve, ldu_gamg.cpp: ensure_hierarchy); the sweep finds their stamps current.  Only plans and
+// layouts that exist already (nothing is built here).  1 = nothing to fill
+int k_blocks_prefill(ldu_addr* a, const double* val, const double* bou, hipStream_t s)
+{
+    BlockPlan* P = a->blocks;
+    if (!P || !P->eligible || P->nBuilt <= 0) return 1;
+    if (P->iface && !bou) return 1;
+    const double* out[BK_NLAY];
+    return bk_values(a, val, bou, s, out);
 }
 
 int k_blocks_prebuild(ldu_addr* a, int k)

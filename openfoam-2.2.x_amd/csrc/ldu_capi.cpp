@@ -238,6 +238,8 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e) c->p2pWindowLevels = atof(e);
     e = getenv("LDU_AGG_OVERLAP");
     if (e) c->aggOverlap = atoi(e);
+    e = getenv("LDU_AGG_PREFILL");
+    if (e) c->aggPrefill = atoi(e);
     e = getenv("LDU_HALO_OVERLAP");
     if (e) c->haloOverlap = atoi(e);
     e = getenv("LDU_WATCHDOG_MS");
@@ -483,7 +485,7 @@ void matrix_free(ldu_matrix* m)
     // the cluster engine keeps converted copies of this matrix's value arrays, keyed by their addresses
     for (const double* v : {(const double*)m->d_valA, (const double*)m->d_valT, (const double*)m->d_valP,
                             (const double*)m->d_valPT})
-        if (v) { cluster_forget(m->a, v); blocks_forget(m->a, v); gs_layouts_forget(m->a, v); m->a->valOrigin.erase(v); }
+        if (v) { cluster_forget(m->a, v); blocks_forget(m->a, v); gs_layouts_forget(m->a, v); m->a->valOrigin.erase(v); m->a->arrStamp.erase(v); }
     if (m->d_lowerO && m->d_lowerO != m->d_upperO) (void)hipFree(m->d_lowerO);
     if (m->d_valT && m->d_valT != m->d_valA) (void)hipFree(m->d_valT);
     void* ptrs[] = {m->d_diagO, m->d_upperO, m->d_diag, m->d_valA, m->d_bou, m->d_int, m->d_rD,
@@ -514,6 +516,7 @@ int matrix_refresh_layout(ldu_matrix* m, hipStream_t onStream)
         blocks_forget(a, m->d_valT);
         gs_layouts_forget(a, m->d_valT);
         a->valOrigin.erase(m->d_valT);
+        a->arrStamp.erase(m->d_valT);
         (void)hipFree(m->d_valT);
         m->d_valT = m->d_valA;
     }
@@ -590,7 +593,9 @@ int ldu_matrix_set_patch_coeffs(ldu_matrix* m, int32_t patchI, const double* bou
         if (!is_device_ptr(bou) || !is_device_ptr(intc)) LDU_CHECK_HIP(hipStreamSynchronize(s));   // (as in set_coeffs)
     }
     m->coeffEpoch++;   // coarse-level interface coefficients follow
-    a->ctx->valStamp++;   // (layouts that hold interface coefficients next to the matrix coefficients: ldu_blocks.hip)
+    // (layouts that hold interface coefficients next to the matrix coefficients: ldu_blocks.hip)
+    if (m->d_valA) val_touch(a, m->d_valA);
+    if (m->d_valT && m->d_valT != m->d_valA) val_touch(a, m->d_valT);
     return 0;
 }
 

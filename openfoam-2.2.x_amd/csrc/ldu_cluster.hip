@@ -723,7 +723,7 @@ static const double* cluster_values(ldu_addr* a, const double* levelVal, hipStre
     ClusterPlan::Conv& C = P->conv[levelVal];
     if (!C.d)
         if (hipMalloc((void**)&C.d, sizeof(double) * (size_t)P->nEntries) != hipSuccess) return nullptr;
-    if (C.stamp != a->ctx->valStamp)
+    if (C.stamp != val_stamp(a, levelVal))
     {
         int grid = (int)std::min<long>((P->nEntries + CL_BLK - 1) / CL_BLK, 8192);
         auto org = a->valOrigin.find(levelVal);
@@ -731,9 +731,16 @@ static const double* cluster_values(ldu_addr* a, const double* levelVal, hipStre
             cl_fill_kernel<<<grid, CL_BLK, 0, s>>>(P->nEntries - 1024, P->d_srcFace, org->second.first, org->second.second, C.d);
         else
             cl_convert_kernel<<<grid, CL_BLK, 0, s>>>(P->nEntries - 1024, P->d_src, levelVal, C.d);
-        C.stamp = a->ctx->valStamp;
+        C.stamp = val_stamp(a, levelVal);
     }
     return C.d;
+}
+
+// (ahead of the first sweep, on the stream of the coefficient chain: see k_blocks_prefill)
+int k_cluster_prefill(ldu_addr* a, const double* val, hipStream_t s)
+{
+    if (!a->cluster || !a->cluster->eligible) return 1;
+    return cluster_values(a, val, s) ? 0 : -1;
 }
 
 template <int MODE, bool DESC>

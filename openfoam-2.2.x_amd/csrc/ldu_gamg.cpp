@@ -46,6 +46,10 @@ struct GamgLevel {
     double* d_src = nullptr;
     int* d_pcStart = nullptr;            // coarse patch face -> fine patch faces (concatenated, asc.)
     int* d_pcFine = nullptr;
+    // this level's matrix (coefficients, level layout, engine copies) is being written on ctx->stream3: recorded behind the
+    // level's last fill; the main stream waits for it before the level's first use in a V-cycle (gamg_join_level)
+    hipEvent_t evReady = nullptr;
+    bool readyPending = false;
 };
 
 struct GamgHierarchy {
@@ -87,6 +91,7 @@ void gamg_free(GamgHierarchy* g)
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (L.mat) matrix_free(L.mat);
         if (L.addr) { plan_free(L.addr); delete L.addr; }
+        if (L.evReady) (void)hipEventDestroy(L.evReady);
     }
     if (g->d_Apsi) (void)hipFree(g->d_Apsi);
     if (g->d_finestCorr) (void)hipFree(g->d_finestCorr);
@@ -714,6 +719,7 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
             LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream3, ctx->evAggFork, 0));
             s = ctx->stream3;
         }
+        // 1. the face-ordered coefficients of every level, each from the level above it (the only sequential part)
         const ldu_matrix* fm = m;
         for (auto& L : g->levels)
         {
@@ -732,8 +738,24 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 if (k_patch_agglomerate(L.addr->nPatchFaces, L.d_pcStart, L.d_pcFine, fm->d_bou, fm->d_int,
                                         cm->d_bou, cm->d_int, s))
                     return -1;
-            if (matrix_refresh_layout(cm, s)) return -1;
             fm = cm;
+        }
+        // 2. per level: the level layout and the smoothing engine's own copies of the coefficients (what the first smoothing
+        //    call used to fill on the main stream), an event behind them.  In the order in which a V-cycle first reads the level
+        //    matrices - without pre-smoothing from the coarsest level up (the way down is restrictions only), so that the large
+        //    fills of the fine levels run beside the sweeps of the coarse ones, which leave the memory system nearly idle
+        const int nLv = (int)g->levels.size();
+        for (int q = 0; q < nLv; q++)
+        {
+            GamgLevel& L = g->levels[c->nPreSweeps ? q : nLv - 1 - q];
+            if (matrix_refresh_layout(L.mat, s)) return -1;
+            if (ctx->aggPrefill && dev_smooth_prefill(L.mat, c->smoother, s)) return -1;
+            if (s != ctx->stream)
+            {
+                if (!L.evReady) LDU_CHECK_HIP(hipEventCreateWithFlags(&L.evReady, hipEventDisableTiming));
+                LDU_CHECK_HIP(hipEventRecord(L.evReady, s));
+                L.readyPending = true;
+            }
         }
         if (s != ctx->stream)
         {
@@ -867,6 +889,17 @@ static int gamg_join_levels(GamgHierarchy* g, ldu_ctx* ctx)
     if (!g->aggPending) return 0;
     LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evAggJoin, 0));
     g->aggPending = false;
+    for (auto& L : g->levels) L.readyPending = false;
+    return 0;
+}
+
+// ... or for ONE level's matrix, before its first use in a V-cycle
+static int gamg_join_level(GamgHierarchy* g, ldu_ctx* ctx, int leveli)
+{
+    GamgLevel& L = g->levels[leveli];
+    if (!L.readyPending) return 0;
+    LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream, L.evReady, 0));
+    L.readyPending = false;
     return 0;
 }
 
@@ -911,7 +944,7 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
         static const bool timeCoarsest = getenv("LDU_GAMG_TIME") != nullptr;
         std::chrono::steady_clock::time_point t0;
         if (timeCoarsest) { (void)hipStreamSynchronize(s); t0 = std::chrono::steady_clock::now(); }
-        if (gamg_join_levels(g, ctx)) return -1;
+        if (gamg_join_level(g, ctx, coarsestLevel)) return -1;
         if (solve_coarsest(g, Lv[coarsestLevel].mat, c, Lv[coarsestLevel].d_corr, Lv[coarsestLevel].d_src)) return -1;
         if (timeCoarsest)
         {
@@ -930,6 +963,7 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
         if (c->nPreSweeps)
             if (k_ew(n, EW_COPY, preSmoothed, L.d_corr, nullptr, s)) return -1;
         if (k_prolong(n, C.d_mapNew, C.d_corr, L.d_corr, s)) return -1;
+        if (gamg_join_level(g, ctx, leveli)) return -1;
         double* ACf = Apsi;
         if (c->interpolateCorrection)
             if (gamg_interpolate(L.mat, L.d_corr, ACf)) return -1;

@@ -242,10 +242,10 @@ int gs_layout_values(ldu_addr* a, const double* levelVal, int k, hipStream_t s, 
         const ldu_addr::GsLayout* Y = a->gsLay[j];
         if (!Y) return 1;
         if (!V.d[j]) LDU_CHECK_HIP(hipMalloc((void**)&V.d[j], sizeof(double) * (size_t)Y->nEntries));
-        if (V.stamp[j] != a->ctx->valStamp)
+        if (V.stamp[j] != val_stamp(a, levelVal))
         {
             if (k_fill_layout(Y, org->second.first, org->second.second, V.d[j], s)) return -1;
-            V.stamp[j] = a->ctx->valStamp;
+            V.stamp[j] = val_stamp(a, levelVal);
         }
         out[j] = V.d[j];
     }

@@ -77,6 +77,7 @@ struct ldu_ctx {
     const void* aggForkOf = nullptr;
     uint64_t aggForkEpoch = 0;
     int aggOverlap = 1;              // LDU_AGG_OVERLAP=0: everything on the main stream
+    int aggPrefill = 1;              // LDU_AGG_PREFILL=0: the engines' coefficient copies are filled by the first smoothing call
     // halo exchange overlapped with the interior rows: the send/recv of an operator application runs on its own
     // stream between pack (initMatrixInterfaces) and apply (updateMatrixInterfaces) - the window the reference
     // itself leaves for the interior loops (lduMatrixUpdateMatrixInterfaces.C:30-93, 127-160; lduMatrixATmul.C:62-89)
@@ -346,6 +347,10 @@ struct ldu_addr {
     std::map<const double*, GsLayVals> gsLayVals;     // level value array -> the layouts' value arrays
     // level-layout coefficient arrays filled from face-ordered ones (fill_sell): value array -> (lower-side, upper-side source)
     std::map<const double*, std::pair<const double*, const double*>> valOrigin;
+    // when a level-layout value array of THIS addressing was last rewritten (a value of ctx->valStamp): what the engines' converted
+    // copies are compared with.  Per array, not per context: the coefficient chain of a GAMG solve fills the level arrays one after
+    // the other and the engine copies of a level right behind its array (ensure_hierarchy), on a stream beside the solve
+    std::map<const double*, unsigned long long> arrStamp;
     std::map<int, GsTasks> gsTasks;
     struct WgTasks { int* d_tasks = nullptr; int n = 0; int steps = 0; };   // one-workgroup engine: 4 ints per (sweep, slice) task
     std::map<int, WgTasks> wgTasks;
@@ -459,6 +464,9 @@ void cluster_free(ldu_addr* a);
 int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);   // 1 = not taken
 bool k_blocks_active(ldu_addr* a);
 int k_blocks_prebuild(ldu_addr* a, int k);
+int k_blocks_prefill(ldu_addr* a, const double* val, const double* bou, hipStream_t s);   // the layouts' coefficient copies, ahead of the sweep (1 = nothing to fill)
+int k_cluster_prefill(ldu_addr* a, const double* val, hipStream_t s);
+int dev_smooth_prefill(ldu_matrix* m, int smoother, hipStream_t s);
 int k_blocks_set_watchdog(unsigned long long budgetTicks, unsigned long long stallTicks);
 int k_blocks_set_trace(unsigned long long* buf);
 int k_blocks_info(ldu_addr* a, int k, long out[8]);
@@ -559,7 +567,14 @@ int k_fv_laplacian_coeffs(int nFaces, const double* delta, const double* gammaMa
 int k_fv_div_coeffs(int nFaces, const double* w, const double* phi, double* lower, double* upper, hipStream_t s);
 
 // ---------------------------------------------------------------- host pieces
-int plan_build(ldu_addr* a);                              // ldu_plan.cpp
+int plan_build(ldu_addr* a);
+// stamp of a value array (an array nobody registered: the context-wide counter - every rewrite anywhere invalidates its copies)
+inline unsigned long long val_stamp(const ldu_addr* a, const double* v)
+{
+    auto it = a->arrStamp.find(v);
+    return it == a->arrStamp.end() ? a->ctx->valStamp : it->second;
+}
+inline void val_touch(ldu_addr* a, const double* v) { a->arrStamp[v] = ++a->ctx->valStamp; }                              // ldu_plan.cpp
 int plan_finalize_patches(ldu_addr* a);
 void plan_free(ldu_addr* a);
 

@@ -58,7 +58,7 @@ __global__ void fill_sell_kernel(int nSlices, const int* __restrict__ sliceRow,
 int k_fill_sell(ldu_addr* a, const double* lowerO, const double* upperO, double* val, hipStream_t s)
 {
     if (a->nSlices == 0) return 0;
-    a->ctx->valStamp++;
+    val_touch(a, val);
     fill_sell_kernel<<<cdiv(a->nSlices, WPB), BLK, 0, s>>>(a->nSlices, a->d_sliceRow, a->d_sliceCnt,
         a->d_sliceEnt, a->d_sliceW, a->d_nL, a->d_face, lowerO, upperO, val);
     LDU_CHECK_HIP(hipGetLastError());
@@ -98,7 +98,7 @@ __global__ void scale_rows_kernel(int nSlices, const int* __restrict__ sliceRow,
 int k_scale_rows(ldu_addr* a, double* valOut, const double* valIn, const double* rowScale, hipStream_t s)
 {
     if (a->nSlices == 0) return 0;
-    a->ctx->valStamp++;
+    val_touch(a, valOut);
     scale_rows_kernel<<<cdiv(a->nSlices, WPB), BLK, 0, s>>>(a->nSlices, a->d_sliceRow, a->d_sliceCnt,
         a->d_sliceEnt, a->d_sliceW, valIn, rowScale, valOut);
     LDU_CHECK_HIP(hipGetLastError());

@@ -386,6 +386,25 @@ static int smooth_dic(ldu_matrix* m, int kind, double* psi, const double* source
     return 0;
 }
 
+// The engine-side copies of this matrix's coefficients that its GaussSeidel smoothing calls will ask for (block layouts,
+// cluster layout), filled on stream s - the coefficient chain of a GAMG solve - instead of by the first smoothing call on the
+// main stream.  The choice of engine is gs_sweeps' own (same predicates); engines whose plans do not exist yet are left to
+// the smoothing call.
+int dev_smooth_prefill(ldu_matrix* m, int smoother, hipStream_t s)
+{
+    ldu_addr* a = m->a;
+    if (smoother != LDU_SM_GAUSSSEIDEL && smoother != LDU_SM_NONBLOCKINGGAUSSSEIDEL) return 0;
+    if (!a->ctx->sweepP2P || !m->d_valA) return 0;
+    if (!a->nPatchFaces)
+    {
+        if (a->ctx->clusterMulti && k_cluster_active(a)) return k_cluster_prefill(a, m->d_valA, s) < 0 ? -1 : 0;
+        if (k_blocks_active(a)) return k_blocks_prefill(a, m->d_valA, nullptr, s) < 0 ? -1 : 0;
+        return 0;
+    }
+    if (smoother == LDU_SM_GAUSSSEIDEL && k_blocks_active(a)) return k_blocks_prefill(a, m->d_valA, m->d_bou, s) < 0 ? -1 : 0;
+    return 0;
+}
+
 int dev_smooth(ldu_matrix* m, int smoother, double* psi, const double* source, int nSweeps)
 {
     switch (smoother)

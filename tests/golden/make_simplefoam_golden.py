@@ -3,8 +3,8 @@
 libfiniteVolume / turbulence / transport / fvOptions units and libOpenFOAM by oracle/build_ref_fv.sh; no plug-in) on
 BASELINE config C2, pitzDaily (oracle/pitzdaily_case.py), 40 SIMPLE iterations - with the tutorial's PCG + DIC for p and
 with the motorBike GAMG block (BASELINE: "GAMG p-solve") - and tests/golden/simplefoam_motorbike_tut.json: the same binary on
-the tutorial-size motorBike mesh of the reference's own blockMesh + snappyHexMesh (oracle/motorbike_simplefoam_case.py; 321 361
-cells, 12 SIMPLE iterations, the tutorial's GAMG block for p, smoothSolver + GaussSeidel for U / k / epsilon).  Run here (needs /root/reference for the build); JSON = data.
+the tutorial-size motorBike mesh of the reference's own blockMesh + snappyHexMesh (oracle/motorbike_simplefoam_case.py; ~321 k
+cells - the fixture records which mesh it was made on, snappyHexMesh is not reproducible across hosts -, 12 SIMPLE iterations, the tutorial's GAMG block for p, smoothSolver + GaussSeidel for U / k / epsilon).  Run here (needs /root/reference for the build); JSON = data.
   python tests/golden/make_simplefoam_golden.py"""
 import json
 import os
@@ -37,9 +37,9 @@ if __name__ == "__main__":
             case = os.path.join(d, "motorBike")
             mc.write(case, MB_STEPS)
             lines = cc.solve_lines(mc.run(case))
-        out = dict(case="simpleFoam on the tutorial-size motorBike mesh (snappyHexMesh, castellated, 321 361 cells), %d SIMPLE iterations, "
-                        "kEpsilon, p: GAMG GaussSeidel faceAreaPair, U/k/epsilon: smoothSolver GaussSeidel" % MB_STEPS,
-                   generator="tests/golden/make_simplefoam_golden.py", lines=lines)
+        out = dict(case="simpleFoam on the tutorial-size motorBike mesh (snappyHexMesh, castellated, %d cells), %d SIMPLE iterations, "
+                        "kEpsilon, p: GAMG GaussSeidel faceAreaPair, U/k/epsilon: smoothSolver GaussSeidel" % (mc.mesh_identity()["nCells"], MB_STEPS),
+                   generator="tests/golden/make_simplefoam_golden.py", mesh=mc.mesh_identity(), lines=lines)
         json.dump(out, open(os.path.join(HERE, "simplefoam_motorbike_tut.json"), "w"))
         print("motorBike", len(lines), lines[3], lines[-3])
     else:

@@ -5,7 +5,10 @@ backend "peer" (ldu_ctx_comm_init_peer): halo values and partial sums stored int
 
 Every rank builds the same decomposition, runs the operations on its own sub-domain and compares its slice with the
 oracle's serial emulation of the N-rank algorithm (oracle_py.System(subs)); a mismatch exits non-zero.
-    python -m torch.distributed.run --nproc-per-node N tests/peer_worker.py <n_ranks> <asym 0|1> [size]"""
+    python -m torch.distributed.run --nproc-per-node N tests/peer_worker.py <n_ranks> <asym 0|1> [size] [peer|rccl]
+The fourth argument selects the carrier: "peer" (default) or "rccl" (ldu_ctx_comm_init, the unique id broadcast over gloo - RCCL
+refuses two ranks on one device, so that needs as many visible GPUs as ranks).  The JSON line reports the device every rank
+took and ldu_ctx_comm_info of rank 0, so that a test on an N-GPU node can assert that the ranks really sat on N GPUs."""
 import json
 import os
 import sys
@@ -23,6 +26,7 @@ def main():
     import torch.distributed as dist
     n, asym = int(sys.argv[1]), bool(int(sys.argv[2]))
     size = sys.argv[3] if len(sys.argv) > 3 else "10"
+    carrier = sys.argv[4] if len(sys.argv) > 4 else "peer"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     assert world == n
     dist.init_process_group("gloo")
@@ -49,8 +53,15 @@ def main():
     sp = subs[rank]
     off = sum(s["nCells"] for s in subs[:rank])
     sl = slice(off, off + sp["nCells"])
-    ctx = capi.Context(rank % max(1, torch.cuda.device_count()))
-    ctx.comm_init_peer(rank, n, capi.oob_torch())
+    device = rank % max(1, torch.cuda.device_count())
+    ctx = capi.Context(device)
+    if carrier == "rccl":
+        uid = [capi.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, n, uid[0])
+    else:
+        ctx.comm_init_peer(rank, n, capi.oob_torch())
+    info = ctx.comm_info()
     a = capi.Addressing(ctx, sp["nCells"], sp["lowerAddr"], sp["upperAddr"], sp.get("faceWeights"), patches=sp["patches_dev"])
     m = capi.Matrix(a)
     m.set_coeffs(sp["diag"], sp["upper"], sp.get("lower"))
@@ -106,9 +117,11 @@ def main():
     m.close(); a.close(); ctx.close()
     allbad = [None] * n
     dist.all_gather_object(allbad, bad)
+    alldev = [None] * n
+    dist.all_gather_object(alldev, device)
     if rank == 0:
-        print(json.dumps(dict(n_ranks=n, asym=asym, devices=torch.cuda.device_count(), mismatches=allbad, solves=its,
-                              counters=counters, fallbacks=fallbacks)))
+        print(json.dumps(dict(n_ranks=n, asym=asym, devices=torch.cuda.device_count(), rank_devices=alldev, carrier=carrier,
+                              comm=info, mismatches=allbad, solves=its, counters=counters, fallbacks=fallbacks)))
     dist.destroy_process_group()
     sys.exit(1 if any(allbad) else 0)
 

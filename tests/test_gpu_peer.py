@@ -29,10 +29,10 @@ def _free_port():
     return port
 
 
-def run_worker(n, asym, size=10, env=None, timeout=600):
+def run_worker(n, asym, size=10, env=None, timeout=600, carrier="peer"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "peer_worker.py"), str(n),
-           str(int(asym)), str(size)]
+           str(int(asym)), str(size), carrier]
     e = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.update(env or {})
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
@@ -46,6 +46,27 @@ def test_ranks_as_processes_against_the_multidomain_oracle(n, asym):
     out = run_worker(n, asym)
     assert not any(out["mismatches"]), out
     assert out["fallbacks"] == 0
+    assert out["counters"]["halo_exchanges"] > 0 and out["counters"]["all_reduces"] > 0
+
+
+@pytest.mark.parametrize("carrier", ["peer", "rccl"])
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_ranks_on_distinct_gpus(n, carrier):
+    """where N GPUs are visible the N ranks must sit on N DISTINCT devices and the carrier must have
+    been initialised over all of them - peer stores crossing xGMI (peer_ranks == N) and RCCL send / recv between distinct
+    ranks (rccl_ranks == N, halo and sums on RCCL) - with every operator and solve against the multi-domain oracle as on
+    one GPU.  Skipped on the 1-GPU boxes of this pool (there the peer carrier runs as N processes on device 0 in the tests
+    above, and RCCL refuses two ranks on one device)."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < n:
+        pytest.skip("needs %d GPUs (found %d)" % (n, torch.cuda.device_count()))
+    out = run_worker(n, False, size=12, timeout=900, carrier=carrier)
+    assert not any(out["mismatches"]), out
+    assert sorted(out["rank_devices"]) == list(range(n)), out
+    if carrier == "peer":
+        assert out["comm"]["peer_ranks"] == n and out["comm"]["halo"] == "peer stores" and out["comm"]["sums"] == "peer stores", out
+    else:
+        assert out["comm"]["rccl_ranks"] == n and out["comm"]["halo"] == "rccl" and out["comm"]["sums"] == "rccl", out
     assert out["counters"]["halo_exchanges"] > 0 and out["counters"]["all_reduces"] > 0
 
 

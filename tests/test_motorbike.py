@@ -25,7 +25,10 @@ def test_compact_form_and_matrix():
     _need("mbtut")
     m = motorbike.load("mbtut")
     l, u = m["lowerAddr"], m["upperAddr"]
-    assert m["meta"]["nCells"] == m["nCells"] == 321362 and l.size == 960833
+    # (snappyHexMesh is not reproducible across hosts: 321 362 cells / 960 833 faces on one machine of the pool, 321 348 / 960 788
+    #  on another with the same binaries and dictionaries - the counts are held to the store's own record and to that range)
+    assert m["meta"]["nCells"] == m["nCells"] and l.size == m["meta"]["nInternalFaces"]
+    assert 321000 < m["nCells"] < 322000 and 960000 < l.size < 962000
     assert np.all(l < u) and np.all(np.diff(l.astype(np.int64) * m["nCells"] + u) > 0)      # upper-triangular order
     assert np.abs(m["level"][l].astype(int) - m["level"][u]).max() == 1                      # 2:1 balance
     assert np.bincount(m["level"]).tolist() == m["meta"]["cells_per_level"]
