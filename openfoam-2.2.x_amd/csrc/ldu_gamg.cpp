@@ -66,6 +66,8 @@ struct GamgHierarchy {
     int peerWgEpoch = -1;                // carrier epoch the levels' one-launch smoother decisions (ldu_addr::peerWg) belong to          // ctx->commEpoch the decision belongs to (ldu_ctx_comm_select changes the carriers)
     int* d_cycPair = nullptr;
     bool aggPending = false;             // level coefficients still being built on ctx->stream3: the main stream joins before it reads them
+    hipEvent_t evFinest = nullptr;       // the finest matrix's engine copy is being filled on ctx->stream3 (refresh_level_coeffs)
+    bool finestPending = false;
 };
 
 template <class T>
@@ -97,6 +99,7 @@ void gamg_free(GamgHierarchy* g)
     if (g->d_finestCorr) (void)hipFree(g->d_finestCorr);
     if (g->d_finestRes) (void)hipFree(g->d_finestRes);
     if (g->d_cycPair) (void)hipFree(g->d_cycPair);
+    if (g->evFinest) (void)hipEventDestroy(g->evFinest);
     delete g;
 }
 
@@ -489,7 +492,10 @@ static int build_level_maps(GamgLevel& L, const ldu_addr* cA, const ldu_addr* fi
     return 0;
 }
 
-static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
+static int refresh_level_coeffs(ldu_matrix* m, const ldu_controls* c);
+// deferCoeffs: the caller runs refresh_level_coeffs itself (gamg_solve: behind the launches of its initial residual - the chain
+// is ~150 launches, 1.2-1.4 ms of HOST time during which the main stream used to sit idle)
+static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c, bool deferCoeffs = false)
 {
     ldu_addr* a = m->a;
     GamgHierarchy* g = m->gamg;
@@ -700,8 +706,15 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
         guard.g = nullptr;
         m->gamg = g;
     }
-    // level coefficients: rebuilt from the fine matrix whenever the coefficients changed
-    // (GAMGSolver.C:86-89 runs agglomerateMatrix for every level in every solver construction)
+    return deferCoeffs ? 0 : refresh_level_coeffs(m, c);
+}
+
+// level coefficients: rebuilt from the fine matrix whenever the coefficients changed
+// (GAMGSolver.C:86-89 runs agglomerateMatrix for every level in every solver construction)
+static int refresh_level_coeffs(ldu_matrix* m, const ldu_controls* c)
+{
+    ldu_addr* a = m->a;
+    GamgHierarchy* g = m->gamg;
     if (g->coeffEpoch != m->coeffEpoch)
     {
         // On a stream of its own, beside the finest level's own work of this solve (its level layout, the initial residual,
@@ -756,6 +769,17 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c)
                 LDU_CHECK_HIP(hipEventRecord(L.evReady, s));
                 L.readyPending = true;
             }
+        }
+        // ... and the finest matrix's own engine copy (its level layout was filled on the main stream by ldu_matrix_set_coeffs,
+        // after the fork: the side stream waits for the main stream as it is now), needed last of all
+        if (s != ctx->stream && ctx->aggPrefill)
+        {
+            if (!g->evFinest) LDU_CHECK_HIP(hipEventCreateWithFlags(&g->evFinest, hipEventDisableTiming));
+            LDU_CHECK_HIP(hipEventRecord(g->evFinest, ctx->stream));
+            LDU_CHECK_HIP(hipStreamWaitEvent(s, g->evFinest, 0));
+            if (dev_smooth_prefill(m, c->smoother, s)) return -1;
+            LDU_CHECK_HIP(hipEventRecord(g->evFinest, s));
+            g->finestPending = true;
         }
         if (s != ctx->stream)
         {
@@ -889,6 +913,7 @@ static int gamg_join_levels(GamgHierarchy* g, ldu_ctx* ctx)
     if (!g->aggPending) return 0;
     LDU_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evAggJoin, 0));
     g->aggPending = false;
+    g->finestPending = false;
     for (auto& L : g->levels) L.readyPending = false;
     return 0;
 }
@@ -1002,6 +1027,11 @@ static int vcycle(ldu_matrix* m, const ldu_controls* c, double* psi, const doubl
     if (scaleCorrection)
         if (gamg_scale(m, finestCorrection, Apsi, finestResidual)) return -1;
     if (k_ew(n0, EW_ADD_INPLACE, psi, finestCorrection, nullptr, s)) return -1;
+    if (g->finestPending)
+    {
+        LDU_CHECK_HIP(hipStreamWaitEvent(s, g->evFinest, 0));
+        g->finestPending = false;
+    }
     return dev_smooth(m, c->smoother, psi, source, c->nFinestSweeps);
 }
 
@@ -1018,7 +1048,7 @@ int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* 
 {
     const bool firstSolve = !m->gamg && getenv("LDU_VERBOSE");
     const auto tSolve0 = std::chrono::steady_clock::now();
-    if (ensure_hierarchy(m, c)) return -1;
+    if (ensure_hierarchy(m, c, true)) return -1;
     const auto tSolve1 = std::chrono::steady_clock::now();
     struct FirstSolveNote {
         bool on; std::chrono::steady_clock::time_point t0, t1; hipStream_t s;
@@ -1046,6 +1076,8 @@ int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* 
         if (k_reduce(ctx, n, RED_SUM, psi, nullptr, nullptr, nullptr, S_SUMPSI, s)) return -1;
         const double cnt = (double)n;
         LDU_CHECK_HIP(hipMemcpyAsync(ctx->S() + S_COUNT, &cnt, sizeof(double), hipMemcpyHostToDevice, s));
+        // (the level coefficients: launched from here, beside the finest level's first kernels)
+        if (refresh_level_coeffs(m, c)) return -1;
         LDU_CHECK_HIP(hipStreamSynchronize(s));
         if (comm_allreduce_scalars(ctx, S_SUMPSI, 1, s)) return -1;
         if (comm_allreduce_scalars(ctx, S_COUNT, 1, s)) return -1;
@@ -1081,6 +1113,8 @@ int gamg_solve(ldu_matrix* m, const ldu_controls* c, double* psi, const double* 
             perf->nHistory++;
         } while (++perf->nIterations < c->maxIter && !check_convergence(perf, c->tolerance, c->relTol));
     }
+    // (a solve that needed no V-cycle: whoever uses the matrices next on the main stream must find the side stream's fills done)
+    if (g->aggPending && gamg_join_levels(g, ctx)) return -1;
     return 0;
 }
 

@@ -1984,11 +1984,11 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
 // (per-sweep layouts, ldu_gslayouts.cpp: tables and coefficients of sweeps 1 .. 3; a task's slice index counts in ITS sweep's layout)
 struct GsLays { SliceTab t[3]; const double* val[3]; int on; };
 
-__global__ void __launch_bounds__(P2P_BLK)
-sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
-                          unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
-                          int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val,
-                          int puSlots, GsLays L)
+__device__ __forceinline__ void
+sweep_p2p_gs_multi_body(const SliceTab& T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
+                        unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
+                        int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val,
+                        int puSlots, const GsLays& L)
 {
     __shared__ int s_chunk[2];
     extern __shared__ double s_pu[];   // [wave][puSlots][64]: parked products of wide upper parts
@@ -2033,6 +2033,17 @@ sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks,
         if (window) __syncthreads();
     }
 }
+
+#define GSM_ARGS T, tasks, nTasks, nChunks, k, ticket, ticketBase, window, doneBase, G, tag0, abortFlag, psi, rhs, diag, val, puSlots, L
+__global__ void __launch_bounds__(P2P_BLK)
+sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
+                          unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
+                          int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val,
+                          int puSlots, GsLays L)
+{
+    sweep_p2p_gs_multi_body(GSM_ARGS);
+}
+#undef GSM_ARGS
 
 
 // (slab engine twin of sweep_p2p_gs_multi_kernel: per-slab task queues)
@@ -3205,6 +3216,8 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     }
     const int window = p2p_window(a, nChunks, k, grid);
     const int puSlots = gs_pu_slots(a);
+    // (held to 128 VGPRs = 4 waves per SIMD instead of 168 / 3 the kernel spills in its hot path: two sweeps of the 12.7 M-cell
+    //  level 3.03 -> 5.67 ms, profiles/r05_gsm_wpe4_probe.log)
     sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE, s>>>(
             T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
             P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val, puSlots, LY);
