@@ -146,6 +146,8 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e && !strcmp(e, "levels")) c->sweepP2P = 0;
     e = getenv("LDU_P2P_MAXBPC");
     if (e && atoi(e) > 0) c->p2pMaxBlocksPerCU = atoi(e);
+    e = getenv("LDU_GSM_WIDE");
+    if (e && atof(e) > 0) c->gsmWideSlices = atof(e);
     e = getenv("LDU_P2P_GATE");
     if (e) c->p2pGate = atoi(e);
     e = getenv("LDU_DUAL_STREAM");

@@ -154,6 +154,7 @@ struct ldu_ctx {
     int p2pBpcForced = 0;            // LDU_P2P_BPC given: the slab engine does not size its own grid
     int numCUs = 256;
     int p2pMaxBlocksPerCU = 5;       // register-limited residency of the sweep kernels
+    double gsmWideSlices = 800.0;    // LDU_GSM_WIDE: slices per dependency level x sweeps in flight from which the pipelined GaussSeidel kernel runs three workgroups per CU instead of two
     // XCD-slab sweep engine: -1 = choose per addressing, 0 = chip-wide engine only, 1..8 = forced
     int p2pSlabs = -1;
     int nXcd = 0;                    // XCDs seen by the placement census (0 = census failed: no slabs)

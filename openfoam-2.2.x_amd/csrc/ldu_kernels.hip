@@ -1984,6 +1984,7 @@ __device__ __forceinline__ void p2p_gs_task(const SliceTab& T, int s, int j, int
 // (per-sweep layouts, ldu_gslayouts.cpp: tables and coefficients of sweeps 1 .. 3; a task's slice index counts in ITS sweep's layout)
 struct GsLays { SliceTab t[3]; const double* val[3]; int on; };
 
+template <bool LAY>
 __device__ __forceinline__ void
 sweep_p2p_gs_multi_body(const SliceTab& T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
                         unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
@@ -2018,7 +2019,7 @@ sweep_p2p_gs_multi_body(const SliceTab& T, const int* __restrict__ tasks, int nT
             if (task >= 0)
             {
                 const int sl = task & 0x0fffffff, j = task >> 28;
-                if (L.on && j > 0)
+                if (LAY && j > 0)
                 {
                     const SliceTab& Tj = j == 1 ? L.t[0] : (j == 2 ? L.t[1] : L.t[2]);
                     const double* vj = j == 1 ? L.val[0] : (j == 2 ? L.val[1] : L.val[2]);
@@ -2034,16 +2035,26 @@ sweep_p2p_gs_multi_body(const SliceTab& T, const int* __restrict__ tasks, int nT
     }
 }
 
-#define GSM_ARGS T, tasks, nTasks, nChunks, k, ticket, ticketBase, window, doneBase, G, tag0, abortFlag, psi, rhs, diag, val, puSlots, L
+
 __global__ void __launch_bounds__(P2P_BLK)
 sweep_p2p_gs_multi_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
                           unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
-                          int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val,
-                          int puSlots, GsLays L)
+                          int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val, int puSlots)
 {
-    sweep_p2p_gs_multi_body(GSM_ARGS);
+    GsLays none = GsLays();
+    sweep_p2p_gs_multi_body<false>(T, tasks, nTasks, nChunks, k, ticket, ticketBase, window, doneBase, G, tag0, abortFlag, psi, rhs, diag,
+                                   val, puSlots, none);
 }
-#undef GSM_ARGS
+// ... with per-sweep layouts (ldu_gslayouts.cpp; off by default): three more sets of tables in the argument list
+__global__ void __launch_bounds__(P2P_BLK)
+sweep_p2p_gs_multi_lay_kernel(SliceTab T, const int* __restrict__ tasks, int nTasks, int nChunks, int k,
+                              unsigned* ticket, unsigned ticketBase, int window, unsigned doneBase, uint4* G, unsigned tag0,
+                              int* abortFlag, double* psi, const double* rhs, const double* diag, const double* val, int puSlots,
+                              GsLays L)
+{
+    sweep_p2p_gs_multi_body<true>(T, tasks, nTasks, nChunks, k, ticket, ticketBase, window, doneBase, G, tag0, abortFlag, psi, rhs, diag,
+                                  val, puSlots, L);
+}
 
 
 // (slab engine twin of sweep_p2p_gs_multi_kernel: per-slab task queues)
@@ -3171,6 +3182,15 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     int bpc = ctx->p2pBlocksPerCU * k;
     if (bpc > ctx->p2pMaxBlocksPerCU) bpc = ctx->p2pMaxBlocksPerCU;
     if (gs_pu_slots(a) > 8 && bpc > 3) bpc = 3;   // 48 KB of LDS per workgroup
+    // The kernel's 168 VGPRs hold three workgroups per CU, and every resident wave beyond the front is one more poller on the
+    // memory system.  Levels that are bound by the hand-off (few slices per dependency level) run faster with TWO per CU, wide
+    // ones - bound by how many tasks are in flight - with three: 12.7 M-cell motorBike mesh, bandCompression: 12.7 M cells x 2
+    // sweeps (485 slices per level) 2.81 / 2.62 ms with 2 / 3 per CU, 6.3 M x 2 2.64 / 2.67, 3.1 M x 3 (75 per level) 3.55 / 4.29
+    // (one per CU: 3.75 / 3.28 / 3.42); snappyHexMesh's numbering 2.28 / 1.95, 1.62 / 1.66, 2.62 / 3.34
+    // (profiles/r05_gsm_bpc_probe.log).  A build whose kernel happened to need 169 VGPRs (two per CU) hid this until round 5.
+    if (!ctx->p2pBpcForced)
+        bpc = std::min(bpc, (double)a->nSlices / std::max(1, a->nLevels) * k >= ctx->gsmWideSlices ? 3 : 2);
+    if (getenv("LDU_GSM_BPC")) bpc = std::max(1, atoi(getenv("LDU_GSM_BPC")));
     int grid = ctx->numCUs * bpc * 256 / P2P_BLK;
     if (grid > nChunks) grid = nChunks;
     if (grid < 1) grid = 1;
@@ -3218,9 +3238,14 @@ int k_sweep_gs_multi(ldu_addr* a, int k, double* psi, const double* rhs, const d
     const int puSlots = gs_pu_slots(a);
     // (held to 128 VGPRs = 4 waves per SIMD instead of 168 / 3 the kernel spills in its hot path: two sweeps of the 12.7 M-cell
     //  level 3.03 -> 5.67 ms, profiles/r05_gsm_wpe4_probe.log)
-    sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE, s>>>(
+    if (lay)
+        sweep_p2p_gs_multi_lay_kernel<<<grid, P2P_BLK, sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE, s>>>(
             T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
             P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val, puSlots, LY);
+    else
+        sweep_p2p_gs_multi_kernel<<<grid, P2P_BLK, sizeof(double) * (size_t)(P2P_BLK / LDU_WAVE) * puSlots * LDU_WAVE, s>>>(
+            T, it->second.d_tasks, nTasks, nChunks, k, P.d_ticket,
+            P.ticketBase, window, P.doneBase, P.d_granule, tag0, ctx->d_abort, psi, rhs, diag, val, puSlots);
     ctx->profStop(a, 4);
     P.ticketBase += (unsigned)(nChunks + grid);
     if (window) P.doneBase += (unsigned)nChunks;
