@@ -715,10 +715,16 @@ static int bk_build(ldu_addr* a)
     int maxSlots = 0, perCU = 0;
     const int pref = ctx->blkWaves == 3 || ctx->blkWaves == 7 ? ctx->blkWaves : (nC >= ctx->blkWideFrom ? 7 : 3);
     bool found = false;
-    for (int cand = 0; cand < 2 && !found; cand++)
+    // Candidates 2 and 3: blobs of equal FOOTPRINT (cells + ghosts, partition_blobs_slots) at 92 % / 85 % of one workgroup's LDS,
+    // 7 + 1 wavefronts, one per CU - for the levels whose equal-size blobs do not fit (3.1 M-cell level of the motorBike mesh:
+    // 242 blobs of 12.9 k cells, the largest with 23.7 k slots = 1.42 x the mean, 18.2 k fit).  Levels above blkEqualMax cells
+    // start there: the first two are known not to fit and cost a partition each.
+    for (int cand = nC > ctx->blkEqualMax ? 2 : 0; cand < 4 && !found; cand++)
     {
-        nw = cand == 0 ? pref : (pref == 7 ? 3 : 7);
-        if (cand == 1 && (ctx->blkWaves == 3 || ctx->blkWaves == 7)) break;      // forced
+        const bool bySlots = cand >= 2;
+        if (bySlots && (P->iface || !ctx->blkBySlots)) break;
+        nw = bySlots ? 7 : (cand == 0 ? pref : (pref == 7 ? 3 : 7));
+        if (cand == 1 && (ctx->blkWaves == 3 || ctx->blkWaves == 7)) continue;      // forced
         int perCUregs = 0;
         if (nw == 7 ? bk_occupancy<7>(1024, &perCUregs) : bk_occupancy<3>(1024, &perCUregs)) return -1;
         if (perCUregs > ctx->blkMaxPerCU) perCUregs = ctx->blkMaxPerCU;
@@ -729,7 +735,15 @@ static int bk_build(ldu_addr* a)
         long nParts = ctx->blkCells > 0 ? ((long)nC + ctx->blkCells - 1) / ctx->blkCells : std::min<long>((long)(0.97 * (double)cap), std::max<long>(1, nC / cmin));
         if (nParts < 1) nParts = 1;
         if (nParts > cap) { if (ctx->blkCells > 0) continue; nParts = cap; }
-        nB = partition_blobs(nC, nF, a->l.data(), a->u.data(), (int)nParts, blk.data());
+        if (bySlots)
+        {
+            const long slotT = (long)((cand == 2 ? 0.92 : 0.85) * (double)((BK_MAX_LDS - 80) / 9));
+            nParts = cap;
+            nB = partition_blobs_slots(nC, nF, a->l.data(), a->u.data(), slotT, (int)cap, blk.data());
+            if (nB == -2) { if (verbose) fprintf(stderr, "[ldugpu] block engine: %d cells: more than %ld blobs of %ld slots\n", nC, cap, slotT); break; }
+        }
+        else
+            nB = partition_blobs(nC, nF, a->l.data(), a->u.data(), (int)nParts, blk.data());
         if (nB < 1) return -1;
         // LDS slots of a block's rows: the order of the level-ordered numbering restricted to the block
         nLocal.assign(nB, 0);

@@ -202,6 +202,10 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e) c->blkMinCells = atoi(e);
     e = getenv("LDU_BLK_MAX");
     if (e) c->blkMaxCells = atoi(e);
+    e = getenv("LDU_BLK_EQUAL_MAX");
+    if (e) c->blkEqualMax = atoi(e);
+    e = getenv("LDU_BLK_BY_SLOTS");
+    if (e) c->blkBySlots = atoi(e);
     e = getenv("LDU_BLK_CELLS");
     if (e) c->blkCells = atoi(e);
     e = getenv("LDU_BLK_CELLS_MIN");

@@ -137,7 +137,9 @@ struct ldu_ctx {
     int blkEngine = 1;               // LDU_BLK=0: off
     int blkMinCells = 100;           // LDU_BLK_MIN (below: the one-workgroup engine)
     int blkWideFrom = 400000;        // LDU_BLK_WIDE_FROM: seven compute wavefronts per block from this many cells, three below
-    int blkMaxCells = 2600000;       // LDU_BLK_MAX (above: more blocks than resident workgroups, and on the motorBike levels nearly all of
+    int blkEqualMax = 2600000;       // above: blobs of equal footprint right away (LDU_BLK_EQUAL_MAX), see bk_build
+    int blkBySlots = 1;              // LDU_BLK_BY_SLOTS=0: no footprint-balanced blobs (levels that do not fit stay on the level engines)
+    int blkMaxCells = 4000000;       // LDU_BLK_MAX (above: more blocks than resident workgroups, and on the motorBike levels nearly all of
                                      // them are open at once - 348 of 349 at 3.1 M cells, 678 of 702 at 6.3 M: profiles/r05_block_open_counts.log)
     int blkCells = 0;                // LDU_BLK_CELLS: cells per block (0 = sized so that all blocks are resident at once)
     int blkCellsMin = 1024;          // LDU_BLK_CELLS_MIN
@@ -473,6 +475,7 @@ int k_blocks_set_trace(unsigned long long* buf);
 int k_blocks_info(ldu_addr* a, int k, long out[8]);
 void blocks_free(ldu_addr* a);
 extern "C" int partition_blobs(int nCells, int nFaces, const int* lowerAddr, const int* upperAddr, int nParts, int* part);   // ldu_mesh.hip
+extern "C" int partition_blobs_slots(int nCells, int nFaces, const int* lowerAddr, const int* upperAddr, long slotTarget, int maxParts, int* part);
 void blocks_forget(ldu_addr* a, const double* levelVal);
 void gs_layouts_free(ldu_addr* a);                                    // ldu_gslayouts.cpp
 void gs_layouts_forget(ldu_addr* a, const double* levelVal);

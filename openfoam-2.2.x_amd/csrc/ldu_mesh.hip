@@ -394,6 +394,103 @@ int partition_blobs(int nCells, int nFaces, const int* lowerAddr, const int* upp
     return used;
 }
 
+// The block engine's partitioner for levels whose equal-SIZE blobs do not fit (ldu_blocks.hip): breadth-first blobs of equal
+// FOOTPRINT - a blob grows until its cells plus the distinct cells outside it that touch it (its ghosts, whichever part they end
+// up in) reach slotTarget.  Equal cell counts leave the footprints 1.3-1.4 x apart (the surface of a blob in an agglomerated level
+// varies a lot), and the footprint of the LARGEST block is what has to fit into a workgroup's LDS.  As many parts as it takes (at
+// most maxParts, else -2); pockets join the neighbouring part of the smallest footprint.  -> parts made
+int partition_blobs_slots(int nCells, int nFaces, const int* lowerAddr, const int* upperAddr, long slotTarget, int maxParts, int* part)
+{
+    if (slotTarget < 8 || maxParts < 1 || nCells < 0) { ldu_set_error("partition_blobs_slots: bad arguments"); return -1; }
+    std::vector<int> start((size_t)nCells + 1, 0), adj(2 * (size_t)nFaces);
+    for (int f = 0; f < nFaces; f++) { start[lowerAddr[f] + 1]++; start[upperAddr[f] + 1]++; }
+    for (int c = 0; c < nCells; c++) start[c + 1] += start[c];
+    {
+        std::vector<int> pos(start.begin(), start.end() - 1);
+        for (int f = 0; f < nFaces; f++) { adj[pos[lowerAddr[f]]++] = upperAddr[f]; adj[pos[upperAddr[f]]++] = lowerAddr[f]; }
+    }
+    for (int c = 0; c < nCells; c++) part[c] = -1;
+    std::vector<long> foot;                          // cells + ghosts of a part
+    std::vector<int> q;
+    std::vector<int> seen((size_t)nCells, -1);       // seen[n] == r: n has been counted as a ghost of blob r
+    std::vector<char> pocket((size_t)nCells, 0);
+    int seed = 0, r = 0;
+    for (;; )
+    {
+        while (seed < nCells && (part[seed] >= 0 || pocket[seed])) seed++;
+        if (seed >= nCells) break;
+        if (r >= maxParts) { ldu_set_error("partition_blobs_slots: more parts than allowed"); return -2; }
+        q.clear();
+        long ghosts = 0;
+        auto take = [&](int c) {
+            part[c] = r;
+            q.push_back(c);
+            if (seen[c] == r) ghosts--;              // was counted as a ghost: a cell of the blob now
+            for (int t = start[c]; t < start[c + 1]; t++)
+            {
+                const int n = adj[t];
+                if (part[n] != r && seen[n] != r) { seen[n] = r; ghosts++; }
+            }
+        };
+        take(seed);
+        size_t h = 0;
+        bool full = false;
+        while (h < q.size() && !full)
+        {
+            const int c = q[h++];
+            for (int t = start[c]; t < start[c + 1]; t++)
+            {
+                const int n = adj[t];
+                if (part[n] >= 0 || pocket[n]) continue;
+                if ((long)q.size() + ghosts + (long)(start[n + 1] - start[n]) > slotTarget) { full = true; break; }
+                take(n);
+            }
+        }
+        if (full || (long)q.size() + ghosts >= slotTarget / 6)
+        {
+            foot.push_back((long)q.size() + ghosts);
+            r++;
+            continue;
+        }
+        // enclosed by earlier blobs before it reached a sixth of a footprint: not a block of its own (a larger remainder is: the
+        // parts around it would have to take it in whatever their own footprint)
+        for (int c : q) { part[c] = -1; pocket[c] = 1; }
+        for (int c : q) seen[c] = -1;
+    }
+    const int nParts = r;
+    if (nParts == 0)
+    {
+        // nothing but pockets (a tiny graph): one part
+        for (int c = 0; c < nCells; c++) part[c] = 0;
+        return nCells ? 1 : 0;
+    }
+    for (;;)
+    {
+        long left = 0, moved = 0;
+        for (int c = 0; c < nCells; c++)
+        {
+            if (part[c] >= 0) continue;
+            left++;
+            int best = -1;
+            for (int t = start[c]; t < start[c + 1]; t++)
+            {
+                const int b = part[adj[t]];
+                if (b >= 0 && (best < 0 || foot[b] < foot[best])) best = b;
+            }
+            if (best >= 0) { part[c] = best; foot[best] += 1 + (start[c + 1] - start[c]) / 2; moved++; }
+        }
+        if (!left) break;
+        if (!moved)
+        {
+            int sm = 0;
+            for (int p = 1; p < nParts; p++) if (foot[p] < foot[sm]) sm = p;
+            for (int c = 0; c < nCells; c++) if (part[c] < 0) { part[c] = sm; foot[sm]++; }
+            break;
+        }
+    }
+    return nParts;
+}
+
 int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
                          int32_t* newOrder)
 {
