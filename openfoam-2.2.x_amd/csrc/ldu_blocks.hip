@@ -230,8 +230,8 @@ __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
     const double* __restrict__ val = T.val[L];
     const bool have = lane < cnt;
     const int4 M = meta[Q.x + (have ? lane : 0)];
-    const long ent = (long)Q.z + (have ? lane : 0);
-    const long ent2 = (long)(Q.z >> 1) + (have ? lane : 0);
+    const long ent2 = (long)(Q.z >> 1) + (have ? lane : 0);    // pairs of coefficients (16 bytes)
+    const long ent8 = (long)(Q.z >> 3) + (have ? lane : 0);    // quads of column words (8 slots, 16 bytes)
     R.rg = M.x;
     R.slot = M.y & 0xffff;
     R.nl = (M.y >> 16) & 31;
@@ -239,10 +239,20 @@ __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
     R.ni = (M.y >> 26) & 31;
     R.hist = M.z;
     R.ifg = M.w;
+    const uint4* __restrict__ col4 = (const uint4*)col;
+    const double2* __restrict__ val2 = (const double2*)val;
 #pragma unroll
-    for (int q = 0; q < 8; q++) R.c2[q] = col[ent2 + (long)q * stride];
+    for (int r = 0; r < 2; r++)
+    {
+        const uint4 c = col4[ent8 + (long)r * stride];
+        R.c2[4 * r] = c.x; R.c2[4 * r + 1] = c.y; R.c2[4 * r + 2] = c.z; R.c2[4 * r + 3] = c.w;
+    }
 #pragma unroll
-    for (int q = 0; q < 16; q++) R.v[q] = val[ent + (long)q * stride];   // (a group's entries: 16 x stride, stride >= its lanes)
+    for (int p = 0; p < 8; p++)      // (a group's entries: 16 x stride, stride >= its lanes)
+    {
+        const double2 v = val2[ent2 + (long)p * stride];
+        R.v[2 * p] = v.x; R.v[2 * p + 1] = v.y;
+    }
     R.have = have;
     R.T = (Q.y >> 8) & 255;
     R.j = j;
@@ -607,9 +617,13 @@ static int bk_build_layout(ldu_addr* a, int L)
                 int q = 0;
                 auto put = [&](int n, int code) {
                     const int tl = q >> 4, qq = q & 15;
-                    const size_t e = (size_t)Y.grpEnt[g] + (size_t)qq * stride + (size_t)(lane0 + tl);
+                    // a lane's entries 2 p, 2 p + 1 are one 16-byte pair (pair p of lane l at grpEnt / 2 + p * stride + l), its
+                    // column slots 8 r ... 8 r + 7 one 16-byte quad of words (quad r at grpEnt / 8 + r * stride + l): a task's
+                    // rows arrive with 2 + 8 load instructions instead of 8 + 16 - groups hold ~10 of 64 lanes, what a
+                    // task's fill costs is the number of instructions, not the bytes
+                    const size_t e = 2 * ((size_t)(Y.grpEnt[g] / 2) + (size_t)(qq >> 1) * stride + (size_t)(lane0 + tl)) + (size_t)(qq & 1);
                     const unsigned sl = code < -1 ? (unsigned)hslot[n] : (unsigned)(blk[n] == b ? slot[n] : gslot[n]);
-                    const size_t e2 = (size_t)(Y.grpEnt[g] / 2) + (size_t)(qq >> 1) * stride + (size_t)(lane0 + tl);
+                    const size_t e2 = 4 * ((size_t)(Y.grpEnt[g] / 8) + (size_t)(qq >> 3) * stride + (size_t)(lane0 + tl)) + (size_t)((qq >> 1) & 3);
                     col[e2] |= (qq & 1) ? sl << 16 : sl;
                     srcFace[e] = code;
                     q++;
