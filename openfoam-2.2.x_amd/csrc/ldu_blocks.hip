@@ -56,6 +56,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <thread>
 #include <vector>
 
 #include "ldu_internal.hpp"
@@ -577,25 +578,27 @@ static int bk_build_layout(ldu_addr* a, int L)
         Y.nEntries = nEnt + 16 * LDU_WAVE;
         // tables
         std::vector<int4> meta((size_t)nLanes);
-        std::vector<int> hslot(P->iface ? nC : 0, -1);     // hist pair (first LDS slot) of a cell in the current block
         std::vector<unsigned> col((size_t)(Y.nEntries / 2), 0);
         std::vector<int> srcFace((size_t)Y.nEntries, -1);
-        {
-            std::vector<int> fill(Y.nGroups, 0);     // lanes placed so far per group
-            int bCur = -1;
-            for (int t = 0; t < nC; t++)
+        std::vector<int> fill(Y.nGroups, 0);     // lanes placed so far per group
+        // (block by block: a block's rows, groups and entries are its own - ranges of blocks on host threads for large levels,
+        //  each with its own ghost-slot look-up; the tables of the 3.1 M-cell level took most of its plan's 0.6 s per sweep)
+        auto fillBlocks = [&](long b0, long b1) {
+            std::vector<int> gslotT;
+            std::vector<int>& gslot_ = (b0 == 0 && b1 == nB) ? gslot : gslotT;
+            if (&gslot_ == &gslotT) gslotT.assign(nC, -1);
+            std::vector<int> hslot(P->iface ? nC : 0, -1);     // hist pair (first LDS slot) of a cell in the current block
+            for (int b = (int)b0; b < (int)b1; b++)
             {
-                const int c = order[t], b = blk[c];
-                if (b != bCur)
+                for (int g = ghostBase[b]; g < ghostBase[b + 1]; g++) gslot_[ghostCell[g]] = nLocal[b] + (g - ghostBase[b]);
+                if (P->iface)
                 {
-                    for (int g = ghostBase[b]; g < ghostBase[b + 1]; g++) gslot[ghostCell[g]] = nLocal[b] + (g - ghostBase[b]);
-                    if (P->iface)
-                    {
-                        const int h0 = nLocal[b] + ghostBase[b + 1] - ghostBase[b];
-                        for (int h = P->histBase[b]; h < P->histBase[b + 1]; h++) hslot[P->histCell[h]] = h0 + 2 * (h - P->histBase[b]);
-                    }
-                    bCur = b;
+                    const int h0 = nLocal[b] + ghostBase[b + 1] - ghostBase[b];
+                    for (int h = P->histBase[b]; h < P->histBase[b + 1]; h++) hslot[P->histCell[h]] = h0 + 2 * (h - P->histBase[b]);
                 }
+            for (int t = rowBase[b]; t < rowBase[b + 1]; t++)
+            {
+                const int c = order[t];
                 const int g = Y.grpOfCell[c], Tc = Y.grpT[g], stride = Y.grpStride[g];
                 const int lane0 = fill[g];
                 fill[g] += Tc;
@@ -622,7 +625,7 @@ static int bk_build_layout(ldu_addr* a, int L)
                     // rows arrive with 2 + 8 load instructions instead of 8 + 16 - groups hold ~10 of 64 lanes, what a
                     // task's fill costs is the number of instructions, not the bytes
                     const size_t e = 2 * ((size_t)(Y.grpEnt[g] / 2) + (size_t)(qq >> 1) * stride + (size_t)(lane0 + tl)) + (size_t)(qq & 1);
-                    const unsigned sl = code < -1 ? (unsigned)hslot[n] : (unsigned)(blk[n] == b ? slot[n] : gslot[n]);
+                    const unsigned sl = code < -1 ? (unsigned)hslot[n] : (unsigned)(blk[n] == b ? slot[n] : gslot_[n]);
                     const size_t e2 = 4 * ((size_t)(Y.grpEnt[g] / 8) + (size_t)(qq >> 3) * stride + (size_t)(lane0 + tl)) + (size_t)((qq >> 1) & 3);
                     col[e2] |= (qq & 1) ? sl << 16 : sl;
                     srcFace[e] = code;
@@ -631,6 +634,27 @@ static int bk_build_layout(ldu_addr* a, int L)
                 for (int e = P->iface ? P->ifStart[c] : 0; e < (P->iface ? P->ifStart[c + 1] : 0); e++) put(P->ifNbr[e], -2 - P->ifPf[e]);
                 for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++) { const int f = a->losort[s]; put(a->l[f], f << 1); }
                 for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) put(a->u[f], (f << 1) | 1);
+            }
+            }
+        };
+        {
+            const int nT = nC >= 200000 ? (int)std::min<long>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), nB) : 1;
+            if (nT <= 1) fillBlocks(0, nB);
+            else
+            {
+                // ranges of blocks with about the same number of rows
+                std::vector<std::thread> th;
+                int b0 = 0;
+                for (int t = 0; t < nT; t++)
+                {
+                    int b1 = b0;
+                    const long want = (long)nC * (t + 1) / nT;
+                    while (b1 < nB && (t == nT - 1 || rowBase[b1 + 1] <= want)) b1++;
+                    if (t == nT - 1) b1 = nB;
+                    if (b1 > b0) th.emplace_back(fillBlocks, (long)b0, (long)b1);
+                    b0 = b1;
+                }
+                for (auto& x : th) x.join();
             }
         }
         // group-level times Phi: groups in ascending T (a group holds one T): all inputs of lower T are final
