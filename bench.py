@@ -793,7 +793,8 @@ def main():
                                  engine_fallbacks=oj["config"]["engine_fallbacks"], residual_history=oj["extra"]["residual_history"],
                                  note="K ranks of the reference inside one context (ldu_addr_set_subdomains): processor-patch "
                                       "coupling between the sub-domains (GaussSeidelSmoother.C:98-145), rank-local agglomeration; "
-                                      "patched levels sweep one by one on the level engines (no block engine, no pipelining yet)")
+                                      "patched levels of up to 4 M cells run pipelined on the block engine (interface cells keep two values by sweep "
+                                      "parity), larger ones sweep by sweep on the level engines")
         except Exception as e:  # pragma: no cover
             subdomain_leg = dict(error=str(e)[:300])
         try:

@@ -513,6 +513,11 @@ int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAdd
  * ldu_addr_set_subdomains' callers use when the case brings no decomposition of its own */
 int ldu_partition_blobs(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr, int32_t nParts,
                         int32_t* part);
+/* the block engine's own cut of a level whose equal-size blobs do not fit into a workgroup's LDS (csrc/ldu_blocks.hip): breadth-
+ * first blobs of equal FOOTPRINT - a blob grows until its cells plus the distinct cells outside it that touch it reach
+ * slotTarget -, as many as that takes (*nParts; more than maxParts: error).  Host code; exported for tests and tools. */
+int ldu_partition_blobs_footprint(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
+                                  int64_t slotTarget, int32_t maxParts, int32_t* part, int32_t* nParts);
 /* the matrix addressing under such a renumbering, back in upper-triangular order (lduAddressing.C:92-126 needs
  * it): faceMap[newFace] = old face, flip[newFace] = 1 when lower/upper of that face swap (may be NULL) */
 int ldu_renumber_addressing(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,

@@ -22,7 +22,7 @@ EXPORTS = [
     "ldu_last_error", "ldu_default_controls", "ldu_ctx_create", "ldu_ctx_destroy", "ldu_ctx_sync",
     "ldu_ctx_set_spin_limit", "ldu_ctx_fallback_count", "ldu_ctx_overlapped_halo_count", "ldu_debug_div_check", "ldu_debug_cluster_trace", "ldu_debug_cluster_levels", "ldu_debug_gs_multi_trace", "ldu_debug_blocks_trace", "ldu_debug_blocks_info", "ldu_debug_gs_layouts", "ldu_debug_slice_levels",
     "ldu_comm_unique_id", "ldu_ctx_comm_init", "ldu_ctx_comm_init_local", "ldu_ctx_comm_init_peer", "ldu_ctx_comm_select", "ldu_ctx_comm_info", "ldu_addr_create", "ldu_addr_add_patch",
-    "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights", "ldu_addr_set_subdomains", "ldu_partition_blobs",
+    "ldu_addr_add_cyclic_patch", "ldu_addr_sweep_engine", "ldu_addr_finalize", "ldu_addr_destroy", "ldu_addr_info", "ldu_addr_set_face_weights", "ldu_addr_set_subdomains", "ldu_partition_blobs", "ldu_partition_blobs_footprint",
     "ldu_addr_set_face_areas", "ldu_addr_get_face_weights", "ldu_device_count",
     "ldu_matrix_create", "ldu_matrix_destroy", "ldu_matrix_set_coeffs", "ldu_matrix_set_patch_coeffs",
     "ldu_amul", "ldu_tmul", "ldu_sumA", "ldu_residual", "ldu_H", "ldu_H1", "ldu_faceH",
@@ -898,6 +898,18 @@ def partition_blobs(nCells, lowerAddr, upperAddr, nParts):
     out = np.zeros(int(nCells), dtype=np.int32)
     _chk(lib().ldu_partition_blobs(int(nCells), l.size, _ptr(l), _ptr(u), int(nParts), _ptr(out)))
     return out
+
+
+def partition_blobs_footprint(nCells, lowerAddr, upperAddr, slotTarget, maxParts):
+    """-> (part of every cell, number of parts): breadth-first blobs of equal footprint (cells + distinct outside neighbours <=
+    slotTarget while a blob grows), the block engine's cut of levels whose equal-size blobs do not fit (host code)"""
+    l, u = _i32(lowerAddr), _i32(upperAddr)
+    out = np.zeros(int(nCells), dtype=np.int32)
+    n = C.c_int32(0)
+    f = lib().ldu_partition_blobs_footprint
+    f.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    _chk(f(int(nCells), l.size, _ptr(l), _ptr(u), int(slotTarget), int(maxParts), _ptr(out), C.byref(n)))
+    return out, int(n.value)
 
 
 def renumber_addressing(nCells, lowerAddr, upperAddr, newOrder):

@@ -321,6 +321,15 @@ int ldu_partition_blobs(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr
     return partition_blobs(nCells, nFaces, lowerAddr, upperAddr, nParts, part) < 0 ? -2 : 0;
 }
 
+int ldu_partition_blobs_footprint(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
+                                  int64_t slotTarget, int32_t maxParts, int32_t* part, int32_t* nParts)
+{
+    const int n = partition_blobs_slots(nCells, nFaces, lowerAddr, upperAddr, (long)slotTarget, maxParts, part);
+    if (n < 0) return -2;
+    if (nParts) *nParts = n;
+    return 0;
+}
+
 // (also the block engine's partitioner, ldu_blocks.hip) -> parts actually made (<= nParts), -1 on bad arguments
 int partition_blobs(int nCells, int nFaces, const int* lowerAddr, const int* upperAddr, int nParts, int* part)
 {
