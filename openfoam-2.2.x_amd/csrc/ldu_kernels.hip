@@ -172,32 +172,36 @@ row_kernel(int nSlices, const int* __restrict__ sliceRow, const int* __restrict_
     else if (MODE == 2) acc = diag[r];
     else acc = 0.0;
     const int W = sliceW[s];   // wave-uniform
-    if (W <= 8 && (MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5))
+    if (MODE == 0 || MODE == 1 || MODE == 3 || MODE == 5)
     {
-        // all of the row's columns, coefficients and x values in flight at once (the loop below issues one
-        // dependent gather per trip); the accumulation order and the k < n guard are unchanged
-        int c[8];
-        double v[8], xv[8];
+        // eight entries at a time: their columns and coefficients, then their x values, in flight together (one dependent
+        // gather per trip - the loop below - cost the agglomerated levels of an unstructured mesh, whose slices are 9-33 entries
+        // wide, as much time for half the rows as the finest level); the accumulation order and the k < n guard are unchanged
+        for (int k0 = 0; k0 < W; k0 += 8)
+        {
+            int c[8];
+            double v[8], xv[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < W)
-            {
-                const long e = ent + (long)k * LDU_WAVE;
-                // columns and coefficients are streamed once: nontemporal, so that L2 keeps the x values the gathers
-                // come back for (216^3 Amul 0.1838 -> 0.1784 ms); padding entries point at the row itself
-                c[k] = __builtin_nontemporal_load(col + e);
-                v[k] = __builtin_nontemporal_load(val + e);
-            }
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < W)
+                {
+                    const long e = ent + (long)(k0 + k) * LDU_WAVE;
+                    // columns and coefficients are streamed once: nontemporal, so that L2 keeps the x values the gathers
+                    // come back for (216^3 Amul 0.1838 -> 0.1784 ms); padding entries point at the row itself
+                    c[k] = __builtin_nontemporal_load(col + e);
+                    v[k] = __builtin_nontemporal_load(val + e);
+                }
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < W) xv[k] = x[c[k]];
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < W) xv[k] = x[c[k]];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (k < W && k < n)
-            {
-                if (MODE == 0 || MODE == 5) acc += v[k] * xv[k];
-                else acc -= v[k] * xv[k];
-            }
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < W && k0 + k < n)
+                {
+                    if (MODE == 0 || MODE == 5) acc += v[k] * xv[k];
+                    else acc -= v[k] * xv[k];
+                }
+        }
         y[r] = acc;
         return;
     }
