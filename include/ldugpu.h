@@ -249,8 +249,8 @@ int ldu_debug_gs_multi_trace(ldu_matrix* m, void* buf);
 int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap);
 /* The block engine (ldu_blocks.hip): per (sweep, group) task 8 x u64 - start, loads issued, dependencies seen, stored
  * [100 MHz wall clock], wavefront, sweep, block, lanes per row; buf = (tasks of k sweeps) * 64 bytes or NULL.
- * ldu_debug_blocks_info: out[0..5] = blocks, compute wavefronts per block, LDS bytes per block, ghosts, groupings, tasks
- * of k sweeps (all 0: the addressing is not on the block engine). */
+ * ldu_debug_blocks_info: out[8]; out[0..5] = blocks, compute wavefronts per block, LDS bytes per block, ghosts, groupings,
+ * tasks of k sweeps, out[6..7] reserved (written as 0) (all 0: the addressing is not on the block engine). */
 int ldu_debug_blocks_trace(ldu_matrix* m, void* buf);
 int ldu_debug_blocks_info(ldu_matrix* m, int32_t k, int64_t* out);
 /* Per-sweep layouts of the chip-wide pipelined GaussSeidel sweeps (ldu_gslayouts.cpp): out[0] = sweeps with a layout of their own

@@ -767,7 +767,7 @@ static int bk_build(ldu_addr* a)
         if (nw == 7 ? bk_occupancy<7>(1024, &perCUregs) : bk_occupancy<3>(1024, &perCUregs)) return -1;
         if (perCUregs > ctx->blkMaxPerCU) perCUregs = ctx->blkMaxPerCU;
         if (perCUregs < 1) continue;
-        const long cap = (long)ctx->numCUs * perCUregs;
+        const long cap = std::max<long>(1, (long)ctx->numCUs * perCUregs / std::max(1, ctx->deviceSharers));
         // as many blocks as fit at once (a few spare: the partitioner can come back with fewer), but not smaller than cmin cells
         const int cmin = nw == 3 ? std::min(ctx->blkCellsMin, 256) : ctx->blkCellsMin;
         long nParts = ctx->blkCells > 0 ? ((long)nC + ctx->blkCells - 1) / ctx->blkCells : std::min<long>((long)(0.97 * (double)cap), std::max<long>(1, nC / cmin));
@@ -857,7 +857,9 @@ static int bk_build(ldu_addr* a)
             if (perCU > ctx->blkMaxPerCU) perCU = ctx->blkMaxPerCU;
         }
         P->ldsBytes = lds;
-        found = perCU >= 1 && (long)nB <= (long)perCU * ctx->numCUs;
+        // (a GPU shared with other ranks' contexts: only this context's share of the workgroup slots may be counted on -
+        //  the others' spinning workgroups hold theirs)
+        found = perCU >= 1 && (long)nB <= (long)perCU * ctx->numCUs / std::max(1, ctx->deviceSharers);
         if (verbose)
             fprintf(stderr, "[ldugpu] block engine: %d cells, %d + 1 wavefronts per block: %d blocks (%ld asked for), largest %d slots (%zu B "
                             "of LDS), %d ghosts in all, %d workgroups per CU -> %ld resident%s\n", nC, nw, nB, nParts, maxSlots, lds,
@@ -866,7 +868,7 @@ static int bk_build(ldu_addr* a)
     if (!found) return 0;
     P->nw = nw;
     if (perCU < 1) return 0;
-    P->capacity = (long)perCU * ctx->numCUs;
+    P->capacity = (long)perCU * ctx->numCUs / std::max(1, ctx->deviceSharers);
     P->nBlocks = nB;
     P->maxSlots = maxSlots;
     P->blkNLocal = nLocal;

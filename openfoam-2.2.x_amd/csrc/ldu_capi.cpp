@@ -230,6 +230,8 @@ static int ctx_init(ldu_ctx* c, int device)
     if (e && atoi(e) > 0) c->blkLayouts = atoi(e);
     e = getenv("LDU_BLK_PER_CU");
     if (e && atoi(e) > 0) c->blkMaxPerCU = atoi(e);
+    e = getenv("LDU_DEVICE_SHARERS");
+    if (e && atoi(e) > 0) c->deviceSharers = atoi(e);
     e = getenv("LDU_SMALL_MAX");
     if (e) c->smallMaxCells = std::min(atoi(e), 16384);
     e = getenv("LDU_P2P_WIDE");

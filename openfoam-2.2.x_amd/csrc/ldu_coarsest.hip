@@ -448,7 +448,8 @@ coarsest_krylov_peer_kernel(CoarsePeer C, int n, int nF, const int* __restrict__
             g = co_allreduce(C, rseq, lane < 1 ? sh[0] : (lane == 1 ? (double)C.abortFlag[LDU_PEER_FLAG] : 0.0), 2, stage);
             final_ = __shfl(g, 0) / nf;
             converged = final_ < tolerance || (relTol > small_ && final_ < relTol * initial);
-            if (lane == 0) shStop = __shfl(g, 1) != 0.0 ? 1 : 0;
+            const double gStop = __shfl(g, 1);           // (every lane takes part: lane 1 is the source)
+            if (lane == 0) shStop = gStop != 0.0 ? 1 : 0;
             __syncthreads();
             if (shStop) break;
         } while (nIterations++ < maxIter && !converged);

@@ -238,6 +238,14 @@ extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oo
         me.pid = (int64_t)getpid();
         me.ptr = (uint64_t)(uintptr_t)W->base;
         me.device = ctx->device;
+        {
+            // which physical GPU (the ordinal means nothing across processes with their own HIP_VISIBLE_DEVICES)
+            int dom = 0, bus = 0, dev = 0;
+            (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, ctx->device);
+            (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, ctx->device);
+            (void)hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, ctx->device);
+            me.pad = (int32_t)(((unsigned)dom << 16) ^ ((unsigned)bus << 8) ^ (unsigned)dev) | 0x40000000;
+        }
         LDU_CHECK_HIP(hipIpcGetMemHandle(&me.handle, W->base));
         std::vector<PeerHello> all(nRanks);
         std::vector<int> peers;
@@ -247,6 +255,11 @@ extern "C" int ldu_ctx_comm_init_peer(ldu_ctx* ctx, int rank, int nRanks, ldu_oo
         for (int r = 0; r < nRanks; r++)
             if (r != rank) { peers.push_back(r); sp.push_back(&me); rp.push_back(&all[r]); nb.push_back(sizeof(PeerHello)); }
         if (peer_oob(ctx, peers, sp, nb, rp, nb)) return -1;
+        // ranks on THIS GPU: the engines whose progress argument counts resident workgroups (ldu_blocks.hip) may count on
+        // their share of the chip only - another rank's spinning workgroups hold the rest
+        int sharers = 1;
+        for (int r = 0; r < nRanks; r++) if (r != rank && all[r].pad == me.pad) sharers++;
+        if (sharers > ctx->deviceSharers) ctx->deviceSharers = sharers;
         for (int r = 0; r < nRanks; r++)
         {
             if (r == rank) continue;

@@ -145,6 +145,7 @@ struct ldu_ctx {
     int blkCellsMin = 1024;          // LDU_BLK_CELLS_MIN
     int blkCellsMax = 9000;          // LDU_BLK_CELLS_MAX (LDS: 9 bytes per local row and per ghost)
     int blkWaves = 0;                // LDU_BLK_WAVES (7 / 3 compute wavefronts per block, + 1 importer; 0 = by size)
+    int deviceSharers = 1;           // contexts that run on this GPU at the same time (peer ranks with the same PCI address; LDU_DEVICE_SHARERS)
     int blkMaxPerCU = 4;             // LDU_BLK_PER_CU: workgroups per CU the grid may count on
     int blkWavesPerSweep = 0;        // LDU_BLK_WPS: wavefronts a sweep's tasks of one block are dealt to (0 = all tasks round-robin over all wavefronts)
     int blkXcdMap = 1;               // LDU_BLK_XCD=0: blocks in launch order instead of contiguous ranges per XCD
@@ -165,6 +166,7 @@ struct ldu_ctx {
     int p2pGen = 0;                  // bumped when a sweep aborted: addressings reset their tickets
     int abortSeen = 0;               // an aborted sweep was detected since run_with_fallback() cleared this
     long nFallbacks = 0;             // operations re-run on the level-kernel engine after an aborted sweep
+    long nDiscardedAborts = 0;       // sweeps of a discarded (speculative) Krylov iteration that gave up waiting: dropped, not an error
     int consecFallbacks = 0;         // ... in a row (three: the context stays on the level kernels)
     // communicator
     int rank = 0, nRanks = 1;

@@ -647,6 +647,7 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
                 return 0;
             };
             int it = 0;
+            bool ahead = false;      // iteration it + 1 is in the queue
             if (queue(0)) return -1;
             for (;;)
             {
@@ -654,6 +655,7 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
                 // for it < maxIter; whether it takes effect is the device's decision)
                 const bool more = it < c->maxIter;
                 if (more && queue(it + 1)) return -1;
+                ahead = more;
                 LDU_CHECK_HIP(hipEventSynchronize(ctx->evRing[it & 1]));
                 const double* H = ctx->h_ring[it & 1];
                 {
@@ -666,6 +668,22 @@ static int solve_krylov(ldu_matrix* m, const ldu_controls* c, double* psi, const
                 hist_push(perf, c, hist);
                 if (!(perf->nIterations++ < c->maxIter && !check_convergence(perf, c->tolerance, c->relTol))) break;
                 it++;
+            }
+            if (ahead)
+            {
+                // The iteration queued behind the last one is discarded work (its update kernel does nothing), but it must
+                // not outlive this call, and what it may have left in the flag words must not surface in the NEXT operation:
+                // a peer time-out is an error of this solve (the ranks are out of step); a sweep of discarded work that gave
+                // up waiting is dropped - words cleared, a new tag generation for the granules it left half written.
+                LDU_CHECK_HIP(hipEventSynchronize(ctx->evRing[(it + 1) & 1]));
+                const int* w = (const int*)(ctx->h_ring[(it + 1) & 1] + S_NSLOTS);
+                if (w[2]) return abort_words_to_error(ctx, w, s);
+                if (w[0] || w[1])
+                {
+                    LDU_CHECK_HIP(hipMemsetAsync(ctx->d_abort, 0, 2 * sizeof(int), s));
+                    ctx->p2pGen++;
+                    ctx->nDiscardedAborts++;
+                }
             }
         }
     }

@@ -143,6 +143,8 @@ orc_gamg* orc_gamg_build(const orc_sys* s, const orc_opts* o, const double* face
 void orc_gamg_free(orc_gamg* g);
 int orc_gamg_nLevels(const orc_gamg* g);
 int orc_gamg_level_nCells(const orc_gamg* g, int lev);
+int orc_gamg_level_nCells_dom(const orc_gamg* g, int lev, int d);
+int orc_gamg_level_nFaces_dom(const orc_gamg* g, int lev, int d);
 int orc_gamg_level_nFaces(const orc_gamg* g, int lev);
 const int* orc_gamg_restrict(const orc_gamg* g, int lev);
 const int* orc_gamg_faceRestrict(const orc_gamg* g, int lev);

@@ -554,6 +554,10 @@ void orc_gamg_free(orc_gamg* g)
 int orc_gamg_nLevels(const orc_gamg* g) { return g->nLevels; }
 int orc_gamg_level_nCells(const orc_gamg* g, int lev) { return g->lev[lev].dl[0].nCells; }
 int orc_gamg_level_nFaces(const orc_gamg* g, int lev) { return g->lev[lev].dl[0].nFaces; }
+/* multi-domain hierarchies: cells / faces of level lev on domain d (the levels are common to all domains: the and-reduce of
+   continueAgglomerating, GAMGAgglomeration.C:53-62) */
+int orc_gamg_level_nCells_dom(const orc_gamg* g, int lev, int d) { return g->lev[lev].dl[d].nCells; }
+int orc_gamg_level_nFaces_dom(const orc_gamg* g, int lev, int d) { return g->lev[lev].dl[d].nFaces; }
 const int* orc_gamg_restrict(const orc_gamg* g, int lev) { return g->lev[lev].dl[0].restrictAddr; }
 const int* orc_gamg_faceRestrict(const orc_gamg* g, int lev) { return g->lev[lev].dl[0].faceRestrictAddr; }
 const int* orc_gamg_level_lower(const orc_gamg* g, int lev) { return g->lev[lev].dl[0].l; }

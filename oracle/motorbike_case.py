@@ -57,9 +57,10 @@ def available():
         os.path.exists(os.path.join(REF, f)) for f in ("blockMesh", "snappyHexMesh", "libautoMesh.so"))
 
 
-def write(case, q=4, box_level=4, surface_levels=(5, 6), max_cells=2000000, binary=True):
+def write(case, q=4, box_level=4, surface_levels=(5, 6), max_cells=2000000, binary=True, snap=False, layers=False):
     """q: background block 5q x 2q x 2q (tutorial 4 -> 20 x 8 x 8); box_level: refinementBox level (tutorial 4);
-    surface_levels: (min max) refinement on the motorBike surface (tutorial 5 6)"""
+    surface_levels: (min max) refinement on the motorBike surface (tutorial 5 6); snap / layers: the tutorial's
+    `snap true; addLayers true;` (motorBike/system/snappyHexMeshDict:18-20) - off for the stored castellated meshes"""
     _w(os.path.join(case, "system", "controlDict"), "dictionary", "controlDict", """
 application     simpleFoam;
 startFrom       latestTime;
@@ -118,8 +119,8 @@ boundary
 """ % (5 * q, 2 * q, 2 * q))
     _w(os.path.join(case, "system", "snappyHexMeshDict"), "dictionary", "snappyHexMeshDict", """
 castellatedMesh true;
-snap            false;
-addLayers       false;
+snap            %s;
+addLayers       %s;
 geometry
 {
     motorBike.obj { type triSurfaceMesh; name motorBike; }
@@ -152,7 +153,7 @@ snapControls
 }
 addLayersControls
 {
-    relativeSizes true; layers {} expansionRatio 1.0; finalLayerThickness 0.3; minThickness 0.1; nGrow 0;
+    relativeSizes true; layers { %s } expansionRatio 1.0; finalLayerThickness 0.3; minThickness 0.1; nGrow 0;
     featureAngle 60; slipFeatureAngle 30; nRelaxIter 3; nSmoothSurfaceNormals 1; nSmoothNormals 3;
     nSmoothThickness 10; maxFaceThicknessRatio 0.5; maxThicknessToMedialRatio 0.3; minMedianAxisAngle 90;
     nBufferCellsNoExtrude 0; nLayerIter 50;
@@ -165,7 +166,9 @@ meshQualityControls
 }
 debug 0;
 mergeTolerance 1e-6;
-""" % (max_cells, max_cells, surface_levels[0], surface_levels[1], box_level))
+""" % ("true" if snap else "false", "true" if layers else "false", max_cells, max_cells, surface_levels[0], surface_levels[1], box_level,
+       # motorBike/system/snappyHexMeshDict:176-182: one layer on the ground and on the surface's regions
+       '"(lowerWall|motorBike).*" { nSurfaceLayers 1; }' if layers else ""))
     tri = os.path.join(case, "constant", "triSurface")
     os.makedirs(tri, exist_ok=True)
     with gzip.open(SURFACE, "rb") as f, open(os.path.join(tri, "motorBike.obj"), "wb") as g:

@@ -320,6 +320,18 @@ class System:
         L.orc_gamg_pre_free(g)
         return t2 - t1, t1 - t0
 
+    def gamg_level_sizes(self, **optkw):
+        """[(cells, faces) summed over the domains] of every coarse level of the K-domain hierarchy"""
+        o = make_opts(**optkw)
+        fw = self.face_weights()
+        L = lib()
+        g = C.c_void_p(L.orc_gamg_build(C.byref(self.sys), C.byref(o), _p(fw)))
+        out = [(sum(L.orc_gamg_level_nCells_dom(g, lev, d) for d in range(len(self.doms))),
+                sum(L.orc_gamg_level_nFaces_dom(g, lev, d) for d in range(len(self.doms))))
+               for lev in range(L.orc_gamg_nLevels(g))]
+        L.orc_gamg_free(g)
+        return out
+
     def gamg_levels(self, **optkw):
         o = make_opts(**optkw)
         fw = self.face_weights()

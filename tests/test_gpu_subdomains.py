@@ -64,6 +64,9 @@ def test_subdomain_mode_against_the_multidomain_oracle(oracle, case, env, monkey
     assert np.max(np.abs(xg - xo)) <= 1e-7 * np.max(np.abs(xo))
     # the hierarchy is the K-rank hierarchy: as many levels, as many cells per level as the oracle's K hierarchies together
     lv = m.gamg_level_sizes(**GAMG)
+    lo = S.gamg_level_sizes(**GAMG)
+    assert len(lv) == len(lo), (len(lv), len(lo))
+    assert [(L["nCells"], L["nFaces"]) for L in lv] == lo, ([(L["nCells"], L["nFaces"]) for L in lv], lo)
     engines = [a.sweep_engine(2)] + [L["engine_gs_multi"] for L in lv]
     if env.get("LDU_BLK_IFACE") == "0":
         assert "blocks" not in engines, engines
