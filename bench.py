@@ -1,11 +1,13 @@
 #!/usr/bin/env python
-"""bench.py - GAMG / PCG iterations per second and achieved HBM GB/s of the 10 M-cell p-solve.
+"""bench.py - GAMG / PCG iterations per second and achieved HBM GB/s of the 10 M-cell motorBike p-solve.
 
-Workload (BASELINE.json configs[2]): the synthetic stand-in for the motorBike
-pressure matrix - structured 216^3 hex box (10 077 696 cells, 30 093 120 faces), variable-
-coefficient 7-point Laplacian (seed 12345), solved with the motorBike tutorial's GAMG block
-(tolerance 1e-7, relTol 0.01, GaussSeidel, nPostSweeps 2, faceAreaPair, nCellsInCoarsestLevel 10,
-mergeLevels 1, cacheAgglomeration on).
+Workload (BASELINE.json configs[2]), default `--mesh motorbike_rcm`: simpleFoam's pressure equation on the REAL
+motorBike mesh - the reference's own blockMesh + snappyHexMesh on its motorBike.obj, refined to 12 699 795 cells / 38 271 555
+internal faces (data/motorbike/mb12.npz, tools/make_motorbike.py), cells renumbered by Foam::bandCompression (renumberMesh) -
+solved with the motorBike tutorial's GAMG block (tolerance 1e-7, relTol 0.01, GaussSeidel, nPostSweeps 2, faceAreaPair,
+nCellsInCoarsestLevel 10, mergeLevels 1, cacheAgglomeration on).  Where the mesh store is absent the line says so
+(config.mesh_fallback) and measures the 216^3 box stand-in of rounds 1-4, which is otherwise a sub-leg (`box216`), like the
+same mesh in snappyHexMesh's own numbering, the 8-sub-domain run and the U-equation / PCG legs on the real mesh (`extra`).
 
 A step = one complete p-solve: coefficients (already resident in HBM) handed to the solver
 (ldu_matrix_set_coeffs: layout + level-matrix agglomeration, as the reference rebuilds them in
@@ -13,9 +15,11 @@ every solver construction), psi reset to 0, then lduMatrix::solver::solve.  One-
 work (dependency levels, agglomeration maps) happens before the timed region, like the
 reference's cached lduAddressing / cacheAgglomeration.
 
-value = V-cycles (the reference's nIterations) of all timed steps / wall time.
+value = V-cycles (the reference's nIterations) of all timed steps / wall time; ms per solve and V-cycles per solve stand beside it.
+cpu_baseline: the reference's own solver (oracle/_ref) on one host core; cpu_baseline_all_cores: the C restatement with one thread
+per sub-domain on all host cores (core count stated).
 N > 1: the same matrix decomposed into N sub-domains (strong scaling), one rank per GPU, halo
-exchange + scalar all-reduces on RCCL.
+exchange + scalar all-reduces on RCCL or peer stores.
 
 Prints ONE JSON line (rank 0).
 """
@@ -661,9 +665,11 @@ def main():
     # config C3's other half: the U-equation solvers of the motorBike case on the ASYMMETRIC matrix of the same box
     # (lower = upper - phi): PBiCG/DILU and the tutorial's own smoothSolver/GaussSeidel
     # (motorBike/system/fvSolution:33-40); fixed iteration counts, it/s and algorithmic GB/s
-    if world == 1 and args.mesh == "box" and not args.no_extras:
+    if world == 1 and not args.no_extras and args.rank_of <= 1 and args.subdomains <= 1:
         try:
-            pa = cases.box3d(n, asym=True)
+            # (the box: box3d's own asymmetric twin; any other mesh: the same recipe on THIS addressing - cases.asymmetric -
+            #  i.e. on the real motorBike mesh for the default line)
+            pa = cases.box3d(n, asym=True) if args.mesh == "box" else cases.asymmetric(lp)
             mat.set_coeffs(torch.from_numpy(pa["diag"]).to(dev), torch.from_numpy(pa["upper"]).to(dev),
                            torch.from_numpy(pa["lower"]).to(dev))
             d_srcA = torch.from_numpy(pa["source"]).to(dev)
@@ -685,6 +691,25 @@ def main():
             mat.set_coeffs(d_diag, d_upper)
         except Exception as e:  # pragma: no cover
             extra["asym_error"] = str(e)
+        try:
+            # north_star's "PCG+GAMG iterations/sec": PCG preconditioned by one GAMG V-cycle (GAMGPreconditioner.C:44-128),
+            # 10 iterations of the symmetric p-matrix; bytes per iteration = one V-cycle (roofline_vcycle's formula) + the
+            # PCG loop around it (PCG.C:123-172: Amul 24 nC + 16 nF, two dot products 32 nC, p / psi / rA updates 72 nC)
+            kwp = dict(solver="PCG", preconditioner="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                       nCellsInCoarsestLevel=10, mergeLevels=1, nVcycles=1, tolerance=0.0, relTol=0.0)
+            mat.solve(d_psi.zero_(), d_source, history=False, **dict(kwp, maxIter=1))
+            d_psi.zero_()
+            barrier()
+            t0 = time.perf_counter()
+            _, pq = mat.solve(d_psi, d_source, history=True, **dict(kwp, maxIter=9))
+            barrier()
+            tq = time.perf_counter() - t0
+            extra["pcg_gamg_iterations_per_s"] = round(pq["nIterations"] / tq, 2)
+            if roof_v and "bytes_per_vcycle" in roof_v:
+                extra["pcg_gamg_GBs_algorithmic"] = round((roof_v["bytes_per_vcycle"] + 128.0 * nC + 16.0 * nF) * pq["nIterations"] / tq / 1e9, 1)
+            extra["pcg_gamg_residual_after_10"] = float("%.4e" % pq["finalResidual"])
+        except Exception as e:  # pragma: no cover
+            extra["pcg_gamg_error"] = str(e)
 
     if world == 1 and args.mesh == "box" and not args.no_extras and args.rank_of <= 1:
         try:
@@ -732,7 +757,24 @@ def main():
     # core, one thread per sub-domain emulating the reference's MPI ranks (oracle/time_allcores.py); a port, never
     # the reference itself (no MPI in this image)
     cpu_all = None
-    if cpu is not None and not args.no_extras and not is_octree and args.mesh != "jump2d":
+    if cpu is not None and not args.no_extras and is_mb:
+        # the metric's own mesh on all host cores: as many compact blobs of the numbering as cores, one thread each
+        import subprocess
+        cores = max(1, min(os.cpu_count() or 1, 64))
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_allcores.py"),
+                                "motorbike:%s%s" % (args.motorbike_name, "" if args.mesh == "motorbike_rcm" else ":snappy"),
+                                str(cores), "2"], capture_output=True, text=True, timeout=900)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            cpu_all = dict(value=round(j["vcycles_per_s"], 4), unit="V-cycles/s", cores=cores, kind="port",
+                           sample="oracle (C restatement, gcc -O2 -fopenmp): the same mesh and numbering cut into %d compact blobs "
+                                  "(ldu_partition_blobs), one thread per sub-domain emulating the reference's ranks (rank-local "
+                                  "GaussSeidel / agglomeration, processor patches, rank-ordered sums): 2 GAMG V-cycles in %.2f s "
+                                  "(agglomeration %.1f s excluded, cached like cacheAgglomeration)"
+                                  % (j["subdomains"], j["seconds"], j["setup_s"]))
+        except Exception as e:  # pragma: no cover
+            cpu_all = dict(error=str(e)[:300], cores=cores)
+    elif cpu is not None and not args.no_extras and not is_octree and args.mesh != "jump2d":
         import subprocess
         cores = max(1, min(os.cpu_count() or 1, 64))
         try:

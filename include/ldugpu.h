@@ -509,6 +509,11 @@ int ldu_mesh_interpolation_factors(ldu_ctx* ctx, int32_t nCells, int32_t nIntern
  * internal faces: newOrder[i] = old label of the cell that becomes cell i (what renumberMesh applies) */
 int ldu_band_compression(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr,
                          int32_t* newOrder);
+/* A numbering for manualRenumber (src/renumber/renumberMethods/manualRenumber/manualRenumber.C:60-136 reads exactly this
+ * newToOld list): `order` (NULL = identity; normally ldu_band_compression's) cut into tiles of tileSize consecutive cells, the
+ * tiles re-ordered by a hash of (seed, tile index), the order inside a tile kept.  Keeps bandCompression's sweep inside a tile
+ * and bounds the GaussSeidel dependency chains of every GAMG level by a handful of tiles (DESIGN "Numbering"); host code. */
+int ldu_tile_shuffle(int32_t nCells, const int32_t* order, int32_t tileSize, uint64_t seed, int32_t* newOrder);
 /* nParts compact sub-domains of nearly equal size (breadth-first blobs in the order of the numbering; host code): the cut
  * ldu_addr_set_subdomains' callers use when the case brings no decomposition of its own */
 int ldu_partition_blobs(int32_t nCells, int32_t nFaces, const int32_t* lowerAddr, const int32_t* upperAddr, int32_t nParts,

@@ -39,7 +39,7 @@ EXPORTS = [
     "ldu_mesh_nonorth_factors", "ldu_mesh_patch_nonorth_factors", "ldu_fv_interpolateDot", "ldu_fv_faceDot",
     "ldu_fv_faceScale", "ldu_fvc_correctedSnGrad", "ldu_fv_interpolateBoundary", "ldu_fvc_gaussGradBoundary",
     "ldu_fvc_surfaceIntegrateFull", "ldu_fvm_sourceMinusVDiv", "ldu_fv_tensorGammaFactors",
-    "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_renumber_addressing",
+    "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_tile_shuffle", "ldu_renumber_addressing",
     "ldu_debug_dag_stats", "ldu_debug_stream", "ldu_debug_slices", "ldu_ctx_set_watchdog", "ldu_ctx_comm_counters", "ldu_comm_paired_patch", "ldu_comm_exchange_order",
 ]
 
@@ -889,6 +889,16 @@ def band_compression(nCells, lowerAddr, upperAddr):
     l, u = _i32(lowerAddr), _i32(upperAddr)
     out = np.zeros(int(nCells), dtype=np.int32)
     _chk(lib().ldu_band_compression(int(nCells), l.size, _ptr(l), _ptr(u), _ptr(out)))
+    return out
+
+
+def tile_shuffle(order, tileSize, seed=1):
+    """ldu_tile_shuffle (host code): tiles of tileSize consecutive cells of `order` in hashed order - a manualRenumber list"""
+    o = _i32(order)
+    out = np.zeros_like(o)
+    f = lib().ldu_tile_shuffle
+    f.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p]
+    _chk(f(int(o.size), _ptr(o), int(tileSize), int(seed), _ptr(out)))
     return out
 
 

@@ -109,6 +109,26 @@ def box3d(nx, ny=None, nz=None, asym=False, seed=12345, seed_asym=54321):
     return p
 
 
+def asymmetric(p, seed=54321, strength=0.3):
+    """SURVEY.md 8d's recipe for config C3's other half (the U-equation solvers) on ANY symmetric problem's addressing:
+    lower[f] = upper[f] - phi[f] with a face flux phi[f] = strength * (2 u01(seed, f) - 1) * |upper[f]| (on the box, where
+    |upper| ~ 1, this is box3d(asym=True)'s operator family), the diagonal re-summed the way negSumDiag does
+    (lduMatrixOperations.C:50-64: diag[l] -= lower, diag[u] -= upper), so what the symmetric problem added to its diagonal
+    (a fixedValue patch, a reference row) stays; b = A x* for the smooth x* the symmetric problem was made with, where
+    known, else sin(1e-3 i)."""
+    l, u, nC = p["lowerAddr"], p["upperAddr"], p["nCells"]
+    up = p["upper"]
+    phi = strength * (2.0 * u01(seed, up.size) - 1.0) * np.abs(up)
+    lower = up - phi
+    q = dict(p)
+    q["lower"] = lower
+    # negSumDiag of the symmetric matrix took `upper` on both sides: the l side now takes `lower`
+    q["diag"] = p["diag"] + np.bincount(l, weights=phi, minlength=nC)
+    q["source"] = amul(q, np.sin(1e-3 * np.arange(nC)))
+    q["psi"] = np.zeros(nC)
+    return q
+
+
 def _u01_key(seed, key):
     """uniform double in [0,1) per 64-bit key (a global cell id * 3 + face direction): the same on every rank"""
     with np.errstate(over="ignore"):

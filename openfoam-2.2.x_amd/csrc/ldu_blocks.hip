@@ -194,6 +194,18 @@ __device__ __forceinline__ void bk_store(uint4* G, int row, double v, unsigned t
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
 }
 
+// Stores of the rare paths (abort flag, trace stamps) as inline asm: a compiler-visible store anywhere in the step loop leaves
+// "loads AND stores pending" on vmcnt (gfx9 counts both; they return out of order with respect to each other), and the
+// waitcnt pass then turns every wait of the loop into s_waitcnt vmcnt(0) - the prefetches in flight included.
+__device__ __forceinline__ void bk_flag_set(int* p)
+{
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(1) : "memory");
+}
+__device__ __forceinline__ void bk_trace_store(unsigned long long* p, unsigned long long v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ bk_u32x4 bk_load(const uint4* p)
 {
     bk_u32x4 g;
@@ -218,17 +230,23 @@ struct BkTab {
 };
 
 // a task's rows in flight: one lane = one row (T = 1) or one sixteen-entry part of a row (T = 2 / 4 / 8 lanes per row)
-struct BkRow { int4 Q; int rg, slot, nl, nn, ni, hist, ifg, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
+struct BkRow { int4 Q; int rg, slot, nl, nn, ni, hist, ifg, sent, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
 
 // stage B of a task's prefetch: everything that depends on the task record (R.Q, loaded a step earlier) alone
 __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
 {
-    const int4 Q = R.Q;
+    // (the record was loaded a step ago into VECTOR registers - see BK_REC - and becomes scalar here, where it is first needed)
+    const int4 Q = make_int4(__builtin_amdgcn_readfirstlane(R.Q.x), __builtin_amdgcn_readfirstlane(R.Q.y),
+                             __builtin_amdgcn_readfirstlane(R.Q.z), __builtin_amdgcn_readfirstlane(R.Q.w));
     const int cnt = Q.y & 255, stride = (Q.y >> 16) & 255, j = Q.w;
     const int L = j < T.nLayouts ? j : T.nLayouts - 1;
-    const int4* __restrict__ meta = T.meta[L];
-    const unsigned* __restrict__ col = T.col[L];
-    const double* __restrict__ val = T.val[L];
+    // (constant indices + scalar selects: T lives in the kernel's argument segment, and T.meta[L] with a run-time L is a scalar
+    //  LOAD from it - s_load + s_waitcnt lgkmcnt(0) - in every step)
+#define BK_SEL(A) (L == 0 ? (A)[0] : L == 1 ? (A)[1] : L == 2 ? (A)[2] : (A)[3])
+    const int4* __restrict__ meta = BK_SEL(T.meta);
+    const unsigned* __restrict__ col = BK_SEL(T.col);
+    const double* __restrict__ val = BK_SEL(T.val);
+#undef BK_SEL
     const bool have = lane < cnt;
     const int4 M = meta[Q.x + (have ? lane : 0)];
     const long ent2 = (long)(Q.z >> 1) + (have ? lane : 0);    // pairs of coefficients (16 bytes)
@@ -238,7 +256,10 @@ __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
     R.nl = (M.y >> 16) & 31;
     R.nn = (M.y >> 21) & 31;
     R.ni = (M.y >> 26) & 31;
-    R.hist = M.z;
+    // M.z: plans with coupled interfaces - the row's hist pair; plans without - the row's SENTINEL: the LDS slot of the input
+    // that the plan expects last (| 1 << 16: a lower neighbour, wanted with this sweep's stamp)
+    R.hist = T.blk2 ? M.z : -1;
+    R.sent = T.blk2 ? -1 : M.z;
     R.ifg = M.w;
     const uint4* __restrict__ col4 = (const uint4*)col;
     const double2* __restrict__ val2 = (const double2*)val;
@@ -297,7 +318,14 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
     // a task's data arrive in three stages, each a step (= one task of this wavefront) ahead of the next: its record; its rows'
     // meta data, columns and coefficients (they depend on the record only); rhs and diagonal (they depend on the row).  The
     // record of a buffer's NEXT task is requested at the start of the step that computes its current one.
-#define BK_REC(R) do { (R).Q = iNext < nTasks ? tasks[iNext] : make_int4(0, 0, 0, 0); iNext++; } while (0)
+    // The record's address is wave-uniform, and the compiler reads a uniform load's result into scalar registers RIGHT BEHIND the
+    // load (global_load; s_waitcnt vmcnt(0); v_readfirstlane): a full memory round trip - and a wait for every prefetch in
+    // flight - at the start of every step, on the dependency chain (0.68 of the 1.1 us of a step in the round-5 trace).  An
+    // index the compiler cannot prove uniform (vz = 0 from an opaque asm) keeps the record in vector registers until
+    // bk_row_load makes it scalar a step later.
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+#define BK_REC(R) do { (R).Q = iNext < nTasks ? tasks[iNext + vz] : make_int4(0, 0, 0, 0); iNext++; } while (0)
 #define BK_FILLB(R) bk_row_load(lane, T, (R))
 #define BK_FILLC(R) do { const int g_ = (R).rg & 0x3fffffff; (R).b = rhs[g_]; (R).d = diag[g_]; } while (0)
     if (wave < NW)
@@ -355,7 +383,7 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
             else
             {
                 __builtin_amdgcn_s_sleep(1);
-                if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; break; }
+                if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { bk_flag_set(abortFlag); break; }
             }
         }
     }
@@ -365,7 +393,7 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
         ldu_debug_stall(firstBlock && wave == 0);    // (tests: the first task of the launch sits still, ldu_ctx_set_watchdog)
         int left = nTasks;      // this wavefront's tasks
         unsigned long long* trc = g_bk_trace ? g_bk_trace + (size_t)t0 * 8 : nullptr;
-#define BK_TRC(k) do { if (trc && lane == 0) trc[k] = wall_clock64(); } while (0)
+#define BK_TRC(k) do { if (trc && lane == 0) bk_trace_store(trc + (k), wall_clock64()); } while (0)
 #define BK_STEP(CUR, NXT, FILL)                                                           \
     do {                                                                                  \
         BK_TRC(0);                                                                        \
@@ -396,7 +424,7 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
                     int sum = 0;                                                          \
                     _Pragma("unroll") for (int q = 0; q < 16; q++) sum += st[q];          \
                     if (__builtin_amdgcn_ballot_w64(have && sum != want) == 0ull) break;  \
-                    if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { *abortFlag = 1; alive = false; } \
+                    if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { bk_flag_set(abortFlag); alive = false; } \
                 }                                                                         \
                 LDU_LDS_ACQUIRE();                                                        \
                 _Pragma("unroll") for (int q = 0; q < 16; q++) xv[q] = x[cc[q]];          \
@@ -443,7 +471,9 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
             }                                                                             \
         }                                                                                 \
         LDU_STEP_FENCE();                                                                 \
-        if (trc && lane == 0) { trc[3] = wall_clock64(); trc[4] = wave; trc[5] = (CUR).j; trc[6] = b; trc[7] = (CUR).T; trc += 8; } \
+        if (trc && lane == 0) { bk_trace_store(trc + 3, wall_clock64()); bk_trace_store(trc + 4, wave); bk_trace_store(trc + 5, (CUR).j); \
+                                bk_trace_store(trc + 6, b); bk_trace_store(trc + 7, (CUR).T); } \
+        if (trc) trc += 8;                                                                \
         --left;                                                                           \
     } while (0)
         while (left > 0)
@@ -615,11 +645,30 @@ static int bk_build_layout(ldu_addr* a, int L)
                     M.y = slot[c] | (lo << 16) | (en << 21) | (fi << 26);
                     M.z = ni ? hslot[c] : -1;
                     M.w = ni ? P->ifIdx[c] : 0;
+                    // (without interfaces M.z becomes the lane's sentinel below; the row itself - its value of the sweep before -
+                    //  until an entry is expected later)
+                    if (!P->iface) M.z = slot[c];
                     meta[(size_t)Y.grpLane0[g] + lane0 + tl] = M;
                 }
                 int q = 0;
+                int sentT[8];
+                for (int tl = 0; tl < 8; tl++) sentT[tl] = L ? RTprev[c] : -1;
                 auto put = [&](int n, int code) {
                     const int tl = q >> 4, qq = q & 15;
+                    if (!P->iface)
+                    {
+                        // when the plan expects this input: a lower neighbour in this sweep, an upper one in the sweep before (sweep
+                        // 0: the initial value, there from the start); two steps more across blocks (the importer's way)
+                        const bool lowerE = !(code & 1);
+                        int te = lowerE ? RT[n] : (L ? RTprev[n] : -2);
+                        if (blk[n] != b && te >= 0) te += 2;
+                        if (te > sentT[tl])
+                        {
+                            sentT[tl] = te;
+                            const unsigned sl_ = (unsigned)(blk[n] == b ? slot[n] : gslot_[n]);
+                            meta[(size_t)Y.grpLane0[g] + lane0 + tl].z = (int)(sl_ | (lowerE ? 0x10000u : 0u));
+                        }
+                    }
                     // a lane's entries 2 p, 2 p + 1 are one 16-byte pair (pair p of lane l at grpEnt / 2 + p * stride + l), its
                     // column slots 8 r ... 8 r + 7 one 16-byte quad of words (quad r at grpEnt / 8 + r * stride + l): a task's
                     // rows arrive with 2 + 8 load instructions instead of 8 + 16 - groups hold ~10 of 64 lanes, what a

@@ -583,4 +583,34 @@ int ldu_renumber_addressing(int32_t nCells, int32_t nFaces, const int32_t* lower
     return 0;
 }
 
+// A cell numbering for the sweep engines (DESIGN "Numbering"): `order` (normally Foam::bandCompression's) cut into tiles of
+// tileSize consecutive cells, the tiles put into the order of a hash of (seed, tile index), the order inside a tile kept.
+// A GaussSeidel sweep in this numbering still runs through every tile in bandCompression's order - a tile is a patch of one
+// or two breadth-first shells - but the longest chain of cells that must be smoothed one after the other no longer spans the
+// mesh: it spans a handful of tiles (the longest increasing path through randomly ranked tiles), and the pair matching of the
+// agglomeration (pairGAMGAgglomerate.C:83-197) hands the same property down to every coarse level, whose numbering is the
+// order in which it reaches the fine cells.  Deterministic (splitmix64), the same on every host.
+int ldu_tile_shuffle(int32_t nCells, const int32_t* order, int32_t tileSize, uint64_t seed, int32_t* newOrder)
+{
+    if (nCells < 0 || tileSize < 1) { ldu_set_error("ldu_tile_shuffle: bad sizes"); return -14; }
+    const long nT = ((long)nCells + tileSize - 1) / tileSize;
+    std::vector<std::pair<uint64_t, long>> key((size_t)nT);
+    for (long t = 0; t < nT; t++)
+    {
+        uint64_t z = (uint64_t)t + (seed << 40) + 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        key[(size_t)t] = {z ^ (z >> 31), t};
+    }
+    std::sort(key.begin(), key.end());
+    long o = 0;
+    for (long i = 0; i < nT; i++)
+    {
+        const long t = key[(size_t)i].second;
+        const long a = t * tileSize, b = std::min<long>(a + tileSize, nCells);
+        for (long c = a; c < b; c++) newOrder[o++] = order ? order[c] : (int32_t)c;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -90,6 +90,69 @@ def test_hip_path_against_the_oracle(oracle, name, rcm):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mb2", "mb12"])
+def test_asymmetric_operators_on_the_real_mesh(oracle, name):
+    """config C3's other half on the metric's own mesh: the U-equation solvers of the motorBike case on an
+    ASYMMETRIC matrix built on the real addressing under Foam::bandCompression (cases.asymmetric: lower = upper - phi, SURVEY
+    8d) - Amul, Tmul (lduMatrixATmul.C:34-150), residual, DILU and its transpose (DILUPreconditioner.C:88-185), GaussSeidel on
+    the asymmetric matrix bit for bit; PBiCG/DILU (PBiCG.C:65-198) and smoothSolver/GaussSeidel by history - the bars of
+    test_gpu_fullsize.py (smoothSolver 1e-6; PBiCG 1e-6 on the first iterations, 2e-5 over the run: tree-summed dot products)."""
+    _need(name)
+    p = motorbike.problem(name)
+    p.pop("cellLevel"); p.pop("meta")
+    p = cases.asymmetric(_renumber(p))
+    S = oracle.System(p)
+    ctx = capi.Context(0)
+    a, m = capi.from_problem(ctx, p)
+    rng = np.random.RandomState(4)
+    x, b = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+    assert np.array_equal(m.Amul(x), S.Amul(x))
+    assert np.array_equal(m.Tmul(x), S.Tmul(x))
+    assert np.array_equal(m.residual(x, b), S.residual(x, b))
+    assert np.array_equal(m.precondition("DILU", b), S.precondition("DILU", b)[0])
+    assert np.array_equal(m.precondition("DILU", b, transpose=True), S.precondition("DILU", b, transpose=True)[0])
+    for k in (1, 2):
+        assert np.array_equal(m.smooth("GaussSeidel", x, b, k), S.smooth("GaussSeidel", x, b, k)), k
+    nIt = 9 if name == "mb12" else 19
+    kw = dict(tolerance=0.0, relTol=0.0, maxIter=nIt)
+    xg, pg = m.solve(p["psi"], p["source"], solver="PBiCG", preconditioner="DILU", **kw)
+    xo, po = S.solve(p["psi"], p["source"], solver="PBiCG", precond="DILU", **kw)
+    assert pg["nIterations"] == po["nIterations"] == nIt + 1
+    np.testing.assert_allclose(pg["history"][:6], po["history"][:6], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(pg["history"], po["history"], rtol=2e-5, atol=1e-12)
+    kw = dict(solver="smoothSolver", smoother="GaussSeidel", nSweeps=1, tolerance=0.0, relTol=0.0, maxIter=nIt)
+    xg, pg = m.solve(p["psi"], p["source"], **kw)
+    xo, po = S.solve(p["psi"], p["source"], **kw)
+    assert pg["nIterations"] == po["nIterations"]
+    np.testing.assert_allclose(pg["history"], po["history"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(xg - xo)) <= 1e-8 * np.max(np.abs(xo))
+    assert ctx.fallback_count() == 0
+    m.close(); a.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_pcg_with_the_gamg_preconditioner_on_the_real_mesh(oracle):
+    """a19 at more than a million cells: PCG preconditioned by one GAMG V-cycle
+    (GAMGPreconditioner.C:44-128) on the 1.73 M-cell mesh, iteration count and residual history against the oracle"""
+    _need("mb2")
+    p = motorbike.problem("mb2")
+    p.pop("cellLevel"); p.pop("meta")
+    p = _renumber(p)
+    S = oracle.System(p)
+    ctx = capi.Context(0)
+    a, m = capi.from_problem(ctx, p)
+    kw = dict(solver="PCG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10, mergeLevels=1,
+              tolerance=1e-7, relTol=1e-4, nVcycles=1)
+    xg, pg = m.solve(p["psi"], p["source"], preconditioner="GAMG", **kw)
+    xo, po = S.solve(p["psi"], p["source"], precond="GAMG", **kw)
+    assert pg["nIterations"] == po["nIterations"] and 3 <= pg["nIterations"] <= 30
+    np.testing.assert_allclose(pg["history"], po["history"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(xg - xo)) <= 1e-7 * np.max(np.abs(xo))
+    assert ctx.fallback_count() == 0
+    m.close(); a.close(); ctx.close()
+
+
+@pytest.mark.gpu
 def test_device_geometry_on_the_real_polymesh():
     """points / faces / owner / neighbour of the tutorial-size snappyHexMesh mesh (faces of 4 ... 8 points) through the
     product's mesh kernels: volumes and face areas equal to the numpy evaluation of the same reference formulas the mesh

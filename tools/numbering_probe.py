@@ -16,6 +16,9 @@ MESH = mbtut | mb2 | mb12 (data/motorbike).  ORDERING:
     shell[:within]  breadth-first shells of the rcm traversal, inside a shell an independent set first (colour, then within)
     blob:K[:within] K breadth-first blobs one after the other, multi-colour inside a blob
     hmc[:iters]     hierarchical multi-colour (see hmc_order)
+    tilerand:K      tiles of K consecutive rcm positions in random order (numpy RNG), rcm order inside a tile
+    tiles:K[:seed]  the same by the library's deterministic ldu_tile_shuffle (what a manualRenumber file would hold)
+    sshell:S[:w]    super-shells of S breadth-first shells, multi-colour inside
 The table: per level cells / dependency levels of one sweep / steps of 2 and 4 pipelined sweeps; their sums over the levels;
 distinct 128-byte lines per 64-row gather on the finest level; --solve: V-cycles and residual history of the bench's solve."""
 import argparse
@@ -196,6 +199,20 @@ def make_order(p, spec, rcm, seed=1):
         ncol, col = colour(nC, p["lowerAddr"], p["upperAddr"], rcm)
         key2 = within_key(f[1] if len(f) > 1 else "rcm", nC, rcm_pos, rng)
         return np.lexsort((key2, col, shell)).astype(np.int32)
+    if f[0] == "sshell":
+        # super-shells of S breadth-first shells one after the other (the sweep still runs through the domain front by front),
+        # multi-colour inside a super-shell
+        S = int(f[1])
+        shell = bfs_shells(nC, p["lowerAddr"], p["upperAddr"], rcm) // S
+        ncol, col = colour(nC, p["lowerAddr"], p["upperAddr"], rcm)
+        key2 = within_key(f[2] if len(f) > 2 else "rcm", nC, rcm_pos, rng)
+        return np.lexsort((key2, col, shell)).astype(np.int32)
+    if f[0] == "tilerand":
+        # tiles of K consecutive bandCompression positions in random order, bandCompression order inside a tile (no colours)
+        return np.argsort(within_key("tile" + f[1], nC, rcm_pos, rng), kind="stable").astype(np.int32)
+    if f[0] == "tiles":
+        # the library's own: ldu_tile_shuffle(bandCompression order, K, seed) - tiles:K[:seed]
+        return capi.tile_shuffle(rcm, int(f[1]), int(f[2]) if len(f) > 2 else 1)
     if f[0] == "blob":
         K = int(f[1])
         part = capi.partition_blobs(nC, p["lowerAddr"], p["upperAddr"], K).astype(np.int64)
