@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=216, help="box edge (216 -> 10.08 M cells)")
     ap.add_argument("--mesh", choices=["box", "renumbered", "irregular", "random", "octree", "octree_hexref", "jump2d",
-                                       "motorbike", "motorbike_rcm", "motorbike_tiles"],
+                                       "motorbike", "motorbike_rcm", "motorbike_tiles", "motorbike_real"],
                     default="motorbike_rcm",
                     help="motorbike: the REAL mesh of the metric's workload - the reference's own blockMesh + snappyHexMesh "
                          "(castellatedMesh) on the reference's motorBike.obj, refined to ~10 M cells "
@@ -185,6 +185,7 @@ def main():
                          "octree_hexref: the same in hexRef8's own numbering (what the tutorial's Allrun solves on); "
                          "jump2d: BASELINE config C5's twin at its size - n x n 2-D 5-point matrix with the coefficient "
                          "jumping 1 <-> 1000 across the diagonal (damBreak p_rgh, --n 2000 = 4.0 M cells)")
+    ap.add_argument("--real-matrix", default="mb2sl_p3", help="--mesh motorbike_real: which stored matrix (data/motorbike/<name>.npz)")
     ap.add_argument("--tile-size", type=int, default=2048, help="--mesh motorbike_tiles: cells per tile (ldu_tile_shuffle)")
     ap.add_argument("--tile-seed", type=int, default=1, help="--mesh motorbike_tiles: seed of the tile order")
     ap.add_argument("--motorbike-name", default="mb12", help="which stored motorBike mesh (data/motorbike/<name>.npz)")
@@ -285,6 +286,16 @@ def main():
         p = cases.random_graph_fast(n ** 3, 7.0, 600)
     elif args.mesh == "jump2d":
         p = cases.jump2d(n, n)
+    elif args.mesh == "motorbike_real":
+        # the matrix the REFERENCE's simpleFoam handed a p-solve on a snapped + layered motorBike mesh (tools/make_motorbike_matrix.py),
+        # cells renumbered by Foam::bandCompression
+        from openfoam_amd import motorbike
+        p = motorbike.dumped_problem(args.real_matrix)
+        mb_meta = p.pop("meta")
+        cell_level_hist = mb_meta["internal_faces_per_cell"]
+        order = capi.band_compression(p["nCells"], p["lowerAddr"], p["upperAddr"])
+        nl, nu, fmap, flip = capi.renumber_addressing(p["nCells"], p["lowerAddr"], p["upperAddr"], order)
+        p = cases.renumbered(p, order, fmap, flip, nl, nu)
     elif args.mesh in ("motorbike", "motorbike_rcm", "motorbike_tiles"):
         from openfoam_amd import motorbike
         p = motorbike.problem(args.motorbike_name)
@@ -324,7 +335,7 @@ def main():
     if world > 1 or args.rank_of > 1:
         # 2x2x2 blocks at 8 ranks, slabs/blocks otherwise
         nr = world if world > 1 else args.rank_of
-        if args.mesh != "box" and not (is_mb and world > 1):
+        if args.mesh != "box" and not is_mb:
             raise SystemExit("bench.py: the block decomposition is defined on the box")
         shape = {2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(nr, (1, 1, nr))
     if p is None:
@@ -336,19 +347,29 @@ def main():
     t_gen = time.perf_counter() - t_gen
     if p is None:
         pass
-    elif is_mb and world > 1:
-        # the real mesh, N-way: equal contiguous ranges of the cell numbering (decomposePar's `simple`-like cut along the
-        # numbering; under Foam::bandCompression the ranges are breadth-first shells around the bike)
-        shape = (1, 1, world)
-        cell_rank = motorbike.decomposition(args.motorbike_name, world) if args.mesh == "motorbike" else None
+    elif is_mb and (world > 1 or args.rank_of > 1):
+        # the real mesh, N-way: the reference's own `hierarchical` decomposition of the cell centres where the store holds one for N
+        # (tools/make_motorbike.py through the reference's libdecompositionMethods; under a renumbering the stored rank of a cell
+        # follows the cell), else equal contiguous ranges of the cell numbering (decomposePar's `simple`-like cut along the
+        # numbering; under Foam::bandCompression the ranges are breadth-first shells around the bike).  decomposePar keeps the
+        # cell order of the mesh inside a sub-domain, and so does decompose.decompose.
+        nr = world if world > 1 else args.rank_of
+        shape = (1, 1, nr)
+        cell_rank = motorbike.decomposition(args.motorbike_name, nr)
         mb_decomp = "the reference's hierarchical decomposition of the cell centres (motorBike/system/decomposeParDict)"
+        if cell_rank is not None and args.mesh != "motorbike":
+            cell_rank = cell_rank[order]          # (order[i] = the stored mesh's label of the cell that is cell i now)
         if cell_rank is None:
-            # (a renumbered mesh, or no stored decomposition: equal contiguous ranges of the numbering)
-            cell_rank = (np.arange(p["nCells"], dtype=np.int64) * world) // p["nCells"]
-            mb_decomp = "%d contiguous ranges of the cell numbering" % world
-        subs, cell_maps = decompose.decompose(p, cell_rank, world, only_rank=rank)
-        lp = subs[rank]
+            cell_rank = (np.arange(p["nCells"], dtype=np.int64) * nr) // p["nCells"]
+            mb_decomp = "%d contiguous ranges of the cell numbering" % nr
+        # --rank-of N: the LARGEST sub-domain (what an N-rank run waits for)
+        my = rank if world > 1 else int(np.argmax(np.bincount(cell_rank, minlength=nr)))
+        subs, cell_maps = decompose.decompose(p, cell_rank, nr, only_rank=my)
+        lp = subs[my]
         del subs
+        if args.rank_of > 1:
+            for q in lp["patches_dev"]:
+                q["nbrRank"] = 0
     elif world > 1 or args.rank_of > 1:
         cell_rank = decompose.block_ranks(n, n, n, *shape)
         subs, cell_maps = decompose.decompose(p, cell_rank, nr, only_rank=rank)
@@ -803,6 +824,7 @@ def main():
     snappy_leg = None
     subdomain_leg = None
     tiles_leg = None
+    real_leg = None
     octree_leg = None
     fallbacks_main = ctx.fallback_count()
     mem_in_use_gb = round((lambda fr, tot: (tot - fr) / 1e9)(*torch.cuda.mem_get_info()), 2)
@@ -880,6 +902,22 @@ def main():
         except Exception as e:  # pragma: no cover
             tiles_leg = dict(error=str(e)[:300])
         try:
+            # the tutorial's actual kind of mesh and matrix - snapped polyhedra, layer prisms, the coefficients
+            # of a real SIMPLE iteration - at 1.85 M cells (the largest the reference's serial snappyHexMesh + simpleFoam make in minutes)
+            from openfoam_amd import motorbike as _mbr
+            if _mbr.available("mb2sl_p3"):
+                oj = run_leg("motorbike_real", ["--no-extras", "--steps", "5", "--warmup", "1"])
+                real_leg = dict(workload=oj["config"]["workload"], vcycles_per_s=oj["value"], ms_per_solve=oj["ms_per_step"],
+                                vcycles_per_solve=oj["config"]["vcycles_per_solve"], residual_history=oj["extra"]["residual_history"],
+                                dependency_levels=[oj["config"]["dependency_levels_finest"]] + [L[2] for L in oj["roofline_vcycle"]["levels"]],
+                                engines=[oj["roofline_vcycle"]["finest"][3]] + [L[3] for L in oj["roofline_vcycle"]["levels"]],
+                                roofline_vcycle_frac=oj["roofline_vcycle"]["frac"], amul_frac=(oj.get("amul") or {}).get("frac"),
+                                engine_fallbacks=oj["config"]["engine_fallbacks"], first_solve_s=oj["extra"]["first_solve_s"])
+            else:
+                real_leg = dict(skipped="data/motorbike/mb2sl_p3.npz is not on this machine (tools/make_motorbike_matrix.py)")
+        except Exception as e:  # pragma: no cover
+            real_leg = dict(error=str(e)[:300])
+        try:
             oj = run_leg("box", ["--steps", "10", "--warmup", "2"])
             box_leg = dict(vcycles_per_s=oj["value"], ms_per_step=oj["ms_per_step"], workload=oj["config"]["workload"],
                            vcycles_per_solve=oj["config"]["vcycles_per_solve"], roofline=oj["roofline"],
@@ -891,11 +929,14 @@ def main():
     if rank == 0 and args.rank_of > 1:
         # a projection, not a measurement of N GPUs: its own line shape so that nobody mistakes it for the metric
         print(json.dumps({
-            "projection": "ONE rank of a %d-rank run on one GPU (bench.py --rank-of %d): rank 0's %d-cell sub-domain of the "
-                          "%d^3 box, %d processor patches (%d faces) exchanging with itself (size-1 RCCL communicator / its own "
+            "projection": "ONE rank of a %d-rank run on one GPU (bench.py --rank-of %d): %s, %d processor patches (%d faces) "
+                          "exchanging with itself (size-1 RCCL communicator / its own "
                           "peer window, LDU_FORCE_COMM=1); inter-GPU latency and load imbalance are NOT in it"
-                          % (args.rank_of, args.rank_of, lp["nCells"], n, len(lp["patches_dev"]),
-                             sum(len(q["faceCells"]) for q in lp["patches_dev"])),
+                          % (args.rank_of, args.rank_of,
+                             ("the largest sub-domain (%d of %d cells) of the motorBike mesh %s under %s; %s" % (
+                                 lp["nCells"], nC_total, args.motorbike_name, args.mesh, mb_decomp)) if is_mb else
+                             "rank 0's %d-cell sub-domain of the %d^3 box" % (lp["nCells"], n),
+                             len(lp["patches_dev"]), sum(len(q["faceCells"]) for q in lp["patches_dev"])),
             "per_rank_vcycles_per_s": round(iters / elapsed, 3), "ms_per_vcycle": round(elapsed / max(1, iters) * 1e3, 3),
             "vcycles_per_solve": perf["nIterations"], "steps": args.steps,
             "per_vcycle": comm_per_vcycle,
@@ -918,9 +959,16 @@ def main():
             "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic" + (" coefficients and right-hand side on the REAL mesh (the reference's blockMesh + snappyHexMesh "
-                                   "on its motorBike.obj)" if is_mb else ""),
-            "config": {"workload": (("simpleFoam motorBike p-solve on the REAL mesh: the reference's blockMesh + snappyHexMesh "
+            "data": ("the reference's own simpleFoam matrix and right-hand side (stored)" if args.mesh == "motorbike_real" else
+                     "synthetic" + (" coefficients and right-hand side on the REAL mesh (the reference's blockMesh + snappyHexMesh "
+                                    "on its motorBike.obj)" if is_mb else "")),
+            "config": {"workload": (("simpleFoam motorBike p-solve, the REAL matrix of a SIMPLE iteration: the reference's blockMesh + snappyHexMesh "
+                                     "(castellate, SNAP, ADD LAYERS) on motorBike.obj (%s), %d SIMPLE iterations of the reference's "
+                                     "simpleFoam, the matrix its last p-solve was handed (laplacian((1|A(U)),p), pEqn.H:14-21); internal faces "
+                                     "per cell %s; %d cells, %d faces; GAMG (GaussSeidel, faceAreaPair, tol 1e-7 relTol 0.01), psi = 0"
+                                     % (mb_meta["mesh_stages"][-1], mb_meta["iteration"], cell_level_hist, nC_total, nF_total))
+                                    if args.mesh == "motorbike_real" else
+                                    ("simpleFoam motorBike p-solve on the REAL mesh: the reference's blockMesh + snappyHexMesh "
                                      "(castellatedMesh) on motorBike.obj, background %dx%dx%d, refinementBox level %d, surface "
                                      "levels %d-%d, cells per refinement level %s; %d cells, %d faces; laplacian coefficients "
                                      "|Sf|/(n.d) x (1 + 0.5 u01), fixedValue outlet, GAMG (GaussSeidel, faceAreaPair, tol 1e-7 "
@@ -948,6 +996,7 @@ def main():
                                        "jump2d": "; 5-point matrix, face coefficient jumping 1 <-> 1000 across the diagonal (two-phase density ratio)",
                                        "motorbike": "; cell numbering as snappyHexMesh wrote it",
                                        "motorbike_rcm": "; cells renumbered by Foam::bandCompression (renumberMesh)",
+                                       "motorbike_real": "; cells renumbered by Foam::bandCompression (renumberMesh)",
                                        "motorbike_tiles": "; cells renumbered by Foam::bandCompression, then its tiles of %d cells shuffled "
                                                           "(ldu_tile_shuffle, seed %d: a manualRenumber numbering)" % (args.tile_size, args.tile_seed),
                                        "octree": "; hexRef8 cell numbering renumbered by Foam::bandCompression",
@@ -985,6 +1034,7 @@ def main():
             "motorbike_snappy_numbering": snappy_leg,
             "subdomains_8": subdomain_leg,
             "motorbike_tile_numbering": tiles_leg,
+            "motorbike_snapped_layered_real_matrix": real_leg,
             "extra": dict(extra, device_memory_in_use_GB=mem_in_use_gb,
                           first_solve_s=round(t_first, 3), addressing_setup_s=round(t_addr, 3),
                           problem_generation_s=round(t_gen, 3),

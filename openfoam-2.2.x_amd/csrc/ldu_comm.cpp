@@ -769,6 +769,18 @@ int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
     }
     if (!remote) return 0;
     if (!ctx->comm) { ldu_set_error("processor patches present but no communicator"); return -4; }
+    if (ctx->comm->peer && !ctx->comm->comm && ctx->nRanks == 1)
+    {
+        // one rank whose processor patches face each other (bench.py --rank-of with the peer carrier alone): the labels of the
+        // paired patch (itself when alone), as peer_addr_setup pairs the windows
+        for (int p = 0; p < (int)patches.size(); p++)
+            if (patches[p].nbrPatch < 0)
+            {
+                const int q = paired_patch(patches, p, patches, ctx->rank);
+                recv[p] = send[q < 0 ? p : q];
+            }
+        return 0;
+    }
     if (ctx->comm->peer && !ctx->comm->comm)
     {
         // out-of-band, one message per neighbour rank: the int lists of all patches towards it, in patch order - the

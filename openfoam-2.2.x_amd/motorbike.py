@@ -95,3 +95,19 @@ def problem(name="mb12", seed=12345, m=None):
     p["cellLevel"] = m["level"]
     p["meta"] = m["meta"]
     return p
+
+
+def dumped_problem(name="mb2sl_p3"):
+    """the p-matrix of a real SIMPLE iteration of the REFERENCE's simpleFoam on a snapped + layered motorBike mesh (polyhedral
+    cells, layer prisms, non-orthogonal faces), as tools/make_motorbike_matrix.py stored it: `laplacian((1|A(U)),p)` with its
+    boundary coefficients (pEqn.H:14-21; negative definite: upper > 0, diag < 0, gaussLaplacianScheme.C:57-73), its source, and
+    the faceAreaPair weights of the mesh's face area vectors.  psi = 0 (the bench's convention)."""
+    if not available(name):
+        raise FileNotFoundError("%s: no such stored matrix (made by tools/make_motorbike_matrix.py where /root/reference exists)" % path(name))
+    z = np.load(path(name))
+    meta = json.loads(bytes(z["meta"]).decode())
+    cnt = z["ownerCount"].astype(np.int64)
+    nC = cnt.size
+    return dict(nCells=nC, lowerAddr=np.repeat(np.arange(nC, dtype=np.int32), cnt), upperAddr=z["upperAddr"].astype(np.int32),
+                diag=z["diag"].astype(np.float64), upper=z["upper"].astype(np.float64), source=z["source"].astype(np.float64),
+                psi=np.zeros(nC), faceWeights=z["faceWeights"].astype(np.float64), meta=meta)

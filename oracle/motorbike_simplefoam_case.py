@@ -54,9 +54,19 @@ def _list(path, cls, obj, rows):
         f.write("\n)\n")
 
 
-def write(case, steps=3, libs=None, gauss="Gauss", smooth="smoothSolver"):
-    g = np.load(STORE)
+def write(case, steps=3, libs=None, gauss="Gauss", smooth="smoothSolver", mesh_from=None, p_solver="GAMG"):
+    """mesh_from: a meshed case directory (snappyHexMesh -overwrite) whose polyMesh is used as it is - e.g. the snapped + layered
+    meshes of tools/make_motorbike_matrix.py - instead of the stored tutorial-size mesh; p_solver: the name under `solver` for p
+    (dumpGAMG = oracle/dump_solver.C: the reference's GAMGSolver behind a matrix dump)"""
     pm = os.path.join(case, "constant", "polyMesh")
+    if mesh_from is not None:
+        import shutil
+        os.makedirs(pm, exist_ok=True)
+        for f in ("points", "faces", "owner", "neighbour", "boundary"):
+            shutil.copy(os.path.join(mesh_from, "constant", "polyMesh", f), os.path.join(pm, f))
+        _write_dicts_and_fields(case, steps, libs, gauss, smooth, p_solver)
+        return
+    g = np.load(STORE)
     pts, fs, fp = g["points"], g["faceStart"], g["facePoints"]
     _list(os.path.join(pm, "points"), "vectorField", "points", ["(%.17g %.17g %.17g)" % (p[0], p[1], p[2]) for p in pts.tolist()])
     fpl, fsl = fp.tolist(), fs.tolist()
@@ -70,6 +80,10 @@ def write(case, steps=3, libs=None, gauss="Gauss", smooth="smoothSolver"):
     pz._w(os.path.join(pm, "boundary"), "polyBoundaryMesh", "boundary",
           "%d\n(\n%s)\n" % (len(names), "".join("%s\n{\n    type %s;\n    nFaces %d;\n    startFace %d;\n}\n" % r
                                                  for r in zip(names, types, sizes, starts))))
+    _write_dicts_and_fields(case, steps, libs, gauss, smooth, p_solver)
+
+
+def _write_dicts_and_fields(case, steps, libs, gauss, smooth, p_solver="GAMG"):
     pz._w(os.path.join(case, "system", "controlDict"), "dictionary", "controlDict",
           "application simpleFoam;\nstartFrom startTime;\nstartTime 0;\nstopAt endTime;\nendTime %d;\ndeltaT 1;\n"
           "writeControl timeStep;\nwriteInterval 100000;\npurgeWrite 0;\nwriteFormat ascii;\nwritePrecision 6;\n"
@@ -112,7 +126,7 @@ relaxationFactors
     fields { p 0.3; }
     equations { U 0.7; k 0.7; epsilon 0.7; }
 }
-""" % (GAMG, other, other, other))
+""" % (GAMG.replace("solver          GAMG;", "solver          %s;" % p_solver), other, other, other))
     pz._w(os.path.join(case, "constant", "RASProperties"), "dictionary", "RASProperties",
           "\nRASModel kEpsilon;\nturbulence on;\nprintCoeffs on;\n")
     pz._w(os.path.join(case, "constant", "transportProperties"), "dictionary", "transportProperties",

@@ -152,6 +152,57 @@ def test_pcg_with_the_gamg_preconditioner_on_the_real_mesh(oracle):
     m.close(); a.close(); ctx.close()
 
 
+def test_real_p_matrix_on_the_snapped_layered_mesh(oracle):
+    """the matrix the reference's simpleFoam handed its third p-solve on the SNAPPED + LAYERED 1.85 M-cell mesh (VERDICT r5 item 8,
+    tools/make_motorbike_matrix.py): negative definite as fvm::laplacian leaves it, polyhedral rows, and the oracle's GAMG
+    converges on it"""
+    _need("mb2sl_p3")
+    p = motorbike.dumped_problem("mb2sl_p3")
+    meta = p.pop("meta")
+    assert meta["snap"] and meta["layers"] and p["nCells"] > 1800000
+    assert np.all(p["upper"] > 0) and np.all(p["diag"] < 0)
+    deg = np.bincount(p["lowerAddr"], minlength=p["nCells"]) + np.bincount(p["upperAddr"], minlength=p["nCells"])
+    assert deg.max() > 12 and (deg > 6).sum() > 50000            # snapped polyhedra / split hexes: not an octree of cubes
+    x, perf = oracle.System(p).solve(p["psi"], p["source"], **GAMG)
+    assert perf["converged"] and 3 <= perf["nIterations"] <= 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rcm", [True, False])
+def test_hip_path_on_the_real_p_matrix_of_the_snapped_layered_mesh(oracle, rcm):
+    """... and the HIP path on it against the oracle: Amul, residual, GaussSeidel 1 / 2 / 4 sweeps, DIC bit for bit, the GAMG
+    solve (6 V-cycles) and 20 PCG / DIC iterations by history"""
+    _need("mb2sl_p3")
+    p = motorbike.dumped_problem("mb2sl_p3")
+    p.pop("meta")
+    if rcm:
+        p = _renumber(p)
+    S = oracle.System(p)
+    ctx = capi.Context(0)
+    a, m = capi.from_problem(ctx, p)
+    rng = np.random.RandomState(6)
+    x, b = rng.randn(p["nCells"]), rng.randn(p["nCells"])
+    assert np.array_equal(m.Amul(x), S.Amul(x))
+    assert np.array_equal(m.residual(x, b), S.residual(x, b))
+    for k in (1, 2, 4):
+        assert np.array_equal(m.smooth("GaussSeidel", x, b, k), S.smooth("GaussSeidel", x, b, k)), k
+    assert np.array_equal(m.precondition("DIC", b), S.precondition("DIC", b)[0])
+    xg, pg = m.solve(p["psi"], p["source"], **GAMG)
+    xo, po = S.solve(p["psi"], p["source"], **GAMG)
+    assert pg["nIterations"] == po["nIterations"]
+    np.testing.assert_allclose(pg["history"], po["history"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(xg - xo)) <= 1e-8 * np.max(np.abs(xo))
+    kw = dict(solver="PCG", tolerance=0.0, relTol=0.0, maxIter=20)
+    xp, pp = m.solve(p["psi"], p["source"], preconditioner="DIC", **kw)
+    xq, pq = S.solve(p["psi"], p["source"], precond="DIC", **kw)
+    np.testing.assert_allclose(pp["history"], pq["history"], rtol=1e-6, atol=1e-12)
+    assert ctx.fallback_count() == 0
+    print("real p-matrix, snapped + layered mesh (%s): %d V-cycles, %d dependency levels on the finest level, engines %s"
+          % ("bandCompression" if rcm else "snappyHexMesh's numbering", pg["nIterations"], a.info()["nLevels"],
+             [L["engine_gs_multi"] for L in m.gamg_level_sizes(**GAMG)][:6]))
+    m.close(); a.close(); ctx.close()
+
+
 @pytest.mark.gpu
 def test_device_geometry_on_the_real_polymesh():
     """points / faces / owner / neighbour of the tutorial-size snappyHexMesh mesh (faces of 4 ... 8 points) through the
