@@ -251,6 +251,10 @@ int ldu_debug_slice_levels(ldu_matrix* m, int32_t* out, int32_t cap);
  * [100 MHz wall clock], wavefront, sweep, block, lanes per row; buf = (tasks of k sweeps) * 64 bytes or NULL.
  * ldu_debug_blocks_info: out[8]; out[0..5] = blocks, compute wavefronts per block, LDS bytes per block, ghosts, groupings,
  * tasks of k sweeps, out[6..7] reserved (written as 0) (all 0: the addressing is not on the block engine). */
+/* The sweep plans of large GAMG levels (block-engine layouts, task orders of pipelined sweeps) are built on host threads behind
+ * the first solves - the level engines sweep meanwhile, with bit-identical results; this waits until all of them are there
+ * (benchmarks: before a timed region).  The engine queries (ldu_addr_sweep_engine, ldu_gamg_level_info) wait as well. */
+int ldu_matrix_wait_plans(ldu_matrix* m);
 int ldu_debug_blocks_trace(ldu_matrix* m, void* buf);
 int ldu_debug_blocks_info(ldu_matrix* m, int32_t k, int64_t* out);
 /* Per-sweep layouts of the chip-wide pipelined GaussSeidel sweeps (ldu_gslayouts.cpp): out[0] = sweeps with a layout of their own

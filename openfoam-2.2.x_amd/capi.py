@@ -39,7 +39,7 @@ EXPORTS = [
     "ldu_mesh_nonorth_factors", "ldu_mesh_patch_nonorth_factors", "ldu_fv_interpolateDot", "ldu_fv_faceDot",
     "ldu_fv_faceScale", "ldu_fvc_correctedSnGrad", "ldu_fv_interpolateBoundary", "ldu_fvc_gaussGradBoundary",
     "ldu_fvc_surfaceIntegrateFull", "ldu_fvm_sourceMinusVDiv", "ldu_fv_tensorGammaFactors",
-    "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_tile_shuffle", "ldu_renumber_addressing",
+    "ldu_mesh_geometry", "ldu_mesh_interpolation_factors", "ldu_band_compression", "ldu_tile_shuffle", "ldu_matrix_wait_plans", "ldu_renumber_addressing",
     "ldu_debug_dag_stats", "ldu_debug_stream", "ldu_debug_slices", "ldu_ctx_set_watchdog", "ldu_ctx_comm_counters", "ldu_comm_paired_patch", "ldu_comm_exchange_order",
 ]
 
@@ -603,6 +603,10 @@ class Matrix:
         lib().ldu_debug_gs_layouts.argtypes = [C.c_void_p, C.c_void_p]
         _chk(lib().ldu_debug_gs_layouts(self.h, o.ctypes.data))
         return dict(built=int(o[0]), slices=[int(v) for v in o[2:5]], level_slices=int(o[5]))
+
+    def wait_plans(self):
+        """sweep plans still being built behind the solves (large GAMG levels): wait for them"""
+        _chk(lib().ldu_matrix_wait_plans(self.h))
 
     def gamg_level_sizes(self, **controls):
         """[(nCells, nFaces, dependency levels, widest row, engine of one GS sweep, engine of pipelined sweeps)] of the

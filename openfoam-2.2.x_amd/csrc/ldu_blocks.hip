@@ -150,7 +150,9 @@ void blocks_free(ldu_addr* a)
 
 void blocks_forget(ldu_addr* a, const double* levelVal)
 {
-    if (!a || !a->blocks) return;
+    if (!a) return;
+    addr_bg_wait(a);      // (a plan thread may be filling a->blocks)
+    if (!a->blocks) return;
     auto it = a->blocks->conv.find(levelVal);
     if (it == a->blocks->conv.end()) return;
     (void)hipStreamSynchronize(a->ctx->stream);
@@ -1154,6 +1156,7 @@ bool k_blocks_active(ldu_addr* a)
     ldu_ctx* ctx = a->ctx;
     if (!ctx->blkEngine || !ctx->sweepP2P || a->nCells < (a->nPatchFaces ? std::min(64, ctx->blkMinCells) : ctx->blkMinCells)
         || a->nCells > ctx->blkMaxCells) return false;
+    if (addr_bg_pending(a)) return false;      // (its plan is being built on a host thread: the level engines meanwhile)
     if (!a->blocks && bk_build(a)) return false;
     return a->blocks && a->blocks->eligible;
 }
@@ -1163,6 +1166,7 @@ bool k_blocks_active(ldu_addr* a)
 // layouts that exist already (nothing is built here).  1 = nothing to fill
 int k_blocks_prefill(ldu_addr* a, const double* val, const double* bou, hipStream_t s)
 {
+    if (addr_bg_pending(a)) return 1;
     BlockPlan* P = a->blocks;
     if (!P || !P->eligible || P->nBuilt <= 0) return 1;
     if (P->iface && !bou) return 1;

@@ -385,6 +385,7 @@ int ldu_addr_add_patch(ldu_addr* a, int32_t n, const int32_t* faceCells, int32_t
 int ldu_addr_sweep_engine(ldu_addr* a, int32_t kind)
 {
     if (kind < 0 || kind > 2) { ldu_set_error("ldu_addr_sweep_engine: kind must be 0..2"); return -2; }
+    addr_bg_wait(a);      // (the engine the addressing ends up on, not the stand-in while its plans are being built)
     return k_engine_of(a, kind);
 }
 
@@ -1001,7 +1002,20 @@ int ldu_gamg_levels(ldu_matrix* m, const ldu_controls* c, int32_t* nLevels, int3
     return gamg_query(m, nLevels, nCells, nFaces);
 }
 
-int ldu_gamg_level_info(ldu_matrix* m, int32_t level, int32_t info[8]) { return gamg_level_info(m, level, info); }
+int ldu_gamg_level_info(ldu_matrix* m, int32_t level, int32_t info[8])
+{
+    (void)ldu_matrix_wait_plans(m);
+    return gamg_level_info(m, level, info);
+}
+
+// sweep plans that are still being built behind the solves (ldu_addr::bgPlan): wait for all of them
+int ldu_matrix_wait_plans(ldu_matrix* m)
+{
+    if (!m) return 0;
+    addr_bg_wait(m->a);
+    gamg_wait_plans(m->gamg);
+    return 0;
+}
 
 int ldu_gamg_level_data(ldu_matrix* m, int32_t level, int32_t* restrictAddr, double* diag, double* upper,
                         double* lower)

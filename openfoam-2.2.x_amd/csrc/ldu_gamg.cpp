@@ -80,9 +80,16 @@ static int up(T** dst, const std::vector<T>& src)
     return 0;
 }
 
+void gamg_wait_plans(GamgHierarchy* g)
+{
+    if (!g) return;
+    for (auto& L : g->levels) if (L.addr) addr_bg_wait(L.addr);
+}
+
 void gamg_free(GamgHierarchy* g)
 {
     if (!g) return;
+    gamg_wait_plans(g);
     if (g->aggPending && !g->levels.empty() && g->levels[0].addr && g->levels[0].addr->ctx->stream3)
         (void)hipStreamSynchronize(g->levels[0].addr->ctx->stream3);   // the level matrices are still being written
     for (auto& L : g->levels)
@@ -553,10 +560,29 @@ static int ensure_hierarchy(ldu_matrix* m, const ldu_controls* c, bool deferCoef
         struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } joinClusters{cth};
         // the task orders of the pipelined GaussSeidel sweeps a level will be asked for (lazily built at the first smoothing
         // call otherwise: 2.3 s of the first solve on the 12.7 M-cell motorBike mesh, one level after the other)
-        auto sweepPlans = [&](ldu_addr* A, int nPost, int nPre) {
-            if (c->smoother != LDU_SM_GAUSSSEIDEL && c->smoother != LDU_SM_NONBLOCKINGGAUSSSEIDEL) return;
-            for (int n : {nPost, nPre})
-                if (n >= 2) (void)k_gs_prebuild(A, n > 4 ? 4 : n);   // (errors: the smoothing call builds again and says)
+        // Large levels: on a thread of their own that OUTLIVES this set-up (ldu_addr::bgPlan) - nothing needs these plans for
+        // correctness, the level engines sweep until they are there (first solve on the 12.7 M-cell mesh 3.9 -> 2.5 s of host
+        // time before the first V-cycle; ldu_matrix_wait_plans / the engine queries wait for them).  LDU_BG_PLANS=0: as before.
+        static const bool bgPlans = !getenv("LDU_BG_PLANS") || atoi(getenv("LDU_BG_PLANS")) != 0;
+        const int smootherKind = c->smoother;
+        const int devId = a->ctx->device;
+        auto sweepPlans = [&, smootherKind, devId](ldu_addr* A, int nPost, int nPre) {
+            if (smootherKind != LDU_SM_GAUSSSEIDEL && smootherKind != LDU_SM_NONBLOCKINGGAUSSSEIDEL) return;
+            auto build = [A, nPost, nPre]() {
+                for (int n : {nPost, nPre})
+                    if (n >= 2) (void)k_gs_prebuild(A, n > 4 ? 4 : n);   // (errors: the smoothing call builds again and says)
+            };
+            addr_bg_wait(A);      // (a hierarchy rebuilt for other controls: the previous plan thread of this addressing first)
+            if (bgPlans && A->nCells >= 50000 && !A->nPatchFaces)
+            {
+                A->bgState.store(1, std::memory_order_release);
+                A->bgPlan = std::thread([A, build, devId]() {
+                    tl_bgPlanThread = true;
+                    if (hipSetDevice(devId) == hipSuccess) build();
+                    A->bgState.store(2, std::memory_order_release);
+                });
+            }
+            else build();
         };
         if (prebuild)   // the finest level's cluster plan (the longest single piece, 1.4 s at 216^3) beside everything else
             cth.emplace_back([&]() {

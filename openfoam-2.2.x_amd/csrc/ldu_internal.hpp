@@ -19,6 +19,7 @@
 
 #include <map>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -224,6 +225,12 @@ struct PeerHalo {
 struct ldu_addr {
     ldu_ctx* ctx = nullptr;
     int nCells = 0, nFaces = 0;
+    // Sweep plans of a GAMG level (block-engine layouts, pipelined task orders: 1.4 of the 3.9 s of the first solve on the
+    // 12.7 M-cell motorBike mesh) are built on a host thread BEHIND the first solves (ldu_gamg.cpp: ensure_hierarchy).  While
+    // bgState is 1 every engine that would use or build them stands back - the level engines sweep one sweep per launch, bit for
+    // bit the same results - and nothing else of this addressing is written by the thread.  2 = built.
+    std::thread bgPlan;
+    std::atomic<int> bgState{0};
     // host addressing (original numbering)
     std::vector<int> l, u, losort, ownerStart, losortStart;
     std::vector<int> perm, iperm;          // perm[new] = old ; iperm[old] = new
@@ -583,6 +590,9 @@ inline unsigned long long val_stamp(const ldu_addr* a, const double* v)
 inline void val_touch(ldu_addr* a, const double* v) { a->arrStamp[v] = ++a->ctx->valStamp; }                              // ldu_plan.cpp
 int plan_finalize_patches(ldu_addr* a);
 void plan_free(ldu_addr* a);
+extern thread_local bool tl_bgPlanThread;      // set on a background plan thread: it IS the builder, the guards below let it through
+inline bool addr_bg_pending(const ldu_addr* a) { return !tl_bgPlanThread && a->bgState.load(std::memory_order_acquire) == 1; }
+inline void addr_bg_wait(ldu_addr* a) { if (a->bgPlan.joinable()) a->bgPlan.join(); }
 
 int comm_allreduce_scalars(ldu_ctx* ctx, int slot, int count, hipStream_t s);   // ldu_comm.cpp
 int comm_exchange(ldu_addr* a, hipStream_t s);                                   // halo send/recv (may return before it ran)
@@ -673,6 +683,7 @@ void gamg_free(GamgHierarchy* g);
 int gamg_build_for_query(ldu_matrix* m, const ldu_controls* c);
 int gamg_query(ldu_matrix* m, int32_t* nLevels, int32_t* nCells, int32_t* nFaces);
 int gamg_level_info(ldu_matrix* m, int level, int32_t out[8]);
+void gamg_wait_plans(GamgHierarchy* g);
 int gamg_level_data(ldu_matrix* m, int level, int32_t* restrictAddr, double* diag, double* upper,
                     double* lower);
 

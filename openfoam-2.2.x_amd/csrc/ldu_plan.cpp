@@ -647,8 +647,11 @@ int plan_finalize_patches(ldu_addr* a)
     return comm_peer_setup_addr(a);
 }
 
+thread_local bool tl_bgPlanThread = false;
+
 void plan_free(ldu_addr* a)
 {
+    addr_bg_wait(a);      // (a sweep plan still being built behind the solves)
     comm_peer_free_addr(a);
     if (a->d_cycPair) { (void)hipFree(a->d_cycPair); a->d_cycPair = nullptr; }
     cluster_free(a);

@@ -237,8 +237,11 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     double* bPrime = nullptr;
     if (a->nPatchFaces || sym) bPrime = m->workVec(12);
     // LDS-resident blocks (ldu_blocks.hip) wherever the cluster engine (structured numberings, <= 6 + 6 neighbours) does not apply
-    const bool blk = !sym && !a->nPatchFaces && a->ctx->sweepP2P && !(a->ctx->clusterMulti && k_cluster_active(a)) && k_blocks_active(a);
-    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && !blk)
+    // (pend: this level's sweep plans are still being built on a host thread - ensure_hierarchy -: one sweep per launch on the
+    //  level engines until they are there; the results are the same bit for bit)
+    const bool pend = addr_bg_pending(a);
+    const bool blk = !pend && !sym && !a->nPatchFaces && a->ctx->sweepP2P && !(a->ctx->clusterMulti && k_cluster_active(a)) && k_blocks_active(a);
+    if (!pend && !sym && !a->nPatchFaces && a->ctx->sweepP2P && !blk)
     {
         // small matrix: every sweep inside one workgroup, solution vector in LDS
         int rc = 1;
@@ -264,7 +267,7 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         const int rc = k_sweep_gs_blocks(a, 1, psi, source, m->d_diag, m->d_valA);   // (LDS-resident blocks: ldu_blocks.hip)
         if (rc <= 0) return rc;
     }
-    if (!sym && !a->nPatchFaces && a->ctx->sweepP2P && a->ctx->gsPipeline && nSweeps >= 2)
+    if (!pend && !sym && !a->nPatchFaces && a->ctx->sweepP2P && a->ctx->gsPipeline && nSweeps >= 2)
     {
         // consecutive sweeps pipelined inside one launch (bit-identical to separate sweeps)
         int left = nSweeps;

@@ -57,6 +57,7 @@ def main():
             return perf
         perf = step()
         t_first = time.perf_counter() - t0
+        mat.wait_plans()
         step()
         ts = []
         for _ in range(reps):
