@@ -51,6 +51,19 @@
 // across it: a row can finish sweep j before its interface neighbour has read its value of sweep j - 1.  One sweep
 // ahead is all it can get (its sweep j + 1 needs the neighbour's sweep j, which has read), so interface cells keep TWO
 // values, by sweep parity - in LDS ("hist" slots, for local cells and for ghosts) and in the granule array.
+//
+// Remote interfaces (processor patches, peer-store backend: ranks of one node).  The cell across a processor-patch face lives
+// on another rank; here it is a MIRROR: a cell label >= nCells (nCells + patch-face index) that belongs to no block and has no
+// row - only a hist pair in the LDS of the blocks that reference it, filled by the importer like any ghost across an interface.
+// What fills it comes through the peer window: the rank across the face stores its interface cells' values - the initial one
+// when its block starts, then the value after every sweep but the last - into THIS rank's window with one system-scope store
+// per face (ldu_peer_dev.hpp: peer_store), tagged bSeq + 1 + sweeps-done, parity = tag & 1 (PeerHalo::d_bdst / d_bsrc, a region
+// of their own: the halo exchanges and the one-launch kernels of small levels keep theirs).  The tag sequence is counted on
+// the host: every rank launches the same smoothing calls on a level, k exchanges per launch of k sweeps.  A face's slot of
+// parity p is rewritten two exchanges later, after the writer's own row across that face has used the value the reader
+// produced from it - the double buffering of ldu_peer.hip, face by face.  Whether a level runs this way is decided
+// collectively (k_blocks_peer_decide: every rank's own plan must exist), because the ranks across its interfaces must speak the
+// same protocol; every wait of such a launch is bounded by the peer time-out (a neighbour may simply be late).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -60,6 +73,7 @@
 #include <vector>
 
 #include "ldu_internal.hpp"
+#include "ldu_peer_dev.hpp"
 
 #define BK_MAX_LDS (160 * 1024)
 #define BK_NLAY 4
@@ -119,7 +133,18 @@ struct BlockPlan {
     std::vector<int> ifIdx;                // [nCells] index among the interface cells, -1
     std::vector<int> histBase, histCell;   // [nBlocks + 1]; cells with a hist pair per block: its own interface cells, then interface ghosts
     int2* d_blk2 = nullptr;                // [nBlocks] {histBase, nHist}
-    int* d_histRow = nullptr;              // [histCell.size()] level-ordered row
+    int* d_histRow = nullptr;              // [histCell.size()] level-ordered row; a mirror: -1 - patch face
+    // remote interfaces (processor patches; see "Remote interfaces" at the top)
+    bool remote = false;
+    std::vector<int> pfCell;               // [nPatchFaces] the local cell of a patch face (old label)
+    // [layout][nPatchFaces] group-level time Phi of the cell ACROSS a processor-patch face in that layout (exchanged when the
+    // plan is made, k_blocks_peer_decide): the Phi of this rank's groups are potentials of the task graph of ALL ranks - a
+    // worker walks its tasks in ascending Phi, and a task that waits for another rank must not stand in front of one that rank
+    // is waiting for
+    std::vector<int> remPhi[BK_NLAY];
+    int* d_histIfg = nullptr;              // [histCell.size()] index among the interface cells of a block's OWN interface cells, else -1
+    int* d_remStart = nullptr;             // [nIf + 1] CSR: the processor-patch faces of an interface cell
+    int* d_remPf = nullptr;
 };
 
 template <class T>
@@ -136,7 +161,8 @@ void blocks_free(ldu_addr* a)
 {
     BlockPlan* P = a->blocks;
     if (!P) return;
-    void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_ticket, P->d_out, P->d_blk2, P->d_histRow};
+    void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_ticket, P->d_out, P->d_blk2, P->d_histRow,
+                    P->d_histIfg, P->d_remStart, P->d_remPf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& L : P->lay)
         for (void* p : {(void*)L.d_meta, (void*)L.d_col, (void*)L.d_srcFace}) if (p) (void)hipFree(p);
@@ -229,7 +255,19 @@ struct BkTab {
     const int4* meta[BK_NLAY]; const unsigned* col[BK_NLAY]; const double* val[BK_NLAY];
     int nLayouts;
     const int4* tasks; const int* taskStart; const int4* imps; const int* impStart;
+    // remote interfaces (null / 0 without): destination and source granules per (parity, patch face) in the peer windows, the tag
+    // of this launch's first exchange, its number of sweeps, the processor-patch faces of the interface cells
+    uint4* const* bdst; const uint4* const* bsrc; int nPF; unsigned S0; int kSweeps;
+    const int* remStart; const int* remPf; const int* histIfg;
 };
+
+// a dependency wait of a launch with remote interfaces is (also) a wait for another rank: the peer time-out, not the 200 ms
+__device__ __forceinline__ bool bk_wait_expired(bool remote, unsigned& spins, int* abortFlag, unsigned long long& tw0)
+{
+    if (!remote) return ldu_wait_expired(spins, 1u << 30, abortFlag, tw0);
+    if ((spins & 255u) == 7u && *(volatile int*)abortFlag) return true;      // (another wave of this rank gave up: drain)
+    return peer_wait_expired(spins, tw0, abortFlag);
+}
 
 // a task's rows in flight: one lane = one row (T = 1) or one sixteen-entry part of a row (T = 2 / 4 / 8 lanes per row)
 struct BkRow { int4 Q; int rg, slot, nl, nn, ni, hist, ifg, sent, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
@@ -341,11 +379,15 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
     for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) { x[i] = psi[T.localRow[rowBase + i]]; stamp[i] = 0; }
     for (int i = tid; i < nGhost; i += LDU_WAVE * (NW + 1)) { x[nLocal + i] = psi[T.ghostRow[ghostBase + i]]; stamp[nLocal + i] = 0; }
     // hist pairs of the interface cells (own and ghosts): slot 0 = the initial value (stamp 0), slot 1 = what sweep 0 leaves
+    const bool remote = T.bsrc != nullptr;
     for (int i = tid; i < nHist; i += LDU_WAVE * (NW + 1))
     {
         const int h = nLocal + nGhost + 2 * i;
-        x[h] = psi[T.histRow[histBase + i]]; x[h + 1] = 0.0;
-        stamp[h] = 0; stamp[h + 1] = 0;
+        const int hr = T.histRow[histBase + i];
+        // (a mirror - the cell across a processor-patch face -: nothing is there yet, stamp 255 matches no sweep; the
+        //  importer brings the neighbour's initial value with stamp 0)
+        x[h] = hr >= 0 ? psi[hr] : 0.0; x[h + 1] = 0.0;
+        stamp[h] = hr >= 0 ? 0 : 255; stamp[h + 1] = 0;
     }
     __syncthreads();
     bool alive = true;
@@ -359,6 +401,17 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
         int i = lane;
         int4 e = i < nImp ? I[i] : make_int4(0, 0, 0, 0);
         int4 en = i + LDU_WAVE < nImp ? I[i + LDU_WAVE] : make_int4(0, 0, 0, 0);
+        // where a record's granule is and what tag it waits for: a row of another block of this rank (G, tagBase + stamp), or -
+        // e.y < 0 - the mirror of processor-patch face -1 - e.y: the granule of this rank's window into which the rank across
+        // the face stores (tag S0 + stamp, parity by tag)
+        const uint4* gp = G;
+        unsigned want = 0;
+#define BK_IMP_PREP()                                                                                     \
+        do {                                                                                              \
+            if (e.y >= 0) { gp = G + e.y; want = tagBase + (unsigned)e.z; }                               \
+            else { want = T.S0 + (unsigned)e.z; gp = T.bsrc[(size_t)(want & 1u) * T.nPF + (-1 - e.y)]; } \
+        } while (0)
+        if (i < nImp) BK_IMP_PREP();
         unsigned spins = 0;
         unsigned long long tw0 = 0;
         while (true)
@@ -368,8 +421,10 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
             bool ok = false;
             if (have)
             {
-                const bk_u32x4 g = bk_load(G + e.y);
-                const unsigned want = tagBase + (unsigned)e.z;
+                // (plans with remote interfaces poll everything with system-scope loads: one load flavour per iteration)
+                bk_u32x4 g;
+                if (remote) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(gp) : "memory");
+                else g = bk_load(gp);
                 ok = g.y == want && g.w == want;
                 if (ok)
                 {
@@ -379,13 +434,14 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
                     i += LDU_WAVE;
                     e = en;
                     en = i + LDU_WAVE < nImp ? I[i + LDU_WAVE] : make_int4(0, 0, 0, 0);
+                    if (i < nImp) BK_IMP_PREP();
                 }
             }
             if (__builtin_amdgcn_ballot_w64(ok) != 0ull) { spins = 0; tw0 = 0; }
             else
             {
                 __builtin_amdgcn_s_sleep(1);
-                if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { bk_flag_set(abortFlag); break; }
+                if (bk_wait_expired(remote, spins, abortFlag, tw0)) { bk_flag_set(abortFlag); break; }
             }
         }
     }
@@ -426,7 +482,7 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
                     int sum = 0;                                                          \
                     _Pragma("unroll") for (int q = 0; q < 16; q++) sum += st[q];          \
                     if (__builtin_amdgcn_ballot_w64(have && sum != want) == 0ull) break;  \
-                    if (ldu_wait_expired(spins, 1u << 30, abortFlag, tw0)) { bk_flag_set(abortFlag); alive = false; } \
+                    if (bk_wait_expired(remote, spins, abortFlag, tw0)) { bk_flag_set(abortFlag); alive = false; } \
                 }                                                                         \
                 LDU_LDS_ACQUIRE();                                                        \
                 _Pragma("unroll") for (int q = 0; q < 16; q++) xv[q] = x[cc[q]];          \
@@ -466,6 +522,13 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
                     /* an interface cell: its value by sweep parity, for the rows across the interface (here and elsewhere) */ \
                     x[hs_ + ((j + 1) & 1)] = xn_;                                         \
                     bk_store(G, T.ifBase + 2 * (CUR).ifg + ((j + 1) & 1), xn_, tagBase + (unsigned)j + 1u); \
+                    if (remote && j + 1 < T.kSweeps)                                      \
+                    {                                                                     \
+                        /* ... and for the ranks across its processor-patch faces (their next sweep reads it) */ \
+                        const unsigned tg_ = T.S0 + (unsigned)j + 1u;                     \
+                        for (int e_ = T.remStart[(CUR).ifg]; e_ < T.remStart[(CUR).ifg + 1]; e_++) \
+                            peer_store(T.bdst[(size_t)(tg_ & 1u) * T.nPF + T.remPf[e_]], xn_, tg_); \
+                    }                                                                     \
                 }                                                                         \
                 LDU_LDS_RELEASE();                                                        \
                 stamp[self] = (unsigned char)(j + 1);                                     \
@@ -494,6 +557,19 @@ gs_blk_kernel(BkTab T, int nBlocks, const int* __restrict__ order, uint4* __rest
 #undef BK_REC
     __syncthreads();
     for (int i = tid; i < nLocal; i += LDU_WAVE * (NW + 1)) psiOut[T.localRow[rowBase + i]] = x[i];
+}
+
+// Remote interfaces: the INITIAL values of this rank's cells at its processor-patch faces, for the ranks across them (tag S0).
+// A launch of its own in front of the block kernel: these values need no block to have started - a block of the other rank may
+// wait for them long before the block that owns the cell here gets its turn.
+__global__ void __launch_bounds__(256) bk_init_export_kernel(int nPF, const int* __restrict__ pfRow, const double* __restrict__ psi,
+                                                             uint4* const* __restrict__ bdst, unsigned S0)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nPF; i += gridDim.x * 256)
+    {
+        uint4* d = bdst[(size_t)(S0 & 1u) * nPF + i];
+        if (d) peer_store(d, psi[pfRow[i]], S0);
+    }
 }
 
 __global__ void __launch_bounds__(256) bk_copy_kernel(long n, const double* __restrict__ src, double* __restrict__ dst)
@@ -546,7 +622,8 @@ static int bk_build_layout(ldu_addr* a, int L)
         {
             int t = L ? RTprev[c] : 0;
             if (L) for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) t = std::max(t, RTprev[a->u[f]]);
-            if (L && P->iface) for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++) t = std::max(t, RTprev[P->ifNbr[e]]);
+            // (a mirror - the cell across a processor-patch face - has no time of its own here: its rank sweeps in step)
+            if (L && P->iface) for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++) if (P->ifNbr[e] < nC) t = std::max(t, RTprev[P->ifNbr[e]]);
             for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++) t = std::max(t, RT[a->l[a->losort[s]]]);
             RT[c] = t + 1;
         }
@@ -619,7 +696,7 @@ static int bk_build_layout(ldu_addr* a, int L)
             std::vector<int> gslotT;
             std::vector<int>& gslot_ = (b0 == 0 && b1 == nB) ? gslot : gslotT;
             if (&gslot_ == &gslotT) gslotT.assign(nC, -1);
-            std::vector<int> hslot(P->iface ? nC : 0, -1);     // hist pair (first LDS slot) of a cell in the current block
+            std::vector<int> hslot(P->iface ? (size_t)nC + a->nPatchFaces : 0, -1);     // hist pair (first LDS slot) of a cell (or mirror) in the current block
             for (int b = (int)b0; b < (int)b1; b++)
             {
                 for (int g = ghostBase[b]; g < ghostBase[b + 1]; g++) gslot_[ghostCell[g]] = nLocal[b] + (g - ghostBase[b]);
@@ -727,7 +804,13 @@ static int bk_build_layout(ldu_addr* a, int L)
                     {
                         ph = std::max(ph, Yp->Phi[Yp->grpOfCell[c]] + 1);
                         for (int f = a->ownerStart[c]; f < a->ownerStart[c + 1]; f++) ph = std::max(ph, Yp->Phi[Yp->grpOfCell[a->u[f]]] + 1);
-                        if (P->iface) for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++) ph = std::max(ph, Yp->Phi[Yp->grpOfCell[P->ifNbr[e]]] + 1);
+                        if (P->iface)
+                            for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++)
+                            {
+                                const int n = P->ifNbr[e];
+                                if (n < nC) ph = std::max(ph, Yp->Phi[Yp->grpOfCell[n]] + 1);
+                                else if ((int)P->remPhi[L - 1].size() == a->nPatchFaces) ph = std::max(ph, P->remPhi[L - 1][n - nC] + 1);
+                            }
                     }
                     for (int s = a->losortStart[c]; s < a->losortStart[c + 1]; s++)
                         ph = std::max(ph, Y.Phi[Y.grpOfCell[a->l[a->losort[s]]]] + 1);
@@ -763,7 +846,12 @@ static int bk_build(ldu_addr* a)
         // coupled patches: cyclic ones only (the neighbour is a cell of this addressing); a processor patch's neighbour lives on
         // another rank - those levels stay on the level engines
         { const char* e = getenv("LDU_BLK_IFACE"); if (e && !atoi(e)) return 0; }      // LDU_BLK_IFACE=0: patched levels on the level engines
-        for (const Patch& q : a->patches) if (q.nbrPatch < 0) return 0;
+        for (const Patch& q : a->patches) if (q.nbrPatch < 0 && q.n) P->remote = true;
+        // processor patches: through the peer windows (see "Remote interfaces"), where this addressing and the ones across its
+        // patches have their regions there and every rank has said so (k_blocks_peer_decide)
+        if (P->remote && !(a->peer && a->peer->bAll && a->peer->d_bdst && comm_peer_carries_halo(ctx))) return 0;
+        P->pfCell.assign(a->nPatchFaces, 0);
+        for (const Patch& q : a->patches) for (int i = 0; i < q.n; i++) P->pfCell[q.offset + i] = q.faceCells[i];
         P->ifStart.assign(nC + 1, 0);
         for (const Patch& q : a->patches) for (int c : q.faceCells) P->ifStart[c + 1]++;
         for (int c = 0; c < nC; c++) P->ifStart[c + 1] += P->ifStart[c];
@@ -772,13 +860,13 @@ static int bk_build(ldu_addr* a)
             std::vector<int> pos(P->ifStart.begin(), P->ifStart.end() - 1);
             for (const Patch& q : a->patches)          // patch order, face order: the order of updateMatrixInterfaces
             {
-                const Patch& nb = a->patches[q.nbrPatch];
-                if (nb.n != q.n) return 0;
+                if (q.nbrPatch >= 0 && a->patches[q.nbrPatch].n != q.n) return 0;
                 for (int i = 0; i < q.n; i++)
                 {
                     const int c = q.faceCells[i];
                     P->ifPf[pos[c]] = q.offset + i;
-                    P->ifNbr[pos[c]++] = nb.faceCells[i];
+                    // (the cell across a processor-patch face: its mirror, label nCells + patch face)
+                    P->ifNbr[pos[c]++] = q.nbrPatch >= 0 ? a->patches[q.nbrPatch].faceCells[i] : nC + q.offset + i;
                 }
             }
         }
@@ -879,7 +967,7 @@ static int bk_build(ldu_addr* a)
             for (int c = 0; c < nC; c++) start[blk[c] + 1]++;
             for (int b = 0; b < nB; b++) start[b + 1] += start[b];
             { std::vector<int> pos(start.begin(), start.end() - 1); for (int r = 0; r < nC; r++) { const int c = a->perm[r]; cellsOf[pos[blk[c]]++] = c; } }
-            std::vector<int> mark(nC, -1);
+            std::vector<int> mark((size_t)nC + a->nPatchFaces, -1);
             for (int b = 0; b < nB; b++)
             {
                 P->histBase[b] = (int)P->histCell.size();
@@ -949,8 +1037,29 @@ static int bk_build(ldu_addr* a)
         std::vector<int2> b2(nB);
         for (int b = 0; b < nB; b++) b2[b] = make_int2(P->histBase[b], P->histBase[b + 1] - P->histBase[b]);
         std::vector<int> hr(P->histCell.size());
-        for (size_t i = 0; i < hr.size(); i++) hr[i] = a->iperm[P->histCell[i]];
+        for (size_t i = 0; i < hr.size(); i++) hr[i] = P->histCell[i] < nC ? a->iperm[P->histCell[i]] : -1 - (P->histCell[i] - nC);
         if (bk_upload(&P->d_blk2, b2) || bk_upload(&P->d_histRow, hr)) return -1;
+        if (P->remote)
+        {
+            // a block's own interface cells (the first entries of its hist range) and their processor-patch faces
+            std::vector<int> hi(P->histCell.size(), -1);
+            for (int b = 0; b < nB; b++)
+                for (int h = P->histBase[b]; h < P->histBase[b + 1]; h++)
+                {
+                    const int c = P->histCell[h];
+                    if (c < nC && P->blk[c] == b) hi[h] = P->ifIdx[c];
+                }
+            std::vector<int> rs(P->nIf + 1, 0), rp;
+            for (int c = 0; c < nC; c++)
+                if (P->ifIdx[c] >= 0)
+                {
+                    for (int e = P->ifStart[c]; e < P->ifStart[c + 1]; e++)
+                        if (P->ifNbr[e] >= nC) rp.push_back(P->ifPf[e]);
+                    rs[P->ifIdx[c] + 1] = (int)rp.size();
+                }
+            // (ifIdx ascends with the cell label: rs is complete)
+            if (bk_upload(&P->d_histIfg, hi) || bk_upload(&P->d_remStart, rs) || bk_upload(&P->d_remPf, rp)) return -1;
+        }
     }
     // granules: one per row, then two per interface cell (by sweep parity)
     LDU_CHECK_HIP(hipMalloc((void**)&P->d_granule, sizeof(uint4) * (size_t)(nC + 1 + 2 * (size_t)P->nIf)));
@@ -1079,6 +1188,20 @@ static int bk_tasks(ldu_addr* a, int k, const BlockPlan::Tasks** out)
                     for (int h = P->histBase[b]; h < P->histBase[b + 1]; h++)
                     {
                         const int n = P->histCell[h];
+                        if (n >= a->nCells)
+                        {
+                            // a mirror: the rank across patch face n - nCells sends its initial value (stamp 0) and the one after
+                            // each sweep but the last; due about when the local cell of the face has done the same sweep
+                            const int pf = n - a->nCells, cl = P->pfCell[pf];
+                            for (int s = 0; s <= k - 1; s++)
+                            {
+                                const bool have = s && (int)P->remPhi[std::min(s - 1, P->nLayouts - 1)].size() == a->nPatchFaces;
+                                const long due = !s ? 0L : (have ? (long)P->remPhi[std::min(s - 1, P->nLayouts - 1)][pf]
+                                                                 : (long)Phi[s - 1][layOf(s - 1).grpOfCell[cl]]);
+                                tmp.emplace_back(s ? ((due << 3) | s) : 0L, make_int4(h0 + 2 * (h - P->histBase[b]) + (s & 1), -1 - pf, s, 0));
+                            }
+                            continue;
+                        }
                         if (P->blk[n] == b) continue;          // (its own cells: written by the producing wavefront itself)
                         for (int s = 1; s <= k - 1; s++)
                             tmp.emplace_back(((long)Phi[s - 1][layOf(s - 1).grpOfCell[n]] << 3) | s,
@@ -1151,14 +1274,89 @@ static int bk_values(ldu_addr* a, const double* levelVal, const double* bou, hip
     return 0;
 }
 
+static thread_local bool tl_blkDeciding = false;
+
 bool k_blocks_active(ldu_addr* a)
 {
     ldu_ctx* ctx = a->ctx;
     if (!ctx->blkEngine || !ctx->sweepP2P || a->nCells < (a->nPatchFaces ? std::min(64, ctx->blkMinCells) : ctx->blkMinCells)
         || a->nCells > ctx->blkMaxCells) return false;
     if (addr_bg_pending(a)) return false;      // (its plan is being built on a host thread: the level engines meanwhile)
+    // remote interfaces: only what every rank has agreed on (k_blocks_peer_decide builds the plan itself)
+    if (a->peer && a->peerBlk != 1 && !tl_blkDeciding) return false;
     if (!a->blocks && bk_build(a)) return false;
     return a->blocks && a->blocks->eligible;
+}
+
+// Remote interfaces, the collective part: an addressing with processor patches runs its pipelined sweeps on the block engine when
+// EVERY rank's plan for it exists (its own regions in the peer windows, the ranks' across its patches, a block plan that fits
+// for 1 ... 4 sweeps) - the ranks across an interface must speak the same protocol.  Every rank calls this for the same
+// addressings in the same order (ldu_gamg.cpp: gamg_decide_peer_smoothers; smooth_gs under LDU_BLK_PEER_FORCE for stand-alone
+// smoothing calls); an addressing without remote faces does not veto.
+int k_blocks_peer_decide(ldu_addr* a)
+{
+    ldu_ctx* ctx = a->ctx;
+    if (a->peerBlkEpoch == ctx->commEpoch) return 0;
+    a->peerBlkEpoch = ctx->commEpoch;
+    if (!ctx->comm) { a->peerBlk = 0; return 0; }
+    int ok = 1;
+    if (a->peer)
+    {
+        ok = 0;
+        const bool off = getenv("LDU_BLK_PEER") && !atoi(getenv("LDU_BLK_PEER"));
+        // (small levels whose sweeps AND exchanges already run in one launch - gs_wg_peer_kernel, decided collectively before
+        //  this - stay there)
+        if (!off && a->peerWg != 1 && ctx->blkEngine && ctx->sweepP2P && comm_peer_carries_halo(ctx) && a->peer->bAll)
+        {
+            addr_bg_wait(a);
+            tl_blkDeciding = true;
+            ok = k_blocks_active(a) && a->blocks->remote ? 1 : 0;
+            tl_blkDeciding = false;
+        }
+    }
+    // 1. every rank has a block plan for this level (or no remote faces on it)
+    if (comm_allreduce_min_int(ctx, &ok)) return -1;
+    // 2. the per-sweep layouts, one after the other on all ranks together: layout L needs the group times of layout L - 1 of
+    //    the cells ACROSS the processor patches (BlockPlan::remPhi) - exchanged face by face like the agglomeration's restrict
+    //    maps (comm_exchange_ints); a rank whose own build fails keeps exchanging (zeros) and vetoes at the end
+    if (ok && a->peer)
+    {
+        BlockPlan* P = a->blocks;
+        int mine = 1;
+        tl_blkDeciding = true;
+        for (int L = 0; L < P->nLayouts; L++)
+        {
+            if (L)
+            {
+                std::vector<std::vector<int>> send(a->patches.size()), recv;
+                const BlockPlan::Layout& Y = P->lay[L - 1];
+                for (size_t p = 0; p < a->patches.size(); p++)
+                {
+                    send[p].assign(a->patches[p].n, 0);
+                    if (mine) for (int i = 0; i < a->patches[p].n; i++) send[p][i] = Y.Phi[Y.grpOfCell[a->patches[p].faceCells[i]]];
+                }
+                if (comm_exchange_ints(ctx, a->patches, send, recv)) { tl_blkDeciding = false; return -1; }
+                P->remPhi[L - 1].assign(a->nPatchFaces, 0);
+                for (size_t p = 0; p < a->patches.size(); p++)
+                    for (int i = 0; i < a->patches[p].n && i < (int)recv[p].size(); i++) P->remPhi[L - 1][a->patches[p].offset + i] = recv[p][i];
+            }
+            if (mine && (P->nBuilt != L || bk_build_layout(a, L) || P->nBuilt != L + 1)) mine = 0;
+        }
+        for (int k = 1; mine && k <= 4; k++)
+        {
+            const BlockPlan::Tasks* W = nullptr;
+            if (bk_tasks(a, k, &W) || !W->usable) mine = 0;
+        }
+        tl_blkDeciding = false;
+        ok = mine;
+    }
+    if (comm_allreduce_min_int(ctx, &ok)) return -1;
+    a->peerBlk = (ok && a->peer) ? 1 : 0;
+    if (!a->peerBlk && a->blocks && a->blocks->remote) a->blocks->eligible = false;
+    if (getenv("LDU_VERBOSE") && a->peer)
+        fprintf(stderr, "[ldugpu] level of %d cells, %d coupled faces: pipelined sweeps with remote interfaces on the block engine: %s\n",
+                a->nCells, a->nPatchFaces, a->peerBlk ? "yes" : "no");
+    return 0;
 }
 
 // the layouts' copies of the coefficients of `val`, filled on stream s ahead of the first sweep that asks for them (the
@@ -1244,6 +1442,20 @@ int k_sweep_gs_blocks_if(ldu_addr* a, int k, double* psi, const double* rhs, con
     for (int L = 0; L < BK_NLAY; L++) { const BlockPlan::Layout& Y = P.lay[std::min(L, P.nBuilt - 1)]; T.meta[L] = Y.d_meta; T.col[L] = Y.d_col; }
     T.nLayouts = P.nLayouts;
     T.tasks = W->d_tasks; T.taskStart = W->d_taskStart; T.imps = W->d_imps; T.impStart = W->d_impStart;
+    T.bdst = nullptr; T.bsrc = nullptr; T.nPF = a->nPatchFaces; T.S0 = 0; T.kSweeps = k;
+    T.remStart = P.d_remStart; T.remPf = P.d_remPf; T.histIfg = P.d_histIfg;
+    if (P.remote)
+    {
+        // k exchanges across the processor patches inside this launch: tags bSeq + 1 ... bSeq + k, the same on every rank
+        // (each launches the same smoothing calls on this level)
+        if (!a->peer || !a->peer->d_bdst || a->peerBlk != 1) return 1;
+        T.bdst = a->peer->d_bdst; T.bsrc = a->peer->d_bsrc;
+        T.S0 = a->peer->bSeq + 1u;
+        a->peer->bSeq += (unsigned)k;
+        ctx->nHaloExchanges += k;
+        ctx->nHaloOverlapped += k;
+        bk_init_export_kernel<<<std::min((a->nPatchFaces + 255) / 256, 1024), 256, 0, s>>>(a->nPatchFaces, a->d_pfCell, psi, T.bdst, T.S0);
+    }
     ctx->profStart(a, 4);
     if (P.nw == 7)
         gs_blk_kernel<7><<<P.nBlocks, LDU_WAVE * 8, P.ldsBytes, s>>>(T, P.nBlocks, W->d_order, P.d_granule, tagBase, P.d_ticket, P.ticketBase,

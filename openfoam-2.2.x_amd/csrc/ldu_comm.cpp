@@ -350,6 +350,16 @@ int comm_peer_setup_addr(ldu_addr* a)
         LDU_CHECK_HIP(hipMalloc((void**)&H->d_kseq, sizeof(unsigned)));
         LDU_CHECK_HIP(hipMemsetAsync(H->d_kseq, 0, sizeof(unsigned), ctx->stream));
     }
+    // the block engine's own regions (pipelined sweeps with remote interfaces): addressings in its range of sizes
+    const bool blkRange = ctx->blkEngine && a->nCells >= 64 && a->nCells <= ctx->blkMaxCells && !getenv("LDU_BLK_PEER_OFF");
+    if (blkRange)
+    {
+        H->bWinBytes = H->winBytes;
+        H->bWinOff = W->alloc(H->bWinBytes);
+        if (H->bWinOff == (size_t)-1) { H->bWinBytes = 0; H->bWinOff = 0; }     // (window full: this addressing stays on the level engines)
+        else LDU_CHECK_HIP(hipMemsetAsync((char*)W->base + H->bWinOff, 0, H->bWinBytes, ctx->stream));
+    }
+    const bool haveB = H->bWinBytes > 0;
     // a region that is reused must not hold tags of its previous owner that a new sequence could reach: zero it
     LDU_CHECK_HIP(hipMemsetAsync((char*)W->base + H->winOff, 0, H->winBytes, ctx->stream));
     LDU_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -367,6 +377,7 @@ int comm_peer_setup_addr(ldu_addr* a)
             buf.push_back((int64_t)(H->winOff / sizeof(uint4) + myOff[p]));
             buf.push_back((int64_t)a->patches[p].n);
             buf.push_back(small ? (int64_t)(H->kWinOff / sizeof(uint4) + myOff[p]) : (int64_t)-1);
+            buf.push_back(haveB ? (int64_t)(H->bWinOff / sizeof(uint4) + myOff[p]) : (int64_t)-1);
         }
         peers.push_back(kv.first);
         rb.emplace_back(buf.size());
@@ -386,9 +397,10 @@ int comm_peer_setup_addr(ldu_addr* a)
         }
         else rb = sb;   // one rank whose patches face each other (projection / tests): handled below
     }
-    std::vector<uint4*> dst(2 * (size_t)nPF, nullptr), kdst(2 * (size_t)nPF, nullptr);
-    std::vector<const uint4*> src(2 * (size_t)nPF, nullptr), ksrc(2 * (size_t)nPF, nullptr);
+    std::vector<uint4*> dst(2 * (size_t)nPF, nullptr), kdst(2 * (size_t)nPF, nullptr), bdst(2 * (size_t)nPF, nullptr);
+    std::vector<const uint4*> src(2 * (size_t)nPF, nullptr), ksrc(2 * (size_t)nPF, nullptr), bsrc(2 * (size_t)nPF, nullptr);
     H->kAll = small;
+    H->bAll = haveB;
     size_t i = 0;
     for (auto& kv : byRank)
     {
@@ -397,7 +409,7 @@ int comm_peer_setup_addr(ldu_addr* a)
         {
             const int p = kv.second[k];
             const Patch& P = a->patches[p];
-            int64_t roff = rb[i][3 * k], rn = rb[i][3 * k + 1], rkoff = rb[i][3 * k + 2];
+            int64_t roff = rb[i][4 * k], rn = rb[i][4 * k + 1], rkoff = rb[i][4 * k + 2], rboff = rb[i][4 * k + 3];
             if (ctx->nRanks == 1)
             {
                 // self-coupled: the k-th patch towards "rank 0" pairs with the patch paired_patch names (itself when alone)
@@ -405,9 +417,11 @@ int comm_peer_setup_addr(ldu_addr* a)
                 const int qq = q < 0 ? p : q;
                 roff = (int64_t)(H->winOff / sizeof(uint4) + myOff[qq]);
                 rkoff = small ? (int64_t)(H->kWinOff / sizeof(uint4) + myOff[qq]) : -1;
+                rboff = haveB ? (int64_t)(H->bWinOff / sizeof(uint4) + myOff[qq]) : -1;
                 rn = a->patches[qq].n;
             }
             if (rkoff < 0) H->kAll = false;
+            if (rboff < 0) H->bAll = false;
             if (rn != P.n)
             {
                 ldu_set_error("peer backend: patch sizes differ between neighbours (" + std::to_string(P.n) + " vs " +
@@ -424,6 +438,11 @@ int comm_peer_setup_addr(ldu_addr* a)
                         kdst[(size_t)par * nPF + P.offset + f] = W->peer[nbr] + rkoff + (size_t)par * P.n + f;
                         ksrc[(size_t)par * nPF + P.offset + f] = W->base + H->kWinOff / sizeof(uint4) + myOff[p] + (size_t)par * P.n + f;
                     }
+                    if (haveB && rboff >= 0)
+                    {
+                        bdst[(size_t)par * nPF + P.offset + f] = W->peer[nbr] + rboff + (size_t)par * P.n + f;
+                        bsrc[(size_t)par * nPF + P.offset + f] = W->base + H->bWinOff / sizeof(uint4) + myOff[p] + (size_t)par * P.n + f;
+                    }
                 }
         }
         i++;
@@ -432,6 +451,13 @@ int comm_peer_setup_addr(ldu_addr* a)
     LDU_CHECK_HIP(hipMalloc((void**)&H->d_src, sizeof(uint4*) * src.size()));
     LDU_CHECK_HIP(hipMemcpy(H->d_dst, dst.data(), sizeof(uint4*) * dst.size(), hipMemcpyHostToDevice));
     LDU_CHECK_HIP(hipMemcpy(H->d_src, src.data(), sizeof(uint4*) * src.size(), hipMemcpyHostToDevice));
+    if (haveB)
+    {
+        LDU_CHECK_HIP(hipMalloc((void**)&H->d_bdst, sizeof(uint4*) * bdst.size()));
+        LDU_CHECK_HIP(hipMalloc((void**)&H->d_bsrc, sizeof(uint4*) * bsrc.size()));
+        LDU_CHECK_HIP(hipMemcpy(H->d_bdst, bdst.data(), sizeof(uint4*) * bdst.size(), hipMemcpyHostToDevice));
+        LDU_CHECK_HIP(hipMemcpy(H->d_bsrc, bsrc.data(), sizeof(uint4*) * bsrc.size(), hipMemcpyHostToDevice));
+    }
     if (small)
     {
         LDU_CHECK_HIP(hipMalloc((void**)&H->d_kdst, sizeof(uint4*) * kdst.size()));
@@ -440,6 +466,12 @@ int comm_peer_setup_addr(ldu_addr* a)
         LDU_CHECK_HIP(hipMemcpy(H->d_ksrc, ksrc.data(), sizeof(uint4*) * ksrc.size(), hipMemcpyHostToDevice));
     }
     return 0;
+}
+
+// halo values travel by peer stores on this context (windows mapped, the carrier selected)
+bool comm_peer_carries_halo(const ldu_ctx* ctx)
+{
+    return ctx->comm && ctx->comm->peer && ctx->comm->peerHalo;
 }
 
 bool comm_peer_kernel_comm(ldu_ctx* ctx, PeerKernelComm* out)
@@ -459,6 +491,9 @@ void comm_peer_free_addr(ldu_addr* a)
     if (!a->peer) return;
     if (a->ctx->comm && a->ctx->comm->peer && a->peer->winBytes) a->ctx->comm->peer->release(a->peer->winOff, a->peer->winBytes);
     if (a->ctx->comm && a->ctx->comm->peer && a->peer->kWinBytes) a->ctx->comm->peer->release(a->peer->kWinOff, a->peer->kWinBytes);
+    if (a->ctx->comm && a->ctx->comm->peer && a->peer->bWinBytes) a->ctx->comm->peer->release(a->peer->bWinOff, a->peer->bWinBytes);
+    if (a->peer->d_bdst) (void)hipFree(a->peer->d_bdst);
+    if (a->peer->d_bsrc) (void)hipFree((void*)a->peer->d_bsrc);
     if (a->peer->d_dst) (void)hipFree(a->peer->d_dst);
     if (a->peer->d_src) (void)hipFree((void*)a->peer->d_src);
     if (a->peer->d_kdst) (void)hipFree(a->peer->d_kdst);

@@ -930,6 +930,10 @@ static int gamg_decide_peer_smoothers(ldu_matrix* m)
             fprintf(stderr, "[ldugpu] level of %d cells, %d coupled faces: GaussSeidel sweeps %s\n", a->nCells, a->nPatchFaces,
                     a->peerWg ? "and their exchanges in one launch (peer stores)" : "one by one, exchange between them");
     }
+    // pipelined sweeps with remote interfaces on the block engine (ldu_blocks.hip, "Remote interfaces"): the finest level and
+    // every coarse one the one-launch smoother above did not take, the same list on every rank
+    if (k_blocks_peer_decide(m->a)) return -1;
+    for (auto& L : g->levels) if (k_blocks_peer_decide(L.addr)) return -1;
     return 0;
 }
 

@@ -216,6 +216,14 @@ struct PeerHalo {
     const uint4** d_ksrc = nullptr;
     unsigned* d_kseq = nullptr;            // device: exchanges the kernel has done so far
     bool kAll = false;                     // every remote face has a kernel-private destination
+    // a third set for the BLOCK engine (ldu_blocks.hip, "Remote interfaces"): the interface values of the k pipelined sweeps of
+    // one launch travel through these regions, tagged bSeq + 1 ... bSeq + k (host-side count: every rank launches the same
+    // smoothing calls on a level), parity = tag & 1
+    size_t bWinOff = 0, bWinBytes = 0;
+    uint4** d_bdst = nullptr;              // [2][nPatchFaces]; null entries: cyclic face / the neighbour has no such region
+    const uint4** d_bsrc = nullptr;
+    unsigned bSeq = 0;
+    bool bAll = false;                     // every remote face has a block-engine destination
 };
 #define LDU_COARSEST_MAXC 64
 #define LDU_COARSEST_MAXF 512
@@ -292,6 +300,7 @@ struct ldu_addr {
     // small patched level: the k sweeps of a smoothing and their exchanges in ONE launch (gs_wg_peer_kernel); the decision is
     // collective (and-reduce over the ranks) and belongs to a carrier epoch of the context
     int peerWg = -1, peerWgEpoch = -1;
+    int peerBlk = -1, peerBlkEpoch = -1;   // block engine with REMOTE interfaces on this addressing: -1 not decided (a collective decision), 0 / 1
     int* d_cycPair = nullptr;              // [nPatchFaces] paired face of a cyclic face, -1 = remote (lazy)
 
     // point-to-point sweep state: one 16-byte {value lo, tag, value hi, tag} granule per row,
@@ -475,6 +484,8 @@ void cluster_free(ldu_addr* a);
 // block engine (ldu_blocks.hip)
 int k_sweep_gs_blocks(ldu_addr* a, int k, double* psi, const double* rhs, const double* diag, const double* val);   // 1 = not taken
 bool k_blocks_active(ldu_addr* a);
+bool comm_peer_carries_halo(const ldu_ctx* ctx);
+int k_blocks_peer_decide(ldu_addr* a);     // collective: remote interfaces on the block engine (ldu_blocks.hip)
 int k_blocks_prebuild(ldu_addr* a, int k);
 int k_blocks_prefill(ldu_addr* a, const double* val, const double* bou, hipStream_t s);   // the layouts' coefficient copies, ahead of the sweep (1 = nothing to fill)
 int k_cluster_prefill(ldu_addr* a, const double* val, hipStream_t s);

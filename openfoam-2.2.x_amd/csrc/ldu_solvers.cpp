@@ -240,6 +240,16 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
     // (pend: this level's sweep plans are still being built on a host thread - ensure_hierarchy -: one sweep per launch on the
     //  level engines until they are there; the results are the same bit for bit)
     const bool pend = addr_bg_pending(a);
+    {
+        // (stand-alone smoothing calls on an addressing with processor patches - tests, tools -: the collective decision about
+        //  the block engine is taken here when the caller says that every rank makes this call, LDU_BLK_PEER_FORCE=1; inside a
+        //  GAMG solve it was taken for all levels at once, gamg_decide_peer_smoothers)
+        if (!sym && a->peer && a->peerBlkEpoch != a->ctx->commEpoch)
+        {
+            const char* fe = getenv("LDU_BLK_PEER_FORCE");      // (read per call: tests switch it within one process)
+            if (fe && atoi(fe) && k_blocks_peer_decide(a)) return -1;
+        }
+    }
     const bool blk = !pend && !sym && !a->nPatchFaces && a->ctx->sweepP2P && !(a->ctx->clusterMulti && k_cluster_active(a)) && k_blocks_active(a);
     if (!pend && !sym && !a->nPatchFaces && a->ctx->sweepP2P && !blk)
     {

@@ -81,6 +81,9 @@ def main():
         same("Tmul", m.Tmul(xs[rank]), S.Tmul(X))
         same("residual", m.residual(xs[rank], bs[rank]), S.residual(X, B))
         same("GaussSeidel", m.smooth("GaussSeidel", xs[rank], bs[rank], 2), S.smooth("GaussSeidel", X, B, 2))
+    for k in (1, 4):
+        same("GaussSeidel x %d" % k, m.smooth("GaussSeidel", xs[rank], bs[rank], k), S.smooth("GaussSeidel", X, B, k))
+    engine = a.sweep_engine(2)      # (with LDU_BLK_PEER_FORCE=1: "blocks" = pipelined sweeps with remote interfaces)
     same("sumA", m.sumA(), S.sumA())
     same("symGaussSeidel", m.smooth("symGaussSeidel", xs[rank], bs[rank], 1), S.smooth("symGaussSeidel", X, B, 1))
     if abs(m.gSumProd(xs[rank], bs[rank]) - S.gSumProd(X, B)) > 1e-10:
@@ -131,9 +134,11 @@ def main():
     dist.all_gather_object(allbad, bad)
     alldev = [None] * n
     dist.all_gather_object(alldev, device)
+    alleng = [None] * n
+    dist.all_gather_object(alleng, engine)
     if rank == 0:
         print(json.dumps(dict(n_ranks=n, asym=asym, devices=torch.cuda.device_count(), rank_devices=alldev, carrier=carrier,
-                              comm=info, mismatches=allbad, solves=its, counters=counters, fallbacks=fallbacks)))
+                              comm=info, mismatches=allbad, solves=its, counters=counters, fallbacks=fallbacks, engines=alleng)))
     dist.destroy_process_group()
     sys.exit(1 if any(allbad) else 0)
 

@@ -86,6 +86,29 @@ def test_real_motorbike_mesh_four_ranks():
     assert not any(out["mismatches"]), out
 
 
+@pytest.mark.parametrize("n,asym,size", [(2, False, 16), (4, False, 20), (3, True, 14), (8, False, 16)])
+def test_pipelined_sweeps_with_remote_interfaces(n, asym, size):
+    """the levels with processor patches on the BLOCK engine - k pipelined GaussSeidel sweeps per launch, the
+    interface values of every sweep stored into the neighbour's window from inside the launch (ldu_blocks.hip, "Remote
+    interfaces") - as N processes: GaussSeidel 1 / 2 / 4 sweeps bit for bit against the N-rank oracle
+    (GaussSeidelSmoother.C:98-145: the neighbour's values of the PREVIOUS sweep), GAMG / Krylov / smoothSolver as before.
+    LDU_BLK_PEER_FORCE=1: the stand-alone smoothing calls take the collective decision too (inside GAMG it is taken anyway)."""
+    out = run_worker(n, asym, size=size, env={"LDU_BLK_PEER_FORCE": "1"}, timeout=900)
+    assert not any(out["mismatches"]), out
+    assert all(e == "blocks" for e in out["engines"]), out["engines"]
+    assert out["fallbacks"] == 0
+
+
+def test_pipelined_sweeps_with_remote_interfaces_on_the_real_mesh():
+    from openfoam_amd import motorbike
+    if not motorbike.available("mbtut"):
+        pytest.skip("data/motorbike/mbtut.npz not present")
+    out = run_worker(4, False, size="mbtut", env={"LDU_BLK_PEER_FORCE": "1"}, timeout=1500)
+    assert not any(out["mismatches"]), out
+    assert all(e == "blocks" for e in out["engines"]), out["engines"]
+    assert out["fallbacks"] == 0
+
+
 def test_short_multirank_fuzz():
     """tools/fuzz_peer.py for 25 s on 3 ranks (random matrices, random decompositions, every operator bit for bit, GAMG and
     Krylov histories): the run that found the set-up memset race of round 4 (interfaceIntCoeffs zeroed again by a late
@@ -108,6 +131,7 @@ def test_one_rank_wired_to_itself(oracle, monkeypatch, asym):
     """one sub-domain whose two processor patches receive what they sent, through the window of this rank (the
     projection bench.py --rank-of measures): bit-exact operators, solver histories against the oracle's emulation"""
     monkeypatch.setenv("LDU_FORCE_COMM", "1")
+    monkeypatch.setenv("LDU_BLK_PEER_FORCE", "1")      # (the sweeps with remote interfaces on the block engine, wired to itself)
     p = _self_coupled(oracle, asym)
     S = oracle.System([p])
     ctx = capi.Context(0)
@@ -124,6 +148,9 @@ def test_one_rank_wired_to_itself(oracle, monkeypatch, asym):
         assert np.array_equal(m.Tmul(x), S.Tmul(x))
         assert np.array_equal(m.residual(x, b), S.residual(x, b))
         assert np.array_equal(m.smooth("GaussSeidel", x, b, 2), S.smooth("GaussSeidel", x, b, 2))
+        for k in (1, 3, 4):
+            assert np.array_equal(m.smooth("GaussSeidel", x, b, k), S.smooth("GaussSeidel", x, b, k)), k
+    print("self-coupled rank: GaussSeidel engine", a.sweep_engine(2), "cells", p["nCells"])
     kw = dict(tolerance=1e-9, relTol=0)
     names = ("PBiCG", "DILU") if asym else ("PCG", "DIC")
     xs, perf = m.solve(p["psi"], p["source"], solver=names[0], preconditioner=names[1], **kw)
