@@ -244,8 +244,9 @@ static int smooth_gs(ldu_matrix* m, double* psi, const double* source, int nSwee
         // (stand-alone smoothing calls on an addressing with processor patches - tests, tools -: the collective decision about
         //  the block engine is taken here when the caller says that every rank makes this call, LDU_BLK_PEER_FORCE=1; inside a
         //  GAMG solve it was taken for all levels at once, gamg_decide_peer_smoothers)
-        if (!sym && a->peer && a->peerBlkEpoch != a->ctx->commEpoch)
+        if (!sym && a->ctx->comm && a->ctx->nRanks > 0 && a->peerBlkEpoch != a->ctx->commEpoch)
         {
+            // (every rank, with or without coupled faces on this addressing: the decision is an all-reduce)
             const char* fe = getenv("LDU_BLK_PEER_FORCE");      // (read per call: tests switch it within one process)
             if (fe && atoi(fe) && k_blocks_peer_decide(a)) return -1;
         }

@@ -130,11 +130,11 @@ def main():
     counters = ctx.comm_counters()
     fallbacks = ctx.fallback_count()
     m.close(); a.close(); ctx.close()
-    allbad = [None] * n
+    allbad = [None] * world
     dist.all_gather_object(allbad, bad)
-    alldev = [None] * n
+    alldev = [None] * world
     dist.all_gather_object(alldev, device)
-    alleng = [None] * n
+    alleng = [None] * world
     dist.all_gather_object(alleng, engine)
     if rank == 0:
         print(json.dumps(dict(n_ranks=n, asym=asym, devices=torch.cuda.device_count(), rank_devices=alldev, carrier=carrier,
