@@ -468,10 +468,11 @@ int comm_peer_setup_addr(ldu_addr* a)
     return 0;
 }
 
-// halo values travel by peer stores on this context (windows mapped, the carrier selected)
+// the peer windows of this context are mapped on every rank (whichever carrier the halo exchanges between launches use: the
+// block engine's in-launch interface stores only need the windows)
 bool comm_peer_carries_halo(const ldu_ctx* ctx)
 {
-    return ctx->comm && ctx->comm->peer && ctx->comm->peerHalo;
+    return ctx->comm && ctx->comm->peer;
 }
 
 bool comm_peer_kernel_comm(ldu_ctx* ctx, PeerKernelComm* out)
