@@ -1333,14 +1333,15 @@ int k_blocks_peer_decide(ldu_addr* a)
                 for (size_t p = 0; p < a->patches.size(); p++)
                 {
                     send[p].assign(a->patches[p].n, 0);
-                    if (mine) for (int i = 0; i < a->patches[p].n; i++) send[p][i] = Y.Phi[Y.grpOfCell[a->patches[p].faceCells[i]]];
+                    if (mine && P->nBuilt >= L) for (int i = 0; i < a->patches[p].n; i++) send[p][i] = Y.Phi[Y.grpOfCell[a->patches[p].faceCells[i]]];
                 }
                 if (comm_exchange_ints(ctx, a->patches, send, recv)) { tl_blkDeciding = false; return -1; }
                 P->remPhi[L - 1].assign(a->nPatchFaces, 0);
                 for (size_t p = 0; p < a->patches.size(); p++)
                     for (int i = 0; i < a->patches[p].n && i < (int)recv[p].size(); i++) P->remPhi[L - 1][a->patches[p].offset + i] = recv[p][i];
             }
-            if (mine && (P->nBuilt != L || bk_build_layout(a, L) || P->nBuilt != L + 1)) mine = 0;
+            // (a decision taken again - the carriers of the context changed -: the layouts are there, every rank's alike)
+            if (mine && P->nBuilt <= L && (P->nBuilt != L || bk_build_layout(a, L) || P->nBuilt != L + 1)) mine = 0;
         }
         for (int k = 1; mine && k <= 4; k++)
         {
