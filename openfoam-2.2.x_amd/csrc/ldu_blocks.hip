@@ -142,7 +142,6 @@ struct BlockPlan {
     // worker walks its tasks in ascending Phi, and a task that waits for another rank must not stand in front of one that rank
     // is waiting for
     std::vector<int> remPhi[BK_NLAY];
-    int* d_histIfg = nullptr;              // [histCell.size()] index among the interface cells of a block's OWN interface cells, else -1
     int* d_remStart = nullptr;             // [nIf + 1] CSR: the processor-patch faces of an interface cell
     int* d_remPf = nullptr;
 };
@@ -162,7 +161,7 @@ void blocks_free(ldu_addr* a)
     BlockPlan* P = a->blocks;
     if (!P) return;
     void* ptrs[] = {P->d_blk, P->d_localRow, P->d_ghostRow, P->d_granule, P->d_ticket, P->d_out, P->d_blk2, P->d_histRow,
-                    P->d_histIfg, P->d_remStart, P->d_remPf};
+                    P->d_remStart, P->d_remPf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& L : P->lay)
         for (void* p : {(void*)L.d_meta, (void*)L.d_col, (void*)L.d_srcFace}) if (p) (void)hipFree(p);
@@ -258,7 +257,7 @@ struct BkTab {
     // remote interfaces (null / 0 without): destination and source granules per (parity, patch face) in the peer windows, the tag
     // of this launch's first exchange, its number of sweeps, the processor-patch faces of the interface cells
     uint4* const* bdst; const uint4* const* bsrc; int nPF; unsigned S0; int kSweeps;
-    const int* remStart; const int* remPf; const int* histIfg;
+    const int* remStart; const int* remPf;
 };
 
 // a dependency wait of a launch with remote interfaces is (also) a wait for another rank: the peer time-out, not the 200 ms
@@ -270,7 +269,7 @@ __device__ __forceinline__ bool bk_wait_expired(bool remote, unsigned& spins, in
 }
 
 // a task's rows in flight: one lane = one row (T = 1) or one sixteen-entry part of a row (T = 2 / 4 / 8 lanes per row)
-struct BkRow { int4 Q; int rg, slot, nl, nn, ni, hist, ifg, sent, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
+struct BkRow { int4 Q; int rg, slot, nl, nn, ni, hist, ifg, T, j; bool have; unsigned c2[8]; double v[16]; double b, d; };
 
 // stage B of a task's prefetch: everything that depends on the task record (R.Q, loaded a step earlier) alone
 __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
@@ -296,10 +295,7 @@ __device__ __forceinline__ void bk_row_load(int lane, const BkTab& T, BkRow& R)
     R.nl = (M.y >> 16) & 31;
     R.nn = (M.y >> 21) & 31;
     R.ni = (M.y >> 26) & 31;
-    // M.z: plans with coupled interfaces - the row's hist pair; plans without - the row's SENTINEL: the LDS slot of the input
-    // that the plan expects last (| 1 << 16: a lower neighbour, wanted with this sweep's stamp)
-    R.hist = T.blk2 ? M.z : -1;
-    R.sent = T.blk2 ? -1 : M.z;
+    R.hist = M.z;
     R.ifg = M.w;
     const uint4* __restrict__ col4 = (const uint4*)col;
     const double2* __restrict__ val2 = (const double2*)val;
@@ -724,30 +720,11 @@ static int bk_build_layout(ldu_addr* a, int L)
                     M.y = slot[c] | (lo << 16) | (en << 21) | (fi << 26);
                     M.z = ni ? hslot[c] : -1;
                     M.w = ni ? P->ifIdx[c] : 0;
-                    // (without interfaces M.z becomes the lane's sentinel below; the row itself - its value of the sweep before -
-                    //  until an entry is expected later)
-                    if (!P->iface) M.z = slot[c];
                     meta[(size_t)Y.grpLane0[g] + lane0 + tl] = M;
                 }
                 int q = 0;
-                int sentT[8];
-                for (int tl = 0; tl < 8; tl++) sentT[tl] = L ? RTprev[c] : -1;
                 auto put = [&](int n, int code) {
                     const int tl = q >> 4, qq = q & 15;
-                    if (!P->iface)
-                    {
-                        // when the plan expects this input: a lower neighbour in this sweep, an upper one in the sweep before (sweep
-                        // 0: the initial value, there from the start); two steps more across blocks (the importer's way)
-                        const bool lowerE = !(code & 1);
-                        int te = lowerE ? RT[n] : (L ? RTprev[n] : -2);
-                        if (blk[n] != b && te >= 0) te += 2;
-                        if (te > sentT[tl])
-                        {
-                            sentT[tl] = te;
-                            const unsigned sl_ = (unsigned)(blk[n] == b ? slot[n] : gslot_[n]);
-                            meta[(size_t)Y.grpLane0[g] + lane0 + tl].z = (int)(sl_ | (lowerE ? 0x10000u : 0u));
-                        }
-                    }
                     // a lane's entries 2 p, 2 p + 1 are one 16-byte pair (pair p of lane l at grpEnt / 2 + p * stride + l), its
                     // column slots 8 r ... 8 r + 7 one 16-byte quad of words (quad r at grpEnt / 8 + r * stride + l): a task's
                     // rows arrive with 2 + 8 load instructions instead of 8 + 16 - groups hold ~10 of 64 lanes, what a
@@ -1041,14 +1018,7 @@ static int bk_build(ldu_addr* a)
         if (bk_upload(&P->d_blk2, b2) || bk_upload(&P->d_histRow, hr)) return -1;
         if (P->remote)
         {
-            // a block's own interface cells (the first entries of its hist range) and their processor-patch faces
-            std::vector<int> hi(P->histCell.size(), -1);
-            for (int b = 0; b < nB; b++)
-                for (int h = P->histBase[b]; h < P->histBase[b + 1]; h++)
-                {
-                    const int c = P->histCell[h];
-                    if (c < nC && P->blk[c] == b) hi[h] = P->ifIdx[c];
-                }
+            // the processor-patch faces of every interface cell
             std::vector<int> rs(P->nIf + 1, 0), rp;
             for (int c = 0; c < nC; c++)
                 if (P->ifIdx[c] >= 0)
@@ -1058,7 +1028,7 @@ static int bk_build(ldu_addr* a)
                     rs[P->ifIdx[c] + 1] = (int)rp.size();
                 }
             // (ifIdx ascends with the cell label: rs is complete)
-            if (bk_upload(&P->d_histIfg, hi) || bk_upload(&P->d_remStart, rs) || bk_upload(&P->d_remPf, rp)) return -1;
+            if (bk_upload(&P->d_remStart, rs) || bk_upload(&P->d_remPf, rp)) return -1;
         }
     }
     // granules: one per row, then two per interface cell (by sweep parity)
@@ -1444,7 +1414,7 @@ int k_sweep_gs_blocks_if(ldu_addr* a, int k, double* psi, const double* rhs, con
     T.nLayouts = P.nLayouts;
     T.tasks = W->d_tasks; T.taskStart = W->d_taskStart; T.imps = W->d_imps; T.impStart = W->d_impStart;
     T.bdst = nullptr; T.bsrc = nullptr; T.nPF = a->nPatchFaces; T.S0 = 0; T.kSweeps = k;
-    T.remStart = P.d_remStart; T.remPf = P.d_remPf; T.histIfg = P.d_histIfg;
+    T.remStart = P.d_remStart; T.remPf = P.d_remPf;
     if (P.remote)
     {
         // k exchanges across the processor patches inside this launch: tags bSeq + 1 ... bSeq + k, the same on every rank

@@ -210,6 +210,11 @@ def make_order(p, spec, rcm, seed=1):
     if f[0] == "tilerand":
         # tiles of K consecutive bandCompression positions in random order, bandCompression order inside a tile (no colours)
         return np.argsort(within_key("tile" + f[1], nC, rcm_pos, rng), kind="stable").astype(np.int32)
+    if f[0] == "stride":
+        # tiles of K consecutive bandCompression positions taken with stride S: tiles 0, S, 2S, ... then 1, S+1, ... (stride:K:S)
+        K, S = int(f[1]), int(f[2])
+        tile = rcm_pos // K
+        return np.lexsort((rcm_pos, tile // S, tile % S)).astype(np.int32)
     if f[0] == "tiles":
         # the library's own: ldu_tile_shuffle(bandCompression order, K, seed) - tiles:K[:seed]
         return capi.tile_shuffle(rcm, int(f[1]), int(f[2]) if len(f) > 2 else 1)
