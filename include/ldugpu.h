@@ -53,7 +53,8 @@ typedef struct ldu_controls {
     int32_t nFinestSweeps;
     int32_t interpolateCorrection;
     int32_t scaleCorrection;      /* -1 = matrix.symmetric() (GAMGSolver.C:74) */
-    int32_t directSolveCoarsest;  /* GAMGSolver.C:76,95-106: LU of the coarsest level (serial, <= 64 cells; else refused) */
+    int32_t directSolveCoarsest;  /* GAMGSolver.C:76,95-106: LU of the coarsest level (<= 64 cells; with coupled patches / several ranks the gathered
+                                     matrix of LUscalarMatrix.C:52-107, <= 128 cells over all ranks; else refused) */
     int32_t nCellsInCoarsestLevel, mergeLevels, agglomerator;
     int32_t nVcycles;
     int32_t historyCapacity;      /* residual history entries the caller's buffer holds */

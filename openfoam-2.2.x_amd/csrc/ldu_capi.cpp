@@ -491,6 +491,7 @@ void matrix_free(ldu_matrix* m)
     if (!m) return;
     if (m->gamg) gamg_free(m->gamg);
     coupled_free(m);
+    coarsest_lu_free(m);
     // the cluster engine keeps converted copies of this matrix's value arrays, keyed by their addresses
     for (const double* v : {(const double*)m->d_valA, (const double*)m->d_valT, (const double*)m->d_valP,
                             (const double*)m->d_valPT})

@@ -614,17 +614,392 @@ coarsest_lu_kernel(int n, int nF, const int* __restrict__ gl, const int* __restr
     for (int i = lane; i < n; i += LDU_WAVE) corrNew[i] = x[perm[i]];
 }
 
-// 0 = solved; -1 = error (said); directSolveCoarsest has no iterative fall-back
-int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src)
+// ---------------------------------------------------------------- directSolveCoarsest with coupled patches / several ranks
+// Serial run with cyclic patches: LUscalarMatrix.C:128-187 (the interfaces' coefficients subtracted from the dense matrix).
+// Parallel run: the reference sends every rank's coarsest-level matrix to the master (LUscalarMatrix.C:52-107), builds ONE
+// dense matrix over all ranks' cells there (:190-318), factorises it, and per V-cycle gathers the sources, back-substitutes
+// and scatters (LUscalarMatrixTemplates.C:31-118).  Here the pieces are ALL-gathered (comm_allgather_host: the addressing
+// once, the coefficients once per set of coefficients, the sources per V-cycle) and EVERY rank assembles, factorises and
+// back-substitutes the same matrix - the master's arithmetic on every rank, the same bits, no scatter - and keeps its slice.
+// Assembly in the reference's order: "set" entries (diag, lower / upper by face) are distinct and written in parallel; the
+// coupling entries are subtracted after them by one lane in the reference's order (rank, patch, face).  One wavefront, the
+// matrix in LDS, R = 1 or 2 rows per lane: up to 128 cells over all ranks (dynamic LDS 132 KB of the CU's 160).
+#define LU_MAXN 128
+struct CoarsestLU {
+    int n = 0, myOff = 0, nMine = 0, nRanks = 0;
+    int nSet = 0, nSub = 0;
+    int* d_ops = nullptr;             // [3 * (nSet + nSub)] row, col, index into the gathered coefficients
+    double* d_G = nullptr;            // gathered coefficients: per rank diag | upper | lower | bouCoeffs
+    std::vector<int64_t> gOff;        // [nRanks + 1] offsets of the ranks' blocks in d_G (doubles)
+    double* d_pack = nullptr;         // this rank's block
+    double* d_M0 = nullptr;           // the assembled matrix, n x n
+    double* d_srcAll = nullptr;       // [n] sources of all ranks, original numbering
+    double* d_srcMine = nullptr;      // [nMine]
+    std::vector<double> hA, hB;
+    uint64_t epoch = ~0ull;
+    int commEpoch = -1;
+    std::string refuse;
+    void release()
+    {
+        for (void* q : {(void*)d_ops, (void*)d_G, (void*)d_pack, (void*)d_M0, (void*)d_srcAll, (void*)d_srcMine})
+            if (q) (void)hipFree(q);
+        d_ops = nullptr; d_G = d_pack = d_M0 = d_srcAll = d_srcMine = nullptr;
+    }
+};
+void coarsest_lu_free(ldu_matrix* m)
+{
+    if (!m->lu) return;
+    m->lu->release();
+    delete m->lu;
+    m->lu = nullptr;
+}
+
+__global__ void __launch_bounds__(LDU_WAVE)
+lu_assemble_kernel(int n, int nSet, int nSub, const int* __restrict__ ops, const double* __restrict__ G, double* __restrict__ M)
+{
+    const int lane = threadIdx.x;
+    for (int e = lane; e < n * n; e += LDU_WAVE) M[e] = 0.0;
+    __syncthreads();
+    for (int o = lane; o < nSet; o += LDU_WAVE) M[ops[3 * o] * n + ops[3 * o + 1]] = G[ops[3 * o + 2]];
+    __syncthreads();
+    if (lane == 0)
+        for (int o = nSet; o < nSet + nSub; o++) M[ops[3 * o] * n + ops[3 * o + 1]] -= G[ops[3 * o + 2]];
+}
+
+__global__ void lu_pack_src_kernel(int n, const int* __restrict__ perm, const double* __restrict__ srcNew, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[perm[i]] = srcNew[i];     // original numbering
+}
+
+// LUDecompose / LUBacksubstitute as coarsest_lu_kernel above, rows lane + 64 q (q < R) per lane
+template <int R>
+__global__ void __launch_bounds__(LDU_WAVE)
+dense_lu_kernel(int n, const double* __restrict__ M0, const double* __restrict__ srcAll, int myOff, int nMine,
+                const int* __restrict__ perm, double* __restrict__ corrNew, int* __restrict__ singular)
+{
+    extern __shared__ double lu_lds[];
+    const int ld = n + 1;
+    double* M = lu_lds;
+    double* vv = M + n * ld;
+    double* x = vv + n;
+    int* piv = (int*)(x + n);
+    const int lane = threadIdx.x;
+    for (int e = lane; e < n * n; e += LDU_WAVE) { const int i = e / n; M[i * ld + (e - i * n)] = M0[e]; }
+    for (int i = lane; i < n; i += LDU_WAVE) x[i] = srcAll[i];   // coarsestCorrField = coarsestSource
+    __syncthreads();
+    int ri[R];
+    bool row[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) { ri[q] = lane + LDU_WAVE * q; row[q] = ri[q] < n; }
+#pragma unroll
+    for (int q = 0; q < R; q++)
+        if (row[q])
+        {
+            double largest = 0.0;
+            for (int j = 0; j < n; j++)
+            {
+                const double t = fabs(M[ri[q] * ld + j]);
+                if (t > largest) largest = t;
+            }
+            if (largest == 0.0) *singular = 1;   // the reference: FatalError "Singular matrix"
+            vv[ri[q]] = 1.0 / largest;
+        }
+    __syncthreads();
+    for (int j = 0; j < n; j++)
+    {
+        double sum[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) sum[q] = row[q] ? M[ri[q] * ld + j] : 0.0;
+        for (int k = 0; k < j; k++)
+        {
+            double mkj;                                       // M[k][j]: final after row k's k-1 subtractions
+            if (R == 1) mkj = __shfl(sum[0], k);
+            else mkj = k < LDU_WAVE ? __shfl(sum[0], k) : __shfl(sum[R - 1], k - LDU_WAVE);
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (row[q] && ri[q] > k) sum[q] -= M[ri[q] * ld + k] * mkj;
+        }
+        double m = -1.0, t[R];
+#pragma unroll
+        for (int q = 0; q < R; q++)
+        {
+            if (row[q]) M[ri[q] * ld + j] = sum[q];
+            t[q] = (row[q] && ri[q] >= j) ? vv[ri[q]] * fabs(sum[q]) : -1.0;
+            m = t[q] > m ? t[q] : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = o > m ? o : m; }
+        if (!(m > 0.0)) m = 0.0;
+        int iMax = j;                                          // the LAST row i >= j whose vv[i]*|sum| equals the largest (`>=` scan)
+#pragma unroll
+        for (int q = 0; q < R; q++)
+        {
+            const unsigned long long hit = __ballot(row[q] && ri[q] >= j && t[q] >= m);
+            if (hit) iMax = LDU_WAVE * q + 63 - __builtin_clzll(hit);
+        }
+        __syncthreads();
+        if (lane == 0) piv[j] = iMax;
+        if (iMax != j)
+        {
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (row[q])
+                {
+                    const double a = M[j * ld + ri[q]], b = M[iMax * ld + ri[q]];
+                    M[j * ld + ri[q]] = b; M[iMax * ld + ri[q]] = a;
+                }
+            __syncthreads();
+            if (lane == 0) vv[iMax] = vv[j];
+        }
+        __syncthreads();
+        if (lane == 0 && M[j * ld + j] == 0.0) M[j * ld + j] = 1e-15;   // SMALL
+        __syncthreads();
+        if (j != n - 1)
+        {
+            const double rDiag = 1.0 / M[j * ld + j];
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (row[q] && ri[q] > j) M[ri[q] * ld + j] *= rDiag;
+        }
+        __syncthreads();
+    }
+    if (lane == 0)
+    {
+        int ii = 0;
+        for (int i = 0; i < n; i++)
+        {
+            const int ip = piv[i];
+            double sum = x[ip];
+            x[ip] = x[i];
+            if (ii != 0) { for (int j = ii - 1; j < i; j++) sum -= M[i * ld + j] * x[j]; }
+            else if (sum != 0.0) ii = i + 1;
+            x[i] = sum;
+        }
+        for (int i = n - 1; i >= 0; i--)
+        {
+            double sum = x[i];
+            for (int j = i + 1; j < n; j++) sum -= M[i * ld + j] * x[j];
+            x[i] = sum / M[i * ld + i];
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < nMine; i += LDU_WAVE) corrNew[i] = x[myOff + perm[i]];
+}
+
+// the gathered addressing -> the assembly table (collective: every rank calls it at the same point of the same V-cycle)
+static int lu_gathered_setup(ldu_matrix* A, CoarsestLU* L)
 {
     ldu_addr* a = A->a;
     ldu_ctx* ctx = a->ctx;
-    if (ctx->nRanks > 1 || a->nPatchFaces)
+    L->release();
+    L->refuse.clear();
+    L->commEpoch = ctx->commEpoch;
+    L->epoch = ~0ull;
+    // this rank's description: nCells, nFaces, nPatches, l, u, then per patch: nbrRank, nbrPatch, n, offset, faceCells
+    std::vector<int> d = {a->nCells, a->nFaces, (int)a->patches.size()};
+    d.insert(d.end(), a->l.begin(), a->l.end());
+    d.insert(d.end(), a->u.begin(), a->u.end());
+    for (auto& P : a->patches)
     {
-        ldu_set_error("directSolveCoarsest: coupled patches / several ranks (the reference gathers the ranks' matrices on the "
-                      "master, LUscalarMatrix.C:52-107) are not implemented");
-        return -1;
+        d.push_back(P.nbrRank); d.push_back(P.nbrPatch); d.push_back(P.n); d.push_back(P.offset);
+        d.insert(d.end(), P.faceCells.begin(), P.faceCells.end());
     }
+    std::vector<std::vector<char>> all;
+    if (comm_allgather_host(ctx, d.data(), (int64_t)(sizeof(int) * d.size()), all)) return -1;
+    const int nR = (int)all.size(), me = nR > 1 ? ctx->rank : 0;
+    struct RP { int nbrRank, nbrPatch, n, offset; const int* fc; };
+    struct RD { int nC, nF; const int *l, *u; std::vector<RP> P; int nPF; };
+    std::vector<RD> D(nR);
+    std::vector<int> cellOff(nR + 1, 0);
+    L->gOff.assign(nR + 1, 0);
+    for (int r = 0; r < nR; r++)
+    {
+        const int* q = (const int*)all[r].data();
+        RD& X = D[r];
+        X.nC = q[0]; X.nF = q[1];
+        const int nP = q[2];
+        X.l = q + 3; X.u = X.l + X.nF;
+        const int* w = X.u + X.nF;
+        X.nPF = 0;
+        for (int p = 0; p < nP; p++)
+        {
+            X.P.push_back(RP{w[0], w[1], w[2], w[3], w + 4});
+            X.nPF = std::max(X.nPF, w[3] + w[2]);
+            w += 4 + w[2];
+        }
+        cellOff[r + 1] = cellOff[r] + X.nC;
+        L->gOff[r + 1] = L->gOff[r] + X.nC + 2 * (int64_t)X.nF + X.nPF;
+    }
+    L->nRanks = nR;
+    L->n = cellOff[nR];
+    L->myOff = cellOff[me];
+    L->nMine = a->nCells;
+    // (every rank sees the same description: the refusals below are taken by all of them)
+    if (L->n > LU_MAXN || L->n == 0)
+    {
+        L->refuse = "directSolveCoarsest: the coarsest level has " + std::to_string(L->n) + " cells over all ranks; the device LU holds up to "
+                    + std::to_string(LU_MAXN);
+        return 0;
+    }
+    std::vector<int> set, sub;
+    auto op = [](std::vector<int>& v, int row, int col, int64_t src) { v.push_back(row); v.push_back(col); v.push_back((int)src); };
+    for (int r = 0; r < nR; r++)
+    {
+        const RD& X = D[r];
+        const int off = cellOff[r];
+        const int64_t g = L->gOff[r], gU = g + X.nC, gL = gU + X.nF, gB = gL + X.nF;
+        for (int c = 0; c < X.nC; c++) op(set, off + c, off + c, g + c);
+        for (int f = 0; f < X.nF; f++)
+        {
+            op(set, off + X.u[f], off + X.l[f], gL + f);
+            op(set, off + X.l[f], off + X.u[f], gU + f);
+        }
+        for (int p = 0; p < (int)X.P.size(); p++)
+        {
+            const RP& P = X.P[p];
+            if (P.nbrPatch >= 0)
+            {
+                if (nR > 1)
+                {
+                    // procLduInterface.C:38-60 gives a cyclic interface myProcNo == neighbProcNo == -1, and
+                    // LUscalarMatrix.C:247-262 then reads it as ONE patch holding both halves: no 2.2.x mesh has that layout
+                    L->refuse = "directSolveCoarsest: a cyclic patch inside a rank of a parallel run (the reference reads it as the "
+                                "pre-2.0 single-patch cyclic, LUscalarMatrix.C:247-262) is not implemented";
+                    return 0;
+                }
+                const RP& N = X.P[P.nbrPatch];                 // LUscalarMatrix.C:160-184
+                for (int f = 0; f < P.n; f++) op(sub, P.fc[f], N.fc[f], gB + N.offset + f);
+                continue;
+            }
+            if (nR == 1 || P.nbrRank < 0 || P.nbrRank >= nR || P.nbrRank == r)
+            {
+                L->refuse = "directSolveCoarsest: a processor patch without a neighbour rank in this communicator";
+                return 0;
+            }
+            if (r > P.nbrRank) continue;                        // :264 myProcNo_ < neighbProcNo_
+            // the neighbour's interface: its k-th patch towards r for my k-th patch towards it (the pairing of every exchange,
+            // ldu_comm.cpp paired_patch; the reference matches by the communication tag, :279-292)
+            int k = 0, j = -1;
+            for (int i = 0; i < p; i++) if (X.P[i].nbrPatch < 0 && X.P[i].nbrRank == P.nbrRank) k++;
+            const RD& Y = D[P.nbrRank];
+            for (int i = 0; i < (int)Y.P.size(); i++)
+                if (Y.P[i].nbrPatch < 0 && Y.P[i].nbrRank == r && k-- == 0) { j = i; break; }
+            if (j < 0 || Y.P[j].n != P.n) { L->refuse = "directSolveCoarsest: unpaired processor patch"; return 0; }
+            const RP& N = Y.P[j];
+            const int noff = cellOff[P.nbrRank];
+            const int64_t gBN = L->gOff[P.nbrRank] + Y.nC + 2 * (int64_t)Y.nF;
+            for (int f = 0; f < P.n; f++)                        // :308-315
+            {
+                const int uCell = P.fc[f] + off, lCell = N.fc[f] + noff;
+                op(sub, uCell, lCell, gBN + N.offset + f);
+                op(sub, lCell, uCell, gB + P.offset + f);
+            }
+        }
+    }
+    L->nSet = (int)set.size() / 3;
+    L->nSub = (int)sub.size() / 3;
+    set.insert(set.end(), sub.begin(), sub.end());
+    LDU_CHECK_HIP(hipMalloc((void**)&L->d_ops, sizeof(int) * (set.size() + 3)));
+    LDU_CHECK_HIP(hipMemcpy(L->d_ops, set.data(), sizeof(int) * set.size(), hipMemcpyHostToDevice));
+    LDU_CHECK_HIP(hipMalloc((void**)&L->d_G, sizeof(double) * (size_t)(L->gOff[nR] + 1)));
+    LDU_CHECK_HIP(hipMalloc((void**)&L->d_pack, sizeof(double) * (size_t)(L->gOff[me + 1] - L->gOff[me] + 1)));
+    LDU_CHECK_HIP(hipMalloc((void**)&L->d_M0, sizeof(double) * (size_t)L->n * L->n));
+    LDU_CHECK_HIP(hipMalloc((void**)&L->d_srcAll, sizeof(double) * (size_t)L->n));
+    LDU_CHECK_HIP(hipMalloc((void**)&L->d_srcMine, sizeof(double) * (size_t)(L->nMine + 1)));
+    static bool attr = false;
+    if (!attr)
+    {
+        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)dense_lu_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)((LU_MAXN * (LU_MAXN + 1) + 2 * LU_MAXN) * sizeof(double) + LU_MAXN * sizeof(int))));
+        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)dense_lu_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)((LDU_WAVE * (LDU_WAVE + 1) + 2 * LDU_WAVE) * sizeof(double) + LDU_WAVE * sizeof(int))));
+        attr = true;
+    }
+    if (getenv("LDU_VERBOSE"))
+        fprintf(stderr, "[ldugpu] directSolveCoarsest: %d cells over %d rank(s), %d matrix entries set, %d coupling entries; every rank "
+                        "factorises the gathered matrix (one wavefront, %d row(s) per lane)\n", L->n, nR, L->nSet, L->nSub, L->n > LDU_WAVE ? 2 : 1);
+    return 0;
+}
+
+static int lu_gathered(ldu_matrix* A, double* corr, const double* src, uint64_t epoch)
+{
+    ldu_addr* a = A->a;
+    ldu_ctx* ctx = a->ctx;
+    hipStream_t s = ctx->stream;
+    if (!A->lu) A->lu = new CoarsestLU();
+    CoarsestLU* L = A->lu;
+    if (L->commEpoch != ctx->commEpoch || L->nMine != a->nCells)
+        if (lu_gathered_setup(A, L)) return -1;
+    if (!L->refuse.empty()) { ldu_set_error(L->refuse); return -1; }
+    const int me = L->nRanks > 1 ? ctx->rank : 0;
+    const size_t nC = (size_t)a->nCells, nF = (size_t)a->nFaces, nPF = (size_t)(L->gOff[me + 1] - L->gOff[me]) - nC - 2 * nF;
+    if (L->epoch != epoch)
+    {
+        // this rank's coefficients (original numbering: the LDU arrays as they are), then everybody's
+        double* dst = L->nRanks > 1 ? L->d_pack : L->d_G;
+        if (nC) LDU_CHECK_HIP(hipMemcpyAsync(dst, A->d_diagO, sizeof(double) * nC, hipMemcpyDeviceToDevice, s));
+        if (nF) LDU_CHECK_HIP(hipMemcpyAsync(dst + nC, A->d_upperO, sizeof(double) * nF, hipMemcpyDeviceToDevice, s));
+        if (nF) LDU_CHECK_HIP(hipMemcpyAsync(dst + nC + nF, A->sym ? A->d_upperO : A->d_lowerO, sizeof(double) * nF, hipMemcpyDeviceToDevice, s));
+        if (nPF) LDU_CHECK_HIP(hipMemcpyAsync(dst + nC + 2 * nF, A->d_bou, sizeof(double) * nPF, hipMemcpyDeviceToDevice, s));
+        if (L->nRanks > 1)
+        {
+            L->hA.resize(nC + 2 * nF + nPF + 1);
+            LDU_CHECK_HIP(hipMemcpyAsync(L->hA.data(), L->d_pack, sizeof(double) * (nC + 2 * nF + nPF), hipMemcpyDeviceToHost, s));
+            LDU_CHECK_HIP(hipStreamSynchronize(s));
+            std::vector<std::vector<char>> all;
+            if (comm_allgather_host(ctx, L->hA.data(), (int64_t)(sizeof(double) * (nC + 2 * nF + nPF)), all)) return -1;
+            L->hB.resize((size_t)L->gOff[L->nRanks] + 1);
+            for (int r = 0; r < L->nRanks; r++)
+            {
+                if ((int64_t)all[r].size() != (int64_t)sizeof(double) * (L->gOff[r + 1] - L->gOff[r]))
+                {
+                    ldu_set_error("directSolveCoarsest: a rank's coefficient block does not match its addressing");
+                    return -1;
+                }
+                memcpy(L->hB.data() + L->gOff[r], all[r].data(), all[r].size());
+            }
+            LDU_CHECK_HIP(hipMemcpyAsync(L->d_G, L->hB.data(), sizeof(double) * (size_t)L->gOff[L->nRanks], hipMemcpyHostToDevice, s));
+        }
+        lu_assemble_kernel<<<1, LDU_WAVE, 0, s>>>(L->n, L->nSet, L->nSub, L->d_ops, L->d_G, L->d_M0);
+        LDU_CHECK_HIP(hipGetLastError());
+        if (L->nRanks > 1) LDU_CHECK_HIP(hipStreamSynchronize(s));     // (hB is reused)
+        L->epoch = epoch;
+    }
+    // the sources of all ranks, original numbering
+    if (nC)
+    {
+        lu_pack_src_kernel<<<((int)nC + 63) / 64, 64, 0, s>>>((int)nC, a->d_perm, src, L->nRanks > 1 ? L->d_srcMine : L->d_srcAll);
+        LDU_CHECK_HIP(hipGetLastError());
+    }
+    if (L->nRanks > 1)
+    {
+        L->hA.resize(nC + 1);
+        if (nC) LDU_CHECK_HIP(hipMemcpyAsync(L->hA.data(), L->d_srcMine, sizeof(double) * nC, hipMemcpyDeviceToHost, s));
+        LDU_CHECK_HIP(hipStreamSynchronize(s));
+        std::vector<std::vector<char>> all;
+        if (comm_allgather_host(ctx, L->hA.data(), (int64_t)(sizeof(double) * nC), all)) return -1;
+        L->hB.resize((size_t)L->n + 1);
+        size_t off = 0;
+        for (int r = 0; r < L->nRanks; r++) { memcpy(L->hB.data() + off, all[r].data(), all[r].size()); off += all[r].size() / sizeof(double); }
+        if ((int)off != L->n) { ldu_set_error("directSolveCoarsest: the gathered sources do not match the gathered addressing"); return -1; }
+        LDU_CHECK_HIP(hipMemcpyAsync(L->d_srcAll, L->hB.data(), sizeof(double) * (size_t)L->n, hipMemcpyHostToDevice, s));
+    }
+    const size_t lds = ((size_t)L->n * (L->n + 1) + 2 * (size_t)L->n) * sizeof(double) + (size_t)L->n * sizeof(int);
+    if (L->n <= LDU_WAVE)
+        dense_lu_kernel<1><<<1, LDU_WAVE, lds, s>>>(L->n, L->d_M0, L->d_srcAll, L->myOff, L->nMine, a->d_perm, corr, ctx->d_abort + 1);
+    else
+        dense_lu_kernel<2><<<1, LDU_WAVE, lds, s>>>(L->n, L->d_M0, L->d_srcAll, L->myOff, L->nMine, a->d_perm, corr, ctx->d_abort + 1);
+    LDU_CHECK_HIP(hipGetLastError());
+    if (L->nRanks > 1) LDU_CHECK_HIP(hipStreamSynchronize(s));         // (hB is reused by the next call)
+    return 0;
+}
+
+// 0 = solved; -1 = error (said); directSolveCoarsest has no iterative fall-back
+int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src, uint64_t epoch)
+{
+    ldu_addr* a = A->a;
+    ldu_ctx* ctx = a->ctx;
+    if ((ctx->comm && ctx->nRanks > 1) || a->nPatchFaces || !a->patches.empty()) return lu_gathered(A, corr, src, epoch);
     if (a->nCells > CO_MAXC || a->nCells == 0)
     {
         ldu_set_error("directSolveCoarsest: the coarsest level has " + std::to_string(a->nCells) + " cells; the device LU holds up to "

@@ -94,6 +94,8 @@ struct ldu_comm_impl {
     bool peerHalo = false, peerReduce = false;   // which operations the peer backend carries (LDU_HALO / LDU_REDUCE)
     int* d_ibuf = nullptr;       // staging for int exchanges (RCCL)
     size_t ibufCap = 0;
+    char* d_gbuf = nullptr;      // staging for comm_allgather_host (RCCL)
+    size_t gbufCap = 0;
 };
 
 static int paired_patch(const std::vector<Patch>& mine, int p, const std::vector<Patch>& theirs, int me);
@@ -509,6 +511,7 @@ void comm_destroy(ldu_ctx* ctx)
     if (!ctx->comm) return;
     if (ctx->comm->comm) ncclCommDestroy(ctx->comm->comm);
     if (ctx->comm->d_ibuf) (void)hipFree(ctx->comm->d_ibuf);
+    if (ctx->comm->d_gbuf) (void)hipFree(ctx->comm->d_gbuf);
     if (PeerWindow* W = ctx->comm->peer)
     {
         for (size_t r = 0; r < W->peer.size(); r++)
@@ -787,6 +790,90 @@ int comm_allreduce_min_int(ldu_ctx* ctx, int* v)
     LDU_CHECK_HIP(hipMemcpyAsync(v, d, sizeof(int), hipMemcpyDeviceToHost, s));
     LDU_CHECK_HIP(hipStreamSynchronize(s));
     (void)hipFree(d);
+    return 0;
+}
+
+// all-gather of one host buffer per rank (sizes may differ): all[r] = rank r's bytes, on every rank.  Host-staged on every
+// carrier - used where the reference itself gathers on the master through Pstream (the coarsest-level matrices and sources of
+// directSolveCoarsest, LUscalarMatrix.C:52-107, LUscalarMatrixTemplates.C:31-118); not a hot path.
+int comm_allgather_host(ldu_ctx* ctx, const void* mine, int64_t nBytes, std::vector<std::vector<char>>& all)
+{
+    const int n = (ctx->comm && ctx->nRanks > 1) ? ctx->nRanks : 1;
+    const int me = n > 1 ? ctx->rank : 0;
+    all.assign(n, std::vector<char>());
+    all[me].assign((const char*)mine, (const char*)mine + nBytes);
+    if (n == 1) return 0;
+    if (ctx->comm->peer && !ctx->comm->comm)
+    {
+        // out-of-band: sizes first, then every rank's bytes to every other rank
+        std::vector<int> peers;
+        std::vector<int64_t> sizes(n, 0), mineSz(n, nBytes), eight;
+        std::vector<const void*> sp;
+        std::vector<void*> rp;
+        for (int r = 0; r < n; r++)
+            if (r != me) { peers.push_back(r); sp.push_back(&mineSz[r]); rp.push_back(&sizes[r]); eight.push_back(sizeof(int64_t)); }
+        if (peer_oob(ctx, peers, sp, eight, rp, eight)) return -1;
+        std::vector<int64_t> sb, rb;
+        sp.clear(); rp.clear();
+        for (int r = 0; r < n; r++)
+            if (r != me)
+            {
+                all[r].resize((size_t)sizes[r]);
+                sp.push_back(all[me].data()); sb.push_back(nBytes);
+                rp.push_back(all[r].data()); rb.push_back(sizes[r]);
+            }
+        return peer_oob(ctx, peers, sp, sb, rp, rb) ? -1 : 0;
+    }
+    if (ctx->comm->local)
+    {
+        LocalGroup* G = ctx->comm->local;
+        static std::mutex mu;
+        static std::map<std::pair<LocalGroup*, int>, const std::vector<char>*> pubs;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            pubs[{G, me}] = &all[me];
+        }
+        G->barrier();
+        for (int r = 0; r < n; r++)
+            if (r != me)
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                all[r] = *pubs[{G, r}];
+            }
+        G->barrier();
+        return 0;
+    }
+    // RCCL: the sizes, then the buffers padded to the largest
+    hipStream_t s = ctx->stream;
+    ldu_comm_impl* C = ctx->comm;
+    auto stage = [&](size_t bytes) -> int {
+        if (C->gbufCap >= bytes) return 0;
+        if (C->d_gbuf) (void)hipFree(C->d_gbuf);
+        C->d_gbuf = nullptr; C->gbufCap = 0;
+        LDU_CHECK_HIP(hipMalloc((void**)&C->d_gbuf, bytes));
+        C->gbufCap = bytes;
+        return 0;
+    };
+    if (stage(sizeof(int64_t) * (size_t)(n + 1))) return -1;
+    std::vector<int64_t> sizes(n, 0);
+    LDU_CHECK_HIP(hipMemcpyAsync(C->d_gbuf, &nBytes, sizeof(int64_t), hipMemcpyHostToDevice, s));
+    LDU_CHECK_NCCL(ncclAllGather(C->d_gbuf, C->d_gbuf + sizeof(int64_t), 1, ncclInt64, C->comm, s));
+    LDU_CHECK_HIP(hipMemcpyAsync(sizes.data(), C->d_gbuf + sizeof(int64_t), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+    LDU_CHECK_HIP(hipStreamSynchronize(s));
+    size_t mx = 1;
+    for (int r = 0; r < n; r++) mx = std::max(mx, (size_t)sizes[r]);
+    mx = (mx + 15) & ~(size_t)15;
+    if (stage(mx * (size_t)(n + 1))) return -1;
+    if (nBytes) LDU_CHECK_HIP(hipMemcpyAsync(C->d_gbuf, mine, (size_t)nBytes, hipMemcpyHostToDevice, s));
+    LDU_CHECK_NCCL(ncclAllGather(C->d_gbuf, C->d_gbuf + mx, mx, ncclChar, C->comm, s));
+    for (int r = 0; r < n; r++)
+        if (r != me)
+        {
+            all[r].resize((size_t)sizes[r]);
+            if (sizes[r])
+                LDU_CHECK_HIP(hipMemcpyAsync(all[r].data(), C->d_gbuf + mx * (size_t)(r + 1), (size_t)sizes[r], hipMemcpyDeviceToHost, s));
+        }
+    LDU_CHECK_HIP(hipStreamSynchronize(s));
     return 0;
 }
 

@@ -844,7 +844,7 @@ static int gamg_interpolate(ldu_matrix* A, double* psi, double* Apsi)
 static int solve_coarsest(GamgHierarchy* g, ldu_matrix* A, const ldu_controls* c, double* corr, const double* src)
 {
     hipStream_t s = A->a->ctx->stream;
-    if (c->directSolveCoarsest) return k_coarsest_lu(A, corr, src);   // GAMGSolverSolve.C:436-440
+    if (c->directSolveCoarsest) return k_coarsest_lu(A, corr, src, g->coeffEpoch);   // GAMGSolverSolve.C:436-440
     if (k_ew(A->a->nCells, EW_ZERO, corr, nullptr, nullptr, s)) return -1;
     if (A->a->nPatchFaces || A->a->ctx->nRanks > 1)
     {

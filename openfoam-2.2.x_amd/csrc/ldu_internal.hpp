@@ -431,8 +431,11 @@ struct ldu_matrix {
     uint64_t coeffEpoch = 0;
     // LduMatrix<Type,scalar,scalar> solvers on these coefficients (ldu_coupled.hip)
     struct CoupledWork* coupled = nullptr;
+    // directSolveCoarsest with coupled patches / several ranks: the gathered coarsest level (ldu_coarsest.hip)
+    struct CoarsestLU* lu = nullptr;
 };
 void coupled_free(ldu_matrix* m);
+void coarsest_lu_free(ldu_matrix* m);
 int dev_halo_start(ldu_matrix* m, const double* x);   // initMatrixInterfaces: pack + exchange
 
 // ---------------------------------------------------------------- kernels (ldu_kernels.hip)
@@ -503,7 +506,7 @@ void cluster_forget(ldu_addr* a, const double* levelVal);   // drop the converte
 int k_sweep_gs_nonblocking(ldu_addr* a, double* psi, const double* source, const double* diag, const double* val,
                            const double* bou);
 int k_coarsest_solve(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src);
-int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src);
+int k_coarsest_lu(ldu_matrix* A, double* corr, const double* src, uint64_t epoch);
 int k_coarsest_solve_peer(ldu_matrix* A, double tolerance, double relTol, int maxIter, double* corr, const double* src,
                           const int* d_cycPair);   // ldu_coarsest.hip: the distributed solve in one kernel per rank; 1 = not taken
 bool k_coarsest_peer_eligible(ldu_matrix* A);   // directSolveCoarsest (ldu_coarsest.hip)
@@ -624,6 +627,7 @@ int k_peer_allreduce(ldu_ctx* ctx, const PeerRed& P, size_t redOff, int me, int 
 struct PeerKernelComm { PeerRed P; size_t redOff; unsigned* d_redSeq; int me, n; };
 bool comm_peer_kernel_comm(ldu_ctx* ctx, PeerKernelComm* out);   // false: peer stores do not carry halos AND sums
 int comm_allreduce_min_int(ldu_ctx* ctx, int* v);
+int comm_allgather_host(ldu_ctx* ctx, const void* mine, int64_t nBytes, std::vector<std::vector<char>>& all);
 int comm_allreduce_abort(ldu_ctx* ctx, hipStream_t s);                             // abort flag := max over the ranks
 int comm_exchange_ints(ldu_ctx* ctx, const std::vector<Patch>& patches,
                        const std::vector<std::vector<int>>& send, std::vector<std::vector<int>>& recv);

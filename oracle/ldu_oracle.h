@@ -87,7 +87,7 @@ typedef struct orc_opts {
     int nFinestSweeps, interpolateCorrection, scaleCorrection /* -1 = matrix.symmetric() */;
     int nCellsInCoarsestLevel, mergeLevels, agglomerator;
     int nVcycles;                 /* GAMGPreconditioner.C:77 default 2 */
-    int directSolveCoarsest;      /* GAMGSolver.C:76,180 default false: LU of the coarsest level (serial runs) */
+    int directSolveCoarsest;      /* GAMGSolver.C:76,180 default false: LU of the coarsest level (parallel: gathered over the ranks) */
 } orc_opts;
 
 typedef struct orc_perf {

@@ -702,31 +702,60 @@ static void ws_free(const orc_gamg* g, vcycle_ws* w)
 
 static int imin(int a, int b) { return a < b ? a : b; }
 
-/* directSolveCoarsest (GAMGSolver.C:95-106, GAMGSolverSolve.C:436-440): the coarsest level as a dense matrix
- * (LUscalarMatrix.C:128-187 convert: diag, lower/upper by face, cyclic interfaces: A[faceCells][nbr faceCells] -= the
- * neighbour patch's interfaceBouCoeffs), Crout LU with implicit scaled partial pivoting (scalarMatrices.C:31-134
- * LUDecompose) and LUBacksubstitute (scalarMatricesTemplates.C:119-164) - every loop in the reference's order.
- * Serial systems only: in a parallel run the reference gathers all ranks' matrices on the master (not emulated). */
+/* directSolveCoarsest (GAMGSolver.C:95-106, GAMGSolverSolve.C:436-440): the coarsest level as a dense matrix, Crout LU with
+ * implicit scaled partial pivoting (scalarMatrices.C:31-134 LUDecompose) and LUBacksubstitute (scalarMatricesTemplates.C:119-164)
+ * - every loop in the reference's order.
+ * One domain (serial run; LUscalarMatrix.C:128-187 convert): diag, lower/upper by face, cyclic interfaces:
+ *   A[faceCells][nbr faceCells] -= the neighbour patch's interfaceBouCoeffs.
+ * Several domains = the ranks of a parallel run (LUscalarMatrix.C:52-107): every rank's matrix travels to the master, which
+ * builds ONE dense matrix over all ranks' cells (rank r's cells at procOffsets[r] = the concatenation used everywhere in this
+ * oracle) - :190-318 convert(lduMatrices): per rank diag, faces; per processor interface with myProcNo < neighbProcNo BOTH
+ * coupling entries ( A[u][l] -= the NEIGHBOUR interface's coeffs, A[l][u] -= this interface's coeffs ) - factorises it there,
+ * and per solve gathers the sources, back-substitutes and scatters (LUscalarMatrixTemplates.C:31-118).  A cyclic patch inside a
+ * rank of a parallel run (myProcNo == neighbProcNo == -1 in procLduInterface.C:38-60) is read by :247-262 as ONE patch holding both
+ * halves - the pre-2.0 layout, which no 2.2.x mesh has: not restated, refused. */
 static void lu_direct_solve(const orc_sys* A, double* x, const double* src)
 {
-    if (A->nDom != 1) { fprintf(stderr, "oracle: directSolveCoarsest is restated for serial systems only\n"); abort(); }
-    const orc_dom* D = &A->dom[0];
-    const int n = D->nCells;
-    double* M = (double*)calloc((size_t)n * n, sizeof(double));
+    const int n = A->nCellsTotal;
+    double* M = (double*)calloc((size_t)n * n + 1, sizeof(double));
     int* piv = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
     double* vv = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
 #define MM(i, j) M[(size_t)(i) * n + (j)]
-    for (int c = 0; c < n; c++) MM(c, c) = D->diag[c];
-    for (int f = 0; f < D->nFaces; f++)
+    for (int d = 0; d < A->nDom; d++)
     {
-        MM(D->u[f], D->l[f]) = D->lower[f];
-        MM(D->l[f], D->u[f]) = D->upper[f];
-    }
-    for (int p = 0; p < D->nPatches; p++)
-    {
-        const orc_patch* P = &D->patches[p];
-        const orc_patch* N = &D->patches[P->nbrPatch];      /* serial: coupled patches are cyclic pairs */
-        for (int f = 0; f < P->n; f++) MM(P->faceCells[f], N->faceCells[f]) -= N->bouCoeffs[f];
+        const orc_dom* D = &A->dom[d];
+        const int off = D->cellOffset;
+        for (int c = 0; c < D->nCells; c++) MM(off + c, off + c) = D->diag[c];
+        for (int f = 0; f < D->nFaces; f++)
+        {
+            MM(off + D->u[f], off + D->l[f]) = D->lower[f];
+            MM(off + D->l[f], off + D->u[f]) = D->upper[f];
+        }
+        for (int p = 0; p < D->nPatches; p++)
+        {
+            const orc_patch* P = &D->patches[p];
+            if (A->nDom == 1)
+            {
+                const orc_patch* N = &D->patches[P->nbrPatch];      /* serial: coupled patches are cyclic pairs */
+                for (int f = 0; f < P->n; f++) MM(P->faceCells[f], N->faceCells[f]) -= N->bouCoeffs[f];
+                continue;
+            }
+            if (P->nbrDom == d)
+            {
+                fprintf(stderr, "oracle: directSolveCoarsest: a cyclic patch inside a rank of a parallel run is not restated\n");
+                abort();
+            }
+            if (d > P->nbrDom) continue;                             /* :264 myProcNo_ < neighbProcNo_ */
+            const orc_dom* DN = &A->dom[P->nbrDom];
+            const orc_patch* N = &DN->patches[P->nbrPatch];
+            const int noff = DN->cellOffset;
+            for (int f = 0; f < P->n; f++)                            /* :308-315 */
+            {
+                const int uCell = P->faceCells[f] + off, lCell = N->faceCells[f] + noff;
+                MM(uCell, lCell) -= N->bouCoeffs[f];
+                MM(lCell, uCell) -= P->bouCoeffs[f];
+            }
+        }
     }
     /* LUDecompose */
     for (int i = 0; i < n; i++)

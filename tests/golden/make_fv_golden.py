@@ -83,6 +83,12 @@ def generate_solve(name):
 CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6": (4, 5, 6, 6, 78),
                "fvsolve3_chain_asym_5x7x6": (3, 5, 7, 6, 79),
                "fvsolve3_chain_nonblocking_4x7x6": (3, 4, 7, 6, 80)}
+# round 6: `directSolveCoarsest true` (GAMGSolver.C:95-106): the coarsest level - all boxes' cells, the cyclic couplings between
+# them - through the reference's LUscalarMatrix (LUscalarMatrix.C:128-187); arithmetically the gathered matrix of an N-rank run
+# (LUscalarMatrix.C:52-107, :190-318).  "_lu_" in the name switches it on; 8 boxes: a coarsest level of more than 64 cells.
+LU_CHAIN_CASES = {"fvsolve4_chain_lu_5x6x6": (4, 5, 6, 6, 84), "fvsolve3_chain_asym_lu_5x7x6": (3, 5, 7, 6, 85)}
+LU_GRID_CASES = {"fvsolve8_blocks_lu_2x2x2_4x4x4": ((2, 2, 2), 4, 4, 4, 86, False)}
+CHAIN_CASES_ALL = dict(CHAIN_CASES, **LU_CHAIN_CASES)
 
 
 # 3-D block decompositions and several patches per rank pair (the coarse-interface ordering rule exercised
@@ -90,16 +96,17 @@ CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6"
 GRID_CASES = {"fvsolve8_blocks_2x2x2_4x4x4": ((2, 2, 2), 4, 4, 4, 81, False),
               "fvsolve2_split_halves_5x6x6": ((2, 1, 1), 5, 6, 6, 82, True),
               "fvsolve4_blocks_2x2x1_split_4x4x5": ((2, 2, 1), 4, 4, 5, 83, True)}
+GRID_CASES_ALL = dict(GRID_CASES, **LU_GRID_CASES)
 
 
 def generate_chain(name):
     """serial emulation of an N-rank run by the reference itself (see fv_case.chain_box_mesh / grid_box_mesh)"""
-    if name in GRID_CASES:
-        g3, nxh, ny, nz, seed, split = GRID_CASES[name]
+    if name in GRID_CASES_ALL:
+        g3, nxh, ny, nz, seed, split = GRID_CASES_ALL[name]
         nB = g3[0] * g3[1] * g3[2]
         mesh = fv_case.grid_box_mesh(g3[0], g3[1], g3[2], nxh, ny, nz, split=split)
     else:
-        nB, nxh, ny, nz, seed = CHAIN_CASES[name]
+        nB, nxh, ny, nz, seed = CHAIN_CASES_ALL[name]
         mesh = fv_case.chain_box_mesh(nB, nxh, ny, nz, axis="z" if "nonblocking" in name else "x")
     rng = np.random.RandomState(seed)
     nC, nF = mesh["nCells"], mesh["nInternalFaces"]
@@ -108,8 +115,9 @@ def generate_chain(name):
         case = os.path.join(d, "case")
         fv_case.write_case(case, mesh)
         res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve",
-                                 controls="nCellsInCoarsestLevel %d;%s%s" % (
+                                 controls="nCellsInCoarsestLevel %d;%s%s%s" % (
                                      10 * nB, " smoother nonBlockingGaussSeidel;" if "nonblocking" in name else "",
+                                     " directSolveCoarsest true;" if "_lu_" in name else "",
                                      " asymmetric" if "asym" in name else ""))
     out = dict(nCells=nC, nHalf=mesh["nHalf"], nBoxes=nB, lowerAddr=mesh["owner"][:nF].astype(np.int32),
                upperAddr=mesh["neighbour"].astype(np.int32))
@@ -152,6 +160,12 @@ def generate_nonorth(name):
 if __name__ == "__main__":
     if not fv_case.driver_available():
         raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
+    if len(sys.argv) > 1 and sys.argv[1] == "lu":
+        for name in list(LU_CHAIN_CASES) + list(LU_GRID_CASES):
+            data = generate_chain(name)
+            np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+            print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grid":
         for name in GRID_CASES:
             data = generate_chain(name)
@@ -173,7 +187,7 @@ if __name__ == "__main__":
         data = generate_solve(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
-    for name in list(CHAIN_CASES) + list(GRID_CASES):
+    for name in list(CHAIN_CASES_ALL) + list(GRID_CASES_ALL):
         data = generate_chain(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])

@@ -96,6 +96,11 @@ def main():
               dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4),
               dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4, mergeLevels=2,
                    nPreSweeps=1)]
+    if not str(size).startswith("mb"):
+        # directSolveCoarsest in a parallel run: the ranks' coarsest levels gathered over the out-of-band channel, every rank
+        # factorises the gathered matrix (ldu_coarsest.hip lu_gathered; LUscalarMatrix.C:52-107)
+        solves.append(dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-8 if asym else 1e-9, relTol=0, nCellsInCoarsestLevel=4,
+                           directSolveCoarsest=1))
     its = []
     for kw in solves:
         okw = dict(kw)
@@ -103,7 +108,7 @@ def main():
             okw["precond"] = okw.pop("preconditioner")
         xo, po = S.solve(X0, B0, **okw)
         x, perf = m.solve(sp["psi"], sp["source"], **kw)
-        tag = kw["solver"] + str(kw.get("mergeLevels", ""))
+        tag = kw["solver"] + str(kw.get("mergeLevels", "")) + ("LU" if kw.get("directSolveCoarsest") else "")
         its.append((tag, perf["nIterations"]))
         hg, ho = np.asarray(perf["history"]), np.asarray(po["history"])
         if abs(perf["nIterations"] - po["nIterations"]) == 1 and min(len(hg), len(ho)) > 60:

@@ -259,6 +259,39 @@ def test_cyclic_patches_single_domain_oracle(oracle, name):
     np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
 
 
+LU_CHAINS = ["fvsolve4_chain_lu_5x6x6", "fvsolve3_chain_asym_lu_5x7x6", "fvsolve8_blocks_lu_2x2x2_4x4x4"]
+
+
+@pytest.mark.parametrize("name", LU_CHAINS)
+def test_direct_solve_coarsest_with_coupled_patches(oracle, name):
+    """directSolveCoarsest with coupled patches (round 6; GAMGSolver.C:95-106): the reference, in ONE process, factorises the
+    coarsest level of N boxes coupled by cyclic pairs with its LUscalarMatrix (LUscalarMatrix.C:128-187) - 30 ... 80 cells.
+    (a) the single-domain oracle with the cyclic patches reproduces it as closely as every other serial solve (1e-9);
+    (b) the N-domain oracle - the gathered matrix of an N-rank run, LUscalarMatrix.C:190-318: the same dense matrix, cells in
+        rank order - reproduces it to the multi-rank bar (rank-ordered sums elsewhere in the V-cycle)."""
+    g = load(name)
+    nB = int(g["nBoxes"]) if "nBoxes" in g else 2
+    r = g["ref_gamg_perf"]
+    sp = cyclic_problem(g)
+    x, perf = oracle.System([sp]).solve(sp["psi"], sp["source"], solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                                        nCellsInCoarsestLevel=10 * nB, mergeLevels=1, tolerance=1e-10, relTol=0,
+                                        directSolveCoarsest=1)
+    assert perf["nIterations"] == int(r[2]) and perf["converged"]
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-11 * np.max(np.abs(g["ref_gamg_psi"]))
+    subs = n_rank_problem(g)
+    b = np.concatenate([s["source"] for s in subs])
+    x, perf = oracle.System(subs).solve(np.zeros(b.size), b, solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                                        nCellsInCoarsestLevel=10, mergeLevels=1, tolerance=1e-10, relTol=0, directSolveCoarsest=1)
+    assert perf["nIterations"] == int(r[2]) and perf["converged"]
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-8 * np.max(np.abs(g["ref_gamg_psi"]))
+    # the LU changes the solve: the same fixture without it takes a different number of V-cycles or lands elsewhere
+    x2, perf2 = oracle.System(subs).solve(np.zeros(b.size), b, solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                                          nCellsInCoarsestLevel=10, mergeLevels=1, tolerance=1e-10, relTol=0)
+    assert perf2["nIterations"] != perf["nIterations"] or not np.array_equal(x, x2)
+
+
 @pytest.mark.parametrize("name", CHAINS)
 def test_smoothers_with_coupled_interfaces_bitexact(oracle, name):
     """GaussSeidel and nonBlockingGaussSeidel (3 sweeps) on the coupled systems, as run by the reference's

@@ -162,6 +162,41 @@ def test_two_ranks_against_reference_cyclic_emulation(name):
         assert np.max(np.abs(x - xr)) <= 1e-8 * np.max(np.abs(xr)), key
 
 
+@pytest.mark.parametrize("name", ["fvsolve4_chain_lu_5x6x6", "fvsolve3_chain_asym_lu_5x7x6", "fvsolve8_blocks_lu_2x2x2_4x4x4"])
+def test_direct_solve_coarsest_gathered_over_ranks(oracle, name):
+    """directSolveCoarsest in a parallel run (round 6; LUscalarMatrix.C:52-107, :190-318, LUscalarMatrixTemplates.C:31-118: the
+    ranks' coarsest-level matrices gathered into ONE dense matrix, factorised, sources gathered per V-cycle): 4 / 3 / 8 ranks
+    (threads, local communicator; every rank factorises the gathered matrix) against the reference's own single-process solve
+    of the same system coupled by cyclic pairs, and the residual history of the N-domain oracle."""
+    from test_fv_oracle_golden import load, n_rank_problem
+    g = load(name)
+    subs = n_rank_problem(g)
+    kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10, mergeLevels=1,
+              tolerance=1e-10, relTol=0, directSolveCoarsest=1)
+    b = np.concatenate([s["source"] for s in subs])
+    xo, po = oracle.System(subs).solve(np.zeros(b.size), b, **kw)
+
+    def fn(r, ctx, a, m):
+        x, perf = m.solve(subs[r]["psi"], subs[r]["source"], history=True, **kw)
+        # again with the same coefficients handed over anew (the gathered matrix is rebuilt), same answer
+        m.set_coeffs(subs[r]["diag"], subs[r]["upper"], subs[r].get("lower"))
+        for i, q in enumerate(subs[r]["patches"]):
+            m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+        x2, perf2 = m.solve(subs[r]["psi"], subs[r]["source"], history=True, **kw)
+        assert np.array_equal(x, x2) and np.array_equal(perf2["history"], perf["history"])
+        return x, perf
+    res = run_ranks(subs, fn)
+    ref = g["ref_gamg_perf"]
+    for x, perf in res:
+        assert perf["nIterations"] == int(ref[2]) == po["nIterations"]
+        np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(perf["initialResidual"], ref[0], rtol=1e-6)
+        np.testing.assert_allclose(perf["finalResidual"], ref[1], rtol=5e-6)
+    x = np.concatenate([r[0] for r in res])
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-8 * np.max(np.abs(g["ref_gamg_psi"]))
+    assert np.max(np.abs(x - xo)) <= 1e-8 * np.max(np.abs(xo))
+
+
 @pytest.mark.parametrize("name", ["fvsolve4_chain_5x6x6", "fvsolve3_chain_nonblocking_4x7x6", "fvsolve8_blocks_2x2x2_4x4x4",
                                   "fvsolve4_blocks_2x2x1_split_4x4x5"])
 def test_smoothers_n_ranks_bitexact_against_reference(name):

@@ -303,6 +303,42 @@ def test_cyclic_patches_against_reference(ctx, name):
     m.close(); a.close()
 
 
+@pytest.mark.parametrize("name", ["fvsolve4_chain_lu_5x6x6", "fvsolve3_chain_asym_lu_5x7x6", "fvsolve8_blocks_lu_2x2x2_4x4x4"])
+def test_direct_solve_coarsest_with_cyclic_patches(ctx, oracle, name):
+    """directSolveCoarsest with cyclic patches on ONE rank (round 6; LUscalarMatrix.C:128-187: the interfaces' coefficients
+    subtracted from the dense matrix): the reference's own solve (golden) and the oracle's history.  40 / 30 cells: one row
+    per lane; the 8-box fixture's coarsest level has more than 64 cells: two rows per lane (dense_lu_kernel<2>)."""
+    from test_fv_oracle_golden import load, cyclic_problem
+    g = load(name)
+    sp = cyclic_problem(g)
+    nB = int(g["nBoxes"]) if "nBoxes" in g else 2
+    kw = dict(solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair", nCellsInCoarsestLevel=10 * nB, mergeLevels=1,
+              tolerance=1e-10, relTol=0, directSolveCoarsest=1)
+    a = capi.Addressing(ctx, sp["nCells"], sp["lowerAddr"], sp["upperAddr"], sp["faceWeights"], patches=sp["patches_dev"])
+    m = capi.Matrix(a)
+    m.set_coeffs(sp["diag"], sp["upper"], sp.get("lower"))
+    for i, q in enumerate(sp["patches"]):
+        m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+    x, perf = m.solve(sp["psi"], sp["source"], history=True, **kw)
+    xo, po = oracle.System([sp]).solve(sp["psi"], sp["source"], **kw)
+    r = g["ref_gamg_perf"]
+    assert perf["nIterations"] == int(r[2]) == po["nIterations"] and perf["converged"]
+    np.testing.assert_allclose(perf["history"], po["history"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-6)
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-8 * np.max(np.abs(g["ref_gamg_psi"]))
+    # a second solve with new coefficients: the gathered matrix follows them
+    m.set_coeffs(1.5 * sp["diag"], sp["upper"], sp.get("lower"))
+    for i, q in enumerate(sp["patches"]):
+        m.set_patch_coeffs(i, q["bouCoeffs"], q["intCoeffs"])
+    sp2 = dict(sp, diag=1.5 * sp["diag"])
+    x2, p2 = m.solve(sp["psi"], sp["source"], history=True, **kw)
+    xo2, po2 = oracle.System([sp2]).solve(sp["psi"], sp["source"], **kw)
+    assert p2["nIterations"] == po2["nIterations"]
+    np.testing.assert_allclose(p2["history"], po2["history"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(x2 - xo2)) <= 1e-8 * np.max(np.abs(xo2))
+    m.close(); a.close()
+
+
 @pytest.mark.parametrize("name", ["fvsolve2_halves_6x8x7", "fvsolve3_chain_asym_5x7x6", "fvsolve3_chain_nonblocking_4x7x6"])
 def test_smoothers_with_cyclic_patches_bitexact(ctx, name):
     """GaussSeidel / nonBlockingGaussSeidel with coupled (cyclic) patches: bit-exact against the reference's
