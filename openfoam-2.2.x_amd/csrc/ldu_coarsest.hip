@@ -906,15 +906,9 @@ static int lu_gathered_setup(ldu_matrix* A, CoarsestLU* L)
     LDU_CHECK_HIP(hipMalloc((void**)&L->d_M0, sizeof(double) * (size_t)L->n * L->n));
     LDU_CHECK_HIP(hipMalloc((void**)&L->d_srcAll, sizeof(double) * (size_t)L->n));
     LDU_CHECK_HIP(hipMalloc((void**)&L->d_srcMine, sizeof(double) * (size_t)(L->nMine + 1)));
-    static bool attr = false;
-    if (!attr)
-    {
-        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)dense_lu_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)((LU_MAXN * (LU_MAXN + 1) + 2 * LU_MAXN) * sizeof(double) + LU_MAXN * sizeof(int))));
-        LDU_CHECK_HIP(hipFuncSetAttribute((const void*)dense_lu_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)((LDU_WAVE * (LDU_WAVE + 1) + 2 * LDU_WAVE) * sizeof(double) + LDU_WAVE * sizeof(int))));
-        attr = true;
-    }
+    // (per device: every set-up sets it for the device this context runs on)
+    LDU_CHECK_HIP(hipFuncSetAttribute((const void*)dense_lu_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((LU_MAXN * (LU_MAXN + 1) + 2 * LU_MAXN) * sizeof(double) + LU_MAXN * sizeof(int))));
     if (getenv("LDU_VERBOSE"))
         fprintf(stderr, "[ldugpu] directSolveCoarsest: %d cells over %d rank(s), %d matrix entries set, %d coupling entries; every rank "
                         "factorises the gathered matrix (one wavefront, %d row(s) per lane)\n", L->n, nR, L->nSet, L->nSub, L->n > LDU_WAVE ? 2 : 1);
