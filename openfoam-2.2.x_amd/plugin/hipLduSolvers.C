@@ -20,6 +20,8 @@
 #include "fieldTypes.H"
 #include "processorLduInterface.H"
 #include "cyclicLduInterface.H"
+#include "cyclicLduInterfaceField.H"
+#include "processorLduInterfaceField.H"
 #include "addToRunTimeSelectionTable.H"
 #include "Pstream.H"
 #include "Switch.H"
@@ -276,6 +278,45 @@ ldu_ctx* hipLduSharedContext()
     return hipContext();
 }
 
+// A coupled patch with a transformation (rotational cyclic, processorCyclic with rotation): the interface FIELD multiplies the
+// neighbour values by pow(diag(forwardT).component(cmpt), rank()) before the coefficients
+// (cyclicLduInterfaceField.C:45-63, processorLduInterfaceField.C:45-63).  For a field of rank 0 - p, k, epsilon, T: every
+// scalar transport equation - that factor is pow(x, 0) = 1 and the product is the value itself, bit for bit: the patch is an
+// ordinary coupled patch for this solve.  For a component of a vector / tensor field the factor is a rotation-dependent number:
+// not implemented, refused.  The check runs at EVERY solve: the device image of an addressing is shared by all fields on it.
+static inline bool hipTransformIsIdentity(const lduInterfaceField& f)
+{
+    const cyclicLduInterfaceField* c = dynamic_cast<const cyclicLduInterfaceField*>(&f);
+    if (c) return !c->doTransform() || c->rank() == 0;
+    const processorLduInterfaceField* p = dynamic_cast<const processorLduInterfaceField*>(&f);
+    if (p) return !p->doTransform() || p->rank() == 0;
+    return false;
+}
+// LduInterfaceField<Type> (the `type coupled;` family) transforms the Type itself: a transformation is never the identity there
+template<class Type>
+static inline bool hipTransformIsIdentity(const LduInterfaceField<Type>&) { return false; }
+
+template<class InterfaceList>
+static void hipCheckTransforms(const InterfaceList& interfaces)
+{
+    forAll(interfaces, patchi)
+    {
+        if (!interfaces.set(patchi)) continue;
+        const lduInterface& li = interfaces[patchi].interface();
+        const processorLduInterface* pp = dynamic_cast<const processorLduInterface*>(&li);
+        const cyclicLduInterface* cp = dynamic_cast<const cyclicLduInterface*>(&li);
+        const bool transformed = (pp && pp->forwardT().size()) || (cp && cp->forwardT().size());
+        if (transformed && !hipTransformIsIdentity(interfaces[patchi]))
+        {
+            FatalErrorIn("hipLookup")
+                << (pp ? "processor" : "cyclic") << " patch " << patchi << " carries a transformation (rotation) and the field "
+                << "solved for is not of rank 0: only scalar fields (whose coupling the transformation leaves unchanged, "
+                << "cyclicLduInterfaceField.C:45-63) are supported across transformed patches on the GPU path"
+                << exit(FatalError);
+        }
+    }
+}
+
 // Device image of (lduAddressing, coupled patches), built once per addressing like the
 // reference's lazily built losort/ownerStart.
 template<class InterfaceList>
@@ -286,6 +327,7 @@ static hipLduEntry& hipLookupAddr
     const polyMesh* pm = NULL
 )
 {
+    hipCheckTransforms(interfaces);
     std::map<const lduAddressing*, hipLduEntry>::iterator it = hipEntries_.find(&la);
     const label nCells = la.size();
     const label nFaces = la.lowerAddr().size();
@@ -339,26 +381,11 @@ static hipLduEntry& hipLookupAddr
                 const labelUList& fc = la.patchAddr(patchi);
                 if (pp)
                 {
-                    // processorFvPatchField::updateInterfaceMatrix applies transformCoupleField(pnf, cmpt)
-                    // (processorFvPatchScalarField.C / processorFvPatchField.C): non-trivial on processorCyclic
-                    // patches with a rotation.  Not implemented here: refuse instead of computing a wrong halo.
-                    if (pp->forwardT().size())
-                    {
-                        FatalErrorIn("hipLookup")
-                            << "processor patch " << patchi << " carries a transformation (processorCyclic with "
-                            << "rotation): only untransformed processor patches are supported on the GPU path"
-                            << exit(FatalError);
-                    }
+                    // (a transformation on the patch: hipCheckTransforms above - identity for the rank-0 field of this solve)
                     hipCheck(ldu_addr_add_patch(e.addr, fc.size(), fc.begin(), pp->neighbProcNo()), "hipLookup");
                 }
                 else if (cp)
                 {
-                    if (cp->forwardT().size())
-                    {
-                        FatalErrorIn("hipLookup")
-                            << "cyclic patch " << patchi << " carries a rotation: only untransformed "
-                            << "(translational) cyclics are supported on the GPU path" << exit(FatalError);
-                    }
                     const label nb = cp->neighbPatchID();
                     if (nb < 0 || nb >= libIndex.size() || libIndex[nb] < 0)
                     {
