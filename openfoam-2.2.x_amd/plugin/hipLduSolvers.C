@@ -382,10 +382,16 @@ static hipLduEntry& hipLookupAddr
                 if (pp)
                 {
                     // (a transformation on the patch: hipCheckTransforms above - identity for the rank-0 field of this solve)
+                    if (pp->forwardT().size() && getenv("LDU_VERBOSE"))
+                        Info<< "[hipLduSolvers] processor patch " << patchi << " carries a transformation: identity for a field of "
+                            << "rank 0, coupled as an ordinary processor patch" << endl;
                     hipCheck(ldu_addr_add_patch(e.addr, fc.size(), fc.begin(), pp->neighbProcNo()), "hipLookup");
                 }
                 else if (cp)
                 {
+                    if (cp->forwardT().size() && getenv("LDU_VERBOSE"))
+                        Info<< "[hipLduSolvers] cyclic patch " << patchi << " carries a transformation (rotational cyclic): identity "
+                            << "for a field of rank 0, coupled as an ordinary cyclic patch" << endl;
                     const label nb = cp->neighbPatchID();
                     if (nb < 0 || nb >= libIndex.size() || libIndex[nb] < 0)
                     {

@@ -21,9 +21,12 @@ HEADER = """FoamFile
 """
 
 
-def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5), cyclic_x=False):
+def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5), cyclic_x=False, sector=False):
     """points (perturbed, graded), faces (vertex lists, owner->neighbour right-handed), owner, neighbour,
-    boundary patches.  Returns dict."""
+    boundary patches.  Returns dict.
+    sector (with cyclic_x): the box bent into a quarter annulus - x becomes the angle (0 ... -90 degrees about the z axis), y the
+    radius (1 ... 1.7): the x-min / x-max patches face each other through a ROTATION and are written as
+    `type cyclic; transform rotational; rotationAxis (0 0 1); rotationCentre (0 0 0);` (cyclicPolyPatch.C calcTransforms)."""
     rng = np.random.RandomState(seed)
 
     def axis(n, g):
@@ -77,7 +80,7 @@ def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5), cyclic_x=
             faces.append(fv); owner.append(c)
         extra = ""
         if cyclic_x and name in ("xmin", "xmax"):
-            extra = "cyclic " + ("xmax" if name == "xmin" else "xmin")
+            extra = "cyclic " + ("xmax" if name == "xmin" else "xmin") + (" rotational" if sector else "")
         patches.append((name, len(flist), start, extra))
 
     add_patch("xmin", [(face_x(0, j, k)[::-1], cid(0, j, k)) for k in range(nz) for j in range(ny)])
@@ -86,6 +89,10 @@ def box_mesh(nx, ny, nz, seed=3, jitter=0.18, grading=(1.0, 2.0, 0.5), cyclic_x=
     add_patch("ymax", [(face_y(i, ny, k), cid(i, ny - 1, k)) for k in range(nz) for i in range(nx)])
     add_patch("zmin", [(face_z(i, j, 0)[::-1], cid(i, j, 0)) for j in range(ny) for i in range(nx)])
     add_patch("zmax", [(face_z(i, j, nz), cid(i, j, nz - 1)) for j in range(ny) for i in range(nx)])
+    if sector:
+        assert cyclic_x
+        th, r = -0.5 * np.pi * pts[:, 0] / X[-1], 1.0 + pts[:, 1]
+        pts = np.stack([r * np.cos(th), r * np.sin(th), pts[:, 2]], axis=1)
     return dict(points=pts, faces=faces, owner=np.array(owner, dtype=np.int32),
                 neighbour=np.array(nei, dtype=np.int32), nInternalFaces=nInt, patches=patches,
                 nCells=nx * ny * nz)
@@ -118,8 +125,10 @@ def write_case(case, mesh, libs=None):
         f.write("%d\n(\n" % len(mesh["patches"]))
         for name, n, start, extra in mesh["patches"]:
             if extra.startswith("cyclic"):
-                f.write("%s\n{\n    type cyclic;\n    neighbourPatch %s;\n    nFaces %d;\n    startFace %d;\n}\n"
-                        % (name, extra.split()[1], n, start))
+                rot = ("    transform rotational;\n    rotationAxis (0 0 1);\n    rotationCentre (0 0 0);\n"
+                       if extra.endswith("rotational") else "")
+                f.write("%s\n{\n    type cyclic;\n    neighbourPatch %s;\n%s    nFaces %d;\n    startFace %d;\n}\n"
+                        % (name, extra.split()[1], rot, n, start))
             else:
                 f.write("%s\n{\n    type patch;\n    nFaces %d;\n    startFace %d;\n}\n" % (name, n, start))
         f.write(")\n")

@@ -80,6 +80,27 @@ def generate_solve(name):
     return out
 
 
+# round 6: a quarter annulus whose x-min / x-max patches are a ROTATIONAL cyclic pair (fv_case.box_mesh sector=True): for the scalar
+# field of these solves the transformation of the coupled values is the identity (cyclicLduInterfaceField.C:45-63, rank 0)
+SECTOR_CASES = {"fvsolve_sector_8x6x5": (8, 6, 5, 11)}
+
+
+def generate_sector(name):
+    nx, ny, nz, seed = SECTOR_CASES[name]
+    mesh = fv_case.box_mesh(nx, ny, nz, seed=seed, cyclic_x=True, sector=True)
+    rng = np.random.RandomState(300 + seed)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
+    with tempfile.TemporaryDirectory() as d:
+        case = os.path.join(d, "case")
+        fv_case.write_case(case, mesh)
+        res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve", controls="nCellsInCoarsestLevel 10;")
+    out = dict(nCells=nC, lowerAddr=mesh["owner"][:nF].astype(np.int32), upperAddr=mesh["neighbour"].astype(np.int32))
+    for k, v in res.items():
+        out[k] = v.astype(np.int32) if k.endswith("_faceCells") else v
+    return out
+
+
 CHAIN_CASES = {"fvsolve2_halves_6x8x7": (2, 6, 8, 7, 77), "fvsolve4_chain_5x6x6": (4, 5, 6, 6, 78),
                "fvsolve3_chain_asym_5x7x6": (3, 5, 7, 6, 79),
                "fvsolve3_chain_nonblocking_4x7x6": (3, 4, 7, 6, 80)}
@@ -160,6 +181,12 @@ def generate_nonorth(name):
 if __name__ == "__main__":
     if not fv_case.driver_available():
         raise SystemExit("oracle/_ref/fv_driver missing: run oracle/build_ref_fv.sh (needs /root/reference)")
+    if len(sys.argv) > 1 and sys.argv[1] == "sector":
+        for name in SECTOR_CASES:
+            data = generate_sector(name)
+            np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+            print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lu":
         for name in list(LU_CHAIN_CASES) + list(LU_GRID_CASES):
             data = generate_chain(name)
@@ -189,6 +216,10 @@ if __name__ == "__main__":
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
     for name in list(CHAIN_CASES_ALL) + list(GRID_CASES_ALL):
         data = generate_chain(name)
+        np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
+        print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
+    for name in SECTOR_CASES:
+        data = generate_sector(name)
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".npz"), **data)
         print(name, "cells", data["nCells"], "GAMG perf", data["ref_gamg_perf"], "PCG perf", data["ref_pcg_perf"])
     for name in GLUEV_CASES:

@@ -259,6 +259,30 @@ def test_cyclic_patches_single_domain_oracle(oracle, name):
     np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
 
 
+def test_rotational_cyclic_is_a_plain_cyclic_for_a_scalar_field(oracle):
+    """round 6: a quarter annulus whose two ends are a ROTATIONAL cyclic pair (fv_case.box_mesh sector=True;
+    `transform rotational` in the boundary file, forwardT() set by cyclicPolyPatch).  For a scalar field the interface multiplies the
+    neighbour values by pow(diag(forwardT).component(cmpt), rank()) with rank() = 0 (cyclicLduInterfaceField.C:45-63): by 1.  The
+    reference's own GAMG and PCG solves on that mesh are reproduced by the oracle with the pair as an ordinary cyclic pair - what
+    the plug-in now hands the library for rank-0 fields (hipLduSolvers.C hipCheckTransforms)."""
+    g = load("fvsolve_sector_8x6x5")
+    assert bool(g["p0_coupled"][0]) and bool(g["p1_coupled"][0]) and not bool(g["p2_coupled"][0])
+    sp = cyclic_problem(g)
+    S = oracle.System([sp])
+    x, perf = S.solve(sp["psi"], sp["source"], solver="GAMG", smoother="GaussSeidel", agglomerator="faceAreaPair",
+                      nCellsInCoarsestLevel=10, mergeLevels=1, tolerance=1e-10, relTol=0)
+    r = g["ref_gamg_perf"]
+    assert perf["nIterations"] == int(r[2]) and perf["converged"]
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
+    assert np.max(np.abs(x - g["ref_gamg_psi"])) <= 1e-11 * np.max(np.abs(g["ref_gamg_psi"]))
+    x, perf = S.solve(sp["psi"], sp["source"], solver="PCG", precond="DIC", tolerance=1e-10, relTol=0)
+    r = g["ref_pcg_perf"]
+    assert perf["nIterations"] == int(r[2])
+    np.testing.assert_allclose([perf["initialResidual"], perf["finalResidual"]], r[:2], rtol=1e-9)
+    for sm in ("GaussSeidel", "nonBlockingGaussSeidel"):
+        assert np.array_equal(S.smooth(sm, g["smooth_x0"], sp["source"], 3), g["ref_smooth_" + sm]), sm
+
+
 LU_CHAINS = ["fvsolve4_chain_lu_5x6x6", "fvsolve3_chain_asym_lu_5x7x6", "fvsolve8_blocks_lu_2x2x2_4x4x4"]
 
 

@@ -106,6 +106,44 @@ def test_fvmatrix_solve_through_plugin_with_cyclic_patches(name, tmp_path, monke
         assert np.max(np.abs(res["ref_%s_psi" % key] - xr)) <= 1e-8 * np.max(np.abs(xr)), key
 
 
+def test_rotational_cyclic_through_plugin(tmp_path, monkeypatch):
+    """round 6: a ROTATIONAL cyclic pair (quarter annulus, `transform rotational;`).  Scalar solves: the transformation of the
+    coupled values is the identity for a field of rank 0 (cyclicLduInterfaceField.C:45-63) - the plug-in registers the pair as
+    an ordinary cyclic pair (and says so) and reproduces the stock run of the golden fixture.  A vector equation on the same
+    mesh (rank 1: the factor is a component of the rotation) stays a FatalError that says why."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    import fv_case
+    import make_fv_golden
+    if not fv_case.driver_available():
+        pytest.skip("oracle/_ref/fv_driver not built")
+    name = "fvsolve_sector_8x6x5"
+    g = dict(np.load(os.path.join(HERE, "golden", name + ".npz")))
+    nx, ny, nz, seed = make_fv_golden.SECTOR_CASES[name]
+    mesh = fv_case.box_mesh(nx, ny, nz, seed=seed, cyclic_x=True, sector=True)
+    rng = np.random.RandomState(300 + seed)
+    nC, nF = mesh["nCells"], mesh["nInternalFaces"]
+    vf, U, phi, gamma = rng.randn(nC), rng.randn(nC, 3), rng.randn(nF), 0.5 + rng.rand(nF)
+    case = str(tmp_path / "case")
+    fv_case.write_case(case, mesh, libs=[os.path.abspath(PLUGIN)])
+    monkeypatch.setenv("LDU_VERBOSE", "1")
+    res = fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="solve", controls="nCellsInCoarsestLevel 10;")
+    out = fv_case.run_driver.last_stdout
+    assert "[hipLduSolvers]" in out and "carries a transformation (rotational cyclic): identity" in out
+    for key in ("gamg", "pcg"):
+        ref, got = g["ref_%s_perf" % key], res["ref_%s_perf" % key]
+        assert int(got[2]) == int(ref[2]), key
+        np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-6)
+        xr = g["ref_%s_psi" % key]
+        assert np.max(np.abs(res["ref_%s_psi" % key] - xr)) <= 1e-8 * np.max(np.abs(xr)), key
+    for sm in ("GaussSeidel", "nonBlockingGaussSeidel"):
+        assert np.array_equal(res["ref_smooth_" + sm], g["ref_smooth_" + sm]), sm
+    with pytest.raises(Exception) as ei:
+        fv_case.run_driver(case, mesh, vf, U, phi, gamma, mode="glueV")
+    assert "not of rank 0" in str(ei.value) or "not of rank 0" in (fv_case.run_driver.last_stdout or "")
+
+
 COUPLED = [("PBiCCCG", "DILU", True), ("PBiCICG", "DILU", True), ("SmoothSolver", "none", True),
            ("PCICG", "diagonal", False)]
 
