@@ -96,7 +96,7 @@ def main():
               dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4),
               dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-9, relTol=0, nCellsInCoarsestLevel=4, mergeLevels=2,
                    nPreSweeps=1)]
-    if not str(size).startswith("mb"):
+    if not str(size).startswith("mb") and n < 8:    # (8 ranks: threads in test_gpu_multidomain.py; 8 processes on one GPU crawl)
         # directSolveCoarsest in a parallel run: the ranks' coarsest levels gathered over the out-of-band channel, every rank
         # factorises the gathered matrix (ldu_coarsest.hip lu_gathered; LUscalarMatrix.C:52-107)
         solves.append(dict(solver="GAMG", smoother="GaussSeidel", tolerance=1e-8 if asym else 1e-9, relTol=0, nCellsInCoarsestLevel=4,
